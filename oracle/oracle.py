@@ -1,0 +1,334 @@
+"""oracle/oracle.py — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes loaders for
+  * ``libcpu_ref.so``  — our plain-C restatement (oracle/cpu_ref.c), always built;
+  * ``_ref/libref_*.so`` — the REAL reference kernels compiled from
+    /root/reference/mpk by oracle/Makefile (present only where they were built).
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg
+import this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_c = ctypes
+
+_CPU = None
+_REF = {}
+
+
+def _as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def cpu():
+    global _CPU
+    if _CPU is None:
+        path = os.path.join(_HERE, "libcpu_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle`")
+        L = ctypes.CDLL(path)
+        L.orc_spmv_csr_fma.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64]
+        L.orc_spmv_csr_muladd.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64]
+        L.orc_spmv_csr_x87.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64]
+        L.orc_spmk_chain.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64]
+        L.orc_gen_layer1.argtypes = [_c.c_int, _i32, _i32, _i32]
+        L.orc_spm2v_fused.argtypes = [_c.c_int, _i32, _i32, _f64, _i32, _f64, _f64, _f64]
+        L.orc_spm2v_fused_x87.argtypes = [_c.c_int, _i32, _i32, _f64, _i32, _f64, _f64, _f64]
+        L.orc_spmkv_fused.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64]
+        L.orc_spmv_bcsr4_fma.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64]
+        L.orc_norm2.argtypes = [_c.c_int, _f64]
+        L.orc_norm2.restype = _c.c_double
+        L.orc_rel_error.argtypes = [_c.c_int, _f64, _f64]
+        L.orc_rel_error.restype = _c.c_double
+        L.orc_dot.argtypes = [_c.c_int, _f64, _f64]
+        L.orc_dot.restype = _c.c_double
+        L.orc_orthogonalize.argtypes = [_c.c_int, _f64, _f64, _f64, _c.c_double]
+        L.orc_orthogonalize.restype = _c.c_double
+        L.orc_axpy.argtypes = [_c.c_int, _c.c_double, _f64, _f64]
+        L.orc_coo2csr.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _f64, _i32, _i32, _f64]
+        L.orc_coo2csr.restype = _c.c_int
+        L.orc_coo2bcsr4.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _f64, _c.c_void_p, _c.c_void_p, _c.c_void_p]
+        L.orc_coo2bcsr4.restype = _c.c_int
+        L.orc_read_mtx.argtypes = [_c.c_char_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int),
+                                   _c.c_void_p, _c.c_void_p, _c.c_void_p]
+        L.orc_read_mtx.restype = _c.c_int
+        L.orc_time_spmv.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64, _c.c_int, _c.c_int]
+        L.orc_time_spmv.restype = _c.c_double
+        _CPU = L
+    return _CPU
+
+
+# ---------------------------------------------------------------- restatement
+
+def spmv(ptrow, indcol, coef, x, kind="fma"):
+    """y = A x.  kind: 'fma' (= SpMV_CSR_OPT/_FMA), 'muladd', 'x87' (= SpMV_CSR)."""
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    y = np.empty(n, np.float64)
+    if kind == "fma":
+        cpu().orc_spmv_csr_fma(n, ptrow, indcol, coef, x, y)
+    elif kind == "muladd":
+        cpu().orc_spmv_csr_muladd(n, ptrow, indcol, coef, x, y)
+    elif kind == "x87":
+        cpu().orc_spmv_csr_x87(n, ptrow, indcol, coef, x, y)
+    else:
+        raise ValueError(kind)
+    return y
+
+
+def spmk_chain(k, ptrow, indcol, coef, x):
+    """[Ax, A^2x, ..., A^k x] as a (k, n) array by k chained fma SpMVs."""
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    Y = np.empty((k, n), np.float64)
+    cpu().orc_spmk_chain(k, n, ptrow, indcol, coef, x, Y.reshape(-1))
+    return Y
+
+
+def gen_layer1(ptrow, indcol):
+    ptrow, indcol = _as_i32(ptrow), _as_i32(indcol)
+    n = len(ptrow) - 1
+    end1 = np.empty(len(indcol), np.int32)
+    cpu().orc_gen_layer1(n, ptrow, indcol, end1)
+    return end1
+
+
+def spm2v_fused(ptrow, indcol, coef, x, arith="fma"):
+    """(y, z) = (Ax, A^2 x) by the reference's first-touch traversal.
+    arith 'fma' = SpM2V_CSR_OPT, 'x87' = SpM2V_CSR object code (mpk/SpM2V.cpp:79-112)."""
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    end1 = gen_layer1(ptrow, indcol)
+    y = np.empty(n, np.float64)
+    z = np.empty(n, np.float64)
+    fn = cpu().orc_spm2v_fused if arith == "fma" else cpu().orc_spm2v_fused_x87
+    fn(n, ptrow, indcol, coef, end1, x, y, z)
+    return y, z
+
+
+ARITH = {"fma": 0, "x87": 1, "muladd": 2}
+
+
+def spmkv_fused(k, ptrow, indcol, coef, x, arith="fma"):
+    """[Ax..A^k x] by the k-level first-touch traversal (SpM2V0/SpM3V/SpM4V)."""
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    Y = np.empty((k, n), np.float64)
+    cpu().orc_spmkv_fused(ARITH[arith], k, n, ptrow, indcol, coef, x, Y.reshape(-1))
+    return Y
+
+
+def spmv_bcsr4(ptrow, indcol, coef, x):
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    nb = len(ptrow) - 1
+    y = np.empty(4 * nb, np.float64)
+    cpu().orc_spmv_bcsr4_fma(nb, ptrow, indcol, coef, x, y)
+    return y
+
+
+def norm2(x):
+    x = _as_f64(x)
+    return cpu().orc_norm2(len(x), x)
+
+
+def rel_error(ref, test):
+    ref, test = _as_f64(ref), _as_f64(test)
+    assert ref.shape == test.shape
+    return cpu().orc_rel_error(len(ref), ref, test)
+
+
+def dot(a, b):
+    a, b = _as_f64(a), _as_f64(b)
+    return cpu().orc_dot(len(a), a, b)
+
+
+def orthogonalize(b, x1, alpha=1e-8):
+    """(beta, x3) with beta = b.x1, x3 = x1 - alpha*beta*b (mpk/SpMVmulti.cpp:146-151)."""
+    b, x1 = _as_f64(b), _as_f64(x1)
+    out = np.empty_like(x1)
+    beta = cpu().orc_orthogonalize(len(b), b, x1, out, alpha)
+    return beta, out
+
+
+def axpy(a, x, y):
+    x = _as_f64(x)
+    y = _as_f64(y).copy()
+    cpu().orc_axpy(len(x), a, x, y)
+    return y
+
+
+def coo2csr(nrow, irow, jcol, val):
+    irow, jcol, val = _as_i32(irow), _as_i32(jcol), _as_f64(val)
+    nnz = len(irow)
+    ptrow = np.empty(nrow + 1, np.int32)
+    indcol = np.empty(max(nnz, 1), np.int32)
+    coef = np.empty(max(nnz, 1), np.float64)
+    stored = cpu().orc_coo2csr(nrow, nnz, irow, jcol, val, ptrow, indcol, coef)
+    return ptrow, indcol[:stored].copy(), coef[:stored].copy()
+
+
+def coo2bcsr4(nrow, irow, jcol, val):
+    irow, jcol, val = _as_i32(irow), _as_i32(jcol), _as_f64(val)
+    nnz = len(irow)
+    nb = cpu().orc_coo2bcsr4(nrow, nnz, irow, jcol, val, None, None, None)
+    ptrow = np.empty(nrow // 4 + 1, np.int32)
+    indcol = np.empty(max(nb, 1), np.int32)
+    coef = np.empty(max(nb, 1) * 16, np.float64)
+    cpu().orc_coo2bcsr4(nrow, nnz, irow, jcol, val, ptrow.ctypes.data, indcol.ctypes.data, coef.ctypes.data)
+    return ptrow, indcol[:nb].copy(), coef[: 16 * nb].copy()
+
+
+def read_mtx(path):
+    """(nrow, irow, jcol, val) with the reference reader's float32 rounding."""
+    nrow, nnz = _c.c_int(0), _c.c_int(0)
+    rc = cpu().orc_read_mtx(path.encode(), _c.byref(nrow), _c.byref(nnz), None, None, None)
+    if rc != 0:
+        raise OSError(f"orc_read_mtx({path}) -> {rc}")
+    irow = np.empty(nnz.value, np.int32)
+    jcol = np.empty(nnz.value, np.int32)
+    val = np.empty(nnz.value, np.float64)
+    rc = cpu().orc_read_mtx(path.encode(), _c.byref(nrow), _c.byref(nnz), irow.ctypes.data,
+                            jcol.ctypes.data, val.ctypes.data)
+    if rc != 0:
+        raise OSError(f"orc_read_mtx({path}) -> {rc}")
+    return nrow.value, irow, jcol, val
+
+
+def time_spmv(ptrow, indcol, coef, x, reps=3, flush=True):
+    """Best-of-reps seconds of the single-thread fma SpMV (cold cache if flush)."""
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    y = np.empty(n, np.float64)
+    return cpu().orc_time_spmv(n, ptrow, indcol, coef, x, y, reps, 1 if flush else 0), y
+
+
+# ------------------------------------------------ the real reference (if built)
+
+def have_ref():
+    return all(os.path.exists(os.path.join(_HERE, "_ref", f"libref_{s}.so")) for s in ("spmv", "spm2v", "multi0"))
+
+
+def ref(which):
+    if which not in _REF:
+        path = os.path.join(_HERE, "_ref", f"libref_{which}.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: `make -C oracle ref` needs /root/reference")
+        L = ctypes.CDLL(path)
+        if which == "spmv":
+            L.ref_spmv_csr.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64]
+            L.ref_spmv_bcsr.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64]
+            L.ref_coo2csr.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _f64, _i32, _i32, _f64]
+            L.ref_coo2bcsr4.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _f64, _c.c_void_p, _c.c_void_p, _c.c_void_p]
+            L.ref_norm2.argtypes = [_c.c_int, _f64]
+            L.ref_norm2.restype = _c.c_double
+            L.ref_rel_error.argtypes = [_c.c_int, _f64, _f64]
+            L.ref_rel_error.restype = _c.c_double
+            L.ref_time_spmv_csr.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64, _c.c_int, _c.c_int]
+            L.ref_time_spmv_csr.restype = _c.c_double
+        elif which == "spm2v":
+            L.ref_gen_layer1.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _i32]
+            L.ref_spm2v_csr.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64, _f64]
+            L.ref_spm2v_bcsr.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64, _f64]
+        elif which == "multi0":
+            L.ref_multi0_powers.argtypes = [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64]
+        _REF[which] = L
+    return _REF[which]
+
+
+REF_VARIANTS = {"scalar": 0, "opt": 1, "fma": 2, "avx2": 3}
+
+
+def ref_spmv(ptrow, indcol, coef, x, variant="scalar"):
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    y = np.full(n, np.nan)
+    rc = ref("spmv").ref_spmv_csr(REF_VARIANTS[variant], n, len(indcol), ptrow, indcol, coef, x, y)
+    assert rc == 0
+    return y
+
+
+def ref_spmv_bcsr(ptrow, indcol, coef, x, variant="fma"):
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    nb = len(ptrow) - 1
+    y = np.full(4 * nb, np.nan)
+    rc = ref("spmv").ref_spmv_bcsr(REF_VARIANTS[variant], nb, len(indcol), ptrow, indcol, coef, x, y)
+    assert rc == 0
+    return y
+
+
+def ref_coo2csr(nrow, irow, jcol, val):
+    irow, jcol, val = _as_i32(irow), _as_i32(jcol), _as_f64(val)
+    nnz = len(irow)
+    ptrow = np.empty(nrow + 1, np.int32)
+    indcol = np.empty(max(nnz, 1), np.int32)
+    coef = np.empty(max(nnz, 1), np.float64)
+    stored = ref("spmv").ref_coo2csr(nrow, nnz, irow, jcol, val, ptrow, indcol, coef)
+    return ptrow, indcol[:stored].copy(), coef[:stored].copy()
+
+
+def ref_coo2bcsr4(nrow, irow, jcol, val):
+    irow, jcol, val = _as_i32(irow), _as_i32(jcol), _as_f64(val)
+    nnz = len(irow)
+    nb = ref("spmv").ref_coo2bcsr4(nrow, nnz, irow, jcol, val, None, None, None)
+    ptrow = np.empty(nrow // 4 + 1, np.int32)
+    indcol = np.empty(max(nb, 1), np.int32)
+    coef = np.empty(max(nb, 1) * 16, np.float64)
+    ref("spmv").ref_coo2bcsr4(nrow, nnz, irow, jcol, val, ptrow.ctypes.data, indcol.ctypes.data, coef.ctypes.data)
+    return ptrow, indcol[:nb].copy(), coef[: 16 * nb].copy()
+
+
+def ref_gen_layer1(ptrow, indcol):
+    ptrow, indcol = _as_i32(ptrow), _as_i32(indcol)
+    end1 = np.empty(len(indcol), np.int32)
+    ref("spm2v").ref_gen_layer1(len(ptrow) - 1, len(indcol), ptrow, indcol, end1)
+    return end1
+
+
+def ref_spm2v(ptrow, indcol, coef, x, variant="opt"):
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    y = np.full(n, np.nan)
+    z = np.full(n, np.nan)
+    rc = ref("spm2v").ref_spm2v_csr(REF_VARIANTS[variant], n, len(indcol), ptrow, indcol, coef, x, y, z)
+    assert rc == 0
+    return y, z
+
+
+def ref_spm2v_bcsr(ptrow, indcol, coef, x, variant="fma"):
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    nb = len(ptrow) - 1
+    y = np.full(4 * nb, np.nan)
+    z = np.full(4 * nb, np.nan)
+    rc = ref("spm2v").ref_spm2v_bcsr(REF_VARIANTS[variant], nb, len(indcol), ptrow, indcol, coef, x, y, z)
+    assert rc == 0
+    return y, z
+
+
+def ref_powers(k, ptrow, indcol, coef, x, fused=True):
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    Y = np.full((k, n), np.nan)
+    rc = ref("multi0").ref_multi0_powers(1 if fused else 0, k, n, len(indcol), ptrow, indcol, coef, x, Y.reshape(-1))
+    assert rc == 0
+    return Y
+
+
+def ref_time_spmv(ptrow, indcol, coef, x, variant="scalar", reps=3, flush=True):
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    y = np.empty(n, np.float64)
+    t = ref("spmv").ref_time_spmv_csr(REF_VARIANTS[variant], n, len(indcol), ptrow, indcol, coef, x, y, reps,
+                                      1 if flush else 0)
+    return t, y
