@@ -1,0 +1,126 @@
+// include/SpMV.h — C++ drop-in for the reference's mpk/SpMV.h, backed by the
+// MI355X HIP library.
+//
+// Every declaration below has the exact name, parameter list and struct layout
+// of the reference interface it replaces (cited as file:line relative to
+// aantoine890/navierstokes), so its symbols mangle identically and existing
+// translation units (mpk/2SpMV.cpp, mpk/SpM2V.cpp, mpk/SpMVmulti*.cpp) link
+// against libmpk_mi355.so instead of mpk/SpMV.cpp + mpk/utils.cpp without a
+// source change.  The bodies live in navierstokes_amd/csrc/mpk_shim.cpp and
+// forward to the C-ABI of include/mi355_spmv.h; a device copy of each matrix is
+// created on first use and cached.
+//
+// Behavioural contract kept from the reference:
+//   * all functions return void and do not validate (mpk/SpMV.h:52-66); a
+//     failing device call prints the C-ABI's message and aborts;
+//   * output vectors are fully overwritten, inputs are never written;
+//   * the four variants of a kernel (scalar/_OPT/_FMA/_AVX2) are one GPU kernel
+//     whose rows are sequential fma chains — bit-equal to _OPT/_FMA;
+//   * COO2CSR keeps the FIRST duplicate, generate_BCSR4 the LAST
+//     (mpk/utils.cpp:29-32 vs :64).
+#ifndef MI355_MPK_SPMV_H
+#define MI355_MPK_SPMV_H
+
+#include <array>
+#include <list>
+#include <utility>
+#include <vector>
+// Not needed by the declarations below: the reference's drivers rely on their
+// SpMV.h to bring these in (std::chrono timers, printf, std::sin, std::fill,
+// std::inner_product), so a drop-in header has to as well.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <numeric>
+
+// ---- containers ------------------------------------------------------------
+
+// mpk/SpMV.h:18-24.  CSR, 0-based, columns ascending within a row.
+struct csrmatrix
+{
+	int n, nnz;
+	std::vector<int> ptrow;    // n + 1 row starts
+	std::vector<int> indcol;   // column of each nonzero
+	std::vector<double> coef;  // value of each nonzero
+};
+
+// mpk/SpMV.h:26-33.  4x4 blocks, 16 doubles each, row-major inside a block;
+// blocks of a block row in first-appearance order (mpk/utils.cpp:69-74).
+struct bcsr4x4_matrix
+{
+	int nrows;    // block rows (= scalar rows / 4, truncating: mpk/utils.cpp:49)
+	int nblocks;
+	std::vector<int> ptrow;
+	std::vector<int> indcol;   // block column of each block
+	std::vector<double> coef;
+};
+
+// ---- format builders (host-side integer work; mpk/utils.cpp:5-127) ---------
+
+void generate_CSR(std::list<int>* ind_cols_tmp, std::list<double>* val_tmp,
+                  int nrow, int nnz, int* irow, int* jcol, double* val);
+
+void generate_BCSR4(std::list<std::pair<int, std::array<double, 16>> >* block_rows,
+                    int nrow, int nnz, const int* irow, const int* jcol, const double* val,
+                    bcsr4x4_matrix& A);
+
+void COO2CSR(csrmatrix& a, int nrow, int nnz, int* irow, int* jcol, double* val);
+
+// ---- parity metric (mpk/utils.cpp:131-143), evaluated on the GPU -----------
+
+double norm2(const std::vector<double>& x);
+
+double rel_error(const std::vector<double>& ref, const std::vector<double>& test);
+
+// ---- y = A x, CSR (mpk/SpMV.cpp:6-85) --------------------------------------
+
+void SpMV_CSR(double* y, double* x, csrmatrix& A);
+void SpMV_CSR_OPT(double* y, double* x, csrmatrix& A);
+void SpMV_CSR_FMA(double* y, double* x, csrmatrix& A);
+void SpMV_CSR_AVX2(double* y, double* x, csrmatrix& A);
+
+// ---- y = A x, BCSR 4x4 (mpk/SpMV.cpp:90-219) -------------------------------
+
+void SpMV_BCSR(double* y, const double* x, const bcsr4x4_matrix& A);
+void SpMV_BCSR_OPT(double* y, const double* x, const bcsr4x4_matrix& A);
+void SpMV_BCSR_FMA(double* y, const double* x, const bcsr4x4_matrix& A);
+void SpMV_BCSR_AVX2(double* y, const double* x, const bcsr4x4_matrix& A);
+
+// mpk/utils.cpp:146-154 evicts the CPU caches before a timed call; here it
+// evicts the GPU's L2 / Infinity Cache (a 512 MiB device fill).
+void flush_cache();
+
+// ---- matrix powers and orthogonalisation ------------------------------------
+// Defined per translation unit in the reference, not in its header; declared
+// here so that new drivers can call the GPU versions under the same names.
+
+// mpk/SpM2V.cpp:5-26 (= mpk/SpMVmulti0.cpp:22-40): first-touch table of the
+// CPU traversal.  Filled faithfully for callers that inspect it; the GPU
+// kernels do not need it.
+void Generate1stlayer(std::vector<int>& ptrowend1, csrmatrix& A);
+
+// mpk/SpM2V.cpp:79-332: y = A x, z = A (A x).
+void SpM2V_CSR(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& ptrowend1);
+void SpM2V_CSR_OPT(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& ptrowend1);
+void SpM2V_CSR_FMA(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& ptrowend1);
+void SpM2V_CSR_AVX2(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& ptrowend1);
+
+// mpk/SpMVmulti0.cpp:132-155 and :189-221: all intermediate powers are returned
+// (y = A x, z = A^2 x, w = A^3 x, v = A^4 x).  The nested first-touch tables are
+// accepted for signature parity and ignored.
+void SpM3V(double* w, double* z, double* y, double* x, csrmatrix& A,
+           std::vector<int>& ptrowend1, std::vector<std::vector<int> >& ptrowend2);
+void SpM4V(double* v, double* w, double* z, double* y, double* x, csrmatrix& A,
+           std::vector<int>& ptrowend1, std::vector<std::vector<int> >& ptrowend2,
+           std::vector<std::vector<std::vector<int> > >& ptrowend3);
+
+// mpk/SpMVmulti.cpp:146-151: x3 = x1 - alpha * (b . x1) * b.
+void orthogonalize(int nrow, const std::vector<double>& b, const std::vector<double>& x1,
+                   std::vector<double>& x3, double alpha = 1e-8);
+// mpk/2SpMV.cpp:3-11: y -= alpha * (x . y) * x, in place.
+void orthogonalize(int nrow, const std::vector<double>& x, std::vector<double>& y, double alpha = 1e-8);
+
+#endif // MI355_MPK_SPMV_H

@@ -1,0 +1,169 @@
+/*
+ * mi355_spmv.h — the C-ABI boundary of the MI355X-native CSR SpMV /
+ * matrix-powers path (libmi355spmv.so).
+ *
+ * Plain C: opaque handles, raw pointers and sizes, int status codes.  These are
+ * the entry points a binding of the reference's hot path attaches to; the
+ * reference interface each one stands behind is cited as file:line relative to
+ * aantoine890/navierstokes.  The C++ drop-in with the reference's exact
+ * mpk/SpMV.h names and signatures (include/SpMV.h, libmpk_mi355.so) is a thin
+ * layer over this header; INTEGRATION.md shows both bindings.
+ *
+ * Conventions
+ *   - every function returns MI_OK (0) or an MI_ERR_* code; mi_last_error()
+ *     gives the detail of the last failure on the calling thread.  The
+ *     reference's functions are void and unchecked (mpk/SpMV.h:52-66); the
+ *     C++ shim aborts with the message on a non-zero status.
+ *   - indices are 0-based int32, values are IEEE double (mpk/SpMV.h:18-24).
+ *   - the caller owns every buffer it passes; the library copies the matrix to
+ *     the device at create time and never retains caller memory.  Output
+ *     vectors are fully overwritten (as mpk/SpMV.cpp:13, mpk/SpM2V.cpp:85-86).
+ *   - "*_dev" entry points take DEVICE pointers (HBM-resident vectors) and a
+ *     hipStream_t passed as void*; they enqueue work and return without
+ *     synchronising.  The others take HOST pointers, copy in/out and
+ *     synchronise — the semantics of the reference's CPU functions.
+ *   - arithmetic: each row of y = A x is ONE sequential fma chain in CSR order,
+ *     bit-identical to the reference's SpMV_CSR_OPT / SpMV_CSR_FMA
+ *     (mpk/SpMV.cpp:23-56) for every matrix and every kernel id.
+ *   - there is no CPU fallback: without a usable HIP device the compute entry
+ *     points fail with MI_ERR_NODEVICE.
+ */
+#ifndef MI355_SPMV_H
+#define MI355_SPMV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_SPMV_VERSION 100 /* 0.1.0 */
+
+enum {
+    MI_OK = 0,
+    MI_ERR_ARG = 1,         /* null pointer, negative size, inconsistent CSR */
+    MI_ERR_NODEVICE = 2,    /* no HIP device / driver */
+    MI_ERR_HIP = 3,         /* a HIP runtime call failed (see mi_last_error) */
+    MI_ERR_ALLOC = 4,       /* host or device allocation failed */
+    MI_ERR_UNSUPPORTED = 5, /* e.g. k outside 1..MI_MAX_POWERS */
+    MI_ERR_STATE = 6        /* handle used before it was finalised / wrong device */
+};
+
+#define MI_MAX_POWERS 16
+
+typedef struct mi_csr_s* mi_csr_t;   /* device-resident CSR matrix (struct csrmatrix, mpk/SpMV.h:18-24) */
+typedef struct mi_bcsr4_s* mi_bcsr4_t; /* device-resident 4x4 BCSR matrix (struct bcsr4x4_matrix, mpk/SpMV.h:26-33) */
+typedef struct mi_part_s* mi_part_t; /* one rank's share of a row-partitioned matrix */
+typedef void* mi_stream_t;           /* hipStream_t; NULL = the default stream */
+
+/* kernel ids for mi_csr_set_kernel (all produce the same bits) */
+enum {
+    MI_KERNEL_AUTO = 0,
+    MI_KERNEL_STREAM = 1,  /* row-block CSR-stream, x gathered through L2 */
+    MI_KERNEL_STREAM_XLDS = 2, /* row-block CSR-stream, x window staged in LDS */
+    MI_KERNEL_ROWPAR = 3   /* one thread per row straight from global memory (reference shape; slow) */
+};
+
+/* ---- library / device ------------------------------------------------- */
+int mi_version(void);
+const char* mi_strerror(int status);
+const char* mi_last_error(void);
+int mi_device_count(int* count);
+int mi_set_device(int device);
+int mi_device_synchronize(void);
+/* Evict the GPU's L2s and 256 MiB Infinity Cache (a 512 MiB device fill, then
+ * a synchronise): the device analogue of flush_cache(), mpk/utils.cpp:146-154,
+ * which the reference calls before every timed kernel. */
+int mi_flush_cache(void);
+
+/* ---- CSR matrix handles ------------------------------------------------ */
+/* Upload a csrmatrix (mpk/SpMV.h:18-24: n, ptrow[n+1], indcol, coef; nnz taken
+ * from ptrow[n], not from the possibly stale csrmatrix::nnz — mpk/utils.cpp:100).
+ * ncols = length of the x vectors (n for the reference's square matrices).
+ * Host pointers. */
+int mi_csr_create(int n, int ncols, const int* ptrow, const int* indcol, const double* coef, mi_csr_t* out);
+/* Same, for a row subset whose results are scattered: row r of this matrix
+ * writes y[rowmap[r]] (rowmap == NULL: y[r]).  Used for the interior/boundary
+ * split of a partitioned matrix. */
+int mi_csr_create_mapped(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
+                         const int* rowmap, mi_csr_t* out);
+int mi_csr_destroy(mi_csr_t A);
+int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz);
+int mi_csr_set_kernel(mi_csr_t A, int kernel_id);
+int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
+/* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
+const char* mi_csr_kernel_name(mi_csr_t A);
+
+/* ---- SpMV: y = A x  (SpMV_CSR{,_OPT,_FMA,_AVX2}, mpk/SpMV.cpp:6-85) ---- */
+int mi_spmv(mi_csr_t A, const double* x, double* y);                           /* host vectors */
+int mi_spmv_dev(mi_csr_t A, const double* d_x, double* d_y, mi_stream_t s);    /* device vectors */
+
+/* ---- matrix powers: y_out[p] = A^(p+1) x, p = 0..k-1 --------------------
+ * SpM2V_CSR (mpk/SpM2V.cpp:79-112: y_out[0]=y, y_out[1]=z), SpM3V / SpM4V
+ * (mpk/SpMVmulti0.cpp:132-155, :189-221: all intermediate powers returned).
+ * Unlike the CPU first-touch traversal, rows of A^p x that no row references
+ * as a column are computed too (SURVEY.md §8a-10 caveat). */
+int mi_spmk(mi_csr_t A, int k, const double* x, double* const* y_out);                      /* host */
+int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s); /* device; d_y_out is a HOST array of k device pointers */
+
+/* ---- BLAS-1 between SpMVs ---------------------------------------------- */
+/* out = sum x_i y_i  (std::inner_product, mpk/SpMVmulti.cpp:147).  Fixed
+ * two-stage reduction tree: deterministic run to run, not the CPU's order. */
+int mi_dot(int n, const double* x, const double* y, double* out);
+int mi_dot_dev(int n, const double* d_x, const double* d_y, double* d_out, mi_stream_t s);
+/* y += a x  (VecAXPY at src/solve_newton.c:1269; the AXPY half of orthogonalize) */
+int mi_axpy(int n, double a, const double* x, double* y);
+int mi_axpy_dev(int n, double a, const double* d_x, double* d_y, mi_stream_t s);
+/* x3 = x1 - alpha * (b . x1) * b ; *beta_out = b . x1
+ * (orthogonalize, mpk/SpMVmulti.cpp:146-151; in-place twin mpk/2SpMV.cpp:3-11) */
+int mi_orthogonalize(int n, const double* b, const double* x1, double* x3, double alpha, double* beta_out);
+int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1, double* d_x3, double alpha,
+                         double* d_beta_out, mi_stream_t s);
+/* sqrt(sum x^2) (norm2, mpk/utils.cpp:131-136) and ||ref-test||/||ref|| (rel_error, :138-143) */
+int mi_norm2(int n, const double* x, double* out);
+int mi_norm2_dev(int n, const double* d_x, double* d_out, mi_stream_t s);
+int mi_rel_error(int n, const double* ref, const double* test, double* out);
+int mi_rel_error_dev(int n, const double* d_ref, const double* d_test, double* d_out, mi_stream_t s);
+/* dst[i] = src[idx[i]] — halo pack */
+int mi_gather_dev(int m, const int* d_idx, const double* d_src, double* d_dst, mi_stream_t s);
+
+/* ---- BCSR 4x4 (SpMV_BCSR*, mpk/SpMV.cpp:90-219; row-major blocks) ------- */
+int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
+                    mi_bcsr4_t* out);
+int mi_bcsr4_destroy(mi_bcsr4_t A);
+int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y);
+int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s);
+
+/* ---- row-range partition of one matrix over the GPUs of a node ----------
+ * New design (the reference has no distributed code).  Rank r
+ * owns global rows [row_starts[r], row_starts[r+1]) and the matching slice of
+ * x and y.  Columns are relabelled to [0,n_local) owned | [n_local,
+ * n_local+n_halo) ghosts (ascending global id, hence contiguous per owner);
+ * rows are split into interior (no ghost column) and boundary rows so the
+ * interior SpMV overlaps the halo exchange.  The exchange itself is done by
+ * the caller (torch.distributed over RCCL in bench.py) between
+ * mi_part_pack_dev and mi_part_spmv_boundary_dev.
+ *
+ * Planning functions are host-only and work without a GPU. */
+int mi_part_create(int nranks, int rank, const long long* row_starts, const int* ptrow,
+                   const int* indcol_global, const double* coef, mi_part_t* out);
+int mi_part_destroy(mi_part_t P);
+int mi_part_sizes(mi_part_t P, int* n_local, int* n_halo, int* n_interior_rows, int* n_boundary_rows);
+int mi_part_recv_counts(mi_part_t P, int* counts /* [nranks] */);
+int mi_part_recv_ids(mi_part_t P, int peer, long long* ids /* [recv_counts[peer]] global, ascending */);
+int mi_part_set_send_ids(mi_part_t P, int peer, int count, const long long* ids /* global ids peer needs from me */);
+int mi_part_send_counts(mi_part_t P, int* counts /* [nranks] */);
+/* local pieces on the host, for CPU checks: which = 0 interior, 1 boundary */
+int mi_part_local_csr(mi_part_t P, int which, int* nrows, const int** ptrow, const int** indcol_local,
+                      const double** coef, const int** rowmap);
+int mi_part_send_index(mi_part_t P, int* total, const int** local_idx /* packed by peer, ascending */);
+/* upload the two pieces and the send index to the current device */
+int mi_part_finalize(mi_part_t P);
+int mi_part_set_kernel(mi_part_t P, int kernel_id);
+/* per step, on device: x_ext = [x_local | halo], sendbuf packed by peer */
+int mi_part_pack_dev(mi_part_t P, const double* d_x_ext, double* d_sendbuf, mi_stream_t s);
+int mi_part_spmv_interior_dev(mi_part_t P, const double* d_x_ext, double* d_y_local, mi_stream_t s);
+int mi_part_spmv_boundary_dev(mi_part_t P, const double* d_x_ext, double* d_y_local, mi_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_SPMV_H */

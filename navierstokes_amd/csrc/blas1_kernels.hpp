@@ -1,0 +1,157 @@
+// blas1_kernels.hpp — the vector primitives that sit between SpMVs in the
+// reference's pipelines: dot + AXPY ("orthogonalize", mpk/SpMVmulti.cpp:146-151,
+// mpk/2SpMV.cpp:3-11), norm2 / rel_error (mpk/utils.cpp:131-143) and the halo
+// pack gather.  All are HBM-bound streams: 16-byte loads per lane, fixed grids,
+// and a fixed two-stage reduction tree (lane chain -> wave shuffle -> LDS across
+// the 4 waves -> one partial per workgroup -> one finishing workgroup), so a
+// result depends only on (n, data), never on scheduling: deterministic run to
+// run, though not the CPU's left-to-right order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355 {
+
+constexpr int kRedWG = 256;
+constexpr int kMaxPartials = 1024; // = 4 per thread of the finishing workgroup
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v; // lane 0 holds the sum
+}
+
+// Sum of one value per thread over the workgroup, fixed order; valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* s_part /* [4] */)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_part[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) t = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+    __syncthreads();
+    return t;
+}
+
+// MODE 0: sum a_i b_i     MODE 1: sum (a_i-b_i)^2 and sum a_i^2 (rel_error)
+// Workgroup g owns the contiguous segment [g*seg, (g+1)*seg); seg is a multiple
+// of 2*kRedWG so every lane's double2 is 16-byte aligned when the bases are.
+template <int MODE>
+__global__ __launch_bounds__(kRedWG) void reduce_stage1(int n, int seg, const double* __restrict__ a,
+                                                        const double* __restrict__ b,
+                                                        double* __restrict__ partial,
+                                                        double* __restrict__ partial2)
+{
+    __shared__ double s_part[4];
+    const long long lo = (long long)blockIdx.x * seg;
+    const long long hi = (lo + seg < n) ? lo + seg : n;
+    double s = 0.0, s2 = 0.0;
+    const bool aligned = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+    if (aligned) {
+        for (long long i = lo + 2 * threadIdx.x; i + 1 < hi; i += 2 * kRedWG) {
+            const double2 av = *reinterpret_cast<const double2*>(a + i);
+            const double2 bv = *reinterpret_cast<const double2*>(b + i);
+            if (MODE == 0) {
+                s = fma(av.x, bv.x, s);
+                s = fma(av.y, bv.y, s);
+            } else {
+                const double d0 = av.x - bv.x, d1 = av.y - bv.y;
+                s = fma(d0, d0, s);
+                s = fma(d1, d1, s);
+                s2 = fma(av.x, av.x, s2);
+                s2 = fma(av.y, av.y, s2);
+            }
+        }
+        // odd tail element of the segment (only the last segment can have one)
+        if (((hi - lo) & 1) && threadIdx.x == 0) {
+            const double av = a[hi - 1], bv = b[hi - 1];
+            if (MODE == 0) s = fma(av, bv, s);
+            else { const double d = av - bv; s = fma(d, d, s); s2 = fma(av, av, s2); }
+        }
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += kRedWG) {
+            const double av = a[i], bv = b[i];
+            if (MODE == 0) s = fma(av, bv, s);
+            else { const double d = av - bv; s = fma(d, d, s); s2 = fma(av, av, s2); }
+        }
+    }
+    const double t = block_sum(s, s_part);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    if (MODE == 1) {
+        const double t2 = block_sum(s2, s_part);
+        if (threadIdx.x == 0) partial2[blockIdx.x] = t2;
+    }
+}
+
+// FIN 0: out = sum   FIN 1: out = sqrt(sum)   FIN 2: out = sqrt(sum)/sqrt(sum2)
+template <int FIN>
+__global__ __launch_bounds__(kRedWG) void reduce_stage2(int np, const double* __restrict__ partial,
+                                                        const double* __restrict__ partial2,
+                                                        double* __restrict__ out)
+{
+    __shared__ double s_part[4];
+    double s = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < np; i += kRedWG) {
+        s += partial[i];
+        if (FIN == 2) s2 += partial2[i];
+    }
+    const double t = block_sum(s, s_part);
+    double t2 = 0.0;
+    if (FIN == 2) t2 = block_sum(s2, s_part);
+    if (threadIdx.x == 0) {
+        if (FIN == 0) out[0] = t;
+        else if (FIN == 1) out[0] = sqrt(t);
+        else out[0] = sqrt(t) / sqrt(t2);
+    }
+}
+
+// y += a x
+__global__ __launch_bounds__(256) void axpy_kernel(int n, double a, const double* __restrict__ x,
+                                                   double* __restrict__ y)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    if (aligned) {
+        const long long n2 = n >> 1;
+        for (long long i = t; i < n2; i += stride) {
+            const double2 xv = reinterpret_cast<const double2*>(x)[i];
+            double2 yv = reinterpret_cast<double2*>(y)[i];
+            yv.x = fma(a, xv.x, yv.x);
+            yv.y = fma(a, xv.y, yv.y);
+            reinterpret_cast<double2*>(y)[i] = yv;
+        }
+        if ((n & 1) && t == 0) y[n - 1] = fma(a, x[n - 1], y[n - 1]);
+    } else {
+        for (long long i = t; i < n; i += stride) y[i] = fma(a, x[i], y[i]);
+    }
+}
+
+// out = x1 - (alpha * beta) * b with beta read from device memory (no host
+// round trip between the dot and the update): the AXPY half of orthogonalize,
+// evaluated exactly as the reference writes it (mpk/SpMVmulti.cpp:149:
+// x1[i] - alpha * beta * b[i], i.e. ((alpha*beta)*b[i]) subtracted, no fma).
+__global__ __launch_bounds__(256) void ortho_update_kernel(int n, double alpha, const double* __restrict__ beta,
+                                                           const double* __restrict__ b,
+                                                           const double* __restrict__ x1,
+                                                           double* __restrict__ out)
+{
+    const double ab = alpha * beta[0];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = __dsub_rn(x1[i], __dmul_rn(ab, b[i]));
+}
+
+// dst[i] = src[idx[i]]
+__global__ __launch_bounds__(256) void gather_kernel(int m, const int* __restrict__ idx,
+                                                     const double* __restrict__ src,
+                                                     double* __restrict__ dst)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+        dst[i] = src[idx[i]];
+}
+
+} // namespace mi355

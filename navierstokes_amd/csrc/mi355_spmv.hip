@@ -1,0 +1,851 @@
+// mi355_spmv.hip — implementation of the C-ABI declared in include/mi355_spmv.h.
+//
+// One translation unit: kernels (spmv_kernels.hpp, blas1_kernels.hpp), the
+// host-side partition planner (partition.hpp) and the handle/launch code below.
+// Built for gfx950 only (navierstokes_amd/csrc/Makefile).  There is no CPU
+// fallback anywhere in this file: every compute entry point needs a HIP device.
+#include "mi355_spmv.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "blas1_kernels.hpp"
+#include "partition.hpp"
+#include "spmv_kernels.hpp"
+
+using namespace mi355;
+
+// ---------------------------------------------------------------- errors
+static thread_local std::string g_err;
+
+static inline void dfree(void* p)
+{
+    if (p) (void)hipFree(p);
+}
+
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            int code_ = (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver) \
+                            ? MI_ERR_NODEVICE                                                           \
+                            : (e_ == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP);                  \
+            return fail(code_, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+        }                                                                                               \
+    } while (0)
+
+#define CHECK_ARG(cond, msg)                        \
+    do {                                            \
+        if (!(cond)) return fail(MI_ERR_ARG, msg);  \
+    } while (0)
+
+static int need_device()
+{
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(MI_ERR_NODEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0") +
+                                         " (libmi355spmv has no CPU fallback)");
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- handles
+struct BlockTable {
+    int nnzb = 0;
+    int nblk = 0;
+    int2* d_blk = nullptr;  // [nblk+1]
+    int2* d_span = nullptr; // [nblk], built on first XLDS use
+};
+
+struct mi_csr_s {
+    int device = 0;
+    int n = 0, ncols = 0;
+    long long nnz = 0;
+    int* d_ptrow = nullptr;
+    int* d_indcol = nullptr;
+    double* d_coef = nullptr;
+    int* d_rowmap = nullptr;
+    std::vector<int> h_ptrow; // kept to (re)build row-block tables
+    std::map<int, BlockTable> tables;
+    int kernel = MI_KERNEL_AUTO;
+    // scratch for the host-pointer entry points
+    double* d_x = nullptr;
+    double* d_y = nullptr;
+    std::vector<double*> d_pow;
+};
+
+struct mi_bcsr4_s {
+    int device = 0;
+    int nbrows = 0, nbcols = 0;
+    long long nblocks = 0;
+    int* d_ptrow = nullptr;
+    int* d_indcol = nullptr;
+    double* d_coef = nullptr;
+    double* d_x = nullptr;
+    double* d_y = nullptr;
+};
+
+struct mi_part_s {
+    PartPlan plan;
+    mi_csr_t piece[2] = {nullptr, nullptr};
+    int* d_send_idx = nullptr;
+    bool finalized = false;
+    int kernel = MI_KERNEL_AUTO;
+};
+
+// per-device reduction workspace (2 * kMaxPartials partials + 1 scalar)
+struct RedWs {
+    double* d = nullptr;
+};
+static std::map<int, RedWs> g_ws;
+
+static int get_ws(double** out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    RedWs& w = g_ws[dev];
+    if (!w.d) HIP_TRY(hipMalloc(&w.d, sizeof(double) * (2 * kMaxPartials + 8)));
+    *out = w.d;
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- library
+extern "C" int mi_version(void) { return MI355_SPMV_VERSION; }
+
+extern "C" const char* mi_strerror(int status)
+{
+    switch (status) {
+    case MI_OK: return "ok";
+    case MI_ERR_ARG: return "invalid argument";
+    case MI_ERR_NODEVICE: return "no HIP device (no CPU fallback)";
+    case MI_ERR_HIP: return "HIP runtime error";
+    case MI_ERR_ALLOC: return "allocation failed";
+    case MI_ERR_UNSUPPORTED: return "unsupported";
+    case MI_ERR_STATE: return "bad handle state";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mi_device_count(int* count)
+{
+    CHECK_ARG(count, "count is null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = (e == hipSuccess) ? c : 0;
+    return MI_OK;
+}
+
+extern "C" int mi_set_device(int device)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return MI_OK;
+}
+
+extern "C" int mi_device_synchronize(void)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return MI_OK;
+}
+
+static std::map<int, void*> g_flush;
+
+extern "C" int mi_flush_cache(void)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const size_t bytes = (size_t)512 << 20;
+    void*& buf = g_flush[dev];
+    if (!buf) HIP_TRY(hipMalloc(&buf, bytes));
+    HIP_TRY(hipMemsetAsync(buf, 1, bytes, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- CSR create
+__global__ void blk_span_kernel(int nblk, const int2* __restrict__ blk, const int* __restrict__ indcol,
+                                int2* __restrict__ span)
+{
+    __shared__ int s_min[4], s_max[4];
+    const int b = blockIdx.x;
+    if (b >= nblk) return;
+    const int p0 = blk[b].y, p1 = blk[b + 1].y;
+    int lo = INT32_MAX, hi = -1;
+    for (int k = p0 + threadIdx.x; k < p1; k += blockDim.x) {
+        const int c = indcol[k];
+        lo = min(lo, c);
+        hi = max(hi, c);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_down(lo, off, 64));
+        hi = max(hi, __shfl_down(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_min[threadIdx.x >> 6] = lo;
+        s_max[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            lo = min(lo, s_min[w]);
+            hi = max(hi, s_max[w]);
+        }
+        if (hi < 0) { lo = 0; hi = 0; }
+        span[b] = make_int2(lo, hi);
+    }
+}
+
+static int get_table(mi_csr_t A, int nnzb, bool want_span, BlockTable** out)
+{
+    BlockTable& T = A->tables[nnzb];
+    if (!T.d_blk) {
+        std::vector<int> rows, ptrs;
+        build_row_blocks(A->n, A->h_ptrow.data(), nnzb, 4 * kWG, rows, ptrs);
+        T.nnzb = nnzb;
+        T.nblk = (int)rows.size() - 1;
+        std::vector<int2> h(rows.size());
+        for (size_t i = 0; i < rows.size(); i++) h[i] = make_int2(rows[i], ptrs[i]);
+        HIP_TRY(hipMalloc(&T.d_blk, sizeof(int2) * h.size()));
+        HIP_TRY(hipMemcpy(T.d_blk, h.data(), sizeof(int2) * h.size(), hipMemcpyHostToDevice));
+    }
+    if (want_span && !T.d_span && T.nblk > 0) {
+        HIP_TRY(hipMalloc(&T.d_span, sizeof(int2) * T.nblk));
+        hipLaunchKernelGGL(blk_span_kernel, dim3(T.nblk), dim3(256), 0, 0, T.nblk, T.d_blk, A->d_indcol, T.d_span);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    *out = &T;
+    return MI_OK;
+}
+
+static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
+                           const int* rowmap, mi_csr_t* out)
+{
+    CHECK_ARG(out, "out is null");
+    *out = nullptr;
+    CHECK_ARG(n >= 0 && ncols >= 0, "negative dimension");
+    CHECK_ARG(ptrow, "ptrow is null");
+    CHECK_ARG(ptrow[0] == 0, "ptrow[0] must be 0");
+    for (int i = 0; i < n; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
+    const long long nnz = ptrow[n];
+    CHECK_ARG(nnz == 0 || (indcol && coef), "indcol/coef is null");
+    for (long long k = 0; k < nnz; k++)
+        CHECK_ARG(indcol[k] >= 0 && indcol[k] < ncols, "column index outside [0, ncols)");
+    int rc = need_device();
+    if (rc) return rc;
+
+    mi_csr_t A = new (std::nothrow) mi_csr_s();
+    if (!A) return fail(MI_ERR_ALLOC, "host allocation failed");
+    A->n = n;
+    A->ncols = ncols;
+    A->nnz = nnz;
+    A->h_ptrow.assign(ptrow, ptrow + n + 1);
+    hipError_t e = hipGetDevice(&A->device);
+    // +8 entries of zero padding behind indcol/coef: vector loads may touch them
+    const size_t pad = 8;
+    auto cleanup = [&]() { mi_csr_destroy(A); };
+#define TRY_OR_CLEAN(expr)                                                          \
+    do {                                                                            \
+        hipError_t e2_ = (expr);                                                    \
+        if (e2_ != hipSuccess) {                                                    \
+            cleanup();                                                              \
+            return fail(e2_ == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP,     \
+                        std::string(#expr) + ": " + hipGetErrorString(e2_));        \
+        }                                                                           \
+    } while (0)
+    TRY_OR_CLEAN(e);
+    TRY_OR_CLEAN(hipMalloc(&A->d_ptrow, sizeof(int) * ((size_t)n + 1)));
+    TRY_OR_CLEAN(hipMalloc(&A->d_indcol, sizeof(int) * ((size_t)nnz + pad)));
+    TRY_OR_CLEAN(hipMalloc(&A->d_coef, sizeof(double) * ((size_t)nnz + pad)));
+    TRY_OR_CLEAN(hipMemset(A->d_indcol + nnz, 0, sizeof(int) * pad));
+    TRY_OR_CLEAN(hipMemset(A->d_coef + nnz, 0, sizeof(double) * pad));
+    TRY_OR_CLEAN(hipMemcpy(A->d_ptrow, ptrow, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    if (nnz) {
+        TRY_OR_CLEAN(hipMemcpy(A->d_indcol, indcol, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        TRY_OR_CLEAN(hipMemcpy(A->d_coef, coef, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    if (rowmap && n > 0) {
+        TRY_OR_CLEAN(hipMalloc(&A->d_rowmap, sizeof(int) * (size_t)n));
+        TRY_OR_CLEAN(hipMemcpy(A->d_rowmap, rowmap, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    }
+#undef TRY_OR_CLEAN
+    *out = A;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_create(int n, int ncols, const int* ptrow, const int* indcol, const double* coef, mi_csr_t* out)
+{
+    return csr_create_impl(n, ncols, ptrow, indcol, coef, nullptr, out);
+}
+
+extern "C" int mi_csr_create_mapped(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
+                                    const int* rowmap, mi_csr_t* out)
+{
+    return csr_create_impl(n, ncols, ptrow, indcol, coef, rowmap, out);
+}
+
+extern "C" int mi_csr_destroy(mi_csr_t A)
+{
+    if (!A) return MI_OK;
+    dfree(A->d_ptrow);
+    dfree(A->d_indcol);
+    dfree(A->d_coef);
+    dfree(A->d_rowmap);
+    dfree(A->d_x);
+    dfree(A->d_y);
+    for (double* p : A->d_pow) dfree(p);
+    for (auto& kv : A->tables) {
+        dfree(kv.second.d_blk);
+        dfree(kv.second.d_span);
+    }
+    delete A;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz)
+{
+    CHECK_ARG(A, "null handle");
+    if (n) *n = A->n;
+    if (ncols) *ncols = A->ncols;
+    if (nnz) *nnz = A->nnz;
+    return MI_OK;
+}
+
+static int resolve_kernel(const mi_csr_s* A)
+{
+    if (A->kernel != MI_KERNEL_AUTO) return A->kernel;
+    return MI_KERNEL_STREAM;
+}
+
+extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_ROWPAR, "unknown kernel id");
+    A->kernel = kernel_id;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_get_kernel(mi_csr_t A, int* kernel_id)
+{
+    CHECK_ARG(A && kernel_id, "null argument");
+    *kernel_id = resolve_kernel(A);
+    return MI_OK;
+}
+
+extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
+{
+    if (!A) return "";
+    switch (resolve_kernel(A)) {
+    case MI_KERNEL_STREAM: return "spmv_csr_stream<2048, false, 1>";
+    case MI_KERNEL_STREAM_XLDS: return "spmv_csr_stream<2048, true, 5632>";
+    case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
+    default: return "";
+    }
+}
+
+// ---------------------------------------------------------------- SpMV launch
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s)
+{
+    if (A->n == 0) return MI_OK;
+    int kid = resolve_kernel(A);
+    if (kid == MI_KERNEL_STREAM_XLDS && (((uintptr_t)d_x) & 15)) kid = MI_KERNEL_STREAM; // 16-B loads of x need alignment
+    CsrView V;
+    V.n = A->n;
+    V.ncols = A->ncols;
+    V.ptrow = A->d_ptrow;
+    V.indcol = A->d_indcol;
+    V.coef = A->d_coef;
+    V.rowmap = A->d_rowmap;
+    V.blk = nullptr;
+    V.blk_span = nullptr;
+    V.nblk = 0;
+    if (kid == MI_KERNEL_ROWPAR) {
+        hipLaunchKernelGGL(spmv_csr_rowpar, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y);
+    } else {
+        BlockTable* T = nullptr;
+        int rc = get_table(A, 2048, kid == MI_KERNEL_STREAM_XLDS, &T);
+        if (rc) return rc;
+        V.blk = T->d_blk;
+        V.blk_span = T->d_span;
+        V.nblk = T->nblk;
+        const int grid = kNXCD * ((T->nblk + kNXCD - 1) / kNXCD);
+        if (kid == MI_KERNEL_STREAM_XLDS)
+            hipLaunchKernelGGL((spmv_csr_stream<2048, true, 5632>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+        else
+            hipLaunchKernelGGL((spmv_csr_stream<2048, false, 1>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_spmv_dev(mi_csr_t A, const double* d_x, double* d_y, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(A->n == 0 || (d_x && d_y), "null vector");
+    return launch_spmv(A, d_x, d_y, (hipStream_t)s);
+}
+
+extern "C" int mi_spmv(mi_csr_t A, const double* x, double* y)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(A->n == 0 || (x && y), "null vector");
+    if (A->d_rowmap) return fail(MI_ERR_UNSUPPORTED, "mapped matrices are device-only (use mi_spmv_dev)");
+    if (A->n == 0) return MI_OK;
+    if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * (size_t)(A->ncols > 0 ? A->ncols : 1)));
+    if (!A->d_y) HIP_TRY(hipMalloc(&A->d_y, sizeof(double) * (size_t)A->n));
+    HIP_TRY(hipMemcpy(A->d_x, x, sizeof(double) * (size_t)A->ncols, hipMemcpyHostToDevice));
+    int rc = launch_spmv(A, A->d_x, A->d_y, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(y, A->d_y, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- matrix powers
+extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(A->n == A->ncols, "matrix powers need a square matrix");
+    CHECK_ARG(!A->d_rowmap, "matrix powers need an unmapped matrix");
+    CHECK_ARG(d_y_out, "null output array");
+    const double* src = d_x;
+    for (int p = 0; p < k; p++) {
+        CHECK_ARG(A->n == 0 || d_y_out[p], "null output vector");
+        int rc = launch_spmv(A, src, d_y_out[p], (hipStream_t)s);
+        if (rc) return rc;
+        src = d_y_out[p];
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_spmk(mi_csr_t A, int k, const double* x, double* const* y_out)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(A->n == A->ncols, "matrix powers need a square matrix");
+    CHECK_ARG(A->n == 0 || (x && y_out), "null vector");
+    if (A->n == 0) return MI_OK;
+    if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * (size_t)A->ncols));
+    while ((int)A->d_pow.size() < k) {
+        double* p = nullptr;
+        HIP_TRY(hipMalloc(&p, sizeof(double) * (size_t)A->n));
+        A->d_pow.push_back(p);
+    }
+    HIP_TRY(hipMemcpy(A->d_x, x, sizeof(double) * (size_t)A->ncols, hipMemcpyHostToDevice));
+    int rc = mi_spmk_dev(A, k, A->d_x, A->d_pow.data(), nullptr);
+    if (rc) return rc;
+    for (int p = 0; p < k; p++) {
+        CHECK_ARG(y_out[p], "null output vector");
+        HIP_TRY(hipMemcpy(y_out[p], A->d_pow[p], sizeof(double) * (size_t)A->n, hipMemcpyDeviceToHost));
+    }
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- BLAS-1
+static int red_geometry(int n, int* np, int* seg)
+{
+    // segments of a multiple of 2*kRedWG elements, at most kMaxPartials of them
+    long long s = ((long long)n + kMaxPartials - 1) / kMaxPartials;
+    const int q = 2 * kRedWG;
+    s = ((s + q - 1) / q) * q;
+    if (s < q) s = q;
+    *seg = (int)s;
+    *np = (int)(((long long)n + s - 1) / s);
+    if (*np < 1) *np = 1;
+    return MI_OK;
+}
+
+template <int MODE, int FIN>
+static int reduce_dev(int n, const double* a, const double* b, double* d_out, hipStream_t s)
+{
+    CHECK_ARG(n >= 0, "negative n");
+    CHECK_ARG(d_out && (n == 0 || (a && b)), "null vector");
+    double* ws = nullptr;
+    int rc = get_ws(&ws);
+    if (rc) return rc;
+    int np, seg;
+    red_geometry(n, &np, &seg);
+    hipLaunchKernelGGL((reduce_stage1<MODE>), dim3(np), dim3(kRedWG), 0, s, n, seg, a, b, ws, ws + kMaxPartials);
+    hipLaunchKernelGGL((reduce_stage2<FIN>), dim3(1), dim3(kRedWG), 0, s, np, ws, ws + kMaxPartials, d_out);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// host-pointer helper: upload up to three vectors, run f on the device copies, download
+struct Scratch {
+    std::vector<double*> bufs;
+    ~Scratch()
+    {
+        for (double* p : bufs) dfree(p);
+    }
+    int up(const double* h, size_t n, double** d)
+    {
+        *d = nullptr;
+        HIP_TRY(hipMalloc(d, sizeof(double) * (n ? n : 1)));
+        bufs.push_back(*d);
+        if (h && n) HIP_TRY(hipMemcpy(*d, h, sizeof(double) * n, hipMemcpyHostToDevice));
+        return MI_OK;
+    }
+};
+
+extern "C" int mi_dot_dev(int n, const double* d_x, const double* d_y, double* d_out, mi_stream_t s)
+{
+    return reduce_dev<0, 0>(n, d_x, d_y, d_out, (hipStream_t)s);
+}
+
+extern "C" int mi_norm2_dev(int n, const double* d_x, double* d_out, mi_stream_t s)
+{
+    return reduce_dev<0, 1>(n, d_x, d_x, d_out, (hipStream_t)s);
+}
+
+extern "C" int mi_rel_error_dev(int n, const double* d_ref, const double* d_test, double* d_out, mi_stream_t s)
+{
+    return reduce_dev<1, 2>(n, d_ref, d_test, d_out, (hipStream_t)s);
+}
+
+extern "C" int mi_axpy_dev(int n, double a, const double* d_x, double* d_y, mi_stream_t s)
+{
+    CHECK_ARG(n >= 0, "negative n");
+    CHECK_ARG(n == 0 || (d_x && d_y), "null vector");
+    if (n == 0) return MI_OK;
+    int grid = (n / 2 + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, n, a, d_x, d_y);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1, double* d_x3, double alpha,
+                                    double* d_beta_out, mi_stream_t s)
+{
+    CHECK_ARG(d_beta_out, "null beta");
+    int rc = reduce_dev<0, 0>(n, d_b, d_x1, d_beta_out, (hipStream_t)s);
+    if (rc) return rc;
+    if (n == 0) return MI_OK;
+    CHECK_ARG(d_x3, "null output");
+    int grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(ortho_update_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, n, alpha, d_beta_out, d_b, d_x1, d_x3);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_gather_dev(int m, const int* d_idx, const double* d_src, double* d_dst, mi_stream_t s)
+{
+    CHECK_ARG(m >= 0, "negative m");
+    if (m == 0) return MI_OK;
+    CHECK_ARG(d_idx && d_src && d_dst, "null pointer");
+    int grid = (m + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, m, d_idx, d_src, d_dst);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_dot(int n, const double* x, const double* y, double* out)
+{
+    CHECK_ARG(n >= 0 && out && (n == 0 || (x && y)), "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    Scratch S;
+    double *dx, *dy, *dout;
+    if ((rc = S.up(x, n, &dx)) || (rc = S.up(y, n, &dy)) || (rc = S.up(nullptr, 1, &dout))) return rc;
+    if ((rc = mi_dot_dev(n, dx, dy, dout, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(out, dout, sizeof(double), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+extern "C" int mi_norm2(int n, const double* x, double* out)
+{
+    CHECK_ARG(n >= 0 && out && (n == 0 || x), "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    Scratch S;
+    double *dx, *dout;
+    if ((rc = S.up(x, n, &dx)) || (rc = S.up(nullptr, 1, &dout))) return rc;
+    if ((rc = mi_norm2_dev(n, dx, dout, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(out, dout, sizeof(double), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+extern "C" int mi_rel_error(int n, const double* ref, const double* test, double* out)
+{
+    CHECK_ARG(n >= 0 && out && (n == 0 || (ref && test)), "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    Scratch S;
+    double *da, *db, *dout;
+    if ((rc = S.up(ref, n, &da)) || (rc = S.up(test, n, &db)) || (rc = S.up(nullptr, 1, &dout))) return rc;
+    if ((rc = mi_rel_error_dev(n, da, db, dout, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(out, dout, sizeof(double), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+extern "C" int mi_axpy(int n, double a, const double* x, double* y)
+{
+    CHECK_ARG(n >= 0 && (n == 0 || (x && y)), "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    Scratch S;
+    double *dx, *dy;
+    if ((rc = S.up(x, n, &dx)) || (rc = S.up(y, n, &dy))) return rc;
+    if ((rc = mi_axpy_dev(n, a, dx, dy, nullptr))) return rc;
+    if (n) HIP_TRY(hipMemcpy(y, dy, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+extern "C" int mi_orthogonalize(int n, const double* b, const double* x1, double* x3, double alpha, double* beta_out)
+{
+    CHECK_ARG(n >= 0 && (n == 0 || (b && x1 && x3)), "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    Scratch S;
+    double *db, *dx1, *dx3, *dbeta;
+    if ((rc = S.up(b, n, &db)) || (rc = S.up(x1, n, &dx1)) || (rc = S.up(nullptr, n, &dx3)) || (rc = S.up(nullptr, 1, &dbeta)))
+        return rc;
+    if ((rc = mi_orthogonalize_dev(n, db, dx1, dx3, alpha, dbeta, nullptr))) return rc;
+    if (n) HIP_TRY(hipMemcpy(x3, dx3, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    double beta = 0.0;
+    HIP_TRY(hipMemcpy(&beta, dbeta, sizeof(double), hipMemcpyDeviceToHost));
+    if (beta_out) *beta_out = beta;
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- BCSR 4x4
+extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
+                               mi_bcsr4_t* out)
+{
+    CHECK_ARG(out, "out is null");
+    *out = nullptr;
+    CHECK_ARG(nbrows >= 0 && nbcols >= 0 && ptrow && ptrow[0] == 0, "bad argument");
+    for (int i = 0; i < nbrows; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
+    const long long nb = ptrow[nbrows];
+    CHECK_ARG(nb == 0 || (indcol && coef), "indcol/coef is null");
+    for (long long k = 0; k < nb; k++) CHECK_ARG(indcol[k] >= 0 && indcol[k] < nbcols, "block column outside [0, nbcols)");
+    int rc = need_device();
+    if (rc) return rc;
+    mi_bcsr4_t A = new (std::nothrow) mi_bcsr4_s();
+    if (!A) return fail(MI_ERR_ALLOC, "host allocation failed");
+    A->nbrows = nbrows;
+    A->nbcols = nbcols;
+    A->nblocks = nb;
+    hipError_t e;
+    if ((e = hipGetDevice(&A->device)) != hipSuccess ||
+        (e = hipMalloc(&A->d_ptrow, sizeof(int) * ((size_t)nbrows + 1))) != hipSuccess ||
+        (e = hipMalloc(&A->d_indcol, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+        (e = hipMalloc(&A->d_coef, sizeof(double) * 16 * ((size_t)nb + 1))) != hipSuccess ||
+        (e = hipMemcpy(A->d_ptrow, ptrow, sizeof(int) * ((size_t)nbrows + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+        (nb && (e = hipMemcpy(A->d_indcol, indcol, sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(A->d_coef, coef, sizeof(double) * 16 * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess)) {
+        mi_bcsr4_destroy(A);
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 upload: ") + hipGetErrorString(e));
+    }
+    *out = A;
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
+{
+    if (!A) return MI_OK;
+    dfree(A->d_ptrow);
+    dfree(A->d_indcol);
+    dfree(A->d_coef);
+    dfree(A->d_x);
+    dfree(A->d_y);
+    delete A;
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nbrows == 0) return MI_OK;
+    CHECK_ARG(d_x && d_y, "null vector");
+    CHECK_ARG((((uintptr_t)d_x) & 15) == 0, "x must be 16-byte aligned");
+    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef};
+    const long long threads = 4LL * A->nbrows;
+    hipLaunchKernelGGL(spmv_bcsr4, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nbrows == 0) return MI_OK;
+    CHECK_ARG(x && y, "null vector");
+    if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * 4 * (size_t)(A->nbcols > 0 ? A->nbcols : 1)));
+    if (!A->d_y) HIP_TRY(hipMalloc(&A->d_y, sizeof(double) * 4 * (size_t)A->nbrows));
+    HIP_TRY(hipMemcpy(A->d_x, x, sizeof(double) * 4 * (size_t)A->nbcols, hipMemcpyHostToDevice));
+    int rc = mi_bcsr4_spmv_dev(A, A->d_x, A->d_y, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(y, A->d_y, sizeof(double) * 4 * (size_t)A->nbrows, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- partition
+extern "C" int mi_part_create(int nranks, int rank, const long long* row_starts, const int* ptrow,
+                              const int* indcol_global, const double* coef, mi_part_t* out)
+{
+    CHECK_ARG(out, "out is null");
+    *out = nullptr;
+    mi_part_t P = new (std::nothrow) mi_part_s();
+    if (!P) return fail(MI_ERR_ALLOC, "host allocation failed");
+    std::string err = P->plan.build(nranks, rank, row_starts, ptrow, indcol_global, coef);
+    if (!err.empty()) {
+        delete P;
+        return fail(MI_ERR_ARG, "mi_part_create: " + err);
+    }
+    *out = P;
+    return MI_OK;
+}
+
+extern "C" int mi_part_destroy(mi_part_t P)
+{
+    if (!P) return MI_OK;
+    mi_csr_destroy(P->piece[0]);
+    mi_csr_destroy(P->piece[1]);
+    if (P->d_send_idx) dfree(P->d_send_idx);
+    delete P;
+    return MI_OK;
+}
+
+extern "C" int mi_part_sizes(mi_part_t P, int* n_local, int* n_halo, int* n_interior_rows, int* n_boundary_rows)
+{
+    CHECK_ARG(P, "null handle");
+    if (n_local) *n_local = P->plan.n_local;
+    if (n_halo) *n_halo = P->plan.n_halo;
+    if (n_interior_rows) *n_interior_rows = (int)P->plan.piece[0].rowmap.size();
+    if (n_boundary_rows) *n_boundary_rows = (int)P->plan.piece[1].rowmap.size();
+    return MI_OK;
+}
+
+extern "C" int mi_part_recv_counts(mi_part_t P, int* counts)
+{
+    CHECK_ARG(P && counts, "null argument");
+    for (int p = 0; p < P->plan.nranks; p++) counts[p] = P->plan.recv_counts[p];
+    return MI_OK;
+}
+
+extern "C" int mi_part_recv_ids(mi_part_t P, int peer, long long* ids)
+{
+    CHECK_ARG(P && peer >= 0 && peer < P->plan.nranks, "bad peer");
+    const int c = P->plan.recv_counts[peer];
+    CHECK_ARG(c == 0 || ids, "null ids");
+    for (int i = 0; i < c; i++) ids[i] = P->plan.halo_ids[P->plan.recv_offsets[peer] + i];
+    return MI_OK;
+}
+
+extern "C" int mi_part_set_send_ids(mi_part_t P, int peer, int count, const long long* ids)
+{
+    CHECK_ARG(P, "null handle");
+    if (P->finalized) return fail(MI_ERR_STATE, "partition already finalized");
+    std::string err = P->plan.set_send(peer, count, ids);
+    if (!err.empty()) return fail(MI_ERR_ARG, "mi_part_set_send_ids: " + err);
+    return MI_OK;
+}
+
+extern "C" int mi_part_send_counts(mi_part_t P, int* counts)
+{
+    CHECK_ARG(P && counts, "null argument");
+    for (int p = 0; p < P->plan.nranks; p++) counts[p] = P->plan.send_counts[p];
+    return MI_OK;
+}
+
+extern "C" int mi_part_local_csr(mi_part_t P, int which, int* nrows, const int** ptrow, const int** indcol_local,
+                                 const double** coef, const int** rowmap)
+{
+    CHECK_ARG(P && (which == 0 || which == 1), "bad argument");
+    const LocalPiece& L = P->plan.piece[which];
+    if (nrows) *nrows = (int)L.rowmap.size();
+    if (ptrow) *ptrow = L.ptrow.data();
+    if (indcol_local) *indcol_local = L.indcol.data();
+    if (coef) *coef = L.coef.data();
+    if (rowmap) *rowmap = L.rowmap.data();
+    return MI_OK;
+}
+
+extern "C" int mi_part_send_index(mi_part_t P, int* total, const int** local_idx)
+{
+    CHECK_ARG(P, "null handle");
+    if (total) *total = (int)P->plan.send_idx.size();
+    if (local_idx) *local_idx = P->plan.send_idx.data();
+    return MI_OK;
+}
+
+extern "C" int mi_part_finalize(mi_part_t P)
+{
+    CHECK_ARG(P, "null handle");
+    if (P->finalized) return MI_OK;
+    if (!P->plan.sends_set && P->plan.nranks > 1)
+        return fail(MI_ERR_STATE, "mi_part_set_send_ids was never called (exchange the recv ids first)");
+    int rc = need_device();
+    if (rc) return rc;
+    const int ncols = P->plan.n_local + P->plan.n_halo;
+    for (int w = 0; w < 2; w++) {
+        const LocalPiece& L = P->plan.piece[w];
+        rc = mi_csr_create_mapped((int)L.rowmap.size(), ncols, L.ptrow.data(), L.indcol.data(), L.coef.data(),
+                                  L.rowmap.data(), &P->piece[w]);
+        if (rc) return rc;
+        P->piece[w]->kernel = P->kernel;
+    }
+    const size_t ns = P->plan.send_idx.size();
+    if (ns) {
+        HIP_TRY(hipMalloc(&P->d_send_idx, sizeof(int) * ns));
+        HIP_TRY(hipMemcpy(P->d_send_idx, P->plan.send_idx.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
+    }
+    P->finalized = true;
+    return MI_OK;
+}
+
+extern "C" int mi_part_set_kernel(mi_part_t P, int kernel_id)
+{
+    CHECK_ARG(P, "null handle");
+    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_ROWPAR, "unknown kernel id");
+    P->kernel = kernel_id;
+    for (int w = 0; w < 2; w++)
+        if (P->piece[w]) P->piece[w]->kernel = kernel_id;
+    return MI_OK;
+}
+
+extern "C" int mi_part_pack_dev(mi_part_t P, const double* d_x_ext, double* d_sendbuf, mi_stream_t s)
+{
+    CHECK_ARG(P, "null handle");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    return mi_gather_dev((int)P->plan.send_idx.size(), P->d_send_idx, d_x_ext, d_sendbuf, s);
+}
+
+extern "C" int mi_part_spmv_interior_dev(mi_part_t P, const double* d_x_ext, double* d_y_local, mi_stream_t s)
+{
+    CHECK_ARG(P, "null handle");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    return mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s);
+}
+
+extern "C" int mi_part_spmv_boundary_dev(mi_part_t P, const double* d_x_ext, double* d_y_local, mi_stream_t s)
+{
+    CHECK_ARG(P, "null handle");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    return mi_spmv_dev(P->piece[1], d_x_ext, d_y_local, s);
+}

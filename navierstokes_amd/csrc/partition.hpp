@@ -1,0 +1,158 @@
+// partition.hpp — host-side planner for a row-range partition of one CSR matrix
+// over the ranks (GPUs) of a node.  Pure C++ integer work, no HIP: it runs and is
+// tested on CPU-only machines (tests/test_partition*.py).
+//
+// New design: the reference is strictly single-process (all PETSc
+// objects are Seq, src/solve_newton.c:972,981).  What it must reproduce is only
+// the arithmetic: every row of y = A x is still the same CSR-ordered fma chain,
+// because the column relabelling below is monotone inside each of the two
+// classes (owned, ghost) but NOT across them — so each local row keeps its
+// nonzeros in the ORIGINAL global-column order and only the x index changes.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mi355 {
+
+struct LocalPiece {           // interior or boundary rows of one rank
+    std::vector<int> ptrow;   // [nrows+1]
+    std::vector<int> indcol;  // local column ids
+    std::vector<double> coef;
+    std::vector<int> rowmap;  // local row index of each piece row
+};
+
+struct PartPlan {
+    int nranks = 0, rank = 0;
+    std::vector<long long> row_starts; // [nranks+1]
+    int n_local = 0, n_halo = 0;
+    std::vector<long long> halo_ids;   // ascending global ids of ghost columns
+    std::vector<int> recv_counts, recv_offsets; // per peer, into halo_ids
+    std::vector<int> send_counts, send_offsets; // per peer, into send_idx
+    std::vector<std::vector<int>> send_lists;   // local ids per peer
+    std::vector<int> send_idx;                  // concatenated by peer
+    LocalPiece piece[2];               // 0 interior, 1 boundary
+    bool sends_set = false;
+
+    // returns "" or an error message
+    std::string build(int nranks_, int rank_, const long long* rs, const int* ptrow, const int* indcol,
+                      const double* coef)
+    {
+        if (nranks_ < 1 || rank_ < 0 || rank_ >= nranks_ || !rs || !ptrow) return "bad rank/row_starts";
+        nranks = nranks_;
+        rank = rank_;
+        row_starts.assign(rs, rs + nranks + 1);
+        for (int p = 0; p < nranks; p++)
+            if (row_starts[p] > row_starts[p + 1]) return "row_starts must be non-decreasing";
+        if (row_starts[0] != 0) return "row_starts[0] must be 0";
+        if (row_starts[nranks] > INT32_MAX) return "global row count exceeds int32 (mpk/SpMV.h:20-22 uses int)";
+        const long long lo = row_starts[rank], hi = row_starts[rank + 1];
+        n_local = (int)(hi - lo);
+        const long long nglob = row_starts[nranks];
+        if (ptrow[0] != 0) return "ptrow must be relative to the rank's first nonzero (ptrow[0] == 0)";
+        const int nnz = ptrow[n_local];
+        if (nnz > 0 && (!indcol || !coef)) return "null indcol/coef";
+
+        // ghost columns
+        std::vector<long long> ghosts;
+        for (int k = 0; k < nnz; k++) {
+            const long long c = indcol[k];
+            if (c < 0 || c >= nglob) return "column index out of range";
+            if (c < lo || c >= hi) ghosts.push_back(c);
+        }
+        std::sort(ghosts.begin(), ghosts.end());
+        ghosts.erase(std::unique(ghosts.begin(), ghosts.end()), ghosts.end());
+        halo_ids.swap(ghosts);
+        n_halo = (int)halo_ids.size();
+        if ((long long)n_local + n_halo > INT32_MAX) return "n_local + n_halo exceeds int32";
+
+        recv_counts.assign(nranks, 0);
+        recv_offsets.assign(nranks + 1, 0);
+        {
+            int p = 0;
+            for (int h = 0; h < n_halo; h++) {
+                while (halo_ids[h] >= row_starts[p + 1]) p++;
+                recv_counts[p]++;
+            }
+            for (int q = 0; q < nranks; q++) recv_offsets[q + 1] = recv_offsets[q] + recv_counts[q];
+        }
+        if (recv_counts[rank] != 0) return "internal: ghost owned by self";
+
+        // relabel + split
+        for (int w = 0; w < 2; w++) {
+            piece[w] = LocalPiece();
+            piece[w].ptrow.push_back(0);
+        }
+        for (int r = 0; r < n_local; r++) {
+            bool boundary = false;
+            for (int k = ptrow[r]; k < ptrow[r + 1]; k++) {
+                const long long c = indcol[k];
+                if (c < lo || c >= hi) { boundary = true; break; }
+            }
+            LocalPiece& P = piece[boundary ? 1 : 0];
+            for (int k = ptrow[r]; k < ptrow[r + 1]; k++) {
+                const long long c = indcol[k];
+                int lc;
+                if (c >= lo && c < hi) lc = (int)(c - lo);
+                else lc = n_local + (int)(std::lower_bound(halo_ids.begin(), halo_ids.end(), c) - halo_ids.begin());
+                P.indcol.push_back(lc);
+                P.coef.push_back(coef[k]);
+            }
+            P.ptrow.push_back((int)P.indcol.size());
+            P.rowmap.push_back(r);
+        }
+        send_counts.assign(nranks, 0);
+        send_offsets.assign(nranks + 1, 0);
+        send_lists.assign(nranks, std::vector<int>());
+        send_idx.clear();
+        sends_set = (nranks == 1);
+        return "";
+    }
+
+    std::string set_send(int peer, int count, const long long* ids)
+    {
+        if (peer < 0 || peer >= nranks || count < 0 || (count > 0 && !ids)) return "bad peer/count";
+        if (peer == rank && count != 0) return "a rank never sends to itself";
+        const long long lo = row_starts[rank], hi = row_starts[rank + 1];
+        std::vector<int> l(count);
+        for (int i = 0; i < count; i++) {
+            if (ids[i] < lo || ids[i] >= hi) return "peer asked for a row this rank does not own";
+            l[i] = (int)(ids[i] - lo);
+        }
+        send_lists[peer].swap(l);
+        // rebuild the concatenation
+        send_idx.clear();
+        for (int p = 0; p < nranks; p++) {
+            send_counts[p] = (int)send_lists[p].size();
+            send_offsets[p + 1] = send_offsets[p] + send_counts[p];
+            send_idx.insert(send_idx.end(), send_lists[p].begin(), send_lists[p].end());
+        }
+        sends_set = true;
+        return "";
+    }
+};
+
+// Row-block table of the stream kernels: consecutive rows with <= nnzb nonzeros
+// (and <= max_rows rows); a row longer than nnzb is a block of its own.
+// out: {first row, first nnz} per block plus the terminator {n, nnz}.
+inline void build_row_blocks(int n, const int* ptrow, int nnzb, int max_rows, std::vector<int>& out_rows,
+                             std::vector<int>& out_ptr)
+{
+    out_rows.clear();
+    out_ptr.clear();
+    int r = 0;
+    while (r < n) {
+        const int start = r;
+        const int p0 = ptrow[r];
+        int e = r + 1; // a block always takes at least one row
+        while (e < n && (e - start) < max_rows && (long long)ptrow[e + 1] - p0 <= nnzb) e++;
+        out_rows.push_back(start);
+        out_ptr.push_back(p0);
+        r = e;
+    }
+    out_rows.push_back(n);
+    out_ptr.push_back(n > 0 ? ptrow[n] : 0);
+}
+
+} // namespace mi355

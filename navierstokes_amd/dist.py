@@ -1,0 +1,178 @@
+"""navierstokes_amd.dist — one matrix row-partitioned over the GPUs of a node.
+
+New design (the reference is single-process).  One process per
+GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on the GPU box,
+``gloo`` in the CPU tests).  Rank r owns global rows
+``[row_starts[r], row_starts[r+1])`` and the same slice of x and y.  Per SpMV:
+
+    1. pack      owned x entries other ranks need -> sendbuf   (HIP gather kernel)
+    2. exchange  one all_to_all_single of the packed halos      (RCCL, its own stream)
+    3. interior  rows without ghost columns                     (overlaps 2.)
+    4. boundary  rows with ghost columns, after the halos land
+
+The planner (column relabelling, interior/boundary split, send lists) is the
+C++ code behind ``mi_part_*`` in the C-ABI; this module only moves the ids and
+halo values between ranks.  Local compute goes through the C-ABI's device
+kernels unless the caller injects ``compute=`` (the CPU tests inject the test
+oracle there; product code never does).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import mpk
+
+_c = ctypes
+_vp = ctypes.c_void_p
+
+
+def balanced_row_starts(n, nranks, nnz_per_row=None):
+    """Contiguous row ranges with (nearly) equal nonzero counts.
+    nnz_per_row: None (equal row counts) or an int64 array of row lengths."""
+    if nnz_per_row is None:
+        return np.array([(n * r) // nranks for r in range(nranks + 1)], dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(np.asarray(nnz_per_row, dtype=np.int64))])
+    targets = cum[-1] * np.arange(1, nranks) / nranks
+    cuts = np.searchsorted(cum, targets, side="left")
+    return np.concatenate([[0], cuts, [n]]).astype(np.int64)
+
+
+class DistCSR:
+    """This rank's share of a row-partitioned csrmatrix."""
+
+    def __init__(self, row_starts, ptrow, indcol_global, coef, group=None, device=None, compute=None, kernel=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.nranks = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.row_starts = np.ascontiguousarray(row_starts, dtype=np.int64)
+        assert len(self.row_starts) == self.nranks + 1
+        ptrow = np.ascontiguousarray(ptrow, dtype=np.int32)
+        indcol_global = np.ascontiguousarray(indcol_global, dtype=np.int32)
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        L = mpk.lib()
+        h = _vp()
+        mpk.check(L.mi_part_create(self.nranks, self.rank, self.row_starts.ctypes.data, ptrow.ctypes.data,
+                                   indcol_global.ctypes.data, coef.ctypes.data, _c.byref(h)))
+        self._h = h
+        nl, nh, ni, nb = _c.c_int(), _c.c_int(), _c.c_int(), _c.c_int()
+        mpk.check(L.mi_part_sizes(h, _c.byref(nl), _c.byref(nh), _c.byref(ni), _c.byref(nb)))
+        self.n_local, self.n_halo, self.n_interior, self.n_boundary = nl.value, nh.value, ni.value, nb.value
+        self.nnz_local = int(ptrow[-1])
+        self.compute = compute
+        self.device = torch.device(device) if device is not None else torch.device("cuda" if compute is None else "cpu")
+
+        # who needs what: recv_counts[p] ids I need from p; tell every owner
+        rc = np.zeros(self.nranks, np.int32)
+        mpk.check(L.mi_part_recv_counts(h, rc.ctypes.data))
+        self.recv_counts = [int(v) for v in rc]
+        recv_ids = np.empty(self.n_halo, np.int64)
+        off = 0
+        for p in range(self.nranks):
+            if rc[p]:
+                mpk.check(L.mi_part_recv_ids(h, p, recv_ids[off:].ctypes.data))
+                off += int(rc[p])
+        comm_dev = self.device if (dist.is_initialized() and dist.get_backend(group) == "nccl") else torch.device("cpu")
+        if self.nranks > 1:
+            t_rc = torch.tensor(self.recv_counts, dtype=torch.int64, device=comm_dev)
+            t_sc = torch.empty_like(t_rc)
+            dist.all_to_all_single(t_sc, t_rc, group=group)
+            self.send_counts = [int(v) for v in t_sc.cpu()]
+            t_ids_in = torch.from_numpy(recv_ids).to(comm_dev)
+            t_ids_out = torch.empty(sum(self.send_counts), dtype=torch.int64, device=comm_dev)
+            dist.all_to_all_single(t_ids_out, t_ids_in, self.send_counts, self.recv_counts, group=group)
+            send_ids = t_ids_out.cpu().numpy()
+            off = 0
+            for p in range(self.nranks):
+                c = self.send_counts[p]
+                ids = np.ascontiguousarray(send_ids[off:off + c])
+                mpk.check(L.mi_part_set_send_ids(h, p, c, ids.ctypes.data if c else None))
+                off += c
+        else:
+            self.send_counts = [0]
+        self.n_send = sum(self.send_counts)
+
+        if compute is None:
+            mpk.check(L.mi_part_finalize(h))
+            if kernel is not None:
+                mpk.check(L.mi_part_set_kernel(h, mpk.KERNELS[kernel] if isinstance(kernel, str) else int(kernel)))
+            self._send_idx = None
+        else:
+            tot, ptr = _c.c_int(), _vp()
+            mpk.check(L.mi_part_send_index(h, _c.byref(tot), _c.byref(ptr)))
+            self._send_idx = (np.ctypeslib.as_array(_c.cast(ptr, _c.POINTER(_c.c_int)), shape=(tot.value,)).copy()
+                              if tot.value else np.zeros(0, np.int32))
+        self.sendbuf = torch.empty(max(self.n_send, 1), dtype=torch.float64, device=self.device)
+
+    # -- host views of the two local pieces (CPU checks) -------------------------------------
+    def local_piece(self, which):
+        """(ptrow, indcol_local, coef, rowmap) of the interior (0) / boundary (1) rows, as numpy copies."""
+        L = mpk.lib()
+        n, p, c, v, m = _c.c_int(), _vp(), _vp(), _vp(), _vp()
+        mpk.check(L.mi_part_local_csr(self._h, which, _c.byref(n), _c.byref(p), _c.byref(c), _c.byref(v), _c.byref(m)))
+        nr = n.value
+        ptrow = np.ctypeslib.as_array(_c.cast(p, _c.POINTER(_c.c_int)), shape=(nr + 1,)).copy()
+        nnz = int(ptrow[-1])
+        if nnz:
+            col = np.ctypeslib.as_array(_c.cast(c, _c.POINTER(_c.c_int)), shape=(nnz,)).copy()
+            val = np.ctypeslib.as_array(_c.cast(v, _c.POINTER(_c.c_double)), shape=(nnz,)).copy()
+        else:
+            col, val = np.zeros(0, np.int32), np.zeros(0)
+        rmap = np.ctypeslib.as_array(_c.cast(m, _c.POINTER(_c.c_int)), shape=(nr,)).copy() if nr else np.zeros(0, np.int32)
+        return ptrow, col, val, rmap
+
+    # -- vectors ---------------------------------------------------------------------------------
+    def new_x_ext(self):
+        """[x_local | halo] buffer; fill the first n_local entries with the owned slice of x."""
+        return torch.zeros(self.n_local + self.n_halo, dtype=torch.float64, device=self.device)
+
+    def new_y(self):
+        return torch.empty(max(self.n_local, 1), dtype=torch.float64, device=self.device)[: self.n_local]
+
+    # -- y_local = (A x)_local ---------------------------------------------------------------------
+    def spmv(self, x_ext, y_local):
+        L = mpk.lib()
+        work = None
+        if self.nranks > 1:
+            if self.compute is None:
+                mpk.check(L.mi_part_pack_dev(self._h, _vp(x_ext.data_ptr()), _vp(self.sendbuf.data_ptr()), mpk._stream_ptr()))
+            elif self.n_send:
+                self.sendbuf[: self.n_send] = x_ext[torch.from_numpy(self._send_idx.astype(np.int64))]
+            halo = x_ext[self.n_local:]
+            work = dist.all_to_all_single(halo, self.sendbuf[: self.n_send], self.recv_counts, self.send_counts,
+                                          group=self.group, async_op=True)
+        if self.compute is None:
+            mpk.check(L.mi_part_spmv_interior_dev(self._h, _vp(x_ext.data_ptr()), _vp(y_local.data_ptr()), mpk._stream_ptr()))
+        else:
+            self.compute(self, 0, x_ext, y_local)
+        if work is not None:
+            work.wait()  # NCCL: the current stream waits for the exchange; no host block
+        if self.compute is None:
+            mpk.check(L.mi_part_spmv_boundary_dev(self._h, _vp(x_ext.data_ptr()), _vp(y_local.data_ptr()), mpk._stream_ptr()))
+        else:
+            self.compute(self, 1, x_ext, y_local)
+        return y_local
+
+    def dot(self, a_local, b_local):
+        """Global dot product: local fixed-tree reduction, then one all_reduce of a double."""
+        if self.compute is None:
+            part = mpk.dot(a_local, b_local)
+        else:
+            part = torch.dot(a_local, b_local).reshape(1)
+        if self.nranks > 1:
+            dist.all_reduce(part, group=self.group)
+        return part
+
+    def close(self):
+        if self._h is not None:
+            mpk.lib().mi_part_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

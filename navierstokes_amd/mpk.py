@@ -1,0 +1,430 @@
+"""navierstokes_amd.mpk — host-side mirror of the reference's mpk/ interface.
+
+Same names, argument order and meaning as the free functions of the
+reference's ``mpk/SpMV.h:52-66`` (plus the per-file kernels ``SpM2V_CSR``
+``mpk/SpM2V.cpp:80``, ``SpM4V`` ``mpk/SpMVmulti0.cpp:191`` and
+``orthogonalize`` ``mpk/SpMVmulti.cpp:146``), so that tests read like the
+reference's harnesses: ``SpMV_CSR(y, x, A)`` overwrites ``y`` with ``A x``.
+
+Everything is computed by the HIP library ``csrc/libmi355spmv.so`` through its
+C-ABI (``include/mi355_spmv.h``).  PyTorch appears only as plumbing: vectors
+may be CUDA/HIP tensors (device-resident, launched on torch's current stream,
+no synchronisation) or numpy arrays (copied in and out like the reference's
+CPU functions).  There is NO CPU fallback: importing this module without the
+built library, or calling it without a GPU, raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi355spmv.so")
+
+MI_OK = 0
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_STREAM_XLDS, KERNEL_ROWPAR = 0, 1, 2, 3
+KERNELS = {"auto": 0, "stream": 1, "stream_xlds": 2, "rowpar": 3}
+
+_c = ctypes
+_vp = ctypes.c_void_p
+_LIB = None
+
+
+class MiError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__(f"libmi355spmv status {status}: {detail}")
+        self.status = status
+
+
+def lib():
+    """The loaded C-ABI library (loads torch's HIP runtime first when torch is around)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing — the HIP extension was not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback for this path."
+        )
+    try:  # one HIP runtime per process: let torch's copy win if torch is installed
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    L.mi_strerror.restype = _c.c_char_p
+    L.mi_last_error.restype = _c.c_char_p
+    L.mi_csr_kernel_name.restype = _c.c_char_p
+    L.mi_csr_kernel_name.argtypes = [_vp]
+    i, ll, d = _c.c_int, _c.c_longlong, _c.c_double
+    P = _c.POINTER
+    sigs = {
+        "mi_version": [],
+        "mi_device_count": [P(i)],
+        "mi_set_device": [i],
+        "mi_device_synchronize": [],
+        "mi_flush_cache": [],
+        "mi_csr_create": [i, i, _vp, _vp, _vp, P(_vp)],
+        "mi_csr_create_mapped": [i, i, _vp, _vp, _vp, _vp, P(_vp)],
+        "mi_csr_destroy": [_vp],
+        "mi_csr_dims": [_vp, P(i), P(i), P(ll)],
+        "mi_csr_set_kernel": [_vp, i],
+        "mi_csr_get_kernel": [_vp, P(i)],
+        "mi_spmv": [_vp, _vp, _vp],
+        "mi_spmv_dev": [_vp, _vp, _vp, _vp],
+        "mi_spmk": [_vp, i, _vp, _vp],
+        "mi_spmk_dev": [_vp, i, _vp, _vp, _vp],
+        "mi_dot": [i, _vp, _vp, P(d)],
+        "mi_dot_dev": [i, _vp, _vp, _vp, _vp],
+        "mi_axpy": [i, d, _vp, _vp],
+        "mi_axpy_dev": [i, d, _vp, _vp, _vp],
+        "mi_orthogonalize": [i, _vp, _vp, _vp, d, P(d)],
+        "mi_orthogonalize_dev": [i, _vp, _vp, _vp, d, _vp, _vp],
+        "mi_norm2": [i, _vp, P(d)],
+        "mi_norm2_dev": [i, _vp, _vp, _vp],
+        "mi_rel_error": [i, _vp, _vp, P(d)],
+        "mi_rel_error_dev": [i, _vp, _vp, _vp, _vp],
+        "mi_gather_dev": [i, _vp, _vp, _vp, _vp],
+        "mi_bcsr4_create": [i, i, _vp, _vp, _vp, P(_vp)],
+        "mi_bcsr4_destroy": [_vp],
+        "mi_bcsr4_spmv": [_vp, _vp, _vp],
+        "mi_bcsr4_spmv_dev": [_vp, _vp, _vp, _vp],
+        "mi_part_create": [i, i, _vp, _vp, _vp, _vp, P(_vp)],
+        "mi_part_destroy": [_vp],
+        "mi_part_sizes": [_vp, P(i), P(i), P(i), P(i)],
+        "mi_part_recv_counts": [_vp, _vp],
+        "mi_part_recv_ids": [_vp, i, _vp],
+        "mi_part_set_send_ids": [_vp, i, i, _vp],
+        "mi_part_send_counts": [_vp, _vp],
+        "mi_part_local_csr": [_vp, i, P(i), P(_vp), P(_vp), P(_vp), P(_vp)],
+        "mi_part_send_index": [_vp, P(i), P(_vp)],
+        "mi_part_finalize": [_vp],
+        "mi_part_set_kernel": [_vp, i],
+        "mi_part_pack_dev": [_vp, _vp, _vp, _vp],
+        "mi_part_spmv_interior_dev": [_vp, _vp, _vp, _vp],
+        "mi_part_spmv_boundary_dev": [_vp, _vp, _vp, _vp],
+    }
+    for name, argt in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = argt
+        fn.restype = _c.c_int
+    _LIB = L
+    return L
+
+
+def check(status):
+    if status != MI_OK:
+        raise MiError(status, lib().mi_last_error().decode(errors="replace"))
+
+
+# ----------------------------------------------------------------- plumbing
+
+def _is_torch(t):
+    return type(t).__module__.startswith("torch")
+
+
+def _stream_ptr():
+    import torch
+
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_ptr(t, n=None, what="vector"):
+    import torch
+
+    if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise TypeError(f"{what}: expected a contiguous float64 CUDA tensor, got {t.dtype} on {t.device}")
+    if n is not None and t.numel() < n:
+        raise ValueError(f"{what}: needs {n} entries, has {t.numel()}")
+    return _vp(t.data_ptr())
+
+
+def _host_f64(a, n=None, what="vector", writable=False):
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous:
+        if writable:
+            raise TypeError(f"{what}: output must be a C-contiguous float64 numpy array")
+        a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and a.size < n:
+        raise ValueError(f"{what}: needs {n} entries, has {a.size}")
+    return a
+
+
+# ------------------------------------------------------------------ matrices
+
+class csrmatrix:
+    """struct csrmatrix of mpk/SpMV.h:18-24 — n, nnz, ptrow, indcol, coef — plus the
+    device handle (lazily created; the matrix is immutable once used)."""
+
+    def __init__(self, n, ptrow, indcol, coef, ncols=None, rowmap=None):
+        self.n = int(n)
+        self.ptrow = np.ascontiguousarray(ptrow, dtype=np.int32)
+        self.indcol = np.ascontiguousarray(indcol, dtype=np.int32)
+        self.coef = np.ascontiguousarray(coef, dtype=np.float64)
+        if len(self.ptrow) != self.n + 1:
+            raise ValueError("ptrow must have n+1 entries")
+        self.nnz = int(self.ptrow[-1]) if self.n > 0 else 0
+        self.ncols = self.n if ncols is None else int(ncols)
+        self.rowmap = None if rowmap is None else np.ascontiguousarray(rowmap, dtype=np.int32)
+        self._h = None
+        self._kernel = KERNEL_AUTO
+
+    @property
+    def handle(self):
+        if self._h is None:
+            h = _vp()
+            if self.rowmap is None:
+                check(lib().mi_csr_create(self.n, self.ncols, self.ptrow.ctypes.data, self.indcol.ctypes.data,
+                                          self.coef.ctypes.data, _c.byref(h)))
+            else:
+                check(lib().mi_csr_create_mapped(self.n, self.ncols, self.ptrow.ctypes.data, self.indcol.ctypes.data,
+                                                 self.coef.ctypes.data, self.rowmap.ctypes.data, _c.byref(h)))
+            self._h = h
+            if self._kernel != KERNEL_AUTO:
+                check(lib().mi_csr_set_kernel(h, self._kernel))
+        return self._h
+
+    def set_kernel(self, kernel):
+        kid = KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
+        self._kernel = kid
+        if self._h is not None:
+            check(lib().mi_csr_set_kernel(self._h, kid))
+        return self
+
+    def kernel_name(self):
+        return lib().mi_csr_kernel_name(self.handle).decode()
+
+    def drop_host_arrays(self):
+        """Free the host copies of indcol/coef once the device handle exists (large benches)."""
+        _ = self.handle
+        self.indcol = self.indcol[:0]
+        self.coef = self.coef[:0]
+
+    def close(self):
+        if self._h is not None:
+            lib().mi_csr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class bcsr4x4_matrix:
+    """struct bcsr4x4_matrix of mpk/SpMV.h:26-33 (row-major 4x4 blocks)."""
+
+    def __init__(self, nrows, ptrow, indcol, coef, nbcols=None):
+        self.nrows = int(nrows)
+        self.ptrow = np.ascontiguousarray(ptrow, dtype=np.int32)
+        self.indcol = np.ascontiguousarray(indcol, dtype=np.int32)
+        self.coef = np.ascontiguousarray(coef, dtype=np.float64)
+        self.nblocks = len(self.indcol)
+        self.nbcols = (int(self.indcol.max()) + 1 if self.nblocks else 0) if nbcols is None else int(nbcols)
+        self.nbcols = max(self.nbcols, self.nrows)
+        self._h = None
+
+    @property
+    def handle(self):
+        if self._h is None:
+            h = _vp()
+            check(lib().mi_bcsr4_create(self.nrows, self.nbcols, self.ptrow.ctypes.data, self.indcol.ctypes.data,
+                                        self.coef.ctypes.data, _c.byref(h)))
+            self._h = h
+        return self._h
+
+    def close(self):
+        if self._h is not None:
+            lib().mi_bcsr4_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def COO2CSR(nrow, irow, jcol, val):
+    """COO -> csrmatrix with the reference's rules (mpk/utils.cpp:5-43, :97-127):
+    columns ascending per row, the FIRST of duplicated (i, j) entries wins.
+    Host-side integer work (numpy): a stable sort on (row, col) keeps COO order
+    among duplicates, so the first survivor of each run is the first COO entry."""
+    irow = np.asarray(irow, dtype=np.int64)
+    jcol = np.asarray(jcol, dtype=np.int64)
+    val = np.asarray(val, dtype=np.float64)
+    order = np.lexsort((np.arange(len(irow)), jcol, irow))
+    r, c, v = irow[order], jcol[order], val[order]
+    keep = np.ones(len(r), bool)
+    keep[1:] = (r[1:] != r[:-1]) | (c[1:] != c[:-1])
+    r, c, v = r[keep], c[keep], v[keep]
+    ptrow = np.zeros(nrow + 1, np.int64)
+    np.add.at(ptrow, r + 1, 1)
+    ptrow = np.cumsum(ptrow)
+    return csrmatrix(nrow, ptrow.astype(np.int32), c.astype(np.int32), v)
+
+
+# --------------------------------------------------------------------- SpMV
+
+def SpMV_CSR(y, x, A):
+    """y = A x — SpMV_CSR(double* y, double* x, csrmatrix& A), mpk/SpMV.cpp:6-20.
+    y is fully overwritten.  Tensors on the GPU: asynchronous on torch's current
+    stream; numpy arrays: copied in/out and synchronised."""
+    if _is_torch(x):
+        check(lib().mi_spmv_dev(A.handle, _dev_ptr(x, A.ncols, "x"), _dev_ptr(y, A.n if A.rowmap is None else None, "y"),
+                                _stream_ptr()))
+    else:
+        xx = _host_f64(x, A.ncols, "x")
+        yy = _host_f64(y, A.n, "y", writable=True)
+        check(lib().mi_spmv(A.handle, xx.ctypes.data, yy.ctypes.data))
+    return y
+
+
+# The reference's four CSR variants differ only in how the CPU is driven
+# (scalar / compiler FMA / __builtin_fma / AVX2, mpk/SpMV.cpp:23-85); on the GPU
+# they are one kernel, bit-equal to _OPT/_FMA.
+SpMV_CSR_OPT = SpMV_CSR
+SpMV_CSR_FMA = SpMV_CSR
+SpMV_CSR_AVX2 = SpMV_CSR
+
+
+def SpMV_BCSR(y, x, A):
+    """y = A x for bcsr4x4_matrix — SpMV_BCSR*, mpk/SpMV.cpp:90-219."""
+    if _is_torch(x):
+        check(lib().mi_bcsr4_spmv_dev(A.handle, _dev_ptr(x, 4 * A.nbcols, "x"), _dev_ptr(y, 4 * A.nrows, "y"), _stream_ptr()))
+    else:
+        xx = _host_f64(x, None, "x")
+        if xx.size < 4 * A.nbcols:  # the reference reads x by block column; pad like its callers' vectors
+            xx = np.concatenate([xx, np.zeros(4 * A.nbcols - xx.size)])
+        yy = _host_f64(y, 4 * A.nrows, "y", writable=True)
+        check(lib().mi_bcsr4_spmv(A.handle, xx.ctypes.data, yy.ctypes.data))
+    return y
+
+
+SpMV_BCSR_OPT = SpMV_BCSR
+SpMV_BCSR_FMA = SpMV_BCSR
+SpMV_BCSR_AVX2 = SpMV_BCSR
+
+
+# ------------------------------------------------------------ matrix powers
+
+def SpMkV(ys, x, A):
+    """ys[p] = A^(p+1) x for p = 0..k-1 (all intermediate powers, as SpM4V returns them)."""
+    k = len(ys)
+    if _is_torch(x):
+        ptrs = (_vp * k)(*[_dev_ptr(t, A.n, f"y{p + 1}").value for p, t in enumerate(ys)])
+        check(lib().mi_spmk_dev(A.handle, k, _dev_ptr(x, A.ncols, "x"), ptrs, _stream_ptr()))
+    else:
+        xx = _host_f64(x, A.ncols, "x")
+        outs = [_host_f64(t, A.n, f"y{p + 1}", writable=True) for p, t in enumerate(ys)]
+        ptrs = (_vp * k)(*[o.ctypes.data for o in outs])
+        check(lib().mi_spmk(A.handle, k, xx.ctypes.data, ptrs))
+    return ys
+
+
+def Generate1stlayer(ptrowend1, A):
+    """Kept for signature parity with mpk/SpM2V.cpp:5-26.  The first-touch table
+    drives the CPU's serial traversal; the GPU path needs no table (each power is
+    a full row-parallel sweep), so this is a no-op that returns its argument."""
+    return ptrowend1
+
+
+def SpM2V_CSR(z, y, x, A, ptrowend1=None):
+    """y = A x, z = A (A x) — SpM2V_CSR(z, y, x, A, ptrowend1), mpk/SpM2V.cpp:79-112."""
+    SpMkV([y, z], x, A)
+    return z, y
+
+
+SpM2V_CSR_OPT = SpM2V_CSR
+SpM2V_CSR_FMA = SpM2V_CSR
+SpM2V_CSR_AVX2 = SpM2V_CSR
+
+
+def SpM3V(w, z, y, x, A, ptrowend1=None, ptrowend2=None):
+    """mpk/SpMVmulti0.cpp:132-155."""
+    SpMkV([y, z, w], x, A)
+    return w, z, y
+
+
+def SpM4V(v, w, z, y, x, A, ptrowend1=None, ptrowend2=None, ptrowend3=None):
+    """y=Ax, z=A^2x, w=A^3x, v=A^4x — SpM4V(v, w, z, y, x, A, ...), mpk/SpMVmulti0.cpp:189-221."""
+    SpMkV([y, z, w, v], x, A)
+    return v, w, z, y
+
+
+# ------------------------------------------------------------------- BLAS-1
+
+def _scalar_dev():
+    import torch
+
+    return torch.empty(1, dtype=torch.float64, device="cuda")
+
+
+def dot(x, y):
+    """sum x_i y_i (std::inner_product at mpk/SpMVmulti.cpp:147).  Device tensors: returns a 1-element device tensor."""
+    n = int(x.numel() if _is_torch(x) else np.size(x))
+    if _is_torch(x):
+        out = _scalar_dev()
+        check(lib().mi_dot_dev(n, _dev_ptr(x), _dev_ptr(y, n), _dev_ptr(out), _stream_ptr()))
+        return out
+    out = _c.c_double(0)
+    check(lib().mi_dot(n, _host_f64(x).ctypes.data, _host_f64(y, n).ctypes.data, _c.byref(out)))
+    return out.value
+
+
+def axpy(a, x, y):
+    """y += a x, in place."""
+    n = int(x.numel() if _is_torch(x) else np.size(x))
+    if _is_torch(x):
+        check(lib().mi_axpy_dev(n, float(a), _dev_ptr(x), _dev_ptr(y, n), _stream_ptr()))
+    else:
+        yy = _host_f64(y, n, "y", writable=True)
+        check(lib().mi_axpy(n, float(a), _host_f64(x).ctypes.data, yy.ctypes.data))
+    return y
+
+
+def orthogonalize(nrow, b, x1, x3, alpha=1e-8):
+    """x3 = x1 - alpha*(b.x1)*b — orthogonalize(nrow, b, x1, x3, alpha), mpk/SpMVmulti.cpp:146-151.
+    Returns beta = b.x1 (float for numpy inputs, 1-element device tensor otherwise)."""
+    if _is_torch(b):
+        beta = _scalar_dev()
+        check(lib().mi_orthogonalize_dev(nrow, _dev_ptr(b, nrow), _dev_ptr(x1, nrow), _dev_ptr(x3, nrow), float(alpha),
+                                         _dev_ptr(beta), _stream_ptr()))
+        return beta
+    out = _c.c_double(0)
+    x3h = _host_f64(x3, nrow, "x3", writable=True)
+    check(lib().mi_orthogonalize(nrow, _host_f64(b, nrow).ctypes.data, _host_f64(x1, nrow).ctypes.data,
+                                 x3h.ctypes.data, float(alpha), _c.byref(out)))
+    return out.value
+
+
+def norm2(x):
+    """sqrt(sum x^2) — norm2, mpk/utils.cpp:131-136."""
+    n = int(x.numel() if _is_torch(x) else np.size(x))
+    if _is_torch(x):
+        out = _scalar_dev()
+        check(lib().mi_norm2_dev(n, _dev_ptr(x), _dev_ptr(out), _stream_ptr()))
+        return out
+    out = _c.c_double(0)
+    check(lib().mi_norm2(n, _host_f64(x).ctypes.data, _c.byref(out)))
+    return out.value
+
+
+def rel_error(ref, test):
+    """||ref - test||_2 / ||ref||_2 — rel_error, mpk/utils.cpp:138-143 (the parity metric)."""
+    n = int(ref.numel() if _is_torch(ref) else np.size(ref))
+    if _is_torch(ref):
+        out = _scalar_dev()
+        check(lib().mi_rel_error_dev(n, _dev_ptr(ref), _dev_ptr(test, n), _dev_ptr(out), _stream_ptr()))
+        return out
+    out = _c.c_double(0)
+    check(lib().mi_rel_error(n, _host_f64(ref).ctypes.data, _host_f64(test, n).ctypes.data, _c.byref(out)))
+    return out.value
+
+
+def flush_cache():
+    """mpk/utils.cpp:146-154 evicts the CPU caches before a timed call.  The GPU
+    analogue (evicting the 256 MiB Infinity Cache) is a 512 MiB device memset."""
+    check(lib().mi_flush_cache())

@@ -1,0 +1,68 @@
+"""Worker for tests/test_dist_gloo.py: world_size ranks over gloo on the CPU.
+Runs the product's DistCSR (planner + torch.distributed exchange) with the local
+SpMV injected from the test oracle, and checks every rank's slice bitwise against
+the global oracle SpMV."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from navierstokes_amd import dist as D  # noqa: E402
+from navierstokes_amd import synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def oracle_compute(dc, which, x_ext, y_local):
+    if not hasattr(dc, "_pieces"):
+        dc._pieces = [dc.local_piece(0), dc.local_piece(1)]
+    p, c, v, rmap = dc._pieces[which]
+    if len(rmap):
+        y_local.numpy()[rmap] = O.spmv(p, c, v, x_ext.numpy())
+
+
+def main():
+    kind, n, w = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    # every rank generates ONLY its own rows (counter-based generator)
+    lens = None
+    if kind == "svar":
+        P, _, _ = synth.rows(kind, n, w=w)
+        lens = np.diff(P)
+    rs = D.balanced_row_starts(n, world, lens)
+    lo, hi = int(rs[rank]), int(rs[rank + 1])
+    p, c, v = synth.rows(kind, n, lo, hi, w=w)
+    dc = D.DistCSR(rs, p, c, v, compute=oracle_compute, device="cpu")
+    x_ext = dc.new_x_ext()
+    x_ext[: dc.n_local] = torch.from_numpy(synth.x_sin(lo, hi))
+    y = dc.new_y()
+    y.fill_(float("nan"))
+    dc.spmv(x_ext, y)
+    # k = 3 chained distributed SpMVs (the k-exchange matrix-powers baseline)
+    ys = [y.clone()]
+    for _ in range(2):
+        xe = dc.new_x_ext()
+        xe[: dc.n_local] = ys[-1]
+        yy = dc.new_y()
+        dc.spmv(xe, yy)
+        ys.append(yy.clone())
+    # global reference on every rank (small n)
+    Pg, Cg, Vg = synth.rows(kind, n, w=w)
+    Y = O.spmk_chain(3, Pg, Cg, Vg, synth.x_sin(0, n))
+    ok = all(np.array_equal(ys[k].numpy().view(np.uint64), Y[k][lo:hi].view(np.uint64)) for k in range(3))
+    g = dc.dot(ys[0], ys[0])
+    ok_dot = abs(float(g) - float(np.dot(Y[0], Y[0]))) <= 1e-12 * float(np.dot(Y[0], Y[0]))
+    flag = torch.tensor([1 if (ok and ok_dot) else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(f"DIST_RESULT ok={int(flag)} world={world} halo={dc.n_halo} boundary={dc.n_boundary} interior={dc.n_interior}")
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""The C-ABI library loads on a CPU-only box, exports every symbol that
+include/mi355_spmv.h declares, refuses to compute without a GPU, and the C++
+shim exports the reference's mpk/SpMV.h symbols.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "navierstokes_amd", "csrc")
+LIB = os.path.join(CSRC, "libmi355spmv.so")
+SHIM = os.path.join(CSRC, "libmpk_mi355.so")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="libmi355spmv.so not built (run __graft_entry__.build())")
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mi355_spmv.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_a_real_api():
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    for must in ("mi_csr_create", "mi_spmv", "mi_spmv_dev", "mi_spmk", "mi_dot", "mi_axpy", "mi_orthogonalize",
+                 "mi_part_create", "mi_bcsr4_spmv"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(LIB)
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    assert not missing, f"declared in include/mi355_spmv.h but not exported: {missing}"
+    L.mi_version.restype = ctypes.c_int
+    assert L.mi_version() == 100
+
+
+def test_python_binding_covers_the_header():
+    from navierstokes_amd import mpk
+    L = mpk.lib()
+    for s in declared_symbols():
+        assert getattr(L, s).restype is not None or s in ("mi_strerror", "mi_last_error", "mi_csr_kernel_name")
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a HIP device every compute entry point must fail loudly (MI_ERR_NODEVICE)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    from navierstokes_amd import mpk
+    A = mpk.csrmatrix(2, [0, 1, 2], [0, 1], [1.0, 2.0])
+    with pytest.raises(mpk.MiError) as e:
+        mpk.SpMV_CSR(np.zeros(2), np.ones(2), A)
+    assert e.value.status == 2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(mpk.MiError):
+        mpk.dot(np.ones(4), np.ones(4))
+
+
+def test_bad_arguments_are_rejected_before_touching_the_device():
+    from navierstokes_amd import mpk
+    L = mpk.lib()
+    h = ctypes.c_void_p()
+    p = np.array([0, 2, 1], np.int32)  # decreasing ptrow
+    c = np.array([0, 1], np.int32)
+    v = np.array([1.0, 2.0])
+    assert L.mi_csr_create(2, 2, p.ctypes.data, c.ctypes.data, v.ctypes.data, ctypes.byref(h)) == 1
+    p = np.array([0, 1, 2], np.int32)
+    c = np.array([0, 5], np.int32)  # column out of range
+    assert L.mi_csr_create(2, 2, p.ctypes.data, c.ctypes.data, v.ctypes.data, ctypes.byref(h)) == 1
+    assert b"column" in L.mi_last_error()
+
+
+@pytest.mark.skipif(not os.path.exists(SHIM), reason="libmpk_mi355.so not built")
+def test_shim_exports_reference_signatures():
+    out = subprocess.check_output(["nm", "-DC", "--defined-only", SHIM], text=True)
+    want = [
+        "SpMV_CSR(double*, double*, csrmatrix&)", "SpMV_CSR_OPT(double*, double*, csrmatrix&)",
+        "SpMV_CSR_FMA(double*, double*, csrmatrix&)", "SpMV_CSR_AVX2(double*, double*, csrmatrix&)",
+        "SpMV_BCSR(double*, double const*, bcsr4x4_matrix const&)", "SpMV_BCSR_AVX2(double*, double const*, bcsr4x4_matrix const&)",
+        "COO2CSR(csrmatrix&, int, int, int*, int*, double*)", "generate_CSR(", "generate_BCSR4(",
+        "norm2(std::vector<double", "rel_error(std::vector<double", "flush_cache()",
+        "Generate1stlayer(std::vector<int", "SpM2V_CSR(double*, double*, double*, csrmatrix&",
+        "SpM4V(double*, double*, double*, double*, double*, csrmatrix&", "orthogonalize(int, std::vector<double",
+    ]
+    for w in want:
+        assert w in out, f"shim does not export {w}"
+
+
+@pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_spmv.so"))),
+                    reason="needs the shim and oracle/_ref")
+def test_shim_is_link_compatible_with_reference_objects():
+    """Every function symbol that the reference's SpMV.cpp + utils.cpp define (mangled) is defined by the shim."""
+    def fsyms(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    ref = {s for s in fsyms(os.path.join(ROOT, "oracle", "_ref", "libref_spmv.so")) if s.startswith("_Z")}
+    ours = fsyms(SHIM)
+    assert ref, "reference library exports nothing?"
+    assert ref <= ours, f"missing: {sorted(ref - ours)}"

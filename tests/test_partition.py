@@ -1,0 +1,141 @@
+"""Row-range partition planner (C++ behind mi_part_*), checked on the CPU: the
+partitioned SpMV — with halos moved by hand here, by gloo in
+test_dist_gloo.py — reproduces the global oracle SpMV BIT FOR BIT."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bit_equal
+from navierstokes_amd import dist as D
+from navierstokes_amd import synth
+from oracle import oracle as O
+
+
+def build_plans(kind, n, w, nranks, balanced=True):
+    P, C, V = synth.rows(kind, n, w=w)
+    rs = D.balanced_row_starts(n, nranks, np.diff(P) if balanced else None)
+    plans = []
+    for r in range(nranks):
+        lo, hi = int(rs[r]), int(rs[r + 1])
+        p = (P[lo:hi + 1] - P[lo]).astype(np.int32)
+        plans.append(_Plan(rs, r, nranks, p, C[P[lo]:P[hi]], V[P[lo]:P[hi]]))
+    return (P, C, V), rs, plans
+
+
+class _Plan(D.DistCSR):
+    """DistCSR without torch.distributed: ids are exchanged by the test itself."""
+
+    def __init__(self, rs, rank, nranks, p, c, v):
+        import ctypes
+        from navierstokes_amd import mpk
+        self.rank, self.nranks = rank, nranks
+        self.row_starts = np.ascontiguousarray(rs, dtype=np.int64)
+        L = mpk.lib()
+        h = ctypes.c_void_p()
+        p = np.ascontiguousarray(p, np.int32)
+        c = np.ascontiguousarray(c, np.int32)
+        v = np.ascontiguousarray(v, np.float64)
+        mpk.check(L.mi_part_create(nranks, rank, self.row_starts.ctypes.data, p.ctypes.data, c.ctypes.data,
+                                   v.ctypes.data, ctypes.byref(h)))
+        self._h = h
+        nl, nh, ni, nb = (ctypes.c_int() for _ in range(4))
+        mpk.check(L.mi_part_sizes(h, *(ctypes.byref(t) for t in (nl, nh, ni, nb))))
+        self.n_local, self.n_halo, self.n_interior, self.n_boundary = nl.value, nh.value, ni.value, nb.value
+        rc = np.zeros(nranks, np.int32)
+        mpk.check(L.mi_part_recv_counts(h, rc.ctypes.data))
+        self.recv_counts = [int(t) for t in rc]
+        self.recv_ids = []
+        for q in range(nranks):
+            ids = np.empty(rc[q], np.int64)
+            if rc[q]:
+                mpk.check(L.mi_part_recv_ids(h, q, ids.ctypes.data))
+            self.recv_ids.append(ids)
+
+    def set_send(self, peer, ids):
+        from navierstokes_amd import mpk
+        ids = np.ascontiguousarray(ids, np.int64)
+        mpk.check(mpk.lib().mi_part_set_send_ids(self._h, peer, len(ids), ids.ctypes.data if len(ids) else None))
+
+    def send_index(self):
+        import ctypes
+        from navierstokes_amd import mpk
+        tot, ptr = ctypes.c_int(), ctypes.c_void_p()
+        mpk.check(mpk.lib().mi_part_send_index(self._h, ctypes.byref(tot), ctypes.byref(ptr)))
+        if not tot.value:
+            return np.zeros(0, np.int32)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int)), shape=(tot.value,)).copy()
+
+    def send_counts_(self):
+        from navierstokes_amd import mpk
+        sc = np.zeros(self.nranks, np.int32)
+        mpk.check(mpk.lib().mi_part_send_counts(self._h, sc.ctypes.data))
+        return sc
+
+
+@pytest.mark.parametrize("kind,n,w,nranks", [("s15", 6000, 300, 1), ("s15", 6000, 300, 2), ("svar", 5000, 200, 3),
+                                              ("sfe", 4000, 240, 4), ("s15", 3000, 2000, 8)])
+def test_partitioned_spmv_equals_global_bitwise(kind, n, w, nranks):
+    (P, C, V), rs, plans = build_plans(kind, n, w, nranks)
+    x = synth.x_sin(0, n)
+    y_ref = O.spmv(P, C, V, x)
+    # exchange the id lists by hand: what q needs from r becomes r's send list to q
+    for r in range(nranks):
+        for q in range(nranks):
+            if q != r:
+                plans[r].set_send(q, plans[q].recv_ids[r])
+    for r, pl in enumerate(plans):
+        lo, hi = int(rs[r]), int(rs[r + 1])
+        assert pl.n_local == hi - lo and pl.n_interior + pl.n_boundary == pl.n_local
+        # halo values as the peers would pack them
+        halo = np.empty(pl.n_halo)
+        off = 0
+        for q in range(nranks):
+            cnt = pl.recv_counts[q]
+            if not cnt:
+                continue
+            sidx = plans[q].send_index()
+            sc = plans[q].send_counts_()
+            s_off = int(sc[:r].sum())
+            qlo = int(rs[q])
+            packed = x[qlo:int(rs[q + 1])][sidx[s_off:s_off + sc[r]]]
+            assert sc[r] == cnt
+            halo[off:off + cnt] = packed
+            off += cnt
+        assert off == pl.n_halo
+        x_ext = np.concatenate([x[lo:hi], halo])
+        y_loc = np.full(pl.n_local, np.nan)
+        for which in (0, 1):
+            p, c, v, rmap = pl.local_piece(which)
+            assert (c < pl.n_local).all() if which == 0 else True
+            if which == 1 and len(rmap):
+                assert all((c[p[i]:p[i + 1]] >= pl.n_local).any() for i in range(len(rmap)))
+            y_loc[rmap] = O.spmv(p, c, v, x_ext)
+        assert_bit_equal(y_loc, y_ref[lo:hi], f"rank {r}/{nranks}")
+        if nranks == 1:
+            assert pl.n_halo == 0 and pl.n_boundary == 0
+
+
+def test_balanced_row_starts():
+    lens = np.array([1, 1, 1, 1, 100, 1, 1, 1, 1, 100], np.int64)
+    rs = D.balanced_row_starts(10, 2, lens)
+    assert rs[0] == 0 and rs[-1] == 10 and 4 <= rs[1] <= 6
+    rs = D.balanced_row_starts(1000, 8)
+    assert (np.diff(rs) == 125).all()
+
+
+def test_planner_rejects_bad_input():
+    import ctypes
+    from navierstokes_amd import mpk
+    L = mpk.lib()
+    h = ctypes.c_void_p()
+    rs = np.array([0, 2, 4], np.int64)
+    p = np.array([0, 1, 2], np.int32)
+    c = np.array([0, 7], np.int32)  # column 7 >= 4
+    v = np.ones(2)
+    assert L.mi_part_create(2, 0, rs.ctypes.data, p.ctypes.data, c.ctypes.data, v.ctypes.data, ctypes.byref(h)) == 1
+    c = np.array([0, 3], np.int32)
+    assert L.mi_part_create(2, 0, rs.ctypes.data, p.ctypes.data, c.ctypes.data, v.ctypes.data, ctypes.byref(h)) == 0
+    bad = np.array([3], np.int64)  # rank 0 owns rows 0..1, cannot send row 3
+    assert L.mi_part_set_send_ids(h, 1, 1, bad.ctypes.data) == 1
+    assert L.mi_part_finalize(h) in (2, 6)  # no GPU here / sends never set
+    L.mi_part_destroy(h)
