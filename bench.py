@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py — fp64 CSR SpMV throughput of the HIP path on 1..N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3] [--kernel ...]
+
+A "step" is one pass of the hot path over the whole (global) matrix: y = A x
+(workloads c2, c4) or the k=4 matrix-powers chain y1..y4 (workload c3).  The
+matrix is synthetic (no matrix ships with the reference):
+generator S15 of SURVEY.md §8d, seed 0x5EED — c4 = 5 M rows / 75 M nnz (the
+configuration BASELINE.json's target is quoted on; it fits one GPU), c2 = 1 M
+rows / 15 M nnz.  For N > 1 (launched by torch.distributed.run, one rank per
+GPU) the SAME global matrix is row-partitioned by nnz, each rank generates only
+its rows, and every step exchanges the packed halo x entries over RCCL while the
+interior rows compute — strong scaling.
+
+Rank 0 prints ONE JSON line.  `value` = 2*nnz*k*K / wall (GFLOP/s, the
+reference's convention, src/benchmark_spmv.c:234), inputs resident in HBM.
+`roofline.achieved` = ALGORITHMIC bytes per launch (12*nnz + 4*(n+1) + 16*n,
+SURVEY.md §8d) / mean launch duration from HIP events recorded on the launch
+stream around the timed region.  `cpu_baseline` = the reference's own SpMV_CSR
+object code (oracle/_ref, kind "reference") or, where that is absent, the C
+restatement (kind "port"), one thread, cold cache, on this host — rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy)
+WORKLOADS = {
+    "c4": dict(kind="s15", n=5_000_000, k=1, desc="S15 synthetic CSR 5,000,000 rows x 15 nnz/row = 75,000,000 nnz, y=Ax"),
+    "c2": dict(kind="s15", n=1_000_000, k=1, desc="S15 synthetic CSR 1,000,000 rows x 15 nnz/row = 15,000,000 nnz, y=Ax"),
+    "c3": dict(kind="s15", n=1_000_000, k=4, desc="S15 synthetic CSR 1,000,000 rows x 15 nnz/row, k=4 matrix powers y1..y4"),
+}
+
+
+def algorithmic_bytes(n, nnz):
+    """values(8)+colidx(4) per nnz, rowptr, x read once, y written once (src/benchmark_spmv.c:197-202)."""
+    return 12 * nnz + 4 * (n + 1) + 8 * n + 8 * n
+
+
+def load_traffic(workload, kernel_name):
+    """HBM bytes per launch from committed PMC profiles (profiles/*_pmc.json), or None."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_pmc.json"):
+                try:
+                    d = json.load(open(os.path.join(pdir, f)))
+                except Exception:
+                    continue
+                if d.get("workload") == workload and d.get("kernel") == kernel_name:
+                    best = d.get("hbm_bytes_per_launch")
+    return best
+
+
+def cpu_baseline(p, c, v, x, seconds_budget=20.0):
+    """Single-thread CPU SpMV on this host, cold cache, best of a few calls (the reference's
+    protocol: flush_cache() then one timed call, mpk/SpM2V.cpp:895-904)."""
+    from oracle import oracle as O  # the checker/baseline, never the measured product
+
+    n, nnz = len(p) - 1, len(c)
+    out = {"unit": "GFLOP/s", "cores": 1}
+    reps = 3
+    if O.have_ref():
+        t, _ = O.ref_time_spmv(p, c, v, x, "scalar", reps=reps, flush=True)
+        out.update(kind="reference", value=2 * nnz / t / 1e9,
+                   sample=f"full workload ({n} rows, {nnz} nnz), reference SpMV_CSR (x87 scalar, mpk/SpMV.cpp:6-20) "
+                          f"object code, 1 thread, best of {reps} cold calls after flush_cache()")
+        extra = {}
+        for var in ("opt", "fma"):
+            tv, _ = O.ref_time_spmv(p, c, v, x, var, reps=2, flush=True)
+            extra[f"SpMV_CSR_{var.upper()}"] = round(2 * nnz / tv / 1e9, 4)
+        out["other_variants_gflops"] = extra
+    else:
+        t, _ = O.time_spmv(p, c, v, x, reps=reps, flush=True)
+        out.update(kind="port", value=2 * nnz / t / 1e9,
+                   sample=f"full workload ({n} rows, {nnz} nnz), oracle/cpu_ref.c fma chain, 1 thread, "
+                          f"best of {reps} cold calls after a 300 MiB flush")
+    out["value"] = round(out["value"], 4)
+    try:
+        out["host_cpu"] = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+        out["host_cores_available"] = os.cpu_count()
+    except Exception:
+        pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "stream_xlds", "rowpar"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from navierstokes_amd import dist as D
+    from navierstokes_amd import mpk, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    mpk.lib()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W = WORKLOADS[args.workload]
+    n, k, kind = W["n"], W["k"], W["kind"]
+    nnz_global = int(synth._lib().synth_count(synth.KINDS[kind], synth.DEFAULT_SEED, n, synth.DEFAULT_W, 0, n))
+
+    # ---- build this rank's share -------------------------------------------------------
+    t_setup = time.perf_counter()
+    rs = D.balanced_row_starts(n, world)  # S15 rows all hold 15 nnz: equal rows == equal nnz
+    lo, hi = int(rs[rank]), int(rs[rank + 1])
+    p, c, v = synth.rows(kind, n, lo, hi)
+    x_host = synth.x_sin(lo, hi)
+    if world == 1:
+        A = mpk.csrmatrix(n, p, c, v)
+        if args.kernel != "auto":
+            A.set_kernel(args.kernel)
+        _ = A.handle
+        kernel_name = A.kernel_name()
+        x = torch.from_numpy(x_host).cuda()
+        ys = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(k)]
+        if k == 1:
+            def step():
+                mpk.SpMV_CSR(ys[0], x, A)
+        else:
+            def step():
+                mpk.SpMkV(ys, x, A)
+        halo_info = None
+    else:
+        if k != 1:
+            sys.exit("workload c3 (matrix powers) is a 1-GPU configuration (BASELINE.json configs[2])")
+        dc = D.DistCSR(rs, p, c, v, kernel=None if args.kernel == "auto" else args.kernel)
+        x_ext = dc.new_x_ext()
+        x_ext[: dc.n_local] = torch.from_numpy(x_host).cuda()
+        y = dc.new_y()
+        kernel_name = "spmv_csr_stream<2048, false, 1>" if args.kernel in ("auto", "stream") else args.kernel
+
+        def step():
+            dc.spmv(x_ext, y)
+        halo_info = dict(n_halo=dc.n_halo, n_send=dc.n_send, interior_rows=dc.n_interior, boundary_rows=dc.n_boundary)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warm-up, then the timed region ---------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    if args.cold:
+        ev_ms = 0.0
+        for _ in range(args.steps):
+            mpk.flush_cache()
+            ev0.record()
+            step()
+            ev1.record()
+            torch.cuda.synchronize()
+            ev_ms += ev0.elapsed_time(ev1)
+        wall = ev_ms / 1e3  # flush time excluded
+    else:
+        ev0.record()
+        for _ in range(args.steps):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
+    barrier()
+    if world > 1:
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(tt[0]), float(tt[1])
+
+    # ---- parity of what was just timed (rank-local rows, against the oracle) ---------------------
+    parity = None
+    if not args.no_parity:
+        from oracle import oracle as O  # checker only
+        if world == 1:
+            Y = O.spmk_chain(k, p, c, v, x_host)
+            got = [t.cpu().numpy() for t in ys]
+            parity = dict(rel_error=max(O.rel_error(Y[i], got[i]) for i in range(k)),
+                          bitwise=all(np.array_equal(Y[i].view(np.uint64), got[i].view(np.uint64)) for i in range(k)),
+                          against="oracle/cpu_ref.c fma chain (= reference SpMV_CSR_OPT/_FMA), full vectors")
+        else:
+            # rank-local check needs the halo values: take them from the generator (x_j = sin(0.001 j))
+            halo_ids = np.empty(dc.n_halo, np.int64)
+            off = 0
+            L = mpk.lib()
+            import ctypes
+            for q in range(world):
+                if dc.recv_counts[q]:
+                    mpk.check(L.mi_part_recv_ids(dc._h, q, halo_ids[off:].ctypes.data))
+                    off += dc.recv_counts[q]
+            xe = np.concatenate([x_host, np.sin(0.001 * halo_ids.astype(np.float64))])
+            # relabel global columns like the planner: owned -> local, ghosts -> n_local + position
+            cl = np.where((c >= lo) & (c < hi), c - lo, dc.n_local + np.searchsorted(halo_ids, c)).astype(np.int32)
+            yo = O.spmv(p, cl, v, xe)
+            g = y.cpu().numpy()
+            bad = torch.tensor([0 if np.array_equal(yo.view(np.uint64), g.view(np.uint64)) else 1], device="cuda")
+            dist.all_reduce(bad)
+            parity = dict(bitwise=bool(int(bad) == 0), against="oracle fma chain on each rank's rows, halos from the generator")
+            del ctypes
+
+    # ---- numbers -------------------------------------------------------------------------------
+    flops = 2.0 * nnz_global * k * args.steps
+    value = flops / wall / 1e9
+    launches = args.steps * k
+    B = algorithmic_bytes(n, nnz_global) if world == 1 else algorithmic_bytes(hi - lo, len(c))
+    launch_s = ev_ms / 1e3 / launches
+    achieved = B / launch_s / 1e9
+    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4),
+                    traffic=load_traffic(args.workload, kernel_name) if world == 1 else None,
+                    kernel=kernel_name, algorithmic_bytes_per_launch=B, launch_us=round(launch_s * 1e6, 2),
+                    timing="HIP events on the launch stream around the timed region / launches"
+                           + (" (per-rank share incl. halo exchange; max over ranks)" if world > 1 else ""))
+    out = dict(metric="fp64 CSR SpMV GFLOP/s & % HBM roofline @ nnz; 1/2/4/8 GPU", value=round(value, 2), unit="GFLOP/s",
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(wall * 1e3 / args.steps, 5),
+               higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=W["desc"], name=args.workload, n=n, nnz=nnz_global, k=k, seed="0x5EED",
+                           half_bandwidth=synth.DEFAULT_W, partition=f"row-range x{world}", cold=bool(args.cold)),
+               roofline=roofline, pct_hbm_roofline=round(100 * achieved / HBM_PEAK_GBS, 2))
+    if parity is not None:
+        out["parity"] = parity
+    if halo_info is not None:
+        out["halo"] = halo_info
+    out["setup_s"] = round(t_setup, 2)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(p, c, v, x_host)
+        out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

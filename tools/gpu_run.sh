@@ -1,0 +1,35 @@
+#!/bin/bash
+# tools/gpu_run.sh — what one gpurun call executes on the MI355X box (development helper).
+# Each step writes under gpurun_out/; a step that times out (rc>=124) stops the script.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+step() { # name timeout cmd...
+  local name=$1 to=$2; shift 2
+  echo "=== $name ($(date +%T))"
+  timeout -k 10 "$to" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "=== $name rc=$rc"
+  tail -n 40 "gpurun_out/$name.log"
+  if [ $rc -ge 124 ]; then echo "step $name timed out / was killed: stopping"; exit $rc; fi
+  return 0
+}
+for s in "$@"; do
+  case $s in
+    kbench)   step kbench 300 ./tools/kbench 0 5000000 2000 5 50 ;;
+    kbench_c2) step kbench_c2 200 ./tools/kbench 0 1000000 2000 5 100 ;;
+    kbench_sfe) step kbench_sfe 300 ./tools/kbench 2 1400000 2000 5 50 ;;
+    kbench_svar) step kbench_svar 300 ./tools/kbench 1 5000000 2000 5 50 ;;
+    tests)    step tests 600 python -m pytest tests -x -q -m gpu ;;
+    smoke)    step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench)    step bench 400 python bench.py ;;
+    bench_c2) step bench_c2 300 python bench.py --workload c2 --no-cpu-baseline ;;
+    bench_c3) step bench_c3 300 python bench.py --workload c3 --no-cpu-baseline ;;
+    bench_cold) step bench_cold 400 python bench.py --cold --steps 30 --warmup 3 --no-cpu-baseline ;;
+    prof)     rm -rf gpurun_out/prof; step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity ;;
+    pmc_fetch) rm -rf gpurun_out/pmc_fetch; step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
+    pmc_write) rm -rf gpurun_out/pmc_write; step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
+    *) echo "unknown step $s"; exit 1 ;;
+  esac
+done
+echo "=== done ($(date +%T))"

@@ -1,0 +1,202 @@
+// tools/kbench.hip — standalone kernel microbenchmark (development tool, not part
+// of the product library or of bench.py).  Generates an S15/SVAR/SFE matrix with
+// the product's generator, runs every SpMV kernel variant in ONE process with
+// interleaved rounds (cdna_hip_programming.md §5.4 rule 24), verifies each result
+// bitwise against a host fma chain, and prints achieved algorithmic GB/s next to
+// two calibration streams (device copy; A-stream read without the x gather).
+//
+//   hipcc -O3 --offload-arch=gfx950 -I../include -I../navierstokes_amd/csrc \
+//         kbench.hip ../navierstokes_amd/csrc/synth_csr.c -o kbench
+//   ./kbench [kind=0|1|2] [n=5000000] [w=2000] [rounds=5] [iters=50]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <functional>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "partition.hpp"
+#include "spmv_kernels.hpp"
+#include "spmv_experimental.hpp"
+
+extern "C" long long synth_count(int kind, unsigned long long seed, int n, int w, long long rb, long long re);
+extern "C" int synth_rows(int kind, unsigned long long seed, int n, int w, long long rb, long long re, int* ptrow,
+                          int* indcol, double* coef);
+extern "C" void synth_x_sin(long long jb, long long je, double* x);
+
+using namespace mi355;
+
+#define CK(e)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (e);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #e, hipGetErrorString(e_)); \
+            exit(2);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+__global__ void copy_kernel(const double2* __restrict__ a, double2* __restrict__ b, size_t n2)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) b[i] = a[i];
+}
+
+// reads coef + indcol like an SpMV would (unit stride) but gathers nothing
+__global__ void astream_kernel(const double* __restrict__ coef, const int* __restrict__ indcol, size_t nnz,
+                               double* __restrict__ sink)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) s += coef[i] * (double)indcol[i];
+    if (s == 123.456) sink[0] = s;
+}
+
+int main(int argc, char** argv)
+{
+    const int kind = argc > 1 ? atoi(argv[1]) : 0;
+    const int n = argc > 2 ? atoi(argv[2]) : 5000000;
+    const int w = argc > 3 ? atoi(argv[3]) : 2000;
+    const int rounds = argc > 4 ? atoi(argv[4]) : 5;
+    const int iters = argc > 5 ? atoi(argv[5]) : 50;
+    const unsigned long long seed = 0x5EED;
+
+    const long long nnz = synth_count(kind, seed, n, w, 0, n);
+    std::vector<int> ptrow(n + 1), indcol(nnz);
+    std::vector<double> coef(nnz), x(n), yref(n);
+    if (synth_rows(kind, seed, n, w, 0, n, ptrow.data(), indcol.data(), coef.data())) return 1;
+    synth_x_sin(0, n, x.data());
+    for (int i = 0; i < n; i++) {
+        double s = 0;
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) s = fma(coef[k], x[indcol[k]], s);
+        yref[i] = s;
+    }
+    const double B = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
+    printf("matrix kind=%d n=%d nnz=%lld w=%d  algorithmic bytes/SpMV = %.1f MB\n", kind, n, nnz, w, B / 1e6);
+
+    int *d_ptrow, *d_indcol;
+    double *d_coef, *d_x, *d_y, *d_sink;
+    CK(hipMalloc(&d_ptrow, sizeof(int) * (n + 1)));
+    CK(hipMalloc(&d_indcol, sizeof(int) * (nnz + 64)));
+    CK(hipMalloc(&d_coef, sizeof(double) * (nnz + 64)));
+    CK(hipMalloc(&d_x, sizeof(double) * (n + 64)));
+    CK(hipMalloc(&d_y, sizeof(double) * n));
+    CK(hipMalloc(&d_sink, 64));
+    CK(hipMemset(d_indcol, 0, sizeof(int) * (nnz + 64)));
+    CK(hipMemset(d_coef, 0, sizeof(double) * (nnz + 64)));
+    CK(hipMemcpy(d_ptrow, ptrow.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_indcol, indcol.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_coef, coef.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_x, x.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+
+    // row-block tables for the block sizes under test
+    struct Tab { int nnzb; int nblk; int2* d_blk; int2* d_span; };
+    auto make_tab = [&](int nnzb, int max_rows) {
+        std::vector<int> rows, ptrs;
+        build_row_blocks(n, ptrow.data(), nnzb, max_rows, rows, ptrs);
+        Tab T;
+        T.nnzb = nnzb;
+        T.nblk = (int)rows.size() - 1;
+        std::vector<int2> h(rows.size());
+        for (size_t i = 0; i < rows.size(); i++) h[i] = make_int2(rows[i], ptrs[i]);
+        std::vector<int2> sp(T.nblk);
+        for (int b = 0; b < T.nblk; b++) {
+            int lo = 1 << 30, hi = 0;
+            for (int k = ptrs[b]; k < ptrs[b + 1]; k++) { lo = std::min(lo, indcol[k]); hi = std::max(hi, indcol[k]); }
+            sp[b] = make_int2(lo, hi);
+        }
+        CK(hipMalloc(&T.d_blk, sizeof(int2) * h.size()));
+        CK(hipMemcpy(T.d_blk, h.data(), sizeof(int2) * h.size(), hipMemcpyHostToDevice));
+        CK(hipMalloc(&T.d_span, sizeof(int2) * (T.nblk + 1)));
+        CK(hipMemcpy(T.d_span, sp.data(), sizeof(int2) * T.nblk, hipMemcpyHostToDevice));
+        return T;
+    };
+    auto view = [&](const Tab& T) {
+        CsrView V;
+        V.n = n; V.ncols = n; V.ptrow = d_ptrow; V.indcol = d_indcol; V.coef = d_coef; V.rowmap = nullptr;
+        V.blk = T.d_blk; V.blk_span = T.d_span; V.nblk = T.nblk;
+        return V;
+    };
+    Tab T1k = make_tab(1024, 1024), T2k = make_tab(2048, 1024), T4k = make_tab(4096, 1024);
+
+    std::vector<Variant> vars;
+    auto grid8 = [](int nblk) { return dim3(kNXCD * ((nblk + kNXCD - 1) / kNXCD)); };
+    {
+        CsrView V = view(T2k);
+        vars.push_back({"stream<2048>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<2048, false, 1>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
+        vars.push_back({"stream_xlds<2048,5632>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<2048, true, 5632>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
+    }
+    {
+        CsrView V = view(T1k);
+        vars.push_back({"stream<1024>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<1024, false, 1>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
+        vars.push_back({"stream_xlds<1024,4352>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<1024, true, 4352>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
+    }
+    {
+        CsrView V = view(T2k);
+        vars.push_back({"rowpar", [=](hipStream_t s) { hipLaunchKernelGGL(spmv_csr_rowpar, dim3((n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y); }});
+    }
+    add_experimental_variants(vars, n, d_ptrow, d_indcol, d_coef, d_x, d_y, view(T1k), view(T2k), view(T4k));
+
+    // calibration streams
+    const size_t copy_bytes = (size_t)1 << 30; // 1 GiB read + 1 GiB write
+    double2 *d_a, *d_b;
+    CK(hipMalloc(&d_a, copy_bytes));
+    CK(hipMalloc(&d_b, copy_bytes));
+    CK(hipMemset(d_a, 1, copy_bytes));
+    Variant vcopy{"copy 1GiB->1GiB (double2)", [=](hipStream_t s) { hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, s, d_a, d_b, copy_bytes / 16); }};
+    Variant vastr{"A-stream read (coef+indcol, no gather)", [=](hipStream_t s) { hipLaunchKernelGGL(astream_kernel, dim3(256 * 8), dim3(256), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }};
+
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto time_it = [&](Variant& v, int it) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < it; i++) v.launch(st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms / it;
+    };
+
+    // correctness first
+    std::vector<double> y(n);
+    for (auto& v : vars) {
+        CK(hipMemsetAsync(d_y, 0xFF, sizeof(double) * n, st));
+        v.launch(st);
+        CK(hipStreamSynchronize(st));
+        CK(hipGetLastError());
+        CK(hipMemcpy(y.data(), d_y, sizeof(double) * n, hipMemcpyDeviceToHost));
+        long long bad = 0;
+        for (int i = 0; i < n; i++) bad += (memcmp(&y[i], &yref[i], 8) != 0);
+        v.ok = (bad == 0);
+        if (!v.ok) printf("  !! %s: %lld rows differ from the host fma chain\n", v.name.c_str(), bad);
+    }
+    // interleaved timing rounds
+    for (auto& v : vars) time_it(v, 5);
+    for (int r = 0; r < rounds; r++) {
+        for (auto& v : vars) v.ms.push_back(time_it(v, iters));
+        vcopy.ms.push_back(time_it(vcopy, 10));
+        vastr.ms.push_back(time_it(vastr, 10));
+    }
+    auto med = [](std::vector<float> a) { std::sort(a.begin(), a.end()); return a[a.size() / 2]; };
+    auto mn = [](std::vector<float> a) { return *std::min_element(a.begin(), a.end()); };
+    printf("%-44s %9s %9s %10s %8s %6s\n", "kernel", "med us", "min us", "GB/s(med)", "%8TB/s", "bits");
+    for (auto& v : vars) {
+        const double us = med(v.ms) * 1e3;
+        printf("%-44s %9.1f %9.1f %10.1f %8.1f %6s\n", v.name.c_str(), us, mn(v.ms) * 1e3, B / us / 1e3, B / us / 1e3 / 80.0, v.ok ? "exact" : "WRONG");
+    }
+    {
+        const double us = med(vcopy.ms) * 1e3;
+        printf("%-44s %9.1f %9.1f %10.1f %8.1f\n", vcopy.name.c_str(), us, mn(vcopy.ms) * 1e3, 2.0 * copy_bytes / us / 1e3, 2.0 * copy_bytes / us / 1e3 / 80.0);
+        const double us2 = med(vastr.ms) * 1e3;
+        printf("%-44s %9.1f %9.1f %10.1f %8.1f\n", vastr.name.c_str(), us2, mn(vastr.ms) * 1e3, 12.0 * nnz / us2 / 1e3, 12.0 * nnz / us2 / 1e3 / 80.0);
+    }
+    return 0;
+}
