@@ -64,6 +64,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk)
 // stream kernel.  NNZB: nonzeros per row block (LDS = 2 * 8 B * sk(NNZB)).
 // XLDS: stage the block's x window in LDS when it fits XWIN doubles.
 // ---------------------------------------------------------------------------
+// Row chain with batched operand fetch: the fma chain of a row stays strictly
+// sequential, but its LDS operands are fetched U at a time (2U ds_reads in
+// flight, one wait) instead of one wait per term.  Slots past the row end are
+// clamped to the last valid slot and their fma is skipped, so the body has no
+// divergent loads.
+template <int U>
+__device__ __forceinline__ double row_chain(const double* s_c, const double* s_x, int ra, int re)
+{
+    double s = 0.0;
+    for (int k0 = ra; k0 < re; k0 += U) {
+        double cc[U], xx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = min(k0 + u, re - 1);
+            cc[u] = s_c[sk(k)];
+            xx[u] = s_x[sk(k)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (k0 + u < re) s = fma(cc[u], xx[u], s);
+    }
+    return s;
+}
+
 template <int NNZB, bool XLDS, int XWIN>
 __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* __restrict__ x,
                                                        double* __restrict__ y)
@@ -81,25 +105,39 @@ __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* 
     const int2 d1 = A.blk[b + 1];
     const int r0 = d0.x, p0 = d0.y, r1 = d1.x, p1 = d1.y;
     const int nn = p1 - p0;
+    const int myrow = r0 + tid;
 
+    if (nn == 0) { // a block of empty rows
+        for (int r = myrow; r < r1; r += kWG) y[A.rowmap ? A.rowmap[r] : r] = 0.0;
+        return;
+    }
     if (nn <= NNZB) {
-        // row extents for phase 2, requested early so they are in flight with the stream
-        int ra = 0, re = 0;
-        const int myrow = r0 + tid;
-        if (myrow < r1) {
-            ra = A.ptrow[myrow] - p0;
-            re = A.ptrow[myrow + 1] - p0;
-        }
+        // Phase 1 is written WITHOUT per-element branches: every thread issues
+        // exactly PER coef loads, PER indcol loads and PER gathers, with the slot
+        // index clamped to the last valid nonzero (lanes past the end re-read and
+        // re-write that last element with identical values — harmless).  With
+        // branches hipcc serialises the loads (one round trip per element); as
+        // straight-line code all 2*PER stream loads are in flight together, then
+        // all PER gathers.
+        const int last = nn - 1;
+        const int rowc = min(myrow, r1 - 1);
+        const int pa = A.ptrow[rowc];     // raw row extents, consumed only in phase 2
+        const int pe = A.ptrow[rowc + 1];
+        // Column ids are kept UNSIGNED: a signed index is sign-extended for the 64-bit
+        // gather address, and hipcc schedules that extension right behind each index
+        // load — one s_waitcnt per load, i.e. PER serial round trips to HBM.
+        const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
         double c[PER];
-        int j[PER];
+        unsigned j[PER];
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const int k = tid + i * kWG;
-            if (k < nn) {
-                c[i] = A.coef[p0 + k];
-                j[i] = A.indcol[p0 + k];
-            }
+            const int k = min(tid + i * kWG, last);
+            c[i] = A.coef[p0 + k];
+            j[i] = ucol[p0 + k];
         }
+        // keep the three groups (stream loads | gathers | LDS stores) apart: left to
+        // itself the scheduler re-fuses them into per-element load-wait-gather-wait-store
+        __builtin_amdgcn_sched_barrier(0);
         bool use_win = false;
         int cmin = 0;
         if (XLDS) {
@@ -108,7 +146,6 @@ __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* 
             const int wlen = sp.y - cmin + 1;
             use_win = (wlen <= XWIN);
             if (use_win) {
-                // coalesced 16-B loads of x[cmin .. cmin+wlen)
                 const double2* src = reinterpret_cast<const double2*>(x + cmin);
                 const int n2 = wlen >> 1;
                 for (int t = tid; t < n2; t += kWG) {
@@ -120,24 +157,21 @@ __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* 
                 __syncthreads();
             }
         }
+        double xv[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) xv[i] = (XLDS && use_win) ? s_win[j[i] - (unsigned)cmin] : x[j[i]];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const int k = tid + i * kWG;
-            if (k < nn) {
-                const double xv = (XLDS && use_win) ? s_win[j[i] - cmin] : x[j[i]];
-                s_c[sk(k)] = c[i];
-                s_x[sk(k)] = xv;
-            }
+            const int k = min(tid + i * kWG, last);
+            s_c[sk(k)] = c[i];
+            s_x[sk(k)] = xv[i];
         }
         __syncthreads();
-        for (int r = myrow; r < r1; r += kWG) {
-            if (r != myrow) {
-                ra = A.ptrow[r] - p0;
-                re = A.ptrow[r + 1] - p0;
-            }
-            double s = 0.0;
-            for (int k = ra; k < re; k++) s = fma(s_c[sk(k)], s_x[sk(k)], s);
-            y[A.rowmap ? A.rowmap[r] : r] = s;
+        if (myrow < r1) y[A.rowmap ? A.rowmap[myrow] : myrow] = row_chain<8>(s_c, s_x, pa - p0, pe - p0);
+        for (int r = myrow + kWG; r < r1; r += kWG) { // blocks of very short rows hold more than kWG rows
+            const int ra = A.ptrow[r] - p0, re = A.ptrow[r + 1] - p0;
+            y[A.rowmap ? A.rowmap[r] : r] = row_chain<8>(s_c, s_x, ra, re);
         }
     } else {
         // one row longer than a block: stream it chunk by chunk; the chain itself

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <map>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -55,6 +56,27 @@ __global__ void astream_kernel(const double* __restrict__ coef, const int* __res
     if (s == 123.456) sink[0] = s;
 }
 
+// like astream_kernel, but organised as the ring kernels stream the matrix: every
+// workgroup walks its OWN contiguous run in 2048-element chunks (tests whether
+// hundreds of concurrent sequential streams cost DRAM efficiency)
+__global__ __launch_bounds__(512) void astream_runs_kernel(const double* __restrict__ coef, const int* __restrict__ indcol,
+                                                           size_t nnz, double* __restrict__ sink)
+{
+    const size_t per = (nnz + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < nnz ? lo + per : nnz;
+    double s = 0;
+#pragma unroll 4
+    for (size_t base = lo; base + 2048 <= hi; base += 2048) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const size_t k = base + threadIdx.x + i * 512;
+            s += coef[k] * (double)indcol[k];
+        }
+    }
+    if (s == 123.456) sink[0] = s;
+}
+
 int main(int argc, char** argv)
 {
     const int kind = argc > 1 ? atoi(argv[1]) : 0;
@@ -63,6 +85,7 @@ int main(int argc, char** argv)
     const int rounds = argc > 4 ? atoi(argv[4]) : 5;
     const int iters = argc > 5 ? atoi(argv[5]) : 50;
     const unsigned long long seed = 0x5EED;
+    const char* filter = argc > 6 ? argv[6] : nullptr; // comma-separated substrings of variant names to keep
 
     const long long nnz = synth_count(kind, seed, n, w, 0, n);
     std::vector<int> ptrow(n + 1), indcol(nnz);
@@ -93,7 +116,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(d_x, x.data(), sizeof(double) * n, hipMemcpyHostToDevice));
 
     // row-block tables for the block sizes under test
-    struct Tab { int nnzb; int nblk; int2* d_blk; int2* d_span; };
+    struct Tab { int nnzb; int nblk; int2* d_blk; int2* d_span; int4* d_meta; };
     auto make_tab = [&](int nnzb, int max_rows) {
         std::vector<int> rows, ptrs;
         build_row_blocks(n, ptrow.data(), nnzb, max_rows, rows, ptrs);
@@ -112,6 +135,11 @@ int main(int argc, char** argv)
         CK(hipMemcpy(T.d_blk, h.data(), sizeof(int2) * h.size(), hipMemcpyHostToDevice));
         CK(hipMalloc(&T.d_span, sizeof(int2) * (T.nblk + 1)));
         CK(hipMemcpy(T.d_span, sp.data(), sizeof(int2) * T.nblk, hipMemcpyHostToDevice));
+        std::vector<int4> mt(T.nblk + 1);
+        for (int b = 0; b < T.nblk; b++) mt[b] = make_int4(rows[b], ptrs[b], sp[b].x, sp[b].y);
+        mt[T.nblk] = make_int4(rows[T.nblk], ptrs[T.nblk], 0, 0);
+        CK(hipMalloc(&T.d_meta, sizeof(int4) * mt.size()));
+        CK(hipMemcpy(T.d_meta, mt.data(), sizeof(int4) * mt.size(), hipMemcpyHostToDevice));
         return T;
     };
     auto view = [&](const Tab& T) {
@@ -122,6 +150,68 @@ int main(int argc, char** argv)
     };
     Tab T1k = make_tab(1024, 1024), T2k = make_tab(2048, 1024), T4k = make_tab(4096, 1024);
 
+    // host-side window plan for the ring5 kernels
+    struct HostTab { std::vector<int> rows, ptrs; std::vector<int2> span; };
+    auto host_tab = [&](int nnzb) {
+        HostTab H;
+        build_row_blocks(n, ptrow.data(), nnzb, 1024, H.rows, H.ptrs);
+        const int nblk = (int)H.rows.size() - 1;
+        H.span.resize(nblk);
+        for (int b = 0; b < nblk; b++) {
+            int lo = 1 << 30, hi = -1;
+            for (int k = H.ptrs[b]; k < H.ptrs[b + 1]; k++) { lo = std::min(lo, indcol[k]); hi = std::max(hi, indcol[k]); }
+            H.span[b] = make_int2(lo, hi);
+        }
+        return H;
+    };
+    std::map<int, HostTab> htabs;
+    auto make_plan = [&](int nnzb, int ring, int maxb, int min_wgs, const int4** P, const int** OK, int* wgs_out, int* bpw_out) {
+        if (!htabs.count(nnzb)) htabs[nnzb] = host_tab(nnzb);
+        const HostTab& H = htabs[nnzb];
+        const int nblk = (int)H.rows.size() - 1;
+        int wgs = std::max(min_wgs, (nblk + maxb - 1) / maxb);
+        wgs = ((wgs + 7) / 8) * 8;
+        const int bpw = (nblk + wgs - 1) / wgs;
+        std::vector<int4> plan(2 * (size_t)nblk);
+        std::vector<int> ok(wgs, 1);
+        for (int g = 0; g < wgs; g++) {
+            int wlo = 0, whi = 0, base = 0;
+            bool live = false;
+            for (int b = g * bpw; b < std::min(nblk, (g + 1) * bpw); b++) {
+                const int nn = H.ptrs[b + 1] - H.ptrs[b], nrows = H.rows[b + 1] - H.rows[b];
+                plan[2 * b] = make_int4(H.rows[b], H.ptrs[b], nrows, nn);
+                plan[2 * b + 1] = make_int4(0, 0, base, 0);
+                if (nn == 0) continue;
+                const int cmin = H.span[b].x, cmax = H.span[b].y;
+                bool use = nn <= nnzb && (cmax - cmin + 1 <= ring);
+                if (use) {
+                    int lo = live ? wlo : cmin, hi = live ? whi : cmin;
+                    bool restart = !live;
+                    if (cmin < lo) use = false;
+                    else {
+                        if (cmin > hi) { lo = cmin; hi = cmin; restart = true; }
+                        const int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
+                        if (cmin < nlo) use = false;
+                        else {
+                            if (restart) base = (lo / ring) * ring;
+                            while (nlo - base >= ring) base += ring;
+                            plan[2 * b + 1] = make_int4(hi, nhi - hi, base, 1);
+                            wlo = nlo; whi = nhi; live = true;
+                        }
+                    }
+                }
+                if (!use) ok[g] = 0;
+            }
+        }
+        int4* dP; int* dOK;
+        CK(hipMalloc(&dP, sizeof(int4) * plan.size()));
+        CK(hipMemcpy(dP, plan.data(), sizeof(int4) * plan.size(), hipMemcpyHostToDevice));
+        CK(hipMalloc(&dOK, sizeof(int) * ok.size()));
+        CK(hipMemcpy(dOK, ok.data(), sizeof(int) * ok.size(), hipMemcpyHostToDevice));
+        int nbad = 0; for (int v : ok) nbad += !v;
+        printf("plan nnzb=%d ring=%d: %d blocks, %d runs of <=%d blocks, %d runs not ring-able\n", nnzb, ring, nblk, wgs, bpw, nbad);
+        *P = dP; *OK = dOK; *wgs_out = wgs; *bpw_out = bpw;
+    };
     std::vector<Variant> vars;
     auto grid8 = [](int nblk) { return dim3(kNXCD * ((nblk + kNXCD - 1) / kNXCD)); };
     {
@@ -138,8 +228,25 @@ int main(int argc, char** argv)
         CsrView V = view(T2k);
         vars.push_back({"rowpar", [=](hipStream_t s) { hipLaunchKernelGGL(spmv_csr_rowpar, dim3((n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y); }});
     }
-    add_experimental_variants(vars, n, d_ptrow, d_indcol, d_coef, d_x, d_y, view(T1k), view(T2k), view(T4k));
+    add_experimental_variants(vars, n, d_ptrow, d_indcol, d_coef, d_x, d_y, view(T1k), view(T2k), view(T4k), T1k.d_meta, T2k.d_meta, T4k.d_meta, make_plan);
 
+    if (filter) {
+        std::vector<Variant> keep;
+        std::string f(filter);
+        for (auto& v : vars) {
+            size_t pos = 0;
+            bool hit = false;
+            while (pos <= f.size()) {
+                size_t q = f.find(',', pos);
+                if (q == std::string::npos) q = f.size();
+                const std::string tok = f.substr(pos, q - pos);
+                if (!tok.empty() && v.name.find(tok) != std::string::npos) hit = true;
+                pos = q + 1;
+            }
+            if (hit) keep.push_back(v);
+        }
+        vars.swap(keep);
+    }
     // calibration streams
     const size_t copy_bytes = (size_t)1 << 30; // 1 GiB read + 1 GiB write
     double2 *d_a, *d_b;
@@ -149,6 +256,9 @@ int main(int argc, char** argv)
     Variant vcopy{"copy 1GiB->1GiB (double2)", [=](hipStream_t s) { hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, s, d_a, d_b, copy_bytes / 16); }};
     Variant vastr{"A-stream read (coef+indcol, no gather)", [=](hipStream_t s) { hipLaunchKernelGGL(astream_kernel, dim3(256 * 8), dim3(256), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }};
 
+    std::vector<Variant> calib;
+    for (int wgs : {512, 1024, 2048, 8192})
+        calib.push_back({"A-stream as " + std::to_string(wgs) + " contiguous runs", [=](hipStream_t s) { hipLaunchKernelGGL(astream_runs_kernel, dim3(wgs), dim3(512), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }});
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -184,6 +294,7 @@ int main(int argc, char** argv)
         for (auto& v : vars) v.ms.push_back(time_it(v, iters));
         vcopy.ms.push_back(time_it(vcopy, 10));
         vastr.ms.push_back(time_it(vastr, 10));
+        for (auto& v : calib) v.ms.push_back(time_it(v, 10));
     }
     auto med = [](std::vector<float> a) { std::sort(a.begin(), a.end()); return a[a.size() / 2]; };
     auto mn = [](std::vector<float> a) { return *std::min_element(a.begin(), a.end()); };
@@ -197,6 +308,10 @@ int main(int argc, char** argv)
         printf("%-44s %9.1f %9.1f %10.1f %8.1f\n", vcopy.name.c_str(), us, mn(vcopy.ms) * 1e3, 2.0 * copy_bytes / us / 1e3, 2.0 * copy_bytes / us / 1e3 / 80.0);
         const double us2 = med(vastr.ms) * 1e3;
         printf("%-44s %9.1f %9.1f %10.1f %8.1f\n", vastr.name.c_str(), us2, mn(vastr.ms) * 1e3, 12.0 * nnz / us2 / 1e3, 12.0 * nnz / us2 / 1e3 / 80.0);
+    }
+    for (auto& v : calib) {
+        const double us = med(v.ms) * 1e3;
+        printf("%-44s %9.1f %9.1f %10.1f %8.1f\n", v.name.c_str(), us, mn(v.ms) * 1e3, 12.0 * nnz / us / 1e3, 12.0 * nnz / us / 1e3 / 80.0);
     }
     return 0;
 }

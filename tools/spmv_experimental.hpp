@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <functional>
 #include <string>
 #include <vector>
@@ -199,11 +200,926 @@ __global__ __launch_bounds__(kWG) void spmv_csr_stream_nogather(CsrView A, const
     }
 }
 
+
+// E4: persistent workgroups with a SLIDING x WINDOW in LDS ("ring").
+// Each workgroup owns a contiguous run of row blocks (XCD-aware: consecutive
+// runs go to the same XCD).  The x entries the current block can reference,
+// [cmin_b, cmax_b], live in an LDS ring indexed by column; moving to the next
+// block only loads the few columns that entered the window (banded / FE-ordered
+// matrices: ~rows-per-block new columns), so x is read from L2 about once per
+// workgroup instead of once per nonzero, and the per-nonzero gather becomes a
+// ds_read_b64.  A block whose columns do not fit the ring's current position
+// (span too wide, or reaching back behind the window) takes the global gather.
+// The matrix stream for block b+1 is issued before block b is reduced.
+template <int T, int NNZB, int RING>
+__global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const double* __restrict__ x,
+                                                   double* __restrict__ y, int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int b_end = min(A.nblk, b_begin + bpw);
+    if (b_begin >= b_end) return;
+
+    // ring state (wave-uniform): holds x[c] for c in [wlo, whi) at s_ring[c - base (mod RING)]
+    int wlo = 0, whi = 0, base = 0;
+    bool ring_live = false;
+
+    double c[PER], cn[PER];
+    int j[PER], jn[PER];
+    int ra = 0, re = 0, ran = 0, ren = 0;
+    bool have = false;
+
+    for (int b = b_begin; b < b_end; b++) {
+        const int2 d0 = A.blk[b], d1 = A.blk[b + 1];
+        const int r0 = d0.x, p0 = d0.y, r1 = d1.x, p1 = d1.y;
+        const int nn = p1 - p0;
+        const int myrow = r0 + tid;
+        if (nn > NNZB) { // long row: serial exact path, global gather
+            double s = 0.0;
+            for (int bs = p0; bs < p1; bs += NNZB) {
+                const int m = min(NNZB, p1 - bs);
+                __syncthreads();
+                for (int k = tid; k < m; k += T) {
+                    s_c[sk(k)] = A.coef[bs + k];
+                    s_x[sk(k)] = x[A.indcol[bs + k]];
+                }
+                __syncthreads();
+                if (tid == 0)
+                    for (int k = 0; k < m; k++) s = fma(s_c[sk(k)], s_x[sk(k)], s);
+            }
+            if (tid == 0) y[A.rowmap ? A.rowmap[r0] : r0] = s;
+            have = false;
+            continue;
+        }
+        if (!have) {
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = tid + i * T;
+                if (k < nn) {
+                    c[i] = A.coef[p0 + k];
+                    j[i] = A.indcol[p0 + k];
+                }
+            }
+            if (myrow < r1) {
+                ra = A.ptrow[myrow] - p0;
+                re = A.ptrow[myrow + 1] - p0;
+            }
+        }
+        // ---- slide the window to cover [cmin, cmax]
+        const int2 sp = A.blk_span[b];
+        const int cmin = sp.x, cmax = sp.y;
+        bool use_ring = (nn > 0) && (cmax - cmin + 1 <= RING);
+        if (use_ring) {
+            int lo = ring_live ? wlo : cmin;
+            int hi = ring_live ? whi : cmin;
+            if (cmin < lo) use_ring = false;        // reaches back behind the window
+            else {
+                if (cmin > hi) { lo = cmin; hi = cmin; } // jumped ahead: restart the window
+                const int nhi = max(hi, cmax + 1);
+                const int nlo = max(lo, nhi - RING);
+                if (cmin < nlo) use_ring = false;   // cannot hold cmin..cmax at once
+                else {
+                    if (!ring_live || lo != wlo || hi != whi) { // restarted
+                        base = (lo / RING) * RING;
+                    }
+                    while (nlo - base >= RING) base += RING;
+                    for (int cc = hi + tid; cc < nhi; cc += T) {
+                        int pos = cc - base;
+                        if (pos >= RING) pos -= RING;
+                        s_ring[pos] = x[cc];
+                    }
+                    wlo = nlo;
+                    whi = nhi;
+                    ring_live = true;
+                }
+            }
+        }
+        __syncthreads(); // ring ready; previous block's reduction is done with s_c/s_x
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = tid + i * T;
+            if (k < nn) {
+                double xv;
+                if (use_ring) {
+                    int pos = j[i] - base;
+                    if (pos >= RING) pos -= RING;
+                    xv = s_ring[pos];
+                } else {
+                    xv = x[j[i]];
+                }
+                s_c[sk(k)] = c[i];
+                s_x[sk(k)] = xv;
+            }
+        }
+        // ---- issue the matrix stream of the next block before reducing this one
+        bool have_next = false;
+        if (b + 1 < b_end) {
+            const int2 e1 = A.blk[b + 2];
+            const int np0 = p1, nr0 = r1, nr1 = e1.x, nnn = e1.y - p1;
+            if (nnn <= NNZB) {
+                have_next = true;
+#pragma unroll
+                for (int i = 0; i < PER; i++) {
+                    const int k = tid + i * T;
+                    if (k < nnn) {
+                        cn[i] = A.coef[np0 + k];
+                        jn[i] = A.indcol[np0 + k];
+                    }
+                }
+                const int nrow = nr0 + tid;
+                if (nrow < nr1) {
+                    ran = A.ptrow[nrow] - np0;
+                    ren = A.ptrow[nrow + 1] - np0;
+                }
+            }
+        }
+        __syncthreads();
+        for (int r = myrow; r < r1; r += T) {
+            if (r != myrow) {
+                ra = A.ptrow[r] - p0;
+                re = A.ptrow[r + 1] - p0;
+            }
+            double s = 0.0;
+            for (int k = ra; k < re; k++) s = fma(s_c[sk(k)], s_x[sk(k)], s);
+            y[A.rowmap ? A.rowmap[r] : r] = s;
+        }
+        if (have_next) {
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                c[i] = cn[i];
+                j[i] = jn[i];
+            }
+            ra = ran;
+            re = ren;
+        }
+        have = have_next;
+    }
+}
+
+
+// E5: stream kernel, RED = 0 simple loop | 1 batched reduce (U=8) | 2 batched (U=16) | 3 no reduce (invalid, timing only)
+template <int NNZB, int RED>
+__global__ __launch_bounds__(kWG) void spmv_csr_stream3(CsrView A, const double* __restrict__ x,
+                                                        double* __restrict__ y)
+{
+    constexpr int PER = NNZB / kWG;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    const int b = xcd_remap(blockIdx.x, A.nblk);
+    if (b >= A.nblk) return;
+    const int tid = threadIdx.x;
+    const int2 d0 = A.blk[b], d1 = A.blk[b + 1];
+    const int r0 = d0.x, p0 = d0.y, r1 = d1.x, p1 = d1.y;
+    const int nn = p1 - p0;
+    if (nn > NNZB) return; // experiment only
+    int ra = 0, re = 0;
+    const int myrow = r0 + tid;
+    if (myrow < r1) {
+        ra = A.ptrow[myrow] - p0;
+        re = A.ptrow[myrow + 1] - p0;
+    }
+    double c[PER];
+    int j[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int k = tid + i * kWG;
+        if (k < nn) {
+            c[i] = A.coef[p0 + k];
+            j[i] = A.indcol[p0 + k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int k = tid + i * kWG;
+        if (k < nn) {
+            s_c[sk(k)] = c[i];
+            s_x[sk(k)] = x[j[i]];
+        }
+    }
+    __syncthreads();
+    if (RED == 3) {
+        if (myrow < r1) y[myrow] = s_c[sk(ra)] + s_x[sk(ra)];
+        return;
+    }
+    for (int r = myrow; r < r1; r += kWG) {
+        if (r != myrow) {
+            ra = A.ptrow[r] - p0;
+            re = A.ptrow[r + 1] - p0;
+        }
+        double s = 0.0;
+        if (RED == 0) for (int k = ra; k < re; k++) s = fma(s_c[sk(k)], s_x[sk(k)], s);
+        else if (RED == 1) s = row_chain<8>(s_c, s_x, ra, re);
+        else s = row_chain<16>(s_c, s_x, ra, re);
+        y[r] = s;
+    }
+}
+
+// E6: pure "stream + gather" upper bound: no LDS, no rows; every thread folds its
+// own nonzeros (invalid SpMV, timing only).
+template <int NNZB>
+__global__ __launch_bounds__(kWG) void spmv_csr_stream_nolds(CsrView A, const double* __restrict__ x,
+                                                             double* __restrict__ y)
+{
+    constexpr int PER = NNZB / kWG;
+    const int b = xcd_remap(blockIdx.x, A.nblk);
+    if (b >= A.nblk) return;
+    const int tid = threadIdx.x;
+    const int2 d0 = A.blk[b], d1 = A.blk[b + 1];
+    const int p0 = d0.y, p1 = d1.y;
+    const int nn = p1 - p0;
+    double c[PER];
+    int j[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int k = tid + i * kWG;
+        if (k < nn) {
+            c[i] = A.coef[p0 + k];
+            j[i] = A.indcol[p0 + k];
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int k = tid + i * kWG;
+        if (k < nn) s = fma(c[i], x[j[i]], s);
+    }
+    if (d0.x + tid < d1.x) y[d0.x + tid] = s;
+}
+
+
+// ---------------------------------------------------------------------------
+// E7: ring2 — E4 with the latencies taken off the per-block critical path:
+//   * block metadata {r0, p0, cmin, cmax} of the workgroup's run is staged in LDS
+//     once (no dependent scalar global loads per block);
+//   * the matrix stream runs D blocks ahead in registers (static stage arrays,
+//     block loop unrolled by D);
+//   * the x columns entering the window for block b+1 are requested while block b
+//     is reduced and written to the ring at the top of b+1;
+//   * the row chains fetch their LDS operands 8 at a time.
+// ---------------------------------------------------------------------------
+struct RingState {
+    int wlo, whi, base;
+    bool live;
+};
+struct RingPlan {
+    bool use;
+    int lo, hi;      // columns [lo, hi) must be loaded into the ring
+    RingState next;
+};
+
+template <int RING>
+__device__ __forceinline__ RingPlan ring_plan(const RingState& st, int cmin, int cmax, int nn)
+{
+    RingPlan p;
+    p.use = false;
+    p.lo = p.hi = 0;
+    p.next = st;
+    if (nn <= 0 || cmax - cmin + 1 > RING) return p;
+    int lo = st.live ? st.wlo : cmin;
+    int hi = st.live ? st.whi : cmin;
+    bool restart = !st.live;
+    if (cmin < lo) return p;             // reaches back behind the window
+    if (cmin > hi) { lo = cmin; hi = cmin; restart = true; }
+    const int nhi = max(hi, cmax + 1);
+    const int nlo = max(lo, nhi - RING);
+    if (cmin < nlo) return p;            // cannot hold [cmin, cmax] at once
+    int base = restart ? (lo / RING) * RING : st.base;
+    while (nlo - base >= RING) base += RING;
+    p.use = true;
+    p.lo = hi;
+    p.hi = nhi;
+    p.next.wlo = nlo;
+    p.next.whi = nhi;
+    p.next.base = base;
+    p.next.live = true;
+    return p;
+}
+
+template <int RING>
+__device__ __forceinline__ int ring_pos(int c, int base)
+{
+    int pos = c - base;
+    return pos >= RING ? pos - RING : pos;
+}
+
+template <int T, int NNZB, int RING, int D>
+__global__ __launch_bounds__(T) void spmv_csr_ring2(CsrView A, const int4* __restrict__ meta,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    constexpr int MAXB = 96;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_meta[MAXB + 2];
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int b_end = min(A.nblk, b_begin + bpw);
+    if (b_begin >= b_end) return;
+
+    RingState st;
+    st.wlo = st.whi = st.base = 0;
+    st.live = false;
+
+    double c[D][PER];
+    int j[D][PER];
+    int ra[D], re[D];
+
+    for (int cb = b_begin; cb < b_end; cb += MAXB) {
+        const int nb = min(MAXB, b_end - cb);
+        __syncthreads();
+        for (int i = tid; i <= nb; i += T) s_meta[i] = meta[cb + i];
+        __syncthreads();
+
+        auto issue = [&](int lb, int s) { // matrix stream of local block lb into stage s
+            const int4 m0 = s_meta[lb], m1 = s_meta[lb + 1];
+            const int p0 = m0.y, nn = m1.y - m0.y;
+            if (nn > NNZB) return;
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = tid + i * T;
+                if (k < nn) {
+                    c[s][i] = A.coef[p0 + k];
+                    j[s][i] = A.indcol[p0 + k];
+                }
+            }
+            const int row = m0.x + tid;
+            if (row < m1.x) {
+                ra[s] = A.ptrow[row] - p0;
+                re[s] = A.ptrow[row + 1] - p0;
+            }
+        };
+
+#pragma unroll
+        for (int s = 0; s < D; s++)
+            if (s < nb) issue(s, s);
+
+        double xr = 0.0;       // prefetched ring entry for the NEXT block
+        bool xr_valid = false; // (uniform)
+
+        for (int g = 0; g < nb; g += D) {
+#pragma unroll
+            for (int s = 0; s < D; s++) {
+                const int lb = g + s;
+                if (lb < nb) {
+                    const int4 m0 = s_meta[lb], m1 = s_meta[lb + 1];
+                    const int r0 = m0.x, p0 = m0.y, r1 = m1.x, p1 = m1.y;
+                    const int nn = p1 - p0;
+                    const int myrow = r0 + tid;
+                    if (nn > NNZB) {
+                        // long row: serial exact path with the global gather
+                        double sacc = 0.0;
+                        for (int bs = p0; bs < p1; bs += NNZB) {
+                            const int m = min(NNZB, p1 - bs);
+                            __syncthreads();
+                            for (int k = tid; k < m; k += T) {
+                                s_c[sk(k)] = A.coef[bs + k];
+                                s_x[sk(k)] = x[A.indcol[bs + k]];
+                            }
+                            __syncthreads();
+                            if (tid == 0)
+                                for (int k = 0; k < m; k++) sacc = fma(s_c[sk(k)], s_x[sk(k)], sacc);
+                        }
+                        if (tid == 0) y[A.rowmap ? A.rowmap[r0] : r0] = sacc;
+                        xr_valid = false;
+                        if (lb + D < nb) issue(lb + D, s);
+                        continue;
+                    }
+                    // ---- A: bring the window over [cmin, cmax]
+                    const RingPlan pl = ring_plan<RING>(st, m0.z, m0.w, nn);
+                    if (pl.use) {
+                        if (xr_valid) {
+                            const int cc = pl.lo + tid;
+                            if (cc < pl.hi) s_ring[ring_pos<RING>(cc, pl.next.base)] = xr;
+                        } else {
+                            for (int cc = pl.lo + tid; cc < pl.hi; cc += T)
+                                s_ring[ring_pos<RING>(cc, pl.next.base)] = x[cc];
+                        }
+                        st = pl.next;
+                    }
+                    __syncthreads(); // B: ring visible; staging free again
+                    // ---- C: gather + stage
+#pragma unroll
+                    for (int i = 0; i < PER; i++) {
+                        const int k = tid + i * T;
+                        if (k < nn) {
+                            const double xv = pl.use ? s_ring[ring_pos<RING>(j[s][i], st.base)] : x[j[s][i]];
+                            s_c[sk(k)] = c[s][i];
+                            s_x[sk(k)] = xv;
+                        }
+                    }
+                    const int mra = ra[s], mre = re[s];
+                    // ---- D: refill this stage with block lb + D; request the next block's new columns
+                    if (lb + D < nb) issue(lb + D, s);
+                    xr_valid = false;
+                    if (lb + 1 < nb) {
+                        const int4 n0 = s_meta[lb + 1], n1 = s_meta[lb + 2];
+                        const int nnn = n1.y - n0.y;
+                        if (nnn <= NNZB) {
+                            const RingPlan pn = ring_plan<RING>(st, n0.z, n0.w, nnn);
+                            if (pn.use && pn.hi - pn.lo <= T) {
+                                xr_valid = true;
+                                const int cc = pn.lo + tid;
+                                if (cc < pn.hi) xr = x[cc];
+                            }
+                        }
+                    }
+                    __syncthreads(); // E: staging complete
+                    // ---- F: row chains
+                    int a = mra, e = mre;
+                    for (int r = myrow; r < r1; r += T) {
+                        if (r != myrow) {
+                            a = A.ptrow[r] - p0;
+                            e = A.ptrow[r + 1] - p0;
+                        }
+                        y[A.rowmap ? A.rowmap[r] : r] = row_chain<8>(s_c, s_x, a, e);
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// E8: ring3 — the ring kernel written the way hipcc needs it to pipeline:
+//   * every load of the steady state is UNCONDITIONAL (addresses clamped), column
+//     ids are unsigned, raw ptrow values are kept (no arithmetic on a load result
+//     near its issue), so the waitcnt pass can count: a stage's data is awaited
+//     with vmcnt((D-1) * loads_per_stage), not vmcnt(0);
+//   * the matrix stream AND the x columns entering the window run D blocks ahead
+//     (same distance, because vector memory returns in order: consuming a young
+//     load drains every older one);
+//   * one workgroup = one run of <= MAXB row blocks whose metadata sits in LDS.
+// ---------------------------------------------------------------------------
+template <int T, int NNZB, int RING, int D, int MAXB>
+__global__ __launch_bounds__(T) void spmv_csr_ring3(CsrView A, const int4* __restrict__ meta,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_meta[MAXB + 2 * D + 2];
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
+    if (nb <= 0) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int nlast = A.n - 1, clast = A.ncols - 1;
+
+    for (int i = tid; i < nb + 2 * D + 2; i += T) {
+        int4 m = meta[min(b_begin + i, A.nblk)];
+        if (i > nb) m = meta[min(b_begin + nb, A.nblk)]; // sentinels: empty blocks at the run's end
+        if (i >= nb) { m.z = 0; m.w = -1; }
+        s_meta[i] = m;
+    }
+    __syncthreads();
+
+    RingState st_cur, st_pf;
+    st_cur.wlo = st_cur.whi = st_cur.base = 0;
+    st_cur.live = false;
+    st_pf = st_cur;
+
+    double c[D][PER];
+    unsigned j[D][PER];
+    int2 pr[D];
+    double xr[D];
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_meta[lb], m1 = s_meta[lb + 1];
+        const int p0 = m0.y, nn = m1.y - m0.y;
+        const int last = max(min(nn, NNZB) - 1, 0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * T, last);
+            c[s][i] = A.coef[p0 + k];
+            j[s][i] = ucol[p0 + k];
+        }
+        const int row = min(min(m0.x + tid, max(m1.x - 1, m0.x)), nlast);
+        pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        // x columns that will enter the window when this block becomes current
+        int cc = 0;
+        if (nn <= NNZB) {
+            const RingPlan pn = ring_plan<RING>(st_pf, m0.z, m0.w, nn);
+            if (pn.use) {
+                cc = pn.lo + tid;
+                st_pf = pn.next;
+            }
+        }
+        xr[s] = x[min(cc, clast)];
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s; // lb >= nb: an empty sentinel block (keeps the load count per iteration fixed)
+            {
+                const int4 m0 = s_meta[lb], m1 = s_meta[lb + 1];
+                const int r0 = m0.x, p0 = m0.y, r1 = m1.x, p1 = m1.y;
+                const int nn = p1 - p0;
+                const int myrow = r0 + tid;
+                if (nn > NNZB) {
+                    // long row: serial exact path with the global gather
+                    double sacc = 0.0;
+                    for (int bs = p0; bs < p1; bs += NNZB) {
+                        const int m = min(NNZB, p1 - bs);
+                        __syncthreads();
+                        for (int k = tid; k < m; k += T) {
+                            s_c[sk(k)] = A.coef[bs + k];
+                            s_x[sk(k)] = x[A.indcol[bs + k]];
+                        }
+                        __syncthreads();
+                        if (tid == 0)
+                            for (int k = 0; k < m; k++) sacc = fma(s_c[sk(k)], s_x[sk(k)], sacc);
+                    }
+                    if (tid == 0) y[r0] = sacc;
+                    issue(lb + D, s);
+                    continue;
+                }
+                // ---- A: bring the window over [cmin, cmax] (same plan the prefetch made)
+                const RingPlan pl = ring_plan<RING>(st_cur, m0.z, m0.w, nn);
+                if (pl.use) {
+                    if (pl.hi - pl.lo <= T) {
+                        const int cc = pl.lo + tid;
+                        if (cc < pl.hi) s_ring[ring_pos<RING>(cc, pl.next.base)] = xr[s];
+                    } else {
+                        for (int cc = pl.lo + tid; cc < pl.hi; cc += T)
+                            s_ring[ring_pos<RING>(cc, pl.next.base)] = x[cc];
+                    }
+                    st_cur = pl.next;
+                }
+                __syncthreads(); // B: ring visible; staging free again
+                // ---- C: gather + stage
+                const int last = max(nn - 1, 0);
+                // each branch finishes its own x values into LDS: a global-gather result
+                // that stayed live across the join would make every later wait a full drain
+                if (pl.use) {
+                    double xv[PER];
+#pragma unroll
+                    for (int i = 0; i < PER; i++) xv[i] = s_ring[ring_pos<RING>((int)j[s][i], st_cur.base)];
+#pragma unroll
+                    for (int i = 0; i < PER; i++) s_x[sk(min(tid + i * T, last))] = xv[i];
+                } else {
+                    double xv[PER];
+#pragma unroll
+                    for (int i = 0; i < PER; i++) xv[i] = x[j[s][i]];
+#pragma unroll
+                    for (int i = 0; i < PER; i++) s_x[sk(min(tid + i * T, last))] = xv[i];
+                }
+#pragma unroll
+                for (int i = 0; i < PER; i++) s_c[sk(min(tid + i * T, last))] = c[s][i];
+                __builtin_amdgcn_sched_barrier(0);
+                const int mra = pr[s].x - p0, mre = pr[s].y - p0;
+                // ---- D: refill this stage with block lb + D
+                issue(lb + D, s);
+                __syncthreads(); // E: staging complete
+                // ---- F: row chains
+                if (nn > 0) {
+                    if (myrow < r1) y[myrow] = row_chain<8>(s_c, s_x, mra, mre);
+                    for (int r = myrow + T; r < r1; r += T) {
+                        const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                        y[r] = row_chain<8>(s_c, s_x, a, e);
+                    }
+                } else {
+                    for (int r = myrow; r < r1; r += T) y[r] = 0.0;
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// E9: ring4 — ring3 with every fallback moved OUT of the pipelined loop.
+// hipcc structurises if/else into two predicated regions laid out one after the
+// other, and its waitcnt pass is path-insensitive: a global gather in the "else"
+// of the hot loop makes every later wait a full drain (vmcnt(0)), even when the
+// branch is never taken.  So thread 0 first replays the ring plan over the run's
+// metadata; a run with a block the ring cannot serve (span wider than the ring,
+// a column behind the window, a row longer than a block) is handled by the plain
+// per-block code, and the pipelined loop contains ring blocks only.
+// ---------------------------------------------------------------------------
+template <int T, int NNZB>
+__device__ __forceinline__ void simple_block(const CsrView& A, const double* __restrict__ x,
+                                             double* __restrict__ y, int r0, int p0, int r1, int p1,
+                                             double* s_c, double* s_x)
+{
+    const int tid = threadIdx.x;
+    const int nn = p1 - p0;
+    __syncthreads();
+    if (nn > NNZB) {
+        double sacc = 0.0;
+        for (int bs = p0; bs < p1; bs += NNZB) {
+            const int m = min(NNZB, p1 - bs);
+            __syncthreads();
+            for (int k = tid; k < m; k += T) {
+                s_c[sk(k)] = A.coef[bs + k];
+                s_x[sk(k)] = x[A.indcol[bs + k]];
+            }
+            __syncthreads();
+            if (tid == 0)
+                for (int k = 0; k < m; k++) sacc = fma(s_c[sk(k)], s_x[sk(k)], sacc);
+        }
+        if (tid == 0) y[A.rowmap ? A.rowmap[r0] : r0] = sacc;
+        return;
+    }
+    for (int k = tid; k < nn; k += T) {
+        s_c[sk(k)] = A.coef[p0 + k];
+        s_x[sk(k)] = x[A.indcol[p0 + k]];
+    }
+    __syncthreads();
+    for (int r = r0 + tid; r < r1; r += T) {
+        const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+        y[A.rowmap ? A.rowmap[r] : r] = row_chain<8>(s_c, s_x, a, e);
+    }
+}
+
+template <int T, int NNZB, int RING, int D, int MAXB>
+__global__ __launch_bounds__(T) void spmv_csr_ring4(CsrView A, const int4* __restrict__ meta,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_meta[MAXB + 2 * D + 2];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
+    if (nb <= 0) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int nlast = A.n - 1, clast = A.ncols - 1;
+
+    for (int i = tid; i < nb + 2 * D + 2; i += T) {
+        int4 m = meta[min(b_begin + min(i, nb), A.nblk)];
+        if (i >= nb) { m.z = 0; m.w = -1; } // sentinels: empty blocks behind the run
+        s_meta[i] = m;
+    }
+    __syncthreads();
+    if (tid == 0) { // replay the window plan; the run is "ring-able" iff every non-empty block is
+        RingState st;
+        st.wlo = st.whi = st.base = 0;
+        st.live = false;
+        int ok = 1;
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_meta[lb], m1 = s_meta[lb + 1];
+            const int nn = m1.y - m0.y;
+            if (nn == 0) continue;
+            if (nn > NNZB) { ok = 0; break; }
+            const RingPlan pl = ring_plan<RING>(st, m0.z, m0.w, nn);
+            if (!pl.use) { ok = 0; break; }
+            st = pl.next;
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) {
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_meta[lb], m1 = s_meta[lb + 1];
+            simple_block<T, NNZB>(A, x, y, m0.x, m0.y, m1.x, m1.y, s_c, s_x);
+        }
+        return;
+    }
+
+    RingState st_cur, st_pf;
+    st_cur.wlo = st_cur.whi = st_cur.base = 0;
+    st_cur.live = false;
+    st_pf = st_cur;
+
+    double c[D][PER];
+    unsigned j[D][PER];
+    int2 pr[D];
+    double xr[D];
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_meta[lb], m1 = s_meta[lb + 1];
+        const int p0 = m0.y, nn = m1.y - m0.y;
+        const int last = max(nn - 1, 0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * T, last);
+            c[s][i] = A.coef[p0 + k];
+            j[s][i] = ucol[p0 + k];
+        }
+        const int row = min(min(m0.x + tid, max(m1.x - 1, m0.x)), nlast);
+        pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        // x column that will enter the window when this block becomes current
+        int cc = 0;
+        const RingPlan pn = ring_plan<RING>(st_pf, m0.z, m0.w, nn);
+        if (pn.use) {
+            cc = pn.lo + tid;
+            st_pf = pn.next;
+        }
+        xr[s] = x[min(cc, clast)];
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s; // lb >= nb: an empty sentinel block (keeps the load count per iteration fixed)
+            const int4 m0 = s_meta[lb], m1 = s_meta[lb + 1];
+            const int r0 = m0.x, p0 = m0.y, r1 = m1.x, p1 = m1.y;
+            const int nn = p1 - p0;
+            const int myrow = r0 + tid;
+            // ---- A: bring the window over [cmin, cmax] (same plan the prefetch made)
+            const RingPlan pl = ring_plan<RING>(st_cur, m0.z, m0.w, nn);
+            if (pl.use) {
+                if (pl.hi - pl.lo <= T) {
+                    const int cc = pl.lo + tid;
+                    if (cc < pl.hi) s_ring[ring_pos<RING>(cc, pl.next.base)] = xr[s];
+                } else {
+                    for (int cc = pl.lo + tid; cc < pl.hi; cc += T)
+                        s_ring[ring_pos<RING>(cc, pl.next.base)] = x[cc];
+                }
+                st_cur = pl.next;
+            }
+            __syncthreads(); // B: ring visible; staging free again
+            // ---- C: gather from the ring + stage
+            const int last = max(nn - 1, 0);
+            double xv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const unsigned pos = (unsigned)ring_pos<RING>((int)j[s][i], st_cur.base);
+                xv[i] = s_ring[min(pos, (unsigned)(RING - 1))]; // clamp: sentinel blocks gather nothing meaningful
+            }
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = sk(min(tid + i * T, last));
+                s_c[k] = c[s][i];
+                s_x[k] = xv[i];
+            }
+            const int2 prs = pr[s];
+            // ---- D: refill this stage with block lb + D
+            issue(lb + D, s);
+            __syncthreads(); // E: staging complete
+            // ---- F: row chains
+            if (myrow < r1) y[myrow] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
+            for (int r = myrow + T; r < r1; r += T) {
+                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                y[r] = row_chain<8>(s_c, s_x, a, e);
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// E10: ring5 — ring4 with the window plan PRECOMPUTED per block (host side, once
+// per matrix and launch shape) instead of replayed by every wave for every block:
+//   plan[2b]   = {first row, first nnz, rows, nnz of the block}
+//   plan[2b+1] = {first new column, number of new columns, ring base, flags}
+// flags bit0: block is served from the ring; run_ok[run] says whether the whole
+// run is (otherwise the run takes the plain per-block path).  The ring write for
+// block b+1 moves into the reduce phase of block b (it only overwrites columns
+// behind b+1's window, which b's gather — finished before the barrier — no longer
+// reads), so a block costs: barrier, gather+stage+refill, barrier, reduce+ringwrite.
+// ---------------------------------------------------------------------------
+template <int T, int NNZB, int RING, int D, int MAXB>
+__global__ __launch_bounds__(T) void spmv_csr_ring5(CsrView A, const int4* __restrict__ plan,
+                                                    const int* __restrict__ run_ok,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
+    if (nb <= 0) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int nlast = A.n - 1, clast = A.ncols - 1;
+
+    for (int i = tid; i < 2 * (nb + 2 * D + 2); i += T) {
+        const int lb = i >> 1;
+        int4 m;
+        if (lb < nb) m = plan[2 * (b_begin + lb) + (i & 1)];
+        else m = (i & 1) ? make_int4(0, 0, 0, 0) : make_int4(A.n, A.ptrow ? (int)0x7fffffff : 0, 0, 0);
+        s_plan[i] = m;
+    }
+    __syncthreads();
+    if (tid == 0) { // sentinel blocks start at the end of the run's last block (valid, padded addresses)
+        const int4 l0 = s_plan[2 * (nb - 1)];
+        for (int lb = nb; lb < nb + 2 * D + 2; lb++) s_plan[2 * lb] = make_int4(l0.x + l0.z, l0.y + l0.w, 0, 0);
+    }
+    __syncthreads();
+    if (!run_ok[gw]) {
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_plan[2 * lb];
+            simple_block<T, NNZB>(A, x, y, m0.x, m0.y, m0.x + m0.z, m0.y + m0.w, s_c, s_x);
+        }
+        return;
+    }
+
+    double c[D][PER];
+    unsigned j[D][PER];
+    int2 pr[D];
+    double xr[D];
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+        const int p0 = m0.y;
+        const int last = max(m0.w - 1, 0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * T, last);
+            c[s][i] = A.coef[p0 + k];
+            j[s][i] = ucol[p0 + k];
+        }
+        const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
+        pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        xr[s] = x[min(m1.x + tid, clast)]; // the column this thread will put into the ring for block lb
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    { // ring content for block 0 (a whole window: more than T columns)
+        const int4 q = s_plan[1];
+        for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+    }
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s; // lb >= nb: an empty sentinel block (keeps the load count per iteration fixed)
+            const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+            const int r0 = m0.x, p0 = m0.y, nrows = m0.z, nn = m0.w;
+            const int base = m1.z;
+            __syncthreads(); // ring holds block lb's window; staging is free again
+            // ---- gather from the ring + stage
+            const int last = max(nn - 1, 0);
+            double xv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const unsigned pos = (unsigned)ring_pos<RING>((int)j[s][i], base);
+                xv[i] = s_ring[min(pos, (unsigned)(RING - 1))]; // clamp: sentinel blocks gather nothing meaningful
+            }
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = sk(min(tid + i * T, last));
+                s_c[k] = c[s][i];
+                s_x[k] = xv[i];
+            }
+            const int2 prs = pr[s];
+            // ---- refill this stage with block lb + D
+            issue(lb + D, s);
+            __syncthreads(); // staging complete; nobody gathers block lb from the ring any more
+            // ---- ring entries for block lb + 1 (prefetched D blocks ago into stage (s+1)%D)
+            {
+                const int4 q = s_plan[2 * (lb + 1) + 1];
+                const double xn = xr[(s + 1) % D];
+                if (q.y <= T) {
+                    if (tid < q.y) s_ring[ring_pos<RING>(q.x + tid, q.z)] = xn;
+                } else { // window restart inside a run (a jump in the column range): synchronous refill
+                    for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+                }
+            }
+            // ---- row chains
+            const int myrow = r0 + tid;
+            if (tid < nrows) y[myrow] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
+            for (int r = myrow + T; r < r0 + nrows; r += T) {
+                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                y[r] = row_chain<8>(s_c, s_x, a, e);
+            }
+        }
+    }
+}
+
 } // namespace mi355
 
 inline void add_experimental_variants(std::vector<Variant>& vars, int n, const int* d_ptrow, const int* d_indcol,
                                       const double* d_coef, const double* d_x, double* d_y, mi355::CsrView V1k,
-                                      mi355::CsrView V2k, mi355::CsrView V4k)
+                                      mi355::CsrView V2k, mi355::CsrView V4k, const int4* M1k = nullptr,
+                                      const int4* M2k = nullptr, const int4* M4k = nullptr,
+                                      std::function<void(int, int, int, int, const int4**, const int**, int*, int*)> make_plan = nullptr)
 {
     using namespace mi355;
     (void)n; (void)d_ptrow; (void)d_indcol; (void)d_coef;
@@ -213,4 +1129,86 @@ inline void add_experimental_variants(std::vector<Variant>& vars, int n, const i
     vars.push_back({"E1 stream_v2<4096> (16B loads)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream_v2<4096>), grid8(V4k.nblk), dim3(kWG), 0, s, V4k, d_x, d_y); }});
     vars.push_back({"E2 stream<2048> no XCD remap", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream_noremap<2048>), dim3(V2k.nblk), dim3(kWG), 0, s, V2k, d_x, d_y); }});
     vars.push_back({"E3 stream<2048> NO GATHER (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream_nogather<2048>), grid8(V2k.nblk), dim3(kWG), 0, s, V2k, d_x, d_y); }});
+    {
+        auto ring_launch = [=](auto kern, CsrView V, int threads, int wgs) {
+            const int bpw = (V.nblk + wgs - 1) / wgs;
+            return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, s, V, d_x, d_y, bpw); };
+        };
+        vars.push_back({"E4 ring<512,2048,5120> 512 WGs", ring_launch(spmv_csr_ring<512, 2048, 5120>, V2k, 512, 512)});
+        vars.push_back({"E4 ring<512,2048,5120> 1024 WGs", ring_launch(spmv_csr_ring<512, 2048, 5120>, V2k, 512, 1024)});
+        vars.push_back({"E4 ring<256,2048,5120> 512 WGs", ring_launch(spmv_csr_ring<256, 2048, 5120>, V2k, 256, 512)});
+        vars.push_back({"E4 ring<256,1024,4608> 768 WGs", ring_launch(spmv_csr_ring<256, 1024, 4608>, V1k, 256, 768)});
+        vars.push_back({"E4 ring<1024,4096,8192> 256 WGs", ring_launch(spmv_csr_ring<1024, 4096, 8192>, V4k, 1024, 256)});
+        vars.push_back({"E4 ring<512,2048,5120> 2048 WGs", ring_launch(spmv_csr_ring<512, 2048, 5120>, V2k, 512, 2048)});
+    }
+    vars.push_back({"E5 stream3<2048> batched-8 reduce", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream3<2048, 1>), grid8(V2k.nblk), dim3(kWG), 0, s, V2k, d_x, d_y); }});
+    vars.push_back({"E5 stream3<2048> batched-16 reduce", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream3<2048, 2>), grid8(V2k.nblk), dim3(kWG), 0, s, V2k, d_x, d_y); }});
+    vars.push_back({"E5 stream3<4096> batched-8 reduce", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream3<4096, 1>), grid8(V4k.nblk), dim3(kWG), 0, s, V4k, d_x, d_y); }});
+    vars.push_back({"E5 stream3<4096> batched-16 reduce", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream3<4096, 2>), grid8(V4k.nblk), dim3(kWG), 0, s, V4k, d_x, d_y); }});
+    vars.push_back({"E5 stream3<1024> batched-16 reduce", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream3<1024, 2>), grid8(V1k.nblk), dim3(kWG), 0, s, V1k, d_x, d_y); }});
+    vars.push_back({"E5 stream3<2048> NO REDUCE (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream3<2048, 3>), grid8(V2k.nblk), dim3(kWG), 0, s, V2k, d_x, d_y); }});
+    vars.push_back({"E6 stream+gather, no LDS (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream_nolds<2048>), grid8(V2k.nblk), dim3(kWG), 0, s, V2k, d_x, d_y); }});
+    vars.push_back({"E6 stream+gather<4096>, no LDS (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream_nolds<4096>), grid8(V4k.nblk), dim3(kWG), 0, s, V4k, d_x, d_y); }});
+    if (M2k) {
+        auto ring2_launch = [=](auto kern, CsrView V, const int4* M, int threads, int wgs) {
+            const int bpw = (V.nblk + wgs - 1) / wgs;
+            return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, s, V, M, d_x, d_y, bpw); };
+        };
+        vars.push_back({"E7 ring2<512,2048,5120,D2> 512 WGs", ring2_launch(spmv_csr_ring2<512, 2048, 5120, 2>, V2k, M2k, 512, 512)});
+        vars.push_back({"E7 ring2<512,2048,5120,D3> 512 WGs", ring2_launch(spmv_csr_ring2<512, 2048, 5120, 3>, V2k, M2k, 512, 512)});
+        vars.push_back({"E7 ring2<512,2048,5120,D4> 512 WGs", ring2_launch(spmv_csr_ring2<512, 2048, 5120, 4>, V2k, M2k, 512, 512)});
+        vars.push_back({"E7 ring2<512,2048,5120,D3> 1024 WGs", ring2_launch(spmv_csr_ring2<512, 2048, 5120, 3>, V2k, M2k, 512, 1024)});
+        vars.push_back({"E7 ring2<256,1024,4608,D4> 768 WGs", ring2_launch(spmv_csr_ring2<256, 1024, 4608, 4>, V1k, M1k, 256, 768)});
+        vars.push_back({"E7 ring2<256,2048,5120,D2> 512 WGs", ring2_launch(spmv_csr_ring2<256, 2048, 5120, 2>, V2k, M2k, 256, 512)});
+        vars.push_back({"E7 ring2<1024,4096,5120,D2> 256 WGs", ring2_launch(spmv_csr_ring2<1024, 4096, 5120, 2>, V4k, M4k, 1024, 256)});
+        vars.push_back({"E7 ring2<1024,4096,5120,D3> 256 WGs", ring2_launch(spmv_csr_ring2<1024, 4096, 5120, 3>, V4k, M4k, 1024, 256)});
+    }
+    if (M2k) {
+        auto ring3_launch = [=](auto kern, CsrView V, const int4* M, int threads, int maxb, int min_wgs) {
+            int wgs = std::max(min_wgs, (V.nblk + maxb - 1) / maxb);
+            wgs = ((wgs + 7) / 8) * 8;
+            const int bpw = (V.nblk + wgs - 1) / wgs;
+            return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, s, V, M, d_x, d_y, bpw); };
+        };
+        vars.push_back({"E8 ring3<512,2048,5120,D2> 512 WGs", ring3_launch(spmv_csr_ring3<512, 2048, 5120, 2, 160>, V2k, M2k, 512, 160, 512)});
+        vars.push_back({"E8 ring3<512,2048,5120,D3> 512 WGs", ring3_launch(spmv_csr_ring3<512, 2048, 5120, 3, 160>, V2k, M2k, 512, 160, 512)});
+        vars.push_back({"E8 ring3<512,2048,5120,D4> 512 WGs", ring3_launch(spmv_csr_ring3<512, 2048, 5120, 4, 160>, V2k, M2k, 512, 160, 512)});
+        vars.push_back({"E8 ring3<512,2048,5120,D3> 1024 WGs", ring3_launch(spmv_csr_ring3<512, 2048, 5120, 3, 160>, V2k, M2k, 512, 160, 1024)});
+        vars.push_back({"E8 ring3<256,1024,4608,D4> 768 WGs", ring3_launch(spmv_csr_ring3<256, 1024, 4608, 4, 160>, V1k, M1k, 256, 160, 768)});
+        vars.push_back({"E8 ring3<1024,4096,5120,D2> 256 WGs", ring3_launch(spmv_csr_ring3<1024, 4096, 5120, 2, 160>, V4k, M4k, 1024, 160, 256)});
+        vars.push_back({"E8 ring3<1024,4096,5120,D3> 256 WGs", ring3_launch(spmv_csr_ring3<1024, 4096, 5120, 3, 160>, V4k, M4k, 1024, 160, 256)});
+    }
+    if (M2k) {
+        auto ring4_launch = [=](auto kern, CsrView V, const int4* M, int threads, int maxb, int min_wgs) {
+            int wgs = std::max(min_wgs, (V.nblk + maxb - 1) / maxb);
+            wgs = ((wgs + 7) / 8) * 8;
+            const int bpw = (V.nblk + wgs - 1) / wgs;
+            return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, s, V, M, d_x, d_y, bpw); };
+        };
+        vars.push_back({"E9 ring4<512,2048,5120,D2> 512 WGs", ring4_launch(spmv_csr_ring4<512, 2048, 5120, 2, 160>, V2k, M2k, 512, 160, 512)});
+        vars.push_back({"E9 ring4<512,2048,5120,D3> 512 WGs", ring4_launch(spmv_csr_ring4<512, 2048, 5120, 3, 160>, V2k, M2k, 512, 160, 512)});
+        vars.push_back({"E9 ring4<512,2048,5120,D4> 512 WGs", ring4_launch(spmv_csr_ring4<512, 2048, 5120, 4, 160>, V2k, M2k, 512, 160, 512)});
+        vars.push_back({"E9 ring4<512,2048,5120,D3> 1024 WGs", ring4_launch(spmv_csr_ring4<512, 2048, 5120, 3, 160>, V2k, M2k, 512, 160, 1024)});
+        vars.push_back({"E9 ring4<256,1024,4608,D4> 768 WGs", ring4_launch(spmv_csr_ring4<256, 1024, 4608, 4, 160>, V1k, M1k, 256, 160, 768)});
+        vars.push_back({"E9 ring4<1024,4096,5120,D2> 256 WGs", ring4_launch(spmv_csr_ring4<1024, 4096, 5120, 2, 160>, V4k, M4k, 1024, 160, 256)});
+        vars.push_back({"E9 ring4<256,2048,5120,D2> 512 WGs", ring4_launch(spmv_csr_ring4<256, 2048, 5120, 2, 160>, V2k, M2k, 256, 160, 512)});
+        vars.push_back({"E9 ring4<512,2048,5120,D2> 2048 WGs", ring4_launch(spmv_csr_ring4<512, 2048, 5120, 2, 160>, V2k, M2k, 512, 160, 2048)});
+        vars.push_back({"E9 ring4<512,2048,5120,D2> 4096 WGs", ring4_launch(spmv_csr_ring4<512, 2048, 5120, 2, 160>, V2k, M2k, 512, 160, 4096)});
+        vars.push_back({"E9 ring4<512,2048,5120,D2> 8192 WGs", ring4_launch(spmv_csr_ring4<512, 2048, 5120, 2, 160>, V2k, M2k, 512, 160, 8192)});
+    }
+    if (make_plan) {
+        // make_plan(nnzb_table(1024|2048|4096), ring, maxb, min_wgs) -> plan, run_ok, wgs, bpw
+        auto ring5_launch = [=](auto kern, CsrView V, int tab, int ring, int threads, int maxb, int min_wgs) {
+            const int4* P; const int* OK; int wgs, bpw;
+            make_plan(tab, ring, maxb, min_wgs, &P, &OK, &wgs, &bpw);
+            return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, s, V, P, OK, d_x, d_y, bpw); };
+        };
+        vars.push_back({"E10 ring5<512,2048,5120,D2> 512 WGs", ring5_launch(spmv_csr_ring5<512, 2048, 5120, 2, 160>, V2k, 2048, 5120, 512, 160, 512)});
+        vars.push_back({"E10 ring5<512,2048,5120,D3> 512 WGs", ring5_launch(spmv_csr_ring5<512, 2048, 5120, 3, 160>, V2k, 2048, 5120, 512, 160, 512)});
+        vars.push_back({"E10 ring5<256,2048,5120,D2> 512 WGs", ring5_launch(spmv_csr_ring5<256, 2048, 5120, 2, 160>, V2k, 2048, 5120, 256, 160, 512)});
+        vars.push_back({"E10 ring5<256,2048,5120,D3> 512 WGs", ring5_launch(spmv_csr_ring5<256, 2048, 5120, 3, 160>, V2k, 2048, 5120, 256, 160, 512)});
+        vars.push_back({"E10 ring5<256,1024,4352,D4> 768 WGs", ring5_launch(spmv_csr_ring5<256, 1024, 4352, 4, 160>, V1k, 1024, 4352, 256, 160, 768)});
+        vars.push_back({"E10 ring5<1024,4096,5120,D2> 256 WGs", ring5_launch(spmv_csr_ring5<1024, 4096, 5120, 2, 160>, V4k, 4096, 5120, 1024, 160, 256)});
+        vars.push_back({"E10 ring5<512,4096,5120,D2> 256 WGs", ring5_launch(spmv_csr_ring5<512, 4096, 5120, 2, 160>, V4k, 4096, 5120, 512, 160, 256)});
+    }
 }
