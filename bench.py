@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "stream_xlds", "rowpar"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
@@ -141,6 +141,7 @@ def main():
             A.set_kernel(args.kernel)
         _ = A.handle
         kernel_name = A.kernel_name()
+        ring_cfg, ring_runs, ring_bad, ring_frac = A.ring_info()
         x = torch.from_numpy(x_host).cuda()
         ys = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(k)]
         if k == 1:
@@ -157,7 +158,7 @@ def main():
         x_ext = dc.new_x_ext()
         x_ext[: dc.n_local] = torch.from_numpy(x_host).cuda()
         y = dc.new_y()
-        kernel_name = "spmv_csr_stream<2048, false, 1>" if args.kernel in ("auto", "stream") else args.kernel
+        kernel_name = "interior+boundary pieces, kernel=" + args.kernel
 
         def step():
             dc.spmv(x_ext, y)
@@ -250,6 +251,9 @@ def main():
                config=dict(workload=W["desc"], name=args.workload, n=n, nnz=nnz_global, k=k, seed="0x5EED",
                            half_bandwidth=synth.DEFAULT_W, partition=f"row-range x{world}", cold=bool(args.cold)),
                roofline=roofline, pct_hbm_roofline=round(100 * achieved / HBM_PEAK_GBS, 2))
+    if world == 1:
+        out["kernel_info"] = dict(kernel=kernel_name, ring_config=ring_cfg, runs=ring_runs, runs_on_plain_path=ring_bad,
+                                  nnz_fraction_ring=round(ring_frac, 4))
     if parity is not None:
         out["parity"] = parity
     if halo_info is not None:

@@ -56,9 +56,9 @@ typedef void* mi_stream_t;           /* hipStream_t; NULL = the default stream *
 
 /* kernel ids for mi_csr_set_kernel (all produce the same bits) */
 enum {
-    MI_KERNEL_AUTO = 0,
-    MI_KERNEL_STREAM = 1,  /* row-block CSR-stream, x gathered through L2 */
-    MI_KERNEL_STREAM_XLDS = 2, /* row-block CSR-stream, x window staged in LDS */
+    MI_KERNEL_AUTO = 0,    /* ring when the matrix's column window fits LDS, else stream */
+    MI_KERNEL_STREAM = 1,  /* row-block CSR-stream, x gathered through L1/L2 (any matrix) */
+    MI_KERNEL_RING = 2,    /* persistent workgroups, sliding x window in LDS, pipelined matrix stream */
     MI_KERNEL_ROWPAR = 3   /* one thread per row straight from global memory (reference shape; slow) */
 };
 
@@ -87,7 +87,10 @@ int mi_csr_create_mapped(int n, int ncols, const int* ptrow, const int* indcol, 
                          const int* rowmap, mi_csr_t* out);
 int mi_csr_destroy(mi_csr_t A);
 int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz);
+/* MI_KERNEL_RING on a matrix whose window does not fit is still correct (its runs take the
+ * per-block path); mi_csr_ring_info reports how much of the matrix the ring serves. */
 int mi_csr_set_kernel(mi_csr_t A, int kernel_id);
+int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable);
 int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
 /* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
 const char* mi_csr_kernel_name(mi_csr_t A);

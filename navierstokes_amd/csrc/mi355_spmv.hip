@@ -18,7 +18,9 @@
 
 #include "blas1_kernels.hpp"
 #include "partition.hpp"
+#include "ring_plan.hpp"
 #include "spmv_kernels.hpp"
+#include "spmv_ring.hpp"
 
 using namespace mi355;
 
@@ -67,7 +69,14 @@ struct BlockTable {
     int nnzb = 0;
     int nblk = 0;
     int2* d_blk = nullptr;  // [nblk+1]
-    int2* d_span = nullptr; // [nblk], built on first XLDS use
+};
+
+struct RingTable {
+    RingConfig cfg{};
+    int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0;
+    double ok_fraction = 0.0; // share of the nonzeros in ring-served runs
+    int* d_plan = nullptr; // 8 ints per block, read as two int4
+    int* d_ok = nullptr;
 };
 
 struct mi_csr_s {
@@ -80,7 +89,9 @@ struct mi_csr_s {
     int* d_rowmap = nullptr;
     std::vector<int> h_ptrow; // kept to (re)build row-block tables
     std::map<int, BlockTable> tables;
+    RingTable ring;           // valid iff ring.d_plan != nullptr
     int kernel = MI_KERNEL_AUTO;
+    int auto_kernel = MI_KERNEL_STREAM;
     // scratch for the host-pointer entry points
     double* d_x = nullptr;
     double* d_y = nullptr;
@@ -183,39 +194,7 @@ extern "C" int mi_flush_cache(void)
 }
 
 // ---------------------------------------------------------------- CSR create
-__global__ void blk_span_kernel(int nblk, const int2* __restrict__ blk, const int* __restrict__ indcol,
-                                int2* __restrict__ span)
-{
-    __shared__ int s_min[4], s_max[4];
-    const int b = blockIdx.x;
-    if (b >= nblk) return;
-    const int p0 = blk[b].y, p1 = blk[b + 1].y;
-    int lo = INT32_MAX, hi = -1;
-    for (int k = p0 + threadIdx.x; k < p1; k += blockDim.x) {
-        const int c = indcol[k];
-        lo = min(lo, c);
-        hi = max(hi, c);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        lo = min(lo, __shfl_down(lo, off, 64));
-        hi = max(hi, __shfl_down(hi, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_min[threadIdx.x >> 6] = lo;
-        s_max[threadIdx.x >> 6] = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) {
-            lo = min(lo, s_min[w]);
-            hi = max(hi, s_max[w]);
-        }
-        if (hi < 0) { lo = 0; hi = 0; }
-        span[b] = make_int2(lo, hi);
-    }
-}
-
-static int get_table(mi_csr_t A, int nnzb, bool want_span, BlockTable** out)
+static int get_table(mi_csr_t A, int nnzb, BlockTable** out)
 {
     BlockTable& T = A->tables[nnzb];
     if (!T.d_blk) {
@@ -227,12 +206,6 @@ static int get_table(mi_csr_t A, int nnzb, bool want_span, BlockTable** out)
         for (size_t i = 0; i < rows.size(); i++) h[i] = make_int2(rows[i], ptrs[i]);
         HIP_TRY(hipMalloc(&T.d_blk, sizeof(int2) * h.size()));
         HIP_TRY(hipMemcpy(T.d_blk, h.data(), sizeof(int2) * h.size(), hipMemcpyHostToDevice));
-    }
-    if (want_span && !T.d_span && T.nblk > 0) {
-        HIP_TRY(hipMalloc(&T.d_span, sizeof(int2) * T.nblk));
-        hipLaunchKernelGGL(blk_span_kernel, dim3(T.nblk), dim3(256), 0, 0, T.nblk, T.d_blk, A->d_indcol, T.d_span);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
     }
     *out = &T;
     return MI_OK;
@@ -249,8 +222,18 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
     for (int i = 0; i < n; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
     const long long nnz = ptrow[n];
     CHECK_ARG(nnz == 0 || (indcol && coef), "indcol/coef is null");
-    for (long long k = 0; k < nnz; k++)
-        CHECK_ARG(indcol[k] >= 0 && indcol[k] < ncols, "column index outside [0, ncols)");
+    std::vector<int> row_min((size_t)n), row_max((size_t)n);
+    for (int i = 0; i < n; i++) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) {
+            const int c = indcol[k];
+            CHECK_ARG(c >= 0 && c < ncols, "column index outside [0, ncols)");
+            lo = c < lo ? c : lo;
+            hi = c > hi ? c : hi;
+        }
+        row_min[i] = lo;
+        row_max[i] = hi;
+    }
     int rc = need_device();
     if (rc) return rc;
 
@@ -288,6 +271,46 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         TRY_OR_CLEAN(hipMalloc(&A->d_rowmap, sizeof(int) * (size_t)n));
         TRY_OR_CLEAN(hipMemcpy(A->d_rowmap, rowmap, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     }
+    // window plan of the ring kernel: first configuration (in preference order) that
+    // serves at least 90 % of the nonzeros; MI355_RING_CONFIG=1|2|3 forces one
+    if (n > 0 && nnz > 0) {
+        int order[3] = {2, 3, 1};
+        int forced = 0;
+        if (const char* e = getenv("MI355_RING_CONFIG")) forced = atoi(e);
+        RingPlanHost best;
+        bool have = false;
+        for (int t = 0; t < 3 && !have; t++) {
+            const int id = forced >= 1 && forced <= 3 ? forced : order[t];
+            RingPlanHost P;
+            build_ring_plan(kRingConfigs[id - 1], n, ptrow, row_min.data(), row_max.data(), P);
+            const double okf = 1.0 - (double)P.bad_nnz / (double)nnz;
+            if (forced || okf >= 0.90 || (t == 2 && false)) {
+                best = std::move(P);
+                have = true;
+            } else if (t == 0) {
+                best = std::move(P); // remember the preferred one for explicit MI_KERNEL_RING requests
+            }
+            if (forced) break;
+        }
+        A->ring.cfg = best.cfg;
+        A->ring.nblk = best.nblk;
+        A->ring.wgs = best.wgs;
+        A->ring.bpw = best.bpw;
+        A->ring.bad_runs = best.bad_runs;
+        A->ring.ok_fraction = 1.0 - (double)best.bad_nnz / (double)nnz;
+        if (best.nblk > 0) {
+            TRY_OR_CLEAN(hipMalloc(&A->ring.d_plan, sizeof(int) * best.plan.size()));
+            TRY_OR_CLEAN(hipMemcpy(A->ring.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
+            TRY_OR_CLEAN(hipMalloc(&A->ring.d_ok, sizeof(int) * best.run_ok.size()));
+            TRY_OR_CLEAN(hipMemcpy(A->ring.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
+        }
+        A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
+    }
+    if (const char* e = getenv("MI355_SPMV_KERNEL")) {
+        if (!strcmp(e, "stream")) A->auto_kernel = MI_KERNEL_STREAM;
+        else if (!strcmp(e, "ring") && A->ring.d_plan) A->auto_kernel = MI_KERNEL_RING;
+        else if (!strcmp(e, "rowpar")) A->auto_kernel = MI_KERNEL_ROWPAR;
+    }
 #undef TRY_OR_CLEAN
     *out = A;
     return MI_OK;
@@ -316,8 +339,9 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     for (double* p : A->d_pow) dfree(p);
     for (auto& kv : A->tables) {
         dfree(kv.second.d_blk);
-        dfree(kv.second.d_span);
     }
+    dfree(A->ring.d_plan);
+    dfree(A->ring.d_ok);
     delete A;
     return MI_OK;
 }
@@ -333,8 +357,19 @@ extern "C" int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz)
 
 static int resolve_kernel(const mi_csr_s* A)
 {
-    if (A->kernel != MI_KERNEL_AUTO) return A->kernel;
-    return MI_KERNEL_STREAM;
+    int k = A->kernel != MI_KERNEL_AUTO ? A->kernel : A->auto_kernel;
+    if (k == MI_KERNEL_RING && !A->ring.d_plan) k = MI_KERNEL_STREAM; // empty matrix: nothing to plan
+    return k;
+}
+
+extern "C" int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable)
+{
+    CHECK_ARG(A, "null handle");
+    if (config_id) *config_id = A->ring.cfg.id;
+    if (runs) *runs = A->ring.wgs;
+    if (runs_not_ringable) *runs_not_ringable = A->ring.bad_runs;
+    if (nnz_fraction_ringable) *nnz_fraction_ringable = A->ring.ok_fraction;
+    return MI_OK;
 }
 
 extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
@@ -356,19 +391,34 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
 {
     if (!A) return "";
     switch (resolve_kernel(A)) {
-    case MI_KERNEL_STREAM: return "spmv_csr_stream<2048, false, 1>";
-    case MI_KERNEL_STREAM_XLDS: return "spmv_csr_stream<2048, true, 5632>";
+    case MI_KERNEL_STREAM: return "spmv_csr_stream<1024>";
+    case MI_KERNEL_RING:
+        switch (A->ring.cfg.id) {
+        case 1: return A->d_rowmap ? "spmv_csr_ring<512, 2048, 5120, 2, 160, true>" : "spmv_csr_ring<512, 2048, 5120, 2, 160, false>";
+        case 2: return A->d_rowmap ? "spmv_csr_ring<512, 4096, 5120, 2, 160, true>" : "spmv_csr_ring<512, 4096, 5120, 2, 160, false>";
+        default: return A->d_rowmap ? "spmv_csr_ring<512, 4096, 11264, 2, 160, true>" : "spmv_csr_ring<512, 4096, 11264, 2, 160, false>";
+        }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
     default: return "";
     }
 }
 
 // ---------------------------------------------------------------- SpMV launch
+template <int T, int NNZB, int RING, int D>
+static void launch_ring(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
+{
+    if (A->d_rowmap)
+        hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, true>), dim3(A->ring.wgs), dim3(T), 0, s, V,
+                           reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, d_x, d_y, A->ring.bpw);
+    else
+        hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, false>), dim3(A->ring.wgs), dim3(T), 0, s, V,
+                           reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, d_x, d_y, A->ring.bpw);
+}
+
 static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s)
 {
     if (A->n == 0) return MI_OK;
-    int kid = resolve_kernel(A);
-    if (kid == MI_KERNEL_STREAM_XLDS && (((uintptr_t)d_x) & 15)) kid = MI_KERNEL_STREAM; // 16-B loads of x need alignment
+    const int kid = resolve_kernel(A);
     CsrView V;
     V.n = A->n;
     V.ncols = A->ncols;
@@ -381,18 +431,21 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
     V.nblk = 0;
     if (kid == MI_KERNEL_ROWPAR) {
         hipLaunchKernelGGL(spmv_csr_rowpar, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y);
+    } else if (kid == MI_KERNEL_RING) {
+        V.nblk = A->ring.nblk;
+        switch (A->ring.cfg.id) {
+        case 1: launch_ring<512, 2048, 5120, 2>(A, V, d_x, d_y, s); break;
+        case 2: launch_ring<512, 4096, 5120, 2>(A, V, d_x, d_y, s); break;
+        default: launch_ring<512, 4096, 11264, 2>(A, V, d_x, d_y, s); break;
+        }
     } else {
         BlockTable* T = nullptr;
-        int rc = get_table(A, 2048, kid == MI_KERNEL_STREAM_XLDS, &T);
+        int rc = get_table(A, 1024, &T);
         if (rc) return rc;
         V.blk = T->d_blk;
-        V.blk_span = T->d_span;
         V.nblk = T->nblk;
         const int grid = kNXCD * ((T->nblk + kNXCD - 1) / kNXCD);
-        if (kid == MI_KERNEL_STREAM_XLDS)
-            hipLaunchKernelGGL((spmv_csr_stream<2048, true, 5632>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
-        else
-            hipLaunchKernelGGL((spmv_csr_stream<2048, false, 1>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+        hipLaunchKernelGGL((spmv_csr_stream<1024>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;

@@ -1,0 +1,100 @@
+// ring_plan.hpp — host-side (no HIP) construction of the per-block window plan that
+// the ring kernel (spmv_ring.hpp) replays.  Pure integer work, done once per
+// matrix at mi_csr_create; testable on a CPU-only machine.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "partition.hpp"
+
+namespace mi355 {
+
+struct RingConfig {
+    int id;      // 1, 2, 3 (see kRingConfigs)
+    int threads; // T
+    int nnzb;    // nonzeros per row block
+    int ring;    // doubles of x window in LDS
+    int depth;   // D, blocks of prefetch
+    int wg_unit; // workgroups per "wave" of the launch: 256 CUs x resident workgroups per CU
+};
+
+constexpr int kRingMaxB = 160; // blocks per run (LDS plan capacity)
+
+// 1: two workgroups per CU (74 KB LDS each); 2: one per CU, bigger blocks (108 KB);
+// 3: one per CU with the widest window that still fits 160 KB (for wider bands).
+static const RingConfig kRingConfigs[3] = {
+    {1, 512, 2048, 5120, 2, 512},
+    {2, 512, 4096, 5120, 2, 256},
+    {3, 512, 4096, 11264, 2, 256},
+};
+
+struct RingPlanHost {
+    RingConfig cfg{};
+    int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0;
+    long long bad_nnz = 0;     // nonzeros living in runs that take the plain path
+    std::vector<int> plan;     // 8 ints per block: {r0, p0, rows, nnz, new_lo, new_cnt, base, flags}
+    std::vector<int> run_ok;   // per run
+};
+
+// row_min/row_max: smallest / largest column of each row (row_min > row_max for an empty row)
+inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, const int* row_min, const int* row_max,
+                            RingPlanHost& out)
+{
+    out = RingPlanHost();
+    out.cfg = cfg;
+    std::vector<int> rows, ptrs;
+    build_row_blocks(n, ptrow, cfg.nnzb, 2 * cfg.threads, rows, ptrs);
+    const int nblk = (int)rows.size() - 1;
+    out.nblk = nblk;
+    if (nblk <= 0) return;
+    int wgs = cfg.wg_unit * ((nblk + kRingMaxB * cfg.wg_unit - 1) / (kRingMaxB * cfg.wg_unit));
+    if (wgs < cfg.wg_unit) wgs = cfg.wg_unit;
+    const int bpw = (nblk + wgs - 1) / wgs;
+    out.wgs = wgs;
+    out.bpw = bpw;
+    out.plan.assign((size_t)8 * nblk, 0);
+    out.run_ok.assign(wgs, 1);
+    const int ring = cfg.ring;
+    for (int g = 0; g < wgs; g++) {
+        int wlo = 0, whi = 0, base = 0;
+        bool live = false;
+        long long run_nnz = 0;
+        bool ok = true;
+        for (int b = g * bpw; b < std::min(nblk, (g + 1) * bpw); b++) {
+            const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b];
+            int* P = &out.plan[(size_t)8 * b];
+            P[0] = rows[b]; P[1] = ptrs[b]; P[2] = nrows; P[3] = nn;
+            P[4] = 0; P[5] = 0; P[6] = base; P[7] = 0;
+            run_nnz += nn;
+            if (nn == 0) continue;
+            int cmin = 0x7fffffff, cmax = -1;
+            for (int r = rows[b]; r < rows[b + 1]; r++)
+                if (row_min[r] <= row_max[r]) { cmin = std::min(cmin, row_min[r]); cmax = std::max(cmax, row_max[r]); }
+            bool use = nn <= cfg.nnzb && (cmax - cmin + 1 <= ring);
+            if (use) {
+                int lo = live ? wlo : cmin, hi = live ? whi : cmin;
+                bool restart = !live;
+                if (cmin < lo) use = false; // reaches back behind the window
+                else {
+                    if (cmin > hi) { lo = cmin; hi = cmin; restart = true; } // jumped ahead: restart the window
+                    const int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
+                    if (cmin < nlo) use = false; // cannot hold [cmin, cmax] at once
+                    else {
+                        if (restart) base = (lo / ring) * ring;
+                        while (nlo - base >= ring) base += ring;
+                        P[4] = hi; P[5] = nhi - hi; P[6] = base; P[7] = 1;
+                        wlo = nlo; whi = nhi; live = true;
+                    }
+                }
+            }
+            if (!use) ok = false;
+        }
+        if (!ok) {
+            out.run_ok[g] = 0;
+            out.bad_runs++;
+            out.bad_nnz += run_nnz;
+        }
+    }
+}
+
+} // namespace mi355

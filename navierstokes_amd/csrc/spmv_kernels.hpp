@@ -23,11 +23,9 @@
 // the rows and the x window it gathers from stays in ITS L2 instead of being
 // pulled into all eight.
 //
-// Kernel "stream_xlds": same, plus the x window [cmin, cmax] of the row block
-// is first staged into LDS with coalesced 16-byte loads and the gather is served
-// by ds_read_b64 instead of 64 divergent global requests per wave instruction.
-// Used when the block's column span fits the LDS budget (banded / FE-ordered
-// matrices); blocks whose span is too wide take the global gather.
+// The gather is what bounds this kernel (~3.0-3.4 TB/s algorithmic on MI355X): for
+// matrices whose column window fits LDS the ring kernel of spmv_ring.hpp, which
+// serves the gather from a sliding LDS window, is the one that gets launched.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,8 +43,8 @@ struct CsrView {
     const int* indcol;     // [nnz]
     const double* coef;    // [nnz]
     const int* rowmap;     // [n] or nullptr: row r writes y[rowmap[r]]
-    const int2* blk;       // [nblk+1] {first row, first nnz}; blk[nblk] = {n, nnz}
-    const int2* blk_span;  // [nblk] {min col, max col} of the block (stream_xlds)
+    const int2* blk;       // [nblk+1] {first row, first nnz}; blk[nblk] = {n, nnz} (stream kernel)
+    const int2* blk_span;  // unused by the product kernels (kept for tools/kbench experiments)
     int nblk;
 };
 
@@ -62,7 +60,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk)
 
 // ---------------------------------------------------------------------------
 // stream kernel.  NNZB: nonzeros per row block (LDS = 2 * 8 B * sk(NNZB)).
-// XLDS: stage the block's x window in LDS when it fits XWIN doubles.
 // ---------------------------------------------------------------------------
 // Row chain with batched operand fetch: the fma chain of a row stays strictly
 // sequential, but its LDS operands are fetched U at a time (2U ds_reads in
@@ -88,7 +85,7 @@ __device__ __forceinline__ double row_chain(const double* s_c, const double* s_x
     return s;
 }
 
-template <int NNZB, bool XLDS, int XWIN>
+template <int NNZB>
 __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* __restrict__ x,
                                                        double* __restrict__ y)
 {
@@ -96,7 +93,6 @@ __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* 
     constexpr int LDSN = NNZB + NNZB / 32 + 1;
     __shared__ double s_c[LDSN];
     __shared__ double s_x[LDSN];
-    __shared__ double s_win[XLDS ? XWIN : 1];
 
     const int b = xcd_remap(blockIdx.x, A.nblk);
     if (b >= A.nblk) return;
@@ -138,28 +134,9 @@ __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* 
         // keep the three groups (stream loads | gathers | LDS stores) apart: left to
         // itself the scheduler re-fuses them into per-element load-wait-gather-wait-store
         __builtin_amdgcn_sched_barrier(0);
-        bool use_win = false;
-        int cmin = 0;
-        if (XLDS) {
-            const int2 sp = A.blk_span[b];
-            cmin = sp.x & ~1; // keep 16-byte alignment of the staged window
-            const int wlen = sp.y - cmin + 1;
-            use_win = (wlen <= XWIN);
-            if (use_win) {
-                const double2* src = reinterpret_cast<const double2*>(x + cmin);
-                const int n2 = wlen >> 1;
-                for (int t = tid; t < n2; t += kWG) {
-                    const double2 v = src[t];
-                    s_win[2 * t] = v.x;
-                    s_win[2 * t + 1] = v.y;
-                }
-                if ((wlen & 1) && tid == 0) s_win[wlen - 1] = x[cmin + wlen - 1];
-                __syncthreads();
-            }
-        }
         double xv[PER];
 #pragma unroll
-        for (int i = 0; i < PER; i++) xv[i] = (XLDS && use_win) ? s_win[j[i] - (unsigned)cmin] : x[j[i]];
+        for (int i = 0; i < PER; i++) xv[i] = x[j[i]];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < PER; i++) {

@@ -1,0 +1,212 @@
+// spmv_ring.hpp — the "ring" fp64 CSR SpMV kernel for gfx950 (MI355X): persistent
+// workgroups, a sliding x window in LDS, the matrix stream pipelined D row blocks
+// ahead in registers.  This is the kernel mi_spmv*() launches for banded /
+// FE-ordered matrices; spmv_kernels.hpp holds the general fallbacks.
+//
+// Why this shape (all numbers measured on MI355X with tools/kbench on the 5 M row /
+// 75 M nnz S15 matrix; DESIGN.md has the table):
+//   * a CSR-stream kernel that gathers x[col] from global memory tops out near
+//     3.0-3.4 TB/s algorithmic: 75 M eight-byte gathers are one L1 tag lookup each
+//     and a 64/128-byte L2 line per miss, i.e. the gather, not HBM, is the bound;
+//   * staging each row block's whole x window in LDS (non-sliding) moves 33 KB of x
+//     per 24 KB of matrix and is slower still;
+//   * so the window SLIDES: a workgroup walks a run of consecutive row blocks and
+//     keeps x[cmin_b .. cmax_b] of the current block in an LDS ring indexed by
+//     column.  Moving to block b+1 loads only the columns that entered the window
+//     (about rows-per-block of them for a banded matrix), x is read from L2 ~once
+//     per run, and every per-nonzero gather is a ds_read_b64.
+//   * the per-block latencies (HBM for the stream, L2 for the new columns) are
+//     taken off the critical path by running both D blocks ahead in registers.
+//     hipcc only pipelines this if the steady-state loop is written so that its
+//     waitcnt pass can COUNT: every load unconditional (addresses clamped, never
+//     predicated), column ids unsigned (a signed id is sign-extended right behind
+//     its load = a wait per load), raw ptrow values kept until use, a fixed number
+//     of loads per iteration (empty sentinel blocks instead of "if (b < nb)"), and
+//     NO global-memory fallback inside the loop (a structurised if/else makes every
+//     later wait a full drain).  Runs the ring cannot serve are therefore detected
+//     up front (host-side plan) and take the plain per-block path.
+//
+// Numerics: identical to every other kernel here — each row is one sequential fma
+// chain in CSR order, bit-equal to the reference's SpMV_CSR_OPT/_FMA
+// (mpk/SpMV.cpp:23-56).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spmv_kernels.hpp"
+
+namespace mi355 {
+
+// Per-block plan records, built on the host once per matrix (ring_plan.hpp):
+//   plan[2b]   = {first row, first nnz, rows, nnz}
+//   plan[2b+1] = {first new column, number of new columns, ring base, flags}
+// The ring holds column c at slot (c - base) mod RING, with base a multiple of
+// RING chosen so that c - base is in [0, 2*RING) for every column of the window.
+template <int RING>
+__device__ __forceinline__ int ring_slot(int c, int base)
+{
+    const int p = c - base;
+    return p >= RING ? p - RING : p;
+}
+
+// Plain per-block SpMV (global gather, any row length): the path of runs the ring
+// cannot serve.  Same arithmetic, no pipelining.
+template <int T, int NNZB, bool MAPPED>
+__device__ __forceinline__ void ring_simple_block(const CsrView& A, const double* __restrict__ x,
+                                                  double* __restrict__ y, int r0, int p0, int nrows, int nn,
+                                                  double* s_c, double* s_x)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (nn > NNZB) { // a single row longer than a block: chunked, chain carried by thread 0
+        double sacc = 0.0;
+        for (int bs = p0; bs < p0 + nn; bs += NNZB) {
+            const int m = min(NNZB, p0 + nn - bs);
+            __syncthreads();
+            for (int k = tid; k < m; k += T) {
+                s_c[sk(k)] = A.coef[bs + k];
+                s_x[sk(k)] = x[A.indcol[bs + k]];
+            }
+            __syncthreads();
+            if (tid == 0)
+                for (int k = 0; k < m; k++) sacc = fma(s_c[sk(k)], s_x[sk(k)], sacc);
+        }
+        if (tid == 0) y[MAPPED ? A.rowmap[r0] : r0] = sacc;
+        return;
+    }
+    for (int k = tid; k < nn; k += T) {
+        s_c[sk(k)] = A.coef[p0 + k];
+        s_x[sk(k)] = x[A.indcol[p0 + k]];
+    }
+    __syncthreads();
+    for (int r = r0 + tid; r < r0 + nrows; r += T) {
+        const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+        y[MAPPED ? A.rowmap[r] : r] = row_chain<8>(s_c, s_x, a, e);
+    }
+}
+
+// T threads, NNZB nonzeros per row block (PER = NNZB/T per thread), RING doubles of
+// x window, D blocks of prefetch, runs of at most MAXB blocks per workgroup.
+// LDS = 16 B * (NNZB + NNZB/32) staging + 8 B * RING + 32 B * (MAXB + 2D + 2) plan.
+template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED>
+__global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __restrict__ plan,
+                                                   const int* __restrict__ run_ok,
+                                                   const double* __restrict__ x, double* __restrict__ y,
+                                                   int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
+    const int tid = threadIdx.x;
+    // XCD-aware run order: workgroups with equal (blockIdx & 7) share an XCD (observed
+    // round-robin dispatch, a speed assumption only) and get neighbouring runs, so
+    // the x columns one run loads are L2 hits for the next.
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
+    if (nb <= 0) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int nlast = A.n - 1, clast = A.ncols - 1;
+
+    for (int i = tid; i < 2 * nb; i += T) s_plan[i] = plan[2 * b_begin + i];
+    __syncthreads();
+    // empty sentinel blocks behind the run: they keep the number of loads per loop
+    // iteration fixed; their (clamped) addresses stay inside the padded arrays
+    {
+        const int4 l0 = s_plan[2 * (nb - 1)];
+        const int4 sent = make_int4(l0.x + l0.z, l0.y + l0.w, 0, 0);
+        for (int i = tid; i < 2 * D + 2; i += T) {
+            s_plan[2 * (nb + i)] = sent;
+            s_plan[2 * (nb + i) + 1] = make_int4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (!run_ok[gw]) {
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_plan[2 * lb];
+            ring_simple_block<T, NNZB, MAPPED>(A, x, y, m0.x, m0.y, m0.z, m0.w, s_c, s_x);
+        }
+        return;
+    }
+
+    double c[D][PER];
+    unsigned j[D][PER];
+    int2 pr[D];   // raw ptrow pair of this thread's row in the staged block
+    double xr[D]; // the column this thread puts into the ring when the staged block becomes current
+    int rm[D];    // rowmap[row] (MAPPED only)
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+        const int p0 = m0.y;
+        const int last = max(m0.w - 1, 0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * T, last);
+            c[s][i] = A.coef[p0 + k];
+            j[s][i] = ucol[p0 + k];
+        }
+        const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
+        pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        if (MAPPED) rm[s] = A.rowmap[row];
+        xr[s] = x[min(m1.x + tid, clast)];
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    { // the whole first window (more than T columns): synchronous fill
+        const int4 q = s_plan[1];
+        for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_slot<RING>(cc, q.z)] = x[cc];
+    }
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s; // lb >= nb: an empty sentinel block
+            const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+            const int r0 = m0.x, p0 = m0.y, nrows = m0.z, nn = m0.w;
+            const int base = m1.z;
+            __syncthreads(); // ring holds block lb's window; staging is free again
+            // ---- gather from the ring, park {coef, x} in the staging arrays
+            const int last = max(nn - 1, 0);
+            double xv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const unsigned pos = (unsigned)ring_slot<RING>((int)j[s][i], base);
+                xv[i] = s_ring[min(pos, (unsigned)(RING - 1))]; // clamp: sentinel blocks gather nothing meaningful
+            }
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = sk(min(tid + i * T, last));
+                s_c[k] = c[s][i];
+                s_x[k] = xv[i];
+            }
+            const int2 prs = pr[s];
+            const int rms = MAPPED ? rm[s] : 0;
+            // ---- refill this stage with block lb + D
+            issue(lb + D, s);
+            __syncthreads(); // staging complete; nobody gathers block lb from the ring any more
+            // ---- ring entries of block lb + 1 (requested D blocks ago into stage (s+1)%D).
+            // They overwrite only columns behind lb+1's window, which lb's gather is done with.
+            {
+                const int4 q = s_plan[2 * (lb + 1) + 1];
+                const double xn = xr[(s + 1) % D];
+                if (q.y <= T) {
+                    if (tid < q.y) s_ring[ring_slot<RING>(q.x + tid, q.z)] = xn;
+                } else { // the window restarts inside the run (a jump in the column range)
+                    for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_slot<RING>(cc, q.z)] = x[cc];
+                }
+            }
+            // ---- row chains
+            if (tid < nrows) y[MAPPED ? rms : r0 + tid] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
+            for (int r = r0 + tid + T; r < r0 + nrows; r += T) { // blocks of very short rows
+                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                y[MAPPED ? A.rowmap[r] : r] = row_chain<8>(s_c, s_x, a, e);
+            }
+        }
+    }
+}
+
+} // namespace mi355

@@ -24,8 +24,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmi355spmv.so")
 
 MI_OK = 0
-KERNEL_AUTO, KERNEL_STREAM, KERNEL_STREAM_XLDS, KERNEL_ROWPAR = 0, 1, 2, 3
-KERNELS = {"auto": 0, "stream": 1, "stream_xlds": 2, "rowpar": 3}
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_RING, KERNEL_ROWPAR = 0, 1, 2, 3
+KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3}
 
 _c = ctypes
 _vp = ctypes.c_void_p
@@ -72,6 +72,7 @@ def lib():
         "mi_csr_dims": [_vp, P(i), P(i), P(ll)],
         "mi_csr_set_kernel": [_vp, i],
         "mi_csr_get_kernel": [_vp, P(i)],
+        "mi_csr_ring_info": [_vp, P(i), P(i), P(i), P(d)],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_spmk": [_vp, i, _vp, _vp],
@@ -194,6 +195,13 @@ class csrmatrix:
 
     def kernel_name(self):
         return lib().mi_csr_kernel_name(self.handle).decode()
+
+    def ring_info(self):
+        """(config id, runs, runs not served by the ring, fraction of nonzeros the ring serves)."""
+        cfg, runs, bad = _c.c_int(), _c.c_int(), _c.c_int()
+        frac = _c.c_double()
+        check(lib().mi_csr_ring_info(self.handle, _c.byref(cfg), _c.byref(runs), _c.byref(bad), _c.byref(frac)))
+        return cfg.value, runs.value, bad.value, frac.value
 
     def drop_host_arrays(self):
         """Free the host copies of indcol/coef once the device handle exists (large benches)."""

@@ -216,13 +216,11 @@ int main(int argc, char** argv)
     auto grid8 = [](int nblk) { return dim3(kNXCD * ((nblk + kNXCD - 1) / kNXCD)); };
     {
         CsrView V = view(T2k);
-        vars.push_back({"stream<2048>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<2048, false, 1>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
-        vars.push_back({"stream_xlds<2048,5632>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<2048, true, 5632>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
+        vars.push_back({"stream<2048>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<2048>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
     }
     {
         CsrView V = view(T1k);
-        vars.push_back({"stream<1024>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<1024, false, 1>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
-        vars.push_back({"stream_xlds<1024,4352>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<1024, true, 4352>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
+        vars.push_back({"stream<1024>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_stream<1024>), grid8(V.nblk), dim3(kWG), 0, s, V, d_x, d_y); }});
     }
     {
         CsrView V = view(T2k);
