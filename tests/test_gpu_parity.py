@@ -233,3 +233,39 @@ def test_full_size_properties_c2():
     # row sums: A * ones == sum of each row's coefficients (different summation order: tolerance)
     rs = np.add.reduceat(v, p[:-1])
     assert O.rel_error(rs, y2.cpu().numpy()) <= 1e-14
+
+
+def test_reference_driver_linked_against_shim(tmp_path):
+    """BASELINE config 1 stand-in (the bundled mesh/matrices are missing blobs): the
+    reference's own mpk/2SpMV.cpp main, compiled against ITS mpk/SpMV.h and linked against
+    libmpk_mi355.so instead of mpk/SpMV.cpp + mpk/utils.cpp (oracle/Makefile target
+    _ref/2spmv_mi355), run on a 268-row FE-like matrix written in PETSc's MatrixMarket layout."""
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "2spmv_mi355")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/2spmv_mi355 not built (needs /root/reference at build time)")
+    n = 268
+    p, c, v = synth.rows("sfe", n, w=40)
+    mtx = tmp_path / "matrix1_aij.mtx"
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{n} {n} {len(c)}\n")
+        rows = np.repeat(np.arange(n), np.diff(p))
+        for i, j, a in zip(rows, c, v):
+            f.write(f"{i + 1} {j + 1} {a:.17g}\n")
+    r = subprocess.run([exe, str(mtx)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"Matrix loaded: {n} rows, {len(c)} nonzeros" in r.stdout
+    errs = [float(m) for m in re.findall(r"rel err = ([0-9.eE+-]+)", r.stdout)]
+    assert len(errs) == 7, r.stdout  # 3 more CSR variants + 4 BCSR variants vs the first
+    assert max(errs) <= 1e-15, r.stdout
+    # and the numbers are right, not merely self-consistent: redo the driver's computation through the
+    # same shim-level entry points and compare with the oracle on the float32-rounded coefficients
+    nrow, ir, jc, va = O.read_mtx(str(mtx))
+    A = mpk.COO2CSR(nrow, ir, jc, va)
+    y = np.empty(n)
+    mpk.SpMV_CSR(y, np.ones(n), A)
+    assert_bit_equal(y, O.spmv(A.ptrow, A.indcol, A.coef, np.ones(n)))
