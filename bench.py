@@ -160,9 +160,12 @@ def main():
         y = dc.new_y()
         kernel_name = "interior+boundary pieces, kernel=" + args.kernel
 
+        sp = mpk._stream_ptr()  # the bench stays on one stream: look it up once, not per step
+
         def step():
-            dc.spmv(x_ext, y)
-        halo_info = dict(n_halo=dc.n_halo, n_send=dc.n_send, interior_rows=dc.n_interior, boundary_rows=dc.n_boundary)
+            dc.spmv(x_ext, y, sp)
+        halo_info = dict(n_halo=dc.n_halo, n_send=dc.n_send, interior_rows=dc.n_interior, boundary_rows=dc.n_boundary,
+                         exchange="native RCCL send/recv (mi_part_spmv_dev)" if dc.native else "torch.distributed all_to_all_single")
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 

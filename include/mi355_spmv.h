@@ -166,6 +166,24 @@ int mi_part_pack_dev(mi_part_t P, const double* d_x_ext, double* d_sendbuf, mi_s
 int mi_part_spmv_interior_dev(mi_part_t P, const double* d_x_ext, double* d_y_local, mi_stream_t s);
 int mi_part_spmv_boundary_dev(mi_part_t P, const double* d_x_ext, double* d_y_local, mi_stream_t s);
 
+/* ---- native halo exchange: RCCL point-to-point over xGMI, driven from C++ ----
+ * Optional fast path for the whole step (pack, exchange on the partition's own comm
+ * stream, interior overlapped, boundary) with no per-step host work outside this
+ * library.  librccl is resolved at run time (dlopen); when it is missing these
+ * return MI_ERR_UNSUPPORTED and the caller keeps exchanging the halos itself.
+ * Bootstrap: rank 0 obtains a 128-byte id and hands it to every rank by any
+ * side channel (bench.py: torch.distributed broadcast); then ALL ranks call
+ * mi_part_comm_init collectively. */
+#define MI_COMM_ID_BYTES 128
+int mi_comm_available(void); /* MI_OK iff librccl could be resolved in this process */
+int mi_comm_unique_id(void* id128);
+int mi_part_comm_init(mi_part_t P, const void* id128);
+/* y_local = (A x)_local: d_x_ext = [x_local | halo], the halo part is overwritten */
+int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s);
+/* development check of the RCCL plumbing on ONE GPU: a communicator of size 1 sends
+ * `count` doubles to itself through the same send/recv/stream/event code path */
+int mi_comm_selftest(int count, double* max_abs_err);
+
 #ifdef __cplusplus
 }
 #endif

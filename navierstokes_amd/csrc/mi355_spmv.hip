@@ -8,8 +8,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <new>
@@ -115,7 +118,14 @@ struct mi_part_s {
     int* d_send_idx = nullptr;
     bool finalized = false;
     int kernel = MI_KERNEL_AUTO;
+    // native exchange (mi_part_comm_init)
+    void* comm = nullptr; // ncclComm_t
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
+    double* d_sendbuf = nullptr;
 };
+
+static void part_comm_release(mi_part_s* P);
 
 // per-device reduction workspace (2 * kMaxPartials partials + 1 scalar)
 struct RedWs {
@@ -757,6 +767,156 @@ extern "C" int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y)
     return MI_OK;
 }
 
+// ---------------------------------------------------------------- RCCL, resolved at run time
+// No link-time dependency: the library must load (and plan partitions) on machines
+// without RCCL.  dlopen picks up the copy already in the process (torch's) if any.
+struct IdByValue { // ncclUniqueId, passed BY VALUE to ncclCommInitRank
+    char internal[MI_COMM_ID_BYTES];
+};
+namespace {
+struct Rccl {
+    bool tried = false, ok = false;
+    std::string why;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, IdByValue, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+} // namespace
+static Rccl g_rccl;
+static const int kNcclDouble = 8; // ncclFloat64 (rccl.h)
+
+static bool rccl_load()
+{
+    Rccl& R = g_rccl;
+    if (R.tried) return R.ok;
+    R.tried = true;
+    void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+        R.why = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found");
+        return false;
+    }
+    auto sym = [&](const char* nm) -> void* {
+        void* p = dlsym(h, nm);
+        if (!p) R.why = std::string("dlsym ") + nm + " failed";
+        return p;
+    };
+    R.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
+    R.CommInitRank = (int (*)(void**, int, IdByValue, int))sym("ncclCommInitRank");
+    R.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    R.GroupStart = (int (*)())sym("ncclGroupStart");
+    R.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    R.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+    R.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+    R.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv && R.GetErrorString;
+    return R.ok;
+}
+
+#define NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        int r_ = (expr);                                                                                \
+        if (r_ != 0) return fail(MI_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));    \
+    } while (0)
+
+static void part_comm_release(mi_part_s* P)
+{
+    if (P->comm && g_rccl.ok) g_rccl.CommDestroy(P->comm);
+    P->comm = nullptr;
+    if (P->comm_stream) (void)hipStreamDestroy(P->comm_stream);
+    if (P->ev_pack) (void)hipEventDestroy(P->ev_pack);
+    if (P->ev_comm) (void)hipEventDestroy(P->ev_comm);
+    P->comm_stream = nullptr;
+    P->ev_pack = P->ev_comm = nullptr;
+}
+
+extern "C" int mi_comm_available(void)
+{
+    if (!rccl_load()) return fail(MI_ERR_UNSUPPORTED, "RCCL unavailable: " + g_rccl.why);
+    return MI_OK;
+}
+
+extern "C" int mi_comm_unique_id(void* id128)
+{
+    CHECK_ARG(id128, "null id");
+    if (!rccl_load()) return fail(MI_ERR_UNSUPPORTED, "RCCL unavailable: " + g_rccl.why);
+    NCCL_TRY(g_rccl.GetUniqueId(id128));
+    return MI_OK;
+}
+
+// the exchange of one step, enqueued on cs: send my packed entries to every peer that
+// needs some, receive my ghosts straight into x_ext's halo region (contiguous per owner)
+static int enqueue_exchange(const PartPlan& pl, void* comm, const double* d_sendbuf, double* d_halo, hipStream_t cs)
+{
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int p = 0; p < pl.nranks; p++) {
+        if (pl.send_counts[p])
+            NCCL_TRY(g_rccl.Send(d_sendbuf + pl.send_offsets[p], (size_t)pl.send_counts[p], kNcclDouble, p, comm, cs));
+        if (pl.recv_counts[p])
+            NCCL_TRY(g_rccl.Recv(d_halo + pl.recv_offsets[p], (size_t)pl.recv_counts[p], kNcclDouble, p, comm, cs));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return MI_OK;
+}
+
+extern "C" int mi_comm_selftest(int count, double* max_abs_err)
+{
+    CHECK_ARG(count > 0 && max_abs_err, "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    if (!rccl_load()) return fail(MI_ERR_UNSUPPORTED, "RCCL unavailable: " + g_rccl.why);
+    IdByValue id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    void* comm = nullptr;
+    NCCL_TRY(g_rccl.CommInitRank(&comm, 1, id, 0));
+    PartPlan pl; // a 1-rank "partition" that sends `count` entries to itself
+    pl.nranks = 1;
+    pl.rank = 0;
+    pl.send_counts = {count};
+    pl.send_offsets = {0, count};
+    pl.recv_counts = {count};
+    pl.recv_offsets = {0, count};
+    std::vector<double> h((size_t)count), back((size_t)count);
+    for (int i = 0; i < count; i++) h[i] = 0.5 * i - 3.0;
+    double *d_src = nullptr, *d_dst = nullptr;
+    hipStream_t s0 = nullptr, cs = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipMalloc(&d_src, sizeof(double) * count));
+    HIP_TRY(hipMalloc(&d_dst, sizeof(double) * count));
+    HIP_TRY(hipStreamCreate(&s0));
+    HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(d_src, h.data(), sizeof(double) * count, hipMemcpyHostToDevice, s0));
+    HIP_TRY(hipMemsetAsync(d_dst, 0, sizeof(double) * count, s0));
+    HIP_TRY(hipEventRecord(e0, s0));
+    HIP_TRY(hipStreamWaitEvent(cs, e0, 0));
+    rc = enqueue_exchange(pl, comm, d_src, d_dst, cs);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e1, cs));
+    HIP_TRY(hipStreamWaitEvent(s0, e1, 0));
+    HIP_TRY(hipMemcpyAsync(back.data(), d_dst, sizeof(double) * count, hipMemcpyDeviceToHost, s0));
+    HIP_TRY(hipStreamSynchronize(s0));
+    double m = 0.0;
+    for (int i = 0; i < count; i++) m = std::max(m, std::fabs(back[i] - h[i]));
+    *max_abs_err = m;
+    g_rccl.CommDestroy(comm);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(cs);
+    (void)hipStreamDestroy(s0);
+    dfree(d_src);
+    dfree(d_dst);
+    return MI_OK;
+}
+
 // ---------------------------------------------------------------- partition
 extern "C" int mi_part_create(int nranks, int rank, const long long* row_starts, const int* ptrow,
                               const int* indcol_global, const double* coef, mi_part_t* out)
@@ -870,6 +1030,44 @@ extern "C" int mi_part_finalize(mi_part_t P)
     }
     P->finalized = true;
     return MI_OK;
+}
+
+extern "C" int mi_part_comm_init(mi_part_t P, const void* id128)
+{
+    CHECK_ARG(P && id128, "null argument");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    if (P->comm) return MI_OK;
+    if (!rccl_load()) return fail(MI_ERR_UNSUPPORTED, "RCCL unavailable: " + g_rccl.why);
+    IdByValue id;
+    memcpy(&id, id128, sizeof id);
+    NCCL_TRY(g_rccl.CommInitRank(&P->comm, P->plan.nranks, id, P->plan.rank));
+    HIP_TRY(hipStreamCreateWithFlags(&P->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&P->ev_pack, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&P->ev_comm, hipEventDisableTiming));
+    const size_t ns = P->plan.send_idx.size();
+    HIP_TRY(hipMalloc(&P->d_sendbuf, sizeof(double) * (ns ? ns : 1)));
+    return MI_OK;
+}
+
+extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s_)
+{
+    CHECK_ARG(P, "null handle");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    hipStream_t s = (hipStream_t)s_;
+    const PartPlan& pl = P->plan;
+    int rc;
+    if (pl.nranks > 1) {
+        if (!P->comm) return fail(MI_ERR_STATE, "mi_part_comm_init was not called");
+        // pack on s -> exchange on the comm stream (waits for the pack; overlaps the interior rows)
+        if ((rc = mi_gather_dev((int)pl.send_idx.size(), P->d_send_idx, d_x_ext, P->d_sendbuf, s))) return rc;
+        HIP_TRY(hipEventRecord(P->ev_pack, s));
+        HIP_TRY(hipStreamWaitEvent(P->comm_stream, P->ev_pack, 0));
+        if ((rc = enqueue_exchange(pl, P->comm, P->d_sendbuf, d_x_ext + pl.n_local, P->comm_stream))) return rc;
+        HIP_TRY(hipEventRecord(P->ev_comm, P->comm_stream));
+    }
+    if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;
+    if (pl.nranks > 1) HIP_TRY(hipStreamWaitEvent(s, P->ev_comm, 0));
+    return mi_spmv_dev(P->piece[1], d_x_ext, d_y_local, s);
 }
 
 extern "C" int mi_part_set_kernel(mi_part_t P, int kernel_id)

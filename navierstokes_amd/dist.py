@@ -6,9 +6,13 @@ GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on the GPU box,
 ``[row_starts[r], row_starts[r+1])`` and the same slice of x and y.  Per SpMV:
 
     1. pack      owned x entries other ranks need -> sendbuf   (HIP gather kernel)
-    2. exchange  one all_to_all_single of the packed halos      (RCCL, its own stream)
+    2. exchange  packed halos, point-to-point                   (RCCL, its own stream)
     3. interior  rows without ghost columns                     (overlaps 2.)
     4. boundary  rows with ghost columns, after the halos land
+
+Two drivers of the same step: ``mi_part_spmv_dev`` (C++, grouped ncclSend/ncclRecv
+on the partition's own stream, no per-step Python) when librccl resolves on every
+rank, else steps 1-4 from here with one ``all_to_all_single``.
 
 The planner (column relabelling, interior/boundary split, send lists) is the
 C++ code behind ``mi_part_*`` in the C-ABI; this module only moves the ids and
@@ -100,12 +104,44 @@ class DistCSR:
             if kernel is not None:
                 mpk.check(L.mi_part_set_kernel(h, mpk.KERNELS[kernel] if isinstance(kernel, str) else int(kernel)))
             self._send_idx = None
+            self.native = self._try_native_exchange()
         else:
+            self.native = False
             tot, ptr = _c.c_int(), _vp()
             mpk.check(L.mi_part_send_index(h, _c.byref(tot), _c.byref(ptr)))
             self._send_idx = (np.ctypeslib.as_array(_c.cast(ptr, _c.POINTER(_c.c_int)), shape=(tot.value,)).copy()
                               if tot.value else np.zeros(0, np.int32))
         self.sendbuf = torch.empty(max(self.n_send, 1), dtype=torch.float64, device=self.device)
+
+    def _try_native_exchange(self):
+        """Set up the C++/RCCL step (mi_part_spmv_dev).  Every decision is collective: either all
+        ranks switch to the native path or none does.  MI355_DIST_NATIVE=0 keeps torch.distributed."""
+        import os
+        if self.nranks == 1 or os.environ.get("MI355_DIST_NATIVE", "1") == "0":
+            return False
+        if dist.get_backend(self.group) != "nccl":
+            return False
+        L = mpk.lib()
+        flag = torch.tensor([1 if L.mi_comm_available() == 0 else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag) == 0:
+            return False
+        idt = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        ok0 = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if self.rank == 0:
+            buf = _c.create_string_buffer(128)
+            if L.mi_comm_unique_id(buf) == 0:
+                idt.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                ok0.fill_(1)
+        dist.broadcast(ok0, src=0, group=self.group)
+        if int(ok0) == 0:
+            return False
+        dist.broadcast(idt, src=0, group=self.group)
+        raw = bytes(idt.cpu().numpy().tobytes())
+        rc = L.mi_part_comm_init(self._h, _c.c_char_p(raw))  # collective inside RCCL
+        flag.fill_(1 if rc == 0 else 0)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag) == 1
 
     # -- host views of the two local pieces (CPU checks) -------------------------------------
     def local_piece(self, which):
@@ -133,25 +169,33 @@ class DistCSR:
         return torch.empty(max(self.n_local, 1), dtype=torch.float64, device=self.device)[: self.n_local]
 
     # -- y_local = (A x)_local ---------------------------------------------------------------------
-    def spmv(self, x_ext, y_local):
+    def spmv(self, x_ext, y_local, stream_ptr=None):
+        """y_local = (A x)_local.  x_ext = [x_local | halo]; the halo part is (re)filled here.
+        stream_ptr: raw hipStream_t of the stream torch is currently on (looked up once if omitted)."""
         L = mpk.lib()
         work = None
+        dev = self.compute is None
+        if dev:
+            sp = stream_ptr if stream_ptr is not None else mpk._stream_ptr()
+            px, py = _vp(x_ext.data_ptr()), _vp(y_local.data_ptr())
+            if self.native:  # the whole step inside the library: pack, RCCL exchange, interior, boundary
+                mpk.check(L.mi_part_spmv_dev(self._h, px, py, sp))
+                return y_local
         if self.nranks > 1:
-            if self.compute is None:
-                mpk.check(L.mi_part_pack_dev(self._h, _vp(x_ext.data_ptr()), _vp(self.sendbuf.data_ptr()), mpk._stream_ptr()))
+            if dev:
+                mpk.check(L.mi_part_pack_dev(self._h, px, _vp(self.sendbuf.data_ptr()), sp))
             elif self.n_send:
                 self.sendbuf[: self.n_send] = x_ext[torch.from_numpy(self._send_idx.astype(np.int64))]
-            halo = x_ext[self.n_local:]
-            work = dist.all_to_all_single(halo, self.sendbuf[: self.n_send], self.recv_counts, self.send_counts,
-                                          group=self.group, async_op=True)
-        if self.compute is None:
-            mpk.check(L.mi_part_spmv_interior_dev(self._h, _vp(x_ext.data_ptr()), _vp(y_local.data_ptr()), mpk._stream_ptr()))
+            work = dist.all_to_all_single(x_ext[self.n_local:], self.sendbuf[: self.n_send], self.recv_counts,
+                                          self.send_counts, group=self.group, async_op=True)
+        if dev:
+            mpk.check(L.mi_part_spmv_interior_dev(self._h, px, py, sp))
         else:
             self.compute(self, 0, x_ext, y_local)
         if work is not None:
             work.wait()  # NCCL: the current stream waits for the exchange; no host block
-        if self.compute is None:
-            mpk.check(L.mi_part_spmv_boundary_dev(self._h, _vp(x_ext.data_ptr()), _vp(y_local.data_ptr()), mpk._stream_ptr()))
+        if dev:
+            mpk.check(L.mi_part_spmv_boundary_dev(self._h, px, py, sp))
         else:
             self.compute(self, 1, x_ext, y_local)
         return y_local

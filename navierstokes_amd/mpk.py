@@ -106,6 +106,11 @@ def lib():
         "mi_part_pack_dev": [_vp, _vp, _vp, _vp],
         "mi_part_spmv_interior_dev": [_vp, _vp, _vp, _vp],
         "mi_part_spmv_boundary_dev": [_vp, _vp, _vp, _vp],
+        "mi_comm_available": [],
+        "mi_comm_unique_id": [_vp],
+        "mi_part_comm_init": [_vp, _vp],
+        "mi_part_spmv_dev": [_vp, _vp, _vp, _vp],
+        "mi_comm_selftest": [i, P(d)],
     }
     for name, argt in sigs.items():
         fn = getattr(L, name)

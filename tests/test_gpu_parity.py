@@ -269,3 +269,15 @@ def test_reference_driver_linked_against_shim(tmp_path):
     y = np.empty(n)
     mpk.SpMV_CSR(y, np.ones(n), A)
     assert_bit_equal(y, O.spmv(A.ptrow, A.indcol, A.coef, np.ones(n)))
+
+
+def test_rccl_plumbing_selftest():
+    """The native halo exchange (dlopen'ed RCCL, grouped send/recv on a side stream, event hand-offs)
+    exercised on ONE GPU: a communicator of size 1 sends to itself through the same code path."""
+    import ctypes
+    L = mpk.lib()
+    if L.mi_comm_available() != 0:
+        pytest.skip("librccl not resolvable here: " + L.mi_last_error().decode())
+    err = ctypes.c_double(-1.0)
+    mpk.check(L.mi_comm_selftest(100_000, ctypes.byref(err)))
+    assert err.value == 0.0

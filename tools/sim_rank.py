@@ -1,0 +1,51 @@
+"""Dev tool: GPU-side time of ONE rank's share of the C4 matrix at N ranks (no exchange):
+pack + interior + boundary kernels, to see what the step costs once the host is out of the way."""
+import sys, os, ctypes, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from navierstokes_amd import mpk, synth, dist as D
+from oracle import oracle as O
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+n = 5_000_000
+rs = D.balanced_row_starts(n, N)
+lo, hi = int(rs[rank]), int(rs[rank + 1])
+p, c, v = synth.rows("s15", n, lo, hi)
+L = mpk.lib()
+h = ctypes.c_void_p()
+mpk.check(L.mi_part_create(N, rank, rs.ctypes.data, p.ctypes.data, c.ctypes.data, v.ctypes.data, ctypes.byref(h)))
+nl, nh, ni, nb = (ctypes.c_int() for _ in range(4))
+mpk.check(L.mi_part_sizes(h, *(ctypes.byref(t) for t in (nl, nh, ni, nb))))
+rc = np.zeros(N, np.int32); mpk.check(L.mi_part_recv_counts(h, rc.ctypes.data))
+# pretend the neighbours ask for what a symmetric band would: my first/last rc entries
+for q in range(N):
+    cnt = int(rc[q])
+    if cnt and q != rank:
+        ids = (np.arange(cnt) + (lo if q < rank else hi - cnt)).astype(np.int64)
+        mpk.check(L.mi_part_set_send_ids(h, q, cnt, ids.ctypes.data))
+mpk.check(L.mi_part_finalize(h))
+halo_ids = np.concatenate([np.empty(0, np.int64)] + [np.empty(int(rc[q]), np.int64) for q in range(N)])
+off = 0
+for q in range(N):
+    if rc[q]:
+        mpk.check(L.mi_part_recv_ids(h, q, halo_ids[off:].ctypes.data)); off += int(rc[q])
+xe = np.concatenate([synth.x_sin(lo, hi), np.sin(0.001 * halo_ids)])
+x_ext = torch.from_numpy(xe).cuda()
+y = torch.full((nl.value,), float("nan"), dtype=torch.float64, device="cuda")
+send = torch.empty(int(rc.sum()) + 1, dtype=torch.float64, device="cuda")
+sp = mpk._stream_ptr(); vp = ctypes.c_void_p
+def step():
+    mpk.check(L.mi_part_pack_dev(h, vp(x_ext.data_ptr()), vp(send.data_ptr()), sp))
+    mpk.check(L.mi_part_spmv_interior_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp))
+    mpk.check(L.mi_part_spmv_boundary_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp))
+for _ in range(20): step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); e0.record()
+for _ in range(500): step()
+e1.record(); torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / 500 * 1e6
+cl = np.where((c >= lo) & (c < hi), c - lo, nl.value + np.searchsorted(halo_ids, c)).astype(np.int32)
+ok = np.array_equal(O.spmv(p, cl, v, xe).view(np.uint64), y.cpu().numpy().view(np.uint64))
+print(f"N={N} rank={rank} rows={nl.value} halo={nh.value} interior={ni.value} boundary={nb.value}: "
+      f"GPU {e0.elapsed_time(e1) / 500 * 1e3:.1f} us/step, host wall {wall:.1f} us/step, bitwise={ok}")
