@@ -37,6 +37,7 @@ WORKLOADS = {
     "c4": dict(kind="s15", n=5_000_000, k=1, desc="S15 synthetic CSR 5,000,000 rows x 15 nnz/row = 75,000,000 nnz, y=Ax"),
     "c2": dict(kind="s15", n=1_000_000, k=1, desc="S15 synthetic CSR 1,000,000 rows x 15 nnz/row = 15,000,000 nnz, y=Ax"),
     "c3": dict(kind="s15", n=1_000_000, k=4, desc="S15 synthetic CSR 1,000,000 rows x 15 nnz/row, k=4 matrix powers y1..y4"),
+    "tiny": dict(kind="s15", n=200_000, k=1, desc="S15 synthetic CSR 200,000 rows x 15 nnz/row (plumbing checks only)"),
 }
 
 
@@ -119,11 +120,17 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if "MI355_FORCE_DEVICE" in os.environ:  # development only: several ranks on one card
+        local_rank = int(os.environ["MI355_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     mpk.lib()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MI355_BENCH_BACKEND", "nccl")  # "gloo": development runs only
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     W = WORKLOADS[args.workload]
     n, k, kind = W["n"], W["k"], W["kind"]
@@ -165,7 +172,8 @@ def main():
         def step():
             dc.spmv(x_ext, y, sp)
         halo_info = dict(n_halo=dc.n_halo, n_send=dc.n_send, interior_rows=dc.n_interior, boundary_rows=dc.n_boundary,
-                         exchange="native RCCL send/recv (mi_part_spmv_dev)" if dc.native else "torch.distributed all_to_all_single")
+                         exchange="native RCCL send/recv (mi_part_spmv_dev)" if dc.native
+                         else ("torch.distributed all_to_all_single" if dc._nccl else "host-staged (non-NCCL backend, development)"))
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
@@ -200,8 +208,9 @@ def main():
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
     barrier()
+    red_dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     if world > 1:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tt[0]), float(tt[1])
 
@@ -230,7 +239,7 @@ def main():
             cl = np.where((c >= lo) & (c < hi), c - lo, dc.n_local + np.searchsorted(halo_ids, c)).astype(np.int32)
             yo = O.spmv(p, cl, v, xe)
             g = y.cpu().numpy()
-            bad = torch.tensor([0 if np.array_equal(yo.view(np.uint64), g.view(np.uint64)) else 1], device="cuda")
+            bad = torch.tensor([0 if np.array_equal(yo.view(np.uint64), g.view(np.uint64)) else 1], device=red_dev)
             dist.all_reduce(bad)
             parity = dict(bitwise=bool(int(bad) == 0), against="oracle fma chain on each rank's rows, halos from the generator")
             del ctypes

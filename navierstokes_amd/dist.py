@@ -79,7 +79,8 @@ class DistCSR:
             if rc[p]:
                 mpk.check(L.mi_part_recv_ids(h, p, recv_ids[off:].ctypes.data))
                 off += int(rc[p])
-        comm_dev = self.device if (dist.is_initialized() and dist.get_backend(group) == "nccl") else torch.device("cpu")
+        self._nccl = bool(dist.is_initialized() and dist.get_backend(group) == "nccl")
+        comm_dev = self.device if self._nccl else torch.device("cpu")
         if self.nranks > 1:
             t_rc = torch.tensor(self.recv_counts, dtype=torch.int64, device=comm_dev)
             t_sc = torch.empty_like(t_rc)
@@ -119,7 +120,7 @@ class DistCSR:
         import os
         if self.nranks == 1 or os.environ.get("MI355_DIST_NATIVE", "1") == "0":
             return False
-        if dist.get_backend(self.group) != "nccl":
+        if not self._nccl:
             return False
         L = mpk.lib()
         flag = torch.tensor([1 if L.mi_comm_available() == 0 else 0], dtype=torch.int32, device=self.device)
@@ -186,8 +187,16 @@ class DistCSR:
                 mpk.check(L.mi_part_pack_dev(self._h, px, _vp(self.sendbuf.data_ptr()), sp))
             elif self.n_send:
                 self.sendbuf[: self.n_send] = x_ext[torch.from_numpy(self._send_idx.astype(np.int64))]
-            work = dist.all_to_all_single(x_ext[self.n_local:], self.sendbuf[: self.n_send], self.recv_counts,
-                                          self.send_counts, group=self.group, async_op=True)
+            if dev and not self._nccl:
+                # a backend without device collectives (gloo; development runs with several ranks on
+                # one card): stage the packed halos through host memory.  Correct, not fast.
+                hs = self.sendbuf[: self.n_send].cpu()
+                hr = torch.empty(self.n_halo, dtype=torch.float64)
+                dist.all_to_all_single(hr, hs, self.recv_counts, self.send_counts, group=self.group)
+                x_ext[self.n_local:].copy_(hr)
+            else:
+                work = dist.all_to_all_single(x_ext[self.n_local:], self.sendbuf[: self.n_send], self.recv_counts,
+                                              self.send_counts, group=self.group, async_op=True)
         if dev:
             mpk.check(L.mi_part_spmv_interior_dev(self._h, px, py, sp))
         else:
@@ -207,7 +216,12 @@ class DistCSR:
         else:
             part = torch.dot(a_local, b_local).reshape(1)
         if self.nranks > 1:
-            dist.all_reduce(part, group=self.group)
+            if part.is_cuda and not self._nccl:
+                host = part.cpu()
+                dist.all_reduce(host, group=self.group)
+                part.copy_(host)
+            else:
+                dist.all_reduce(part, group=self.group)
         return part
 
     def close(self):
