@@ -264,8 +264,10 @@ def main():
                            half_bandwidth=synth.DEFAULT_W, partition=f"row-range x{world}", cold=bool(args.cold)),
                roofline=roofline, pct_hbm_roofline=round(100 * achieved / HBM_PEAK_GBS, 2))
     if world == 1:
+        tr, ts = A.tune_info()
         out["kernel_info"] = dict(kernel=kernel_name, ring_config=ring_cfg, runs=ring_runs, runs_on_plain_path=ring_bad,
-                                  nnz_fraction_ring=round(ring_frac, 4))
+                                  nnz_fraction_ring=round(ring_frac, 4),
+                                  autotune_us=dict(ring=round(tr, 1), stream=round(ts, 1)))
     if parity is not None:
         out["parity"] = parity
     if halo_info is not None:

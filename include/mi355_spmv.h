@@ -91,6 +91,12 @@ int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz);
  * per-block path); mi_csr_ring_info reports how much of the matrix the ring serves. */
 int mi_csr_set_kernel(mi_csr_t A, int kernel_id);
 int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable);
+/* MI_KERNEL_AUTO is decided by measurement: mi_csr_create times the candidate kernels (ring if
+ * >= 90 % of the nonzeros are ring-served, stream) on the new handle, a few launches each, and
+ * keeps the faster.  All kernels produce the same bits, so the choice never changes a result.
+ * Reports the measured microseconds per launch (0 = candidate not eligible / not timed).
+ * MI355_SPMV_KERNEL=ring|stream|rowpar or MI355_SPMV_AUTOTUNE=0 skip the measurement. */
+int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
 int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
 /* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
 const char* mi_csr_kernel_name(mi_csr_t A);

@@ -95,6 +95,8 @@ struct mi_csr_s {
     RingTable ring;           // valid iff ring.d_plan != nullptr
     int kernel = MI_KERNEL_AUTO;
     int auto_kernel = MI_KERNEL_STREAM;
+    double tune_us_ring = 0.0, tune_us_stream = 0.0;
+    int n_out = 0; // length of the y a launch may write (n, or max rowmap + 1)
     // scratch for the host-pointer entry points
     double* d_x = nullptr;
     double* d_y = nullptr;
@@ -221,6 +223,8 @@ static int get_table(mi_csr_t A, int nnzb, BlockTable** out)
     return MI_OK;
 }
 
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s);
+
 static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
                            const int* rowmap, mi_csr_t* out)
 {
@@ -316,10 +320,50 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         }
         A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     }
+    A->n_out = n;
+    if (rowmap)
+        for (int i = 0; i < n; i++) A->n_out = rowmap[i] + 1 > A->n_out ? rowmap[i] + 1 : A->n_out;
+    bool forced_kernel = false;
     if (const char* e = getenv("MI355_SPMV_KERNEL")) {
+        forced_kernel = true;
         if (!strcmp(e, "stream")) A->auto_kernel = MI_KERNEL_STREAM;
         else if (!strcmp(e, "ring") && A->ring.d_plan) A->auto_kernel = MI_KERNEL_RING;
         else if (!strcmp(e, "rowpar")) A->auto_kernel = MI_KERNEL_ROWPAR;
+        else forced_kernel = false;
+    }
+    const char* at = getenv("MI355_SPMV_AUTOTUNE");
+    if (!forced_kernel && !(at && !strcmp(at, "0")) && A->auto_kernel == MI_KERNEL_RING && nnz >= 200000) {
+        // measure ring vs stream on this very matrix (x = 0: timing does not depend on the values)
+        double *tx = nullptr, *ty = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        TRY_OR_CLEAN(hipMalloc(&tx, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
+        TRY_OR_CLEAN(hipMalloc(&ty, sizeof(double) * (size_t)(A->n_out > 0 ? A->n_out : 1)));
+        TRY_OR_CLEAN(hipMemset(tx, 0, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
+        TRY_OR_CLEAN(hipEventCreate(&e0));
+        TRY_OR_CLEAN(hipEventCreate(&e1));
+        const int cand[2] = {MI_KERNEL_RING, MI_KERNEL_STREAM};
+        double us[2] = {0, 0};
+        for (int c = 0; c < 2; c++) {
+            A->kernel = cand[c];
+            for (int w = 0; w < 2; w++)
+                if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+            TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+            for (int w = 0; w < 5; w++)
+                if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+            TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+            TRY_OR_CLEAN(hipEventSynchronize(e1));
+            float ms = 0.f;
+            TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+            us[c] = ms * 1e3 / 5;
+        }
+        A->kernel = MI_KERNEL_AUTO;
+        A->tune_us_ring = us[0];
+        A->tune_us_stream = us[1];
+        if (us[1] > 0 && us[1] < us[0]) A->auto_kernel = MI_KERNEL_STREAM;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        dfree(tx);
+        dfree(ty);
     }
 #undef TRY_OR_CLEAN
     *out = A;
@@ -370,6 +414,14 @@ static int resolve_kernel(const mi_csr_s* A)
     int k = A->kernel != MI_KERNEL_AUTO ? A->kernel : A->auto_kernel;
     if (k == MI_KERNEL_RING && !A->ring.d_plan) k = MI_KERNEL_STREAM; // empty matrix: nothing to plan
     return k;
+}
+
+extern "C" int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream)
+{
+    CHECK_ARG(A, "null handle");
+    if (us_ring) *us_ring = A->tune_us_ring;
+    if (us_stream) *us_stream = A->tune_us_stream;
+    return MI_OK;
 }
 
 extern "C" int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable)

@@ -136,8 +136,10 @@ struct PartPlan {
 // Row-block table of the stream kernels: consecutive rows with <= nnzb nonzeros
 // (and <= max_rows rows); a row longer than nnzb is a block of its own.
 // out: {first row, first nnz} per block plus the terminator {n, nnz}.
+// row_align > 1: block boundaries are pulled back to multiples of row_align rows where possible,
+// so that the y segment a block writes starts on a 128-byte line (row_align = 16).
 inline void build_row_blocks(int n, const int* ptrow, int nnzb, int max_rows, std::vector<int>& out_rows,
-                             std::vector<int>& out_ptr)
+                             std::vector<int>& out_ptr, int row_align = 1)
 {
     out_rows.clear();
     out_ptr.clear();
@@ -147,6 +149,10 @@ inline void build_row_blocks(int n, const int* ptrow, int nnzb, int max_rows, st
         const int p0 = ptrow[r];
         int e = r + 1; // a block always takes at least one row
         while (e < n && (e - start) < max_rows && (long long)ptrow[e + 1] - p0 <= nnzb) e++;
+        if (row_align > 1 && e < n) {
+            const int ea = (e / row_align) * row_align;
+            if (ea > start) e = ea;
+        }
         out_rows.push_back(start);
         out_ptr.push_back(p0);
         r = e;

@@ -73,6 +73,7 @@ def lib():
         "mi_csr_set_kernel": [_vp, i],
         "mi_csr_get_kernel": [_vp, P(i)],
         "mi_csr_ring_info": [_vp, P(i), P(i), P(i), P(d)],
+        "mi_csr_tune_info": [_vp, P(d), P(d)],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_spmk": [_vp, i, _vp, _vp],
@@ -207,6 +208,12 @@ class csrmatrix:
         frac = _c.c_double()
         check(lib().mi_csr_ring_info(self.handle, _c.byref(cfg), _c.byref(runs), _c.byref(bad), _c.byref(frac)))
         return cfg.value, runs.value, bad.value, frac.value
+
+    def tune_info(self):
+        """(us per launch measured for ring, for stream) at create time; zeros if not measured."""
+        a, b = _c.c_double(), _c.c_double()
+        check(lib().mi_csr_tune_info(self.handle, _c.byref(a), _c.byref(b)))
+        return a.value, b.value
 
     def drop_host_arrays(self):
         """Free the host copies of indcol/coef once the device handle exists (large benches)."""

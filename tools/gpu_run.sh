@@ -29,6 +29,13 @@ for s in "$@"; do
               step kprof_tc 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/kprof/tc -- ./tools/kbench 0 5000000 2000 1 3 "$F"
               step kprof_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/kprof/fetch -- ./tools/kbench 0 5000000 2000 1 3 "$F"
               ;;
+    kprof2)   F="${KFILTER:-ABL skeleton no y stores,ABL ring5a no reduce+gather+stage}"
+              rm -rf gpurun_out/kprof2; mkdir -p gpurun_out/kprof2
+              step kprof2_a 300 rocprofv3 --pmc SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d gpurun_out/kprof2/a -- ./tools/kbench 0 5000000 2000 1 3 "$F"
+              step kprof2_b 300 rocprofv3 --pmc TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/kprof2/b -- ./tools/kbench 0 5000000 2000 1 3 "$F"
+              step kprof2_c 300 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum --output-format csv -d gpurun_out/kprof2/c -- ./tools/kbench 0 5000000 2000 1 3 "$F"
+              step kprof2_d 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCC_TAG_STALL_sum --output-format csv -d gpurun_out/kprof2/d -- ./tools/kbench 0 5000000 2000 1 3 "$F"
+              ;;
     tests)    step tests 600 python -m pytest tests -x -q -m gpu ;;
     smoke)    step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)    step bench 400 python bench.py ;;

@@ -77,6 +77,98 @@ __global__ __launch_bounds__(512) void astream_runs_kernel(const double* __restr
     if (s == 123.456) sink[0] = s;
 }
 
+// run-organised stream with U loads of each array in flight per thread
+template <int T, int U>
+__global__ __launch_bounds__(T) void astream_runs2_kernel(const double* __restrict__ coef, const int* __restrict__ indcol,
+                                                          size_t nnz, double* __restrict__ sink)
+{
+    const size_t per = (nnz + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < nnz ? lo + per : nnz;
+    double s = 0;
+    for (size_t base = lo; base + (size_t)T * U <= hi; base += (size_t)T * U) {
+        double c[U];
+        int j[U];
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            c[i] = coef[base + threadIdx.x + (size_t)i * T];
+            j[i] = indcol[base + threadIdx.x + (size_t)i * T];
+        }
+#pragma unroll
+        for (int i = 0; i < U; i++) s += c[i] * (double)j[i];
+    }
+    if (s == 123.456) sink[0] = s;
+}
+
+// run-organised stream, software-pipelined like the ring kernels: D stages of PER loads each,
+// consume the oldest stage, refill it, repeat (FEAT bit0: clamp indices to a per-block "last";
+// bit1: one 8-byte store per thread per block; bit2: per-block metadata through LDS)
+template <int T, int PER, int D, int FEAT>
+__global__ __launch_bounds__(T) void astream_pipe_kernel(const double* __restrict__ coef, const unsigned* __restrict__ indcol,
+                                                         size_t nnz, double* __restrict__ sink, double* __restrict__ ydummy)
+{
+    __shared__ int s_meta[1024];
+    const size_t per = (nnz + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < nnz ? lo + per : nnz;
+    const int nblk = (int)((hi - lo) / ((size_t)T * PER));
+    if (FEAT & 4) {
+        for (int i = threadIdx.x; i < 1024; i += T) s_meta[i] = (T * PER - 1) - (i & 1);
+        __syncthreads();
+    }
+    double c[D][PER];
+    unsigned j[D][PER];
+    auto issue = [&](int b, int s) {
+        const size_t base = lo + (size_t)min(b, nblk - 1) * T * PER;
+        int last = T * PER - 1;
+        if (FEAT & 4) last = s_meta[b & 1023];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            int k = threadIdx.x + i * T;
+            if (FEAT & 1) k = min(k, last);
+            c[s][i] = coef[base + k];
+            j[s][i] = indcol[base + k];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    double acc = 0;
+    for (int g = 0; g < nblk; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            double t = 0;
+#pragma unroll
+            for (int i = 0; i < PER; i++) t += c[s][i] * (double)j[s][i];
+            acc += t;
+            issue(g + s + D, s);
+            if (FEAT & 2) ydummy[(size_t)blockIdx.x * T * 4 + ((g + s) & 3) * T + threadIdx.x] = t;
+            if (FEAT & 8) __builtin_nontemporal_store(t, &ydummy[(size_t)blockIdx.x * T * 4 + ((g + s) & 3) * T + threadIdx.x]);
+            if ((FEAT & 16) && threadIdx.x >= T - 64) ydummy[(size_t)blockIdx.x * T * 4 + ((g + s) & 3) * T + threadIdx.x] = t; // one wave stores
+            if ((FEAT & 32) && threadIdx.x < 273) ydummy[(size_t)blockIdx.x * T * 4 + ((g + s) & 3) * T + threadIdx.x] = t;     // 273 rows like S15
+            if ((FEAT & 64) && ((g + s) & 3) == 3) { // every 4th block, 4x the data
+                double4 v4 = make_double4(t, t, t, t);
+                *reinterpret_cast<double4*>(&ydummy[(size_t)blockIdx.x * T * 4 + threadIdx.x * 4]) = v4;
+            }
+            if ((FEAT & 256) && threadIdx.x < 273) ydummy[(size_t)blockIdx.x * 19600 + (size_t)(g + s) * 273 + threadIdx.x] = t; // fresh lines, like y
+            if ((FEAT & 512) && threadIdx.x < 273) __builtin_nontemporal_store(t, &ydummy[(size_t)blockIdx.x * 19600 + (size_t)(g + s) * 273 + threadIdx.x]);
+            if ((FEAT & 1024) && threadIdx.x < 273) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(&ydummy[(size_t)blockIdx.x * 19600 + (size_t)(g + s) * 273 + threadIdx.x]), "v"(t) : "memory"); }
+            if ((FEAT & 2048) && ((g + s) & 7) == 7) { // fresh lines, one 16 KB burst per 8 blocks
+                double4 v4 = make_double4(t, t, t, t);
+                *reinterpret_cast<double4*>(&ydummy[(size_t)blockIdx.x * 19600 + (size_t)((g + s) >> 3) * 2048 + threadIdx.x * 4]) = v4;
+            }
+            if ((FEAT & 4096) && ((g + s) & 31) == 31) { // fresh lines, 64 KB burst per 32 blocks (4 x double4 per thread)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    double4 v4 = make_double4(t, t, t, t);
+                    *reinterpret_cast<double4*>(&ydummy[(size_t)blockIdx.x * 19600 + (size_t)((g + s) >> 5) * 8192 + q * 2048 + threadIdx.x * 4]) = v4;
+                }
+            }
+            if (FEAT & 128) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(&ydummy[(size_t)blockIdx.x * T * 4 + ((g + s) & 3) * T + threadIdx.x]), "v"(t) : "memory"); }
+        }
+    }
+    if (acc == 123.456) sink[0] = acc;
+}
+
 int main(int argc, char** argv)
 {
     const int kind = argc > 1 ? atoi(argv[1]) : 0;
@@ -106,7 +198,7 @@ int main(int argc, char** argv)
     CK(hipMalloc(&d_indcol, sizeof(int) * (nnz + 64)));
     CK(hipMalloc(&d_coef, sizeof(double) * (nnz + 64)));
     CK(hipMalloc(&d_x, sizeof(double) * (n + 64)));
-    CK(hipMalloc(&d_y, sizeof(double) * n));
+    CK(hipMalloc(&d_y, sizeof(double) * ((size_t)n + 8192 * 1024))); // + scratch behind y for the unconditional-store experiment
     CK(hipMalloc(&d_sink, 64));
     CK(hipMemset(d_indcol, 0, sizeof(int) * (nnz + 64)));
     CK(hipMemset(d_coef, 0, sizeof(double) * (nnz + 64)));
@@ -152,9 +244,10 @@ int main(int argc, char** argv)
 
     // host-side window plan for the ring5 kernels
     struct HostTab { std::vector<int> rows, ptrs; std::vector<int2> span; };
+    int g_row_align = 1;
     auto host_tab = [&](int nnzb) {
         HostTab H;
-        build_row_blocks(n, ptrow.data(), nnzb, 1024, H.rows, H.ptrs);
+        build_row_blocks(n, ptrow.data(), nnzb, 1024, H.rows, H.ptrs, g_row_align);
         const int nblk = (int)H.rows.size() - 1;
         H.span.resize(nblk);
         for (int b = 0; b < nblk; b++) {
@@ -165,9 +258,11 @@ int main(int argc, char** argv)
         return H;
     };
     std::map<int, HostTab> htabs;
+    int g_stagger = 0;
     auto make_plan = [&](int nnzb, int ring, int maxb, int min_wgs, const int4** P, const int** OK, int* wgs_out, int* bpw_out) {
-        if (!htabs.count(nnzb)) htabs[nnzb] = host_tab(nnzb);
-        const HostTab& H = htabs[nnzb];
+        const int hkey = nnzb * 64 + g_row_align;
+        if (!htabs.count(hkey)) htabs[hkey] = host_tab(nnzb);
+        const HostTab& H = htabs[hkey];
         const int nblk = (int)H.rows.size() - 1;
         int wgs = std::max(min_wgs, (nblk + maxb - 1) / maxb);
         wgs = ((wgs + 7) / 8) * 8;
@@ -177,27 +272,31 @@ int main(int argc, char** argv)
         for (int g = 0; g < wgs; g++) {
             int wlo = 0, whi = 0, base = 0;
             bool live = false;
-            for (int b = g * bpw; b < std::min(nblk, (g + 1) * bpw); b++) {
+            const int b0 = g * bpw, b1 = std::min(nblk, (g + 1) * bpw), cnt = b1 - b0;
+            if (cnt <= 0) continue;
+            // processing order of the run: rotated by a per-run offset (stagger) so that the
+            // workgroups do not all sit at the same phase of their equally long runs
+            const int rot = g_stagger ? (int)(((long long)g * g_stagger) % cnt) : 0;
+            for (int pos = 0; pos < cnt; pos++) {
+                const int b = b0 + (pos + rot) % cnt; // actual block
+                const int slot = b0 + pos;             // where the kernel finds it
                 const int nn = H.ptrs[b + 1] - H.ptrs[b], nrows = H.rows[b + 1] - H.rows[b];
-                plan[2 * b] = make_int4(H.rows[b], H.ptrs[b], nrows, nn);
-                plan[2 * b + 1] = make_int4(0, 0, base, 0);
+                plan[2 * slot] = make_int4(H.rows[b], H.ptrs[b], nrows, nn);
+                plan[2 * slot + 1] = make_int4(0, 0, base, 0);
                 if (nn == 0) continue;
                 const int cmin = H.span[b].x, cmax = H.span[b].y;
                 bool use = nn <= nnzb && (cmax - cmin + 1 <= ring);
                 if (use) {
                     int lo = live ? wlo : cmin, hi = live ? whi : cmin;
                     bool restart = !live;
-                    if (cmin < lo) use = false;
+                    if (cmin < lo || cmin > hi) { lo = cmin; hi = cmin; restart = true; } // jump: restart the window
+                    const int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
+                    if (cmin < nlo) use = false;
                     else {
-                        if (cmin > hi) { lo = cmin; hi = cmin; restart = true; }
-                        const int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
-                        if (cmin < nlo) use = false;
-                        else {
-                            if (restart) base = (lo / ring) * ring;
-                            while (nlo - base >= ring) base += ring;
-                            plan[2 * b + 1] = make_int4(hi, nhi - hi, base, 1);
-                            wlo = nlo; whi = nhi; live = true;
-                        }
+                        if (restart) base = (lo / ring) * ring;
+                        while (nlo - base >= ring) base += ring;
+                        plan[2 * slot + 1] = make_int4(hi, nhi - hi, base, 1);
+                        wlo = nlo; whi = nhi; live = true;
                     }
                 }
                 if (!use) ok[g] = 0;
@@ -209,8 +308,9 @@ int main(int argc, char** argv)
         CK(hipMalloc(&dOK, sizeof(int) * ok.size()));
         CK(hipMemcpy(dOK, ok.data(), sizeof(int) * ok.size(), hipMemcpyHostToDevice));
         int nbad = 0; for (int v : ok) nbad += !v;
-        printf("plan nnzb=%d ring=%d: %d blocks, %d runs of <=%d blocks, %d runs not ring-able\n", nnzb, ring, nblk, wgs, bpw, nbad);
+        printf("plan row_align=%d stagger=%d nnzb=%d ring=%d: %d blocks, %d runs of <=%d blocks, %d runs not ring-able\n", g_row_align, g_stagger, nnzb, ring, nblk, wgs, bpw, nbad);
         *P = dP; *OK = dOK; *wgs_out = wgs; *bpw_out = bpw;
+        g_last_plan_nblk = nblk;
     };
     std::vector<Variant> vars;
     auto grid8 = [](int nblk) { return dim3(kNXCD * ((nblk + kNXCD - 1) / kNXCD)); };
@@ -226,7 +326,7 @@ int main(int argc, char** argv)
         CsrView V = view(T2k);
         vars.push_back({"rowpar", [=](hipStream_t s) { hipLaunchKernelGGL(spmv_csr_rowpar, dim3((n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y); }});
     }
-    add_experimental_variants(vars, n, d_ptrow, d_indcol, d_coef, d_x, d_y, view(T1k), view(T2k), view(T4k), T1k.d_meta, T2k.d_meta, T4k.d_meta, make_plan);
+    add_experimental_variants(vars, n, d_ptrow, d_indcol, d_coef, d_x, d_y, view(T1k), view(T2k), view(T4k), T1k.d_meta, T2k.d_meta, T4k.d_meta, make_plan, &g_stagger, &g_row_align);
 
     if (filter) {
         std::vector<Variant> keep;
@@ -255,8 +355,35 @@ int main(int argc, char** argv)
     Variant vastr{"A-stream read (coef+indcol, no gather)", [=](hipStream_t s) { hipLaunchKernelGGL(astream_kernel, dim3(256 * 8), dim3(256), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }};
 
     std::vector<Variant> calib;
-    for (int wgs : {512, 1024, 2048, 8192})
-        calib.push_back({"A-stream as " + std::to_string(wgs) + " contiguous runs", [=](hipStream_t s) { hipLaunchKernelGGL(astream_runs_kernel, dim3(wgs), dim3(512), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }});
+    for (int wgs : {256, 512, 1024, 2048, 8192})
+        calib.push_back({"A-stream as " + std::to_string(wgs) + " contiguous runs x512 thr", [=](hipStream_t s) { hipLaunchKernelGGL(astream_runs_kernel, dim3(wgs), dim3(512), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }});
+    for (int wgs : {256, 512})
+        calib.push_back({"A-stream as " + std::to_string(wgs) + " runs x1024 thr (u8)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_runs2_kernel<1024, 8>), dim3(wgs), dim3(1024), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }});
+    for (int wgs : {256, 512})
+        calib.push_back({"A-stream as " + std::to_string(wgs) + " runs x512 thr (u16)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_runs2_kernel<512, 16>), dim3(wgs), dim3(512), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }});
+    {
+        const unsigned* ucol = reinterpret_cast<const unsigned*>(d_indcol);
+        double* ydum = d_y;
+        calib.push_back({"pipe 256x512 PER8 D2", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 0>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D3", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 3, 0>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +clamp", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 1>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +store", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 2>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +nt store", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 8>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +store by last wave only", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 16>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +store 273 thr", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 32>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +store x4 every 4th", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 64>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +sc0sc1 store", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 128>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +store fresh lines (y-like)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 256>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +nt store fresh lines", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 512>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +sc0sc1nt store fresh", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 1024>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +fresh 16KB burst / 8 blocks", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 2048>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +fresh 64KB burst / 32 blocks", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 4096>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D3 +store", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 3, 2>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +ldsmeta+clamp", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 5>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +all", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 7>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 512x256 PER8 D2 +all", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<256, 8, 2, 7>), dim3(512), dim3(256), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+    }
+    calib.push_back({"A-stream as 256 runs x512 thr (u32)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_runs2_kernel<512, 32>), dim3(256), dim3(512), 0, s, d_coef, d_indcol, (size_t)nnz, d_sink); }});
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
@@ -306,6 +433,18 @@ int main(int argc, char** argv)
         printf("%-44s %9.1f %9.1f %10.1f %8.1f\n", vcopy.name.c_str(), us, mn(vcopy.ms) * 1e3, 2.0 * copy_bytes / us / 1e3, 2.0 * copy_bytes / us / 1e3 / 80.0);
         const double us2 = med(vastr.ms) * 1e3;
         printf("%-44s %9.1f %9.1f %10.1f %8.1f\n", vastr.name.c_str(), us2, mn(vastr.ms) * 1e3, 12.0 * nnz / us2 / 1e3, 12.0 * nnz / us2 / 1e3 / 80.0);
+    }
+    if (g_prof_ptr) {
+        unsigned long long h[16];
+        CK(hipMemcpy(h, g_prof_ptr, sizeof h, hipMemcpyDeviceToHost));
+        const char* names[5] = {"wait barrier1", "gather+stage", "issue loads", "wait barrier2", "ringwrite+reduce+store"};
+        for (int w = 0; w < 2; w++) {
+            double tot = 0;
+            for (int i = 0; i < 5; i++) tot += (double)h[w * 8 + i];
+            printf("ring5t phase shares, %s wave:", w == 0 ? "first (reduces rows)" : "last (no rows)");
+            for (int i = 0; i < 5; i++) printf("  %s %.1f%%", names[i], 100.0 * h[w * 8 + i] / tot);
+            printf("\n");
+        }
     }
     for (auto& v : calib) {
         const double us = med(v.ms) * 1e3;

@@ -12,6 +12,9 @@
 
 #include "spmv_kernels.hpp"
 
+static unsigned long long* g_prof_ptr = nullptr;
+static int g_last_plan_nblk = 0;
+
 struct Variant {
     std::string name;
     std::function<void(hipStream_t)> launch;
@@ -1113,13 +1116,553 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5(CsrView A, const int4* __res
     }
 }
 
+
+// ablation copy of ring5 (timing only; results invalid when ABL != 0)
+template <int T, int NNZB, int RING, int D, int MAXB, int ABL>
+__global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __restrict__ plan,
+                                                    const int* __restrict__ run_ok,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
+    constexpr int YB = (ABL & 512) ? 6144 : 1; // rows of y parked in LDS between flushes
+    __shared__ double s_yb[YB];
+    int yb_cnt = 0, yb_row0 = 0;
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
+    if (nb <= 0) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int nlast = A.n - 1, clast = A.ncols - 1;
+
+    for (int i = tid; i < 2 * (nb + 2 * D + 2); i += T) {
+        const int lb = i >> 1;
+        int4 m;
+        if (lb < nb) m = plan[2 * (b_begin + lb) + (i & 1)];
+        else m = (i & 1) ? make_int4(0, 0, 0, 0) : make_int4(A.n, A.ptrow ? (int)0x7fffffff : 0, 0, 0);
+        s_plan[i] = m;
+    }
+    __syncthreads();
+    if (tid == 0) { // sentinel blocks start at the end of the run's last block (valid, padded addresses)
+        const int4 l0 = s_plan[2 * (nb - 1)];
+        for (int lb = nb; lb < nb + 2 * D + 2; lb++) s_plan[2 * lb] = make_int4(l0.x + l0.z, l0.y + l0.w, 0, 0);
+    }
+    __syncthreads();
+    if (!run_ok[gw]) {
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_plan[2 * lb];
+            simple_block<T, NNZB>(A, x, y, m0.x, m0.y, m0.x + m0.z, m0.y + m0.w, s_c, s_x);
+        }
+        return;
+    }
+
+    double c[D][PER];
+    unsigned j[D][PER];
+    int2 pr[D];
+    double xr[D];
+    double ysum = 0.0;
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+        const int p0 = m0.y;
+        const int last = max(m0.w - 1, 0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * T, last);
+            c[s][i] = A.coef[p0 + k];
+            j[s][i] = ucol[p0 + k];
+        }
+        const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
+        if (ABL & 32) pr[s] = make_int2(p0, p0 + 15); else pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        if (ABL & 16) xr[s] = 0.0; else xr[s] = x[min(m1.x + tid, clast)];
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    { // ring content for block 0 (a whole window: more than T columns)
+        const int4 q = s_plan[1];
+        for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+    }
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s; // lb >= nb: an empty sentinel block (keeps the load count per iteration fixed)
+            const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+            const int r0 = m0.x, p0 = m0.y, nrows = m0.z, nn = m0.w;
+            const int base = m1.z;
+            if (!(ABL & 8)) __syncthreads(); // ring holds block lb's window; staging is free again
+            // ---- gather from the ring + stage
+            const int last = max(nn - 1, 0);
+            double xv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const unsigned pos = (unsigned)ring_pos<RING>((int)j[s][i], base);
+                if (ABL & 2) xv[i] = (double)pos;
+                else xv[i] = s_ring[min(pos, (unsigned)(RING - 1))];
+            }
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = sk(min(tid + i * T, last));
+                if (ABL & 4) { asm volatile("" ::"v"(c[s][i]), "v"(xv[i]), "v"(k)); }
+                else { s_c[k] = c[s][i]; s_x[k] = xv[i]; }
+            }
+            const int2 prs = pr[s];
+            // ---- refill this stage with block lb + D
+            issue(lb + D, s);
+            if (!(ABL & 8)) __syncthreads(); // staging complete; nobody gathers block lb from the ring any more
+            // ---- ring entries for block lb + 1 (prefetched D blocks ago into stage (s+1)%D)
+            {
+                const int4 q = s_plan[2 * (lb + 1) + 1];
+                const double xn = xr[(s + 1) % D];
+                if (q.y <= T) {
+                    if (tid < q.y) s_ring[ring_pos<RING>(q.x + tid, q.z)] = xn;
+                } else { // window restart inside a run (a jump in the column range): synchronous refill
+                    for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+                }
+            }
+            // ---- row chains
+            const int myrow = r0 + tid;
+            if (ABL & 64) { if (tid < nrows) ysum += (ABL & 1) ? s_c[sk(min(max(prs.x - p0, 0), NNZB - 1))] + (double)(prs.y - p0) : row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0); }
+            else if (ABL & 1) { if (tid < nrows) y[myrow] = s_c[sk(min(max(prs.x - p0, 0), NNZB - 1))] + (double)(prs.y - p0); }
+            else if (ABL & 512) { // park the block's y values in LDS; flush every few blocks with all threads
+                if (yb_cnt == 0) yb_row0 = r0;
+                if (tid < nrows) s_yb[yb_cnt + tid] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
+                yb_cnt += nrows;
+                const int nxt = s_plan[2 * (lb + 1)].z;
+                if (yb_cnt + nxt > YB || lb + 1 >= nb) {
+                    __syncthreads();
+                    for (int r = tid; r < yb_cnt; r += T) y[yb_row0 + r] = s_yb[r];
+                    yb_cnt = 0;
+                }
+            }
+            else if (ABL & 128) { // unconditional store: rowless threads write a scratch slot behind y
+                const double v = row_chain<8>(s_c, s_x, tid < nrows ? prs.x - p0 : 0, tid < nrows ? prs.y - p0 : 0);
+                double* dst = tid < nrows ? &y[myrow] : &y[(size_t)A.n + (size_t)blockIdx.x * T + tid];
+                *dst = v;
+            }
+            else if (tid < nrows) y[myrow] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
+            for (int r = myrow + T; r < r0 + nrows; r += T) {
+                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                y[r] = row_chain<8>(s_c, s_x, a, e);
+            }
+        }
+    }
+    if (ABL & 64) y[b_begin * 16 + tid] = ysum;
+}
+
+
+
+// diagnostic copy of ring5 with s_memtime stamps (shares of the block loop per phase)
+template <int T, int NNZB, int RING, int D, int MAXB>
+__global__ __launch_bounds__(T) void spmv_csr_ring5t(CsrView A, const int4* __restrict__ plan, unsigned long long* __restrict__ prof,
+                                                    const int* __restrict__ run_ok,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
+    if (nb <= 0) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int nlast = A.n - 1, clast = A.ncols - 1;
+
+    for (int i = tid; i < 2 * (nb + 2 * D + 2); i += T) {
+        const int lb = i >> 1;
+        int4 m;
+        if (lb < nb) m = plan[2 * (b_begin + lb) + (i & 1)];
+        else m = (i & 1) ? make_int4(0, 0, 0, 0) : make_int4(A.n, A.ptrow ? (int)0x7fffffff : 0, 0, 0);
+        s_plan[i] = m;
+    }
+    __syncthreads();
+    if (tid == 0) { // sentinel blocks start at the end of the run's last block (valid, padded addresses)
+        const int4 l0 = s_plan[2 * (nb - 1)];
+        for (int lb = nb; lb < nb + 2 * D + 2; lb++) s_plan[2 * lb] = make_int4(l0.x + l0.z, l0.y + l0.w, 0, 0);
+    }
+    __syncthreads();
+    if (!run_ok[gw]) {
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_plan[2 * lb];
+            simple_block<T, NNZB>(A, x, y, m0.x, m0.y, m0.x + m0.z, m0.y + m0.w, s_c, s_x);
+        }
+        return;
+    }
+
+    double c[D][PER];
+    unsigned j[D][PER];
+    int2 pr[D];
+    double xr[D];
+    long long acc[6] = {0, 0, 0, 0, 0, 0};
+    long long t0 = clock64(), t1;
+#define STAMP(i) t1 = clock64(); acc[i] += t1 - t0; t0 = t1;
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+        const int p0 = m0.y;
+        const int last = max(m0.w - 1, 0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * T, last);
+            c[s][i] = A.coef[p0 + k];
+            j[s][i] = ucol[p0 + k];
+        }
+        const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
+        pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        xr[s] = x[min(m1.x + tid, clast)]; // the column this thread will put into the ring for block lb
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    { // ring content for block 0 (a whole window: more than T columns)
+        const int4 q = s_plan[1];
+        for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+    }
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s; // lb >= nb: an empty sentinel block (keeps the load count per iteration fixed)
+            const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+            const int r0 = m0.x, p0 = m0.y, nrows = m0.z, nn = m0.w;
+            const int base = m1.z;
+            STAMP(4)
+            __syncthreads(); // ring holds block lb's window; staging is free again
+            STAMP(0)
+            // ---- gather from the ring + stage
+            const int last = max(nn - 1, 0);
+            double xv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const unsigned pos = (unsigned)ring_pos<RING>((int)j[s][i], base);
+                xv[i] = s_ring[min(pos, (unsigned)(RING - 1))]; // clamp: sentinel blocks gather nothing meaningful
+            }
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = sk(min(tid + i * T, last));
+                s_c[k] = c[s][i];
+                s_x[k] = xv[i];
+            }
+            const int2 prs = pr[s];
+            STAMP(1)
+            // ---- refill this stage with block lb + D
+            issue(lb + D, s);
+            STAMP(2)
+            __syncthreads(); // staging complete; nobody gathers block lb from the ring any more
+            STAMP(3)
+            // ---- ring entries for block lb + 1 (prefetched D blocks ago into stage (s+1)%D)
+            {
+                const int4 q = s_plan[2 * (lb + 1) + 1];
+                const double xn = xr[(s + 1) % D];
+                if (q.y <= T) {
+                    if (tid < q.y) s_ring[ring_pos<RING>(q.x + tid, q.z)] = xn;
+                } else { // window restart inside a run (a jump in the column range): synchronous refill
+                    for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+                }
+            }
+            // ---- row chains
+            const int myrow = r0 + tid;
+            if (tid < nrows) y[myrow] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
+            for (int r = myrow + T; r < r0 + nrows; r += T) {
+                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                y[r] = row_chain<8>(s_c, s_x, a, e);
+            }
+        }
+    }
+    STAMP(4)
+    if ((tid & 63) == 0) {
+        const int w = (tid >> 6) == 0 ? 0 : ((tid >> 6) == (T / 64 - 1) ? 1 : 2);
+        if (w < 2)
+            for (int i = 0; i < 5; i++) atomicAdd(&prof[w * 8 + i], (unsigned long long)acc[i]);
+    }
+#undef STAMP
+}
+
+
+
+// ---------------------------------------------------------------------------
+// E11: ring6 — ring5 with trimmed index arithmetic:
+//   * staging slots sk(tid + i*T) (as LDS byte offsets) precomputed once per thread;
+//     per block only the clamp to the block's last nonzero remains (cmp + select);
+//   * sentinel blocks point at the run's LAST block, whose columns are inside the
+//     final window, so the gather needs no range clamp;
+//   * U (operands fetched per batch in the row chain) is a template parameter.
+// ---------------------------------------------------------------------------
+template <int T, int NNZB, int RING, int D, int MAXB, int U>
+__global__ __launch_bounds__(T) void spmv_csr_ring6(CsrView A, const int4* __restrict__ plan,
+                                                    const int* __restrict__ run_ok,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int nb = min(A.nblk, b_begin + bpw) - b_begin;
+    if (nb <= 0) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int nlast = A.n - 1, clast = A.ncols - 1;
+
+    for (int i = tid; i < 2 * nb; i += T) s_plan[i] = plan[2 * b_begin + i];
+    __syncthreads();
+    {
+        const int4 l0 = s_plan[2 * (nb - 1)], l1 = s_plan[2 * (nb - 1) + 1];
+        // sentinels re-read the first nonzero of the run's last block: a column of the final window
+        const int4 sent0 = make_int4(l0.x + l0.z, l0.y, 0, 0);
+        const int4 sent1 = make_int4(0, 0, l1.z, 0);
+        for (int i = tid; i < 2 * D + 2; i += T) {
+            s_plan[2 * (nb + i)] = sent0;
+            s_plan[2 * (nb + i) + 1] = sent1;
+        }
+    }
+    __syncthreads();
+    if (!run_ok[gw]) {
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_plan[2 * lb];
+            simple_block<T, NNZB>(A, x, y, m0.x, m0.y, m0.x + m0.z, m0.y + m0.w, s_c, s_x);
+        }
+        return;
+    }
+
+    int kk[PER], ksk[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        kk[i] = tid + i * T;
+        ksk[i] = sk(kk[i]);
+    }
+    double c[D][PER];
+    unsigned j[D][PER];
+    int2 pr[D];
+    double xr[D];
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+        const int p0 = m0.y;
+        const int last = max(m0.w - 1, 0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(kk[i], last);
+            c[s][i] = A.coef[p0 + k];
+            j[s][i] = ucol[p0 + k];
+        }
+        const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
+        pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        xr[s] = x[min(m1.x + tid, clast)];
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    {
+        const int4 q = s_plan[1];
+        for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+    }
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s;
+            const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+            const int r0 = m0.x, p0 = m0.y, nrows = m0.z, nn = m0.w;
+            const int base = m1.z;
+            __syncthreads();
+            const int last = max(nn - 1, 0);
+            const int lsk = sk(last);
+            double xv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) xv[i] = s_ring[ring_pos<RING>((int)j[s][i], base)];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = kk[i] <= last ? ksk[i] : lsk;
+                s_c[k] = c[s][i];
+                s_x[k] = xv[i];
+            }
+            const int2 prs = pr[s];
+            issue(lb + D, s);
+            __syncthreads();
+            {
+                const int4 q = s_plan[2 * (lb + 1) + 1];
+                const double xn = xr[(s + 1) % D];
+                if (q.y <= T) {
+                    if (tid < q.y) s_ring[ring_pos<RING>(q.x + tid, q.z)] = xn;
+                } else {
+                    for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+                }
+            }
+            const int myrow = r0 + tid;
+            if (tid < nrows) y[myrow] = row_chain<U>(s_c, s_x, prs.x - p0, prs.y - p0);
+            for (int r = myrow + T; r < r0 + nrows; r += T) {
+                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                y[r] = row_chain<U>(s_c, s_x, a, e);
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// E12: ring7 — ring5 + a WRITER WAVE.  Measured: the y stores, although only 4 % of
+// the bytes, cost 10-20 % when they sit in the same in-order vector-memory queue as
+// the prefetched matrix stream (ablation: identical kernel without the stores runs
+// at the pure streaming rate).  So the T worker threads never store: row results go
+// to an LDS array, and one extra wave (threads T..T+63), which issues no loads,
+// writes block b-1's results to y while the workers gather block b.
+// ---------------------------------------------------------------------------
+template <int T, int NNZB, int RING, int D, int MAXB, int MAXROWS>
+__global__ __launch_bounds__(T + 64) void spmv_csr_ring7(CsrView A, const int4* __restrict__ plan,
+                                                         const int* __restrict__ run_ok,
+                                                         const double* __restrict__ x, double* __restrict__ y,
+                                                         int bpw)
+{
+    constexpr int PER = NNZB / T;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    constexpr int TW = T + 64;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ double s_yv[MAXROWS];
+    __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
+    const int tid = threadIdx.x;
+    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int b_begin = gw * bpw;
+    const int nb = min(A.nblk, b_begin + bpw) - b_begin;
+    if (nb <= 0) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int nlast = A.n - 1, clast = A.ncols - 1;
+
+    for (int i = tid; i < 2 * nb; i += TW) s_plan[i] = plan[2 * b_begin + i];
+    __syncthreads();
+    {
+        const int4 l0 = s_plan[2 * (nb - 1)];
+        const int4 sent = make_int4(l0.x + l0.z, l0.y + l0.w, 0, 0);
+        for (int i = tid; i < 2 * D + 2; i += TW) {
+            s_plan[2 * (nb + i)] = sent;
+            s_plan[2 * (nb + i) + 1] = make_int4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (!run_ok[gw]) {
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_plan[2 * lb];
+            simple_block<TW, NNZB>(A, x, y, m0.x, m0.y, m0.x + m0.z, m0.y + m0.w, s_c, s_x);
+        }
+        return;
+    }
+    const int nbp = ((nb + D - 1) / D) * D; // blocks incl. sentinels, same for workers and writer
+
+    if (tid >= T) {
+        // ------------------------------------------------ writer wave
+        const int lane = tid - T;
+        for (int lb = 0; lb < nbp; lb++) {
+            __syncthreads(); // (1) of block lb: s_yv holds block lb-1
+            if (lb > 0) {
+                const int4 m0 = s_plan[2 * (lb - 1)];
+                for (int r = lane; r < m0.z; r += 64) y[m0.x + r] = s_yv[r];
+            }
+            __syncthreads(); // (2) of block lb
+        }
+        __syncthreads(); // final: s_yv holds the last block
+        {
+            const int4 m0 = s_plan[2 * (nbp - 1)];
+            for (int r = lane; r < m0.z; r += 64) y[m0.x + r] = s_yv[r];
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- workers
+    double c[D][PER];
+    unsigned j[D][PER];
+    int2 pr[D];
+    double xr[D];
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+        const int p0 = m0.y;
+        const int last = max(m0.w - 1, 0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * T, last);
+            c[s][i] = A.coef[p0 + k];
+            j[s][i] = ucol[p0 + k];
+        }
+        const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
+        pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        xr[s] = x[min(m1.x + tid, clast)];
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    {
+        const int4 q = s_plan[1];
+        for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+    }
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s;
+            const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
+            const int p0 = m0.y, nrows = m0.z, nn = m0.w;
+            const int base = m1.z;
+            __syncthreads(); // (1)
+            const int last = max(nn - 1, 0);
+            double xv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const unsigned pos = (unsigned)ring_pos<RING>((int)j[s][i], base);
+                xv[i] = s_ring[min(pos, (unsigned)(RING - 1))];
+            }
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = sk(min(tid + i * T, last));
+                s_c[k] = c[s][i];
+                s_x[k] = xv[i];
+            }
+            const int2 prs = pr[s];
+            issue(lb + D, s);
+            __syncthreads(); // (2) staging complete; the writer is done with s_yv of block lb-1
+            {
+                const int4 q = s_plan[2 * (lb + 1) + 1];
+                const double xn = xr[(s + 1) % D];
+                if (q.y <= T) {
+                    if (tid < q.y) s_ring[ring_pos<RING>(q.x + tid, q.z)] = xn;
+                } else {
+                    for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
+                }
+            }
+            if (tid < nrows) s_yv[tid] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
+            for (int r = tid + T; r < nrows; r += T) {
+                const int a = A.ptrow[m0.x + r] - p0, e = A.ptrow[m0.x + r + 1] - p0;
+                s_yv[r] = row_chain<8>(s_c, s_x, a, e);
+            }
+        }
+    }
+    __syncthreads(); // final: hand the last block's results to the writer
+}
+
 } // namespace mi355
 
 inline void add_experimental_variants(std::vector<Variant>& vars, int n, const int* d_ptrow, const int* d_indcol,
                                       const double* d_coef, const double* d_x, double* d_y, mi355::CsrView V1k,
                                       mi355::CsrView V2k, mi355::CsrView V4k, const int4* M1k = nullptr,
                                       const int4* M2k = nullptr, const int4* M4k = nullptr,
-                                      std::function<void(int, int, int, int, const int4**, const int**, int*, int*)> make_plan = nullptr)
+                                      std::function<void(int, int, int, int, const int4**, const int**, int*, int*)> make_plan = nullptr, int* stagger = nullptr, int* row_align = nullptr)
 {
     using namespace mi355;
     (void)n; (void)d_ptrow; (void)d_indcol; (void)d_coef;
@@ -1210,5 +1753,83 @@ inline void add_experimental_variants(std::vector<Variant>& vars, int n, const i
         vars.push_back({"E10 ring5<256,1024,4352,D4> 768 WGs", ring5_launch(spmv_csr_ring5<256, 1024, 4352, 4, 160>, V1k, 1024, 4352, 256, 160, 768)});
         vars.push_back({"E10 ring5<1024,4096,5120,D2> 256 WGs", ring5_launch(spmv_csr_ring5<1024, 4096, 5120, 2, 160>, V4k, 4096, 5120, 1024, 160, 256)});
         vars.push_back({"E10 ring5<512,4096,5120,D2> 256 WGs", ring5_launch(spmv_csr_ring5<512, 4096, 5120, 2, 160>, V4k, 4096, 5120, 512, 160, 256)});
+        {
+            const int4* P; const int* OK; int wgs, bpw;
+            make_plan(4096, 5120, 160, 256, &P, &OK, &wgs, &bpw);
+            unsigned long long* prof = nullptr;
+            (void)hipMalloc(&prof, 16 * sizeof(unsigned long long));
+            (void)hipMemset(prof, 0, 16 * sizeof(unsigned long long));
+            g_prof_ptr = prof;
+            CsrView V = V4k;
+            vars.push_back({"DIAG ring5t stamps <512,4096,5120,D2>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5t<512, 4096, 5120, 2, 160>), dim3(wgs), dim3(512), 0, s, V, P, prof, OK, d_x, d_y, bpw); }});
+        }
+    }
+    if (make_plan) {
+        auto ring6_launch = [=](auto kern, CsrView V, int tab, int ring, int threads, int maxb, int min_wgs) {
+            const int4* P; const int* OK; int wgs, bpw;
+            make_plan(tab, ring, maxb, min_wgs, &P, &OK, &wgs, &bpw);
+            return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, s, V, P, OK, d_x, d_y, bpw); };
+        };
+        {
+            const int4* P; const int* OK; int wgs, bpw;
+            make_plan(4096, 5120, 160, 256, &P, &OK, &wgs, &bpw);
+            CsrView V = V4k;
+            vars.push_back({"ABL ring5a full (ABL=0)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 0>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL ring5a no reduce (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 1>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL ring5a no gather (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 2>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL ring5a no stage writes (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 4>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL ring5a no reduce+gather+stage (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 7>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL skeleton D3 (ABL=7)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 3, 160, 7>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL skeleton D4 (ABL=7)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 4, 160, 7>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL skeleton D2 no barriers (ABL=15)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 15>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL skeleton D2 no barriers, no xr (31)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 31>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL skeleton D2 no barr, no xr, no ptrow (63)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 63>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL skeleton D4 no barr, no xr, no ptrow (63)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 4, 160, 63>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            for (int st : {7, 29, 37}) {
+                *stagger = st;
+                const int4* P2; const int* OK2; int wgs2, bpw2;
+                make_plan(4096, 5120, 160, 256, &P2, &OK2, &wgs2, &bpw2);
+                *stagger = 0;
+                vars.push_back({"STAG" + std::to_string(st) + " ring5 full <512,4096,5120,D2>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 0>), dim3(wgs2), dim3(512), 0, s, V, P2, OK2, d_x, d_y, bpw2); }});
+                vars.push_back({"STAG" + std::to_string(st) + " skeleton D2 (ABL=7)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 7>), dim3(wgs2), dim3(512), 0, s, V, P2, OK2, d_x, d_y, bpw2); }});
+            }
+            for (int al : {16, 32, 64}) {
+                *row_align = al;
+                const int4* P3; const int* OK3; int wgs3, bpw3;
+                make_plan(4096, 5120, 160, 256, &P3, &OK3, &wgs3, &bpw3);
+                *row_align = 1;
+                CsrView V3 = V;
+                V3.nblk = wgs3 * bpw3; // upper bound; runs clamp through the plan's terminator below
+                V3.nblk = g_last_plan_nblk;
+                vars.push_back({"ALIGN" + std::to_string(al) + " ring5 full <512,4096,5120,D2>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 0>), dim3(wgs3), dim3(512), 0, s, V3, P3, OK3, d_x, d_y, bpw3); }});
+                vars.push_back({"ALIGN" + std::to_string(al) + " skeleton (7)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 7>), dim3(wgs3), dim3(512), 0, s, V3, P3, OK3, d_x, d_y, bpw3); }});
+            }
+            vars.push_back({"FIX y parked in LDS, flush per ~22 blocks (512)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 512>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"FIX unconditional y store D2 (128)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 128>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"FIX unconditional y store D3 (128)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 3, 160, 128>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL full but NO y stores (64)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 64>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL skeleton no y stores (7+64)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 71>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL skeleton no barr/xr/ptrow/stores (127)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 127>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"ABL ring5a no reduce+stage (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 5>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+        }
+        vars.push_back({"E11 ring6<512,4096,5120,D2,U8> 256 WGs", ring6_launch(spmv_csr_ring6<512, 4096, 5120, 2, 160, 8>, V4k, 4096, 5120, 512, 160, 256)});
+        vars.push_back({"E11 ring6<512,4096,5120,D2,U16> 256 WGs", ring6_launch(spmv_csr_ring6<512, 4096, 5120, 2, 160, 16>, V4k, 4096, 5120, 512, 160, 256)});
+        vars.push_back({"E11 ring6<512,4096,5120,D3,U16> 256 WGs", ring6_launch(spmv_csr_ring6<512, 4096, 5120, 3, 160, 16>, V4k, 4096, 5120, 512, 160, 256)});
+        vars.push_back({"E11 ring6<512,2048,5120,D2,U16> 512 WGs", ring6_launch(spmv_csr_ring6<512, 2048, 5120, 2, 160, 16>, V2k, 2048, 5120, 512, 160, 512)});
+        vars.push_back({"E11 ring6<256,2048,5120,D2,U16> 512 WGs", ring6_launch(spmv_csr_ring6<256, 2048, 5120, 2, 160, 16>, V2k, 2048, 5120, 256, 160, 512)});
+        vars.push_back({"E11 ring6<256,4096,5120,D2,U16> 256 WGs", ring6_launch(spmv_csr_ring6<256, 4096, 5120, 2, 160, 16>, V4k, 4096, 5120, 256, 160, 256)});
+        vars.push_back({"E11 ring6<1024,4096,5120,D2,U16> 256 WGs", ring6_launch(spmv_csr_ring6<1024, 4096, 5120, 2, 160, 16>, V4k, 4096, 5120, 1024, 160, 256)});
+    }
+    if (make_plan) {
+        auto ring7_launch = [=](auto kern, CsrView V, int tab, int ring, int threads, int maxb, int min_wgs) {
+            const int4* P; const int* OK; int wgs, bpw;
+            make_plan(tab, ring, maxb, min_wgs, &P, &OK, &wgs, &bpw);
+            return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads + 64), 0, s, V, P, OK, d_x, d_y, bpw); };
+        };
+        vars.push_back({"E12 ring7<512,4096,5120,D2>+writer 256 WGs", ring7_launch(spmv_csr_ring7<512, 4096, 5120, 2, 160, 1024>, V4k, 4096, 5120, 512, 160, 256)});
+        vars.push_back({"E12 ring7<512,4096,5120,D3>+writer 256 WGs", ring7_launch(spmv_csr_ring7<512, 4096, 5120, 3, 160, 1024>, V4k, 4096, 5120, 512, 160, 256)});
+        vars.push_back({"E12 ring7<512,2048,5120,D2>+writer 512 WGs", ring7_launch(spmv_csr_ring7<512, 2048, 5120, 2, 160, 1024>, V2k, 2048, 5120, 512, 160, 512)});
+        vars.push_back({"E12 ring7<256,2048,5120,D2>+writer 512 WGs", ring7_launch(spmv_csr_ring7<256, 2048, 5120, 2, 160, 1024>, V2k, 2048, 5120, 256, 160, 512)});
+        vars.push_back({"E12 ring7<256,2048,5120,D3>+writer 512 WGs", ring7_launch(spmv_csr_ring7<256, 2048, 5120, 3, 160, 1024>, V2k, 2048, 5120, 256, 160, 512)});
     }
 }
