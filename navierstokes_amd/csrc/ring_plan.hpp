@@ -74,17 +74,20 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
             if (use) {
                 int lo = live ? wlo : cmin, hi = live ? whi : cmin;
                 bool restart = !live;
-                if (cmin < lo) use = false; // reaches back behind the window
+                // a block that reaches back behind the window (block minima are not monotone, e.g.
+                // FE rows) or jumps ahead of it restarts the window: its whole span is reloaded
+                if (cmin < lo || cmin > hi) restart = true;
+                if (restart) { // start as low as the ring allows: later blocks may dip below this one's cmin
+                    lo = std::max(0, std::min(cmin, cmax + 1 - ring));
+                    hi = lo;
+                }
+                const int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
+                if (cmin < nlo) use = false; // cannot hold [cmin, cmax] at once
                 else {
-                    if (cmin > hi) { lo = cmin; hi = cmin; restart = true; } // jumped ahead: restart the window
-                    const int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
-                    if (cmin < nlo) use = false; // cannot hold [cmin, cmax] at once
-                    else {
-                        if (restart) base = (lo / ring) * ring;
-                        while (nlo - base >= ring) base += ring;
-                        P[4] = hi; P[5] = nhi - hi; P[6] = base; P[7] = 1;
-                        wlo = nlo; whi = nhi; live = true;
-                    }
+                    if (restart) base = (lo / ring) * ring;
+                    while (nlo - base >= ring) base += ring;
+                    P[4] = hi; P[5] = nhi - hi; P[6] = base; P[7] = 1;
+                    wlo = nlo; whi = nhi; live = true;
                 }
             }
             if (!use) ok = false;

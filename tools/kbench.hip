@@ -163,6 +163,13 @@ __global__ __launch_bounds__(T) void astream_pipe_kernel(const double* __restric
                     *reinterpret_cast<double4*>(&ydummy[(size_t)blockIdx.x * 19600 + (size_t)((g + s) >> 5) * 8192 + q * 2048 + threadIdx.x * 4]) = v4;
                 }
             }
+            if (FEAT & 8192) { // fresh lines, 8x the y volume: every thread stores PER values per block
+#pragma unroll
+                for (int i = 0; i < PER; i++) ydummy[(size_t)blockIdx.x * (size_t)(nblk + 4) * T * PER + (size_t)(g + s) * T * PER + i * T + threadIdx.x] = t + i;
+            }
+            if (FEAT & 16384) { // fresh lines, all 512 threads store one value per block (2x the y-like volume)
+                ydummy[(size_t)blockIdx.x * (size_t)(nblk + 4) * T + (size_t)(g + s) * T + threadIdx.x] = t;
+            }
             if (FEAT & 128) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(&ydummy[(size_t)blockIdx.x * T * 4 + ((g + s) & 3) * T + threadIdx.x]), "v"(t) : "memory"); }
         }
     }
@@ -364,6 +371,7 @@ int main(int argc, char** argv)
     {
         const unsigned* ucol = reinterpret_cast<const unsigned*>(d_indcol);
         double* ydum = d_y;
+        double* d_a_as_y = reinterpret_cast<double*>(d_a); // 1 GiB scratch (the copy source) as a big write target
         calib.push_back({"pipe 256x512 PER8 D2", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 0>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D3", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 3, 0>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +clamp", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 1>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
@@ -378,6 +386,8 @@ int main(int argc, char** argv)
         calib.push_back({"pipe 256x512 PER8 D2 +sc0sc1nt store fresh", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 1024>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +fresh 16KB burst / 8 blocks", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 2048>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +fresh 64KB burst / 32 blocks", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 4096>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +fresh, 512 thr x 8B (4 KB/blk)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 16384>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, d_a_as_y); }});
+        calib.push_back({"pipe 256x512 PER8 D2 +fresh, 512 thr x 64B (32 KB/blk)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 8192>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, d_a_as_y); }});
         calib.push_back({"pipe 256x512 PER8 D3 +store", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 3, 2>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +ldsmeta+clamp", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 5>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +all", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 7>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
