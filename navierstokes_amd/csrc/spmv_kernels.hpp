@@ -205,16 +205,30 @@ __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __r
     const int g = blockIdx.x * kWG + threadIdx.x;
     const int bi = g >> 2, q = g & 3;
     if (bi >= A.nbrows) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int ia0 = A.ptrow[bi], ia1 = A.ptrow[bi + 1];
     double s = 0.0;
-    for (int ia = A.ptrow[bi]; ia < A.ptrow[bi + 1]; ia++) {
-        const double2* row = reinterpret_cast<const double2*>(A.coef + 16 * (size_t)ia + 4 * q);
-        const double2 a01 = row[0], a23 = row[1];
-        const double2* xb = reinterpret_cast<const double2*>(x + 4 * (size_t)A.indcol[ia]);
-        const double2 x01 = xb[0], x23 = xb[1];
-        s = fma(a01.x, x01.x, s);
-        s = fma(a01.y, x01.y, s);
-        s = fma(a23.x, x23.x, s);
-        s = fma(a23.y, x23.y, s);
+    if (ia0 < ia1) {
+        // two-deep software pipeline: block ia+1's coefficients and column are requested before
+        // block ia's x values are consumed (indices clamped, loads unconditional)
+        const double2* row = reinterpret_cast<const double2*>(A.coef + 16 * (size_t)ia0 + 4 * q);
+        double2 a01 = row[0], a23 = row[1];
+        unsigned bj = ucol[ia0];
+        for (int ia = ia0; ia < ia1; ia++) {
+            const int nx = min(ia + 1, ia1 - 1);
+            const double2* nrow = reinterpret_cast<const double2*>(A.coef + 16 * (size_t)nx + 4 * q);
+            const double2 n01 = nrow[0], n23 = nrow[1];
+            const unsigned nbj = ucol[nx];
+            const double2* xb = reinterpret_cast<const double2*>(x + 4 * (size_t)bj);
+            const double2 x01 = xb[0], x23 = xb[1];
+            s = fma(a01.x, x01.x, s);
+            s = fma(a01.y, x01.y, s);
+            s = fma(a23.x, x23.x, s);
+            s = fma(a23.y, x23.y, s);
+            a01 = n01;
+            a23 = n23;
+            bj = nbj;
+        }
     }
     y[4 * (size_t)bi + q] = s;
 }

@@ -176,6 +176,17 @@ __global__ __launch_bounds__(T) void astream_pipe_kernel(const double* __restric
     if (acc == 123.456) sink[0] = acc;
 }
 
+// background writer for the interference experiment: few workgroups write fresh lines at a throttled rate
+__global__ __launch_bounds__(256) void bg_writer_kernel(double* __restrict__ dst, size_t n, int sleep_cycles, int reps)
+{
+    for (int r = 0; r < reps; r++) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+            dst[i] = (double)i;
+            for (int q = 0; q < sleep_cycles; q++) __builtin_amdgcn_s_sleep(16); // ~1024 cycles each
+        }
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int kind = argc > 1 ? atoi(argv[1]) : 0;
@@ -430,6 +441,32 @@ int main(int argc, char** argv)
         vcopy.ms.push_back(time_it(vcopy, 10));
         vastr.ms.push_back(time_it(vastr, 10));
         for (auto& v : calib) v.ms.push_back(time_it(v, 10));
+    }
+    // ---- interference experiment: the store-free skeleton (or any variant named by BGV) timed alone and
+    // while a small kernel on another stream writes fresh lines
+    if (const char* bgv = getenv("BGV")) {
+        hipStream_t st2;
+        CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        double* d_bg = reinterpret_cast<double*>(d_b); // 1 GiB scratch
+        for (auto& v : vars) {
+            if (v.name.find(bgv) == std::string::npos) continue;
+            float alone = time_it(v, iters);
+            struct Cfg { int wg, sleep; };
+            for (Cfg c : {Cfg{64, 1}, Cfg{64, 4}, Cfg{256, 4}, Cfg{256, 16}, Cfg{256, 64}}) {
+                // throttled writers: 8 B per thread per ~sleep*1024 cycles; measure their own rate too
+                hipEvent_t b0, b1;
+                CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+                const size_t nwr = (size_t)c.wg * 256 * 600 / (c.sleep > 16 ? 8 : 1);
+                CK(hipEventRecord(b0, st2));
+                hipLaunchKernelGGL(bg_writer_kernel, dim3(c.wg), dim3(256), 0, st2, d_bg, nwr, c.sleep, 1);
+                CK(hipEventRecord(b1, st2));
+                float with_bg = time_it(v, iters);
+                CK(hipStreamSynchronize(st2));
+                float bms; CK(hipEventElapsedTime(&bms, b0, b1));
+                printf("BG %-36s alone %.1f us | %3d writer WGs sleep %2d: %.1f us   (writers: %.1f MB in %.0f us = %.2f TB/s, main ran %.0f us)\n",
+                       v.name.c_str(), alone * 1e3, c.wg, c.sleep, with_bg * 1e3, nwr * 8 / 1e6, bms * 1e3, nwr * 8 / (bms * 1e-3) / 1e12, with_bg * 1e3 * iters);
+            }
+        }
     }
     auto med = [](std::vector<float> a) { std::sort(a.begin(), a.end()); return a[a.size() / 2]; };
     auto mn = [](std::vector<float> a) { return *std::min_element(a.begin(), a.end()); };
