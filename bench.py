@@ -38,6 +38,9 @@ WORKLOADS = {
     "c2": dict(kind="s15", n=1_000_000, k=1, desc="S15 synthetic CSR 1,000,000 rows x 15 nnz/row = 15,000,000 nnz, y=Ax"),
     "c3": dict(kind="s15", n=1_000_000, k=4, desc="S15 synthetic CSR 1,000,000 rows x 15 nnz/row, k=4 matrix powers y1..y4"),
     "tiny": dict(kind="s15", n=200_000, k=1, desc="S15 synthetic CSR 200,000 rows x 15 nnz/row (plumbing checks only)"),
+    # the reference's own matrix family: NS FE matrix, 4 dofs/node, <=60 nnz/row, 68^3 cells
+    "fe": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, desc="NS P1-P1 FE matrix (src/integration.c + benchmark_spmv.c block rule) on a 68^3-cell Kuhn box: 1,314,036 rows, CSR, y=Ax"),
+    "fe_bcsr": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, bcsr=True, desc="same FE matrix as BCSR 4x4 (SpMV_BCSR path, mpk/SpMV.cpp:90-219), y=Ax"),
 }
 
 
@@ -134,15 +137,32 @@ def main():
 
     W = WORKLOADS[args.workload]
     n, k, kind = W["n"], W["k"], W["kind"]
-    nnz_global = int(synth._lib().synth_count(synth.KINDS[kind], synth.DEFAULT_SEED, n, synth.DEFAULT_W, 0, n))
+    is_fe = kind == "fe"
+    if is_fe and world > 1:
+        sys.exit("the fe workloads are 1-GPU configurations")
+    nnz_global = (int(synth._lib().fe_matrix_count(W["cells"], W["cells"], W["cells"])) if is_fe else
+                  int(synth._lib().synth_count(synth.KINDS[kind], synth.DEFAULT_SEED, n, synth.DEFAULT_W, 0, n)))
 
     # ---- build this rank's share -------------------------------------------------------
     t_setup = time.perf_counter()
     rs = D.balanced_row_starts(n, world)  # S15 rows all hold 15 nnz: equal rows == equal nnz
     lo, hi = int(rs[rank]), int(rs[rank + 1])
-    p, c, v = synth.rows(kind, n, lo, hi)
+    p, c, v = synth.fe_matrix(W["cells"]) if is_fe else synth.rows(kind, n, lo, hi)
     x_host = synth.x_sin(lo, hi)
-    if world == 1:
+    bcsr = bool(W.get("bcsr"))
+    if world == 1 and bcsr:
+        bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+        A = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
+        _ = A.handle
+        kernel_name = "spmv_bcsr4"
+        ring_cfg, ring_runs, ring_bad, ring_frac = 0, 0, 0, 0.0
+        x = torch.from_numpy(x_host).cuda()
+        ys = [torch.empty(n, dtype=torch.float64, device="cuda")]
+
+        def step():
+            mpk.SpMV_BCSR(ys[0], x, A)
+        halo_info = None
+    elif world == 1:
         A = mpk.csrmatrix(n, p, c, v)
         if args.kernel != "auto":
             A.set_kernel(args.kernel)
@@ -218,7 +238,12 @@ def main():
     parity = None
     if not args.no_parity:
         from oracle import oracle as O  # checker only
-        if world == 1:
+        if world == 1 and bcsr:
+            Yb = O.spmv_bcsr4(bp, bc, bv, x_host)
+            got = ys[0].cpu().numpy()
+            parity = dict(rel_error=O.rel_error(Yb, got), bitwise=bool(np.array_equal(Yb.view(np.uint64), got.view(np.uint64))),
+                          against="oracle SpMV_BCSR_FMA restatement (bit-pinned to the reference's object code)")
+        elif world == 1:
             Y = O.spmk_chain(k, p, c, v, x_host)
             got = [t.cpu().numpy() for t in ys]
             parity = dict(rel_error=max(O.rel_error(Y[i], got[i]) for i in range(k)),
@@ -248,7 +273,11 @@ def main():
     flops = 2.0 * nnz_global * k * args.steps
     value = flops / wall / 1e9
     launches = args.steps * k
-    B = algorithmic_bytes(n, nnz_global) if world == 1 else algorithmic_bytes(hi - lo, len(c))
+    if bcsr:  # 16 values + 1 block column per block, block-row pointers, x once, y once
+        nblk = nnz_global // 16
+        B = 132 * nblk + 4 * (n // 4 + 1) + 16 * n
+    else:
+        B = algorithmic_bytes(n, nnz_global) if world == 1 else algorithmic_bytes(hi - lo, len(c))
     launch_s = ev_ms / 1e3 / launches
     achieved = B / launch_s / 1e9
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -263,7 +292,7 @@ def main():
                config=dict(workload=W["desc"], name=args.workload, n=n, nnz=nnz_global, k=k, seed="0x5EED",
                            half_bandwidth=synth.DEFAULT_W, partition=f"row-range x{world}", cold=bool(args.cold)),
                roofline=roofline, pct_hbm_roofline=round(100 * achieved / HBM_PEAK_GBS, 2))
-    if world == 1:
+    if world == 1 and not bcsr:
         tr, ts = A.tune_info()
         out["kernel_info"] = dict(kernel=kernel_name, ring_config=ring_cfg, runs=ring_runs, runs_on_plain_path=ring_bad,
                                   nnz_fraction_ring=round(ring_frac, 4),

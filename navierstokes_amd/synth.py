@@ -41,6 +41,15 @@ def _lib():
                                    ctypes.c_longlong, ctypes.c_longlong, i32p, i32p, f64p]
         lib.synth_x_sin.restype = None
         lib.synth_x_sin.argtypes = [ctypes.c_longlong, ctypes.c_longlong, f64p]
+        lib.fe_matrix_rows.restype = ctypes.c_longlong
+        lib.fe_matrix_rows.argtypes = [ctypes.c_int] * 3
+        lib.fe_matrix_count.restype = ctypes.c_longlong
+        lib.fe_matrix_count.argtypes = [ctypes.c_int] * 3
+        lib.fe_matrix_assemble.restype = ctypes.c_int
+        lib.fe_matrix_assemble.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_ulonglong, i32p, i32p, f64p]
+        lib.fe_element_blocks.restype = None
+        lib.fe_element_blocks.argtypes = [f64p, ctypes.c_double, ctypes.c_double, f64p]
         _LIB = lib
     return _LIB
 
@@ -79,3 +88,57 @@ def x_sin(jb, je):
 def x_ones(n):
     """x = 1.0 — what the reference harnesses multiply by (mpk/SpM2V.cpp:879)."""
     return np.ones(n, np.float64)
+
+
+def fe_matrix(nx, ny=None, nz=None, Re=100.0, delta=0.05, jitter=0.1, seed=DEFAULT_SEED):
+    """The reference's Navier-Stokes FE matrix on an (nx x ny x nz)-cell box of Kuhn tetrahedra:
+    stabilised P1-P1, 4 dofs per node, assembled in 4x4 node blocks exactly as
+    assemble_ns_matrix does (src/benchmark_spmv.c:76-123, Re=100, delta=0.05 at :156) from the
+    element matrices of src/integration.c.  Returns (ptrow, indcol, coef); n = 4*(nx+1)(ny+1)(nz+1),
+    interior rows hold 60 nonzeros (the reference's unstructured meshes give 44-58)."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    lib = _lib()
+    n = lib.fe_matrix_rows(nx, ny, nz)
+    nnz = lib.fe_matrix_count(nx, ny, nz)
+    if n >= 2**31 or nnz >= 2**31:
+        raise ValueError("mesh too large for int32 indices")
+    ptrow = np.empty(n + 1, np.int32)
+    indcol = np.empty(nnz, np.int32)
+    coef = np.empty(nnz, np.float64)
+    rc = lib.fe_matrix_assemble(nx, ny, nz, Re, delta, jitter, seed, ptrow, indcol, coef)
+    if rc != 0:
+        raise ValueError(f"fe_matrix_assemble({nx}, {ny}, {nz}) -> {rc}")
+    return ptrow, indcol, coef
+
+
+def fe_element_blocks(a, Re=100.0, delta=0.05):
+    """The sixteen 4x4 node blocks [i][j][4][4] of one tetrahedron with vertices a[4][3]."""
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(4, 3)
+    out = np.empty(256, np.float64)
+    _lib().fe_element_blocks(a.reshape(-1), Re, delta, out)
+    return out.reshape(4, 4, 4, 4)
+
+
+def csr_to_bcsr4(ptrow, indcol, coef):
+    """CSR whose rows come in groups of 4 sharing 4-aligned column groups (FE matrices) -> BCSR 4x4
+    arrays (ptrow, indcol, coef) with row-major blocks, block columns ascending."""
+    n = len(ptrow) - 1
+    assert n % 4 == 0
+    lens = np.diff(ptrow)
+    assert (lens % 4 == 0).all() and (lens[0::4] == lens[1::4]).all() and (lens[0::4] == lens[3::4]).all()
+    nb = n // 4
+    bl = lens[0::4] // 4
+    bptr = np.concatenate([[0], np.cumsum(bl)]).astype(np.int32)
+    first = indcol[np.concatenate([np.arange(ptrow[4 * b], ptrow[4 * b + 1], 4) for b in range(nb)])] if nb < 2000 else None
+    # vectorised: positions of the first column of every 4-group in the first row of each block row
+    starts = np.repeat(ptrow[0:n:4].astype(np.int64), bl) + 4 * (np.arange(bptr[-1]) - np.repeat(bptr[:-1].astype(np.int64), bl))
+    bcol = (indcol[starts] // 4).astype(np.int32)
+    if first is not None:
+        assert np.array_equal(first // 4, bcol)
+    bval = np.empty((int(bptr[-1]), 4, 4), np.float64)
+    for r in range(4):
+        rs = np.repeat(ptrow[r:n:4].astype(np.int64), bl) + 4 * (np.arange(bptr[-1]) - np.repeat(bptr[:-1].astype(np.int64), bl))
+        for c in range(4):
+            bval[:, r, c] = coef[rs + c]
+    return bptr, bcol, bval.reshape(-1)

@@ -1,0 +1,157 @@
+"""FE matrix generator (navierstokes_amd/csrc/fe_matrix.c): element blocks against the
+reference's src/integration.c object code (live when oracle/_ref is built, else the committed
+goldens), assembly rule, structure, and GPU parity on the assembled matrix."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, assert_bit_equal
+from navierstokes_amd import synth
+from oracle import oracle as O
+
+REFLIB = os.path.join(ROOT, "oracle", "_ref", "libref_integration.so")
+
+
+def reference_blocks(a, Re, delta):
+    """Compose the 16 node blocks from the reference's element matrices with the rule of
+    assemble_ns_matrix (src/benchmark_spmv.c:104-118)."""
+    L = ctypes.CDLL(REFLIB)
+    f = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    L.tet_volum.restype = ctypes.c_double
+    L.tet_volum.argtypes = [f, f, f, f]
+    L.mass_matrix.argtypes = [f, f, f, f, f]
+    L.diffusion_matrix.argtypes = [f, ctypes.c_double, f]
+    L.tet_gradients.argtypes = [f, f]
+    L.divergence_matrix.argtypes = [f, ctypes.c_double, f]
+    L.pressure_stabilization_matrix.argtypes = [f, ctypes.c_double, f]
+    a = np.ascontiguousarray(a, np.float64)
+    vol = L.tet_volum(a[0].copy(), a[1].copy(), a[2].copy(), a[3].copy())
+    M, A0 = np.zeros((12, 12)), np.zeros((12, 12))
+    g, B, D = np.zeros((4, 3)), np.zeros((4, 12)), np.zeros((4, 4))
+    L.mass_matrix(a[0].copy(), a[1].copy(), a[2].copy(), a[3].copy(), M.reshape(-1))
+    L.diffusion_matrix(a.reshape(-1).copy(), Re, A0.reshape(-1))
+    L.tet_gradients(a.reshape(-1).copy(), g.reshape(-1))
+    L.divergence_matrix(g.reshape(-1), vol, B.reshape(-1))
+    L.pressure_stabilization_matrix(a.reshape(-1).copy(), delta, D.reshape(-1))
+    ref = np.zeros((4, 4, 4, 4))
+    for i in range(4):
+        for j in range(4):
+            ref[i, j, :3, :3] = A0[3 * i:3 * i + 3, 3 * j:3 * j + 3] + M[3 * i:3 * i + 3, 3 * j:3 * j + 3]
+            ref[i, j, :3, 3] = B[j, 3 * i:3 * i + 3]
+            ref[i, j, 3, :3] = -B[i, 3 * j:3 * j + 3]
+            ref[i, j, 3, 3] = D[i, j]
+    return ref
+
+
+def positive_tets(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        a = rng.uniform(-1, 1, (4, 3))
+        e = a[1:] - a[0]
+        det = np.linalg.det(e)
+        if abs(det) < 0.05:
+            continue
+        if det < 0:
+            a[[2, 3]] = a[[3, 2]]
+        out.append(a)
+    return out
+
+
+def test_element_blocks_golden():
+    g = np.load(os.path.join(GOLDEN, "fe_elements.npz"))
+    for a, ref in zip(g["tets"], g["blocks"]):
+        mine = synth.fe_element_blocks(a, float(g["Re"]), float(g["delta"]))
+        assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max()
+    # the commented single-tet demo of the reference (src/integration.c:335-353: unit tet, Re = 1, delta = 0.1)
+    unit = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    mine = synth.fe_element_blocks(unit, 1.0, 0.1)
+    assert np.abs(mine - g["unit_blocks"]).max() <= 1e-13 * np.abs(g["unit_blocks"]).max()
+
+
+@pytest.mark.skipif(not os.path.exists(REFLIB), reason="oracle/_ref/libref_integration.so not built")
+def test_element_blocks_vs_reference_object_code():
+    for a in positive_tets(300, 11):
+        ref = reference_blocks(a, 100.0, 0.05)
+        mine = synth.fe_element_blocks(a, 100.0, 0.05)
+        assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def dense_from_elements(nx, Re, delta, blocks_fn):
+    """Independent assembly in numpy (dense) for a tiny mesh: same Kuhn split, orientation fix and node
+    numbering as the generator, blocks from blocks_fn."""
+    import itertools
+    nn = (nx + 1) ** 3
+    A = np.zeros((4 * nn, 4 * nn))
+    nid = lambda v: v[0] + (nx + 1) * (v[1] + (nx + 1) * v[2])
+    for cz, cy, cx in itertools.product(range(nx), repeat=3):
+        for perm in itertools.permutations(range(3)):
+            v = [np.array([cx, cy, cz])]
+            for ax in perm:
+                w = v[-1].copy()
+                w[ax] += 1
+                v.append(w)
+            a = np.array(v, dtype=np.float64)
+            if np.linalg.det(a[1:] - a[0]) < 0:
+                v[2], v[3] = v[3], v[2]
+                a = np.array(v, dtype=np.float64)
+            blk = blocks_fn(a, Re, delta)
+            for i in range(4):
+                for j in range(4):
+                    A[4 * nid(v[i]):4 * nid(v[i]) + 4, 4 * nid(v[j]):4 * nid(v[j]) + 4] += blk[i, j]
+    return A
+
+
+def test_assembly_matches_independent_dense_assembly():
+    nx = 3
+    p, c, v = synth.fe_matrix(nx, Re=100.0, delta=0.05, jitter=0.0)
+    n = len(p) - 1
+    A = np.zeros((n, n))
+    rows = np.repeat(np.arange(n), np.diff(p))
+    A[rows, c] = v
+    fn = reference_blocks if os.path.exists(REFLIB) else synth.fe_element_blocks
+    D = dense_from_elements(nx, 100.0, 0.05, fn)
+    assert np.abs(A - D).max() <= 1e-12 * np.abs(D).max()
+    # structure: stored pattern = union of the 4x4 node blocks (explicit zeros kept), ascending columns
+    assert (np.diff(p) % 4 == 0).all()
+    inner = np.ones(len(c), bool)
+    inner[p[1:-1]] = False
+    assert (np.diff(c)[inner[1:]] > 0).all()
+
+
+def test_structure_and_row_lengths():
+    p, c, v = synth.fe_matrix(12)
+    lens = np.diff(p)
+    assert lens.max() == 60 and lens.min() == 20  # interior 15 node blocks, box corners 5 (one diagonal end: 8)
+    assert np.isfinite(v).all() and len(c) == p[-1]
+    bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+    x = synth.x_sin(0, len(p) - 1)
+    assert_bit_equal(O.spmv_bcsr4(bp, bc, bv, x), O.spmv(p, c, v, x), "BCSR4 view of the FE matrix = CSR result")
+
+
+@pytest.mark.gpu
+def test_fe_matrix_gpu_parity():
+    import torch
+    from navierstokes_amd import mpk
+    p, c, v = synth.fe_matrix(40)  # 275 684 rows, ~15.9 M nnz
+    n = len(p) - 1
+    x = synth.x_sin(0, n)
+    yr = O.spmv(p, c, v, x)
+    dx = torch.from_numpy(x).cuda()
+    for kern in ("auto", "ring", "stream", "rowpar"):
+        A = mpk.csrmatrix(n, p, c, v).set_kernel(kern)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(y, dx, A)
+        assert_bit_equal(y.cpu().numpy(), yr, f"FE matrix, kernel {kern}")
+    bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+    B = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
+    yb = torch.empty(n, dtype=torch.float64, device="cuda")
+    mpk.SpMV_BCSR(yb, dx, B)
+    assert_bit_equal(yb.cpu().numpy(), O.spmv_bcsr4(bp, bc, bv, x), "FE matrix, BCSR4")
+    Y = O.spmk_chain(3, p, c, v, x)
+    ys = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    mpk.SpM3V(ys[2], ys[1], ys[0], dx, A)
+    for k in range(3):
+        assert_bit_equal(ys[k].cpu().numpy(), Y[k], f"FE matrix, A^{k + 1} x")

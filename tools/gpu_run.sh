@@ -41,6 +41,8 @@ for s in "$@"; do
     bench)    step bench 400 python bench.py ;;
     bench_c2) step bench_c2 300 python bench.py --workload c2 --no-cpu-baseline ;;
     bench_c3) step bench_c3 300 python bench.py --workload c3 --no-cpu-baseline ;;
+    bench_fe) step bench_fe 300 python bench.py --workload fe --no-cpu-baseline ;;
+    bench_fe_bcsr) step bench_fe_bcsr 300 python bench.py --workload fe_bcsr --no-cpu-baseline ;;
     bench_cold) step bench_cold 400 python bench.py --cold --steps 30 --warmup 3 --no-cpu-baseline ;;
     prof)     rm -rf gpurun_out/prof; step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity ;;
     pmc_fetch) rm -rf gpurun_out/pmc_fetch; step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
