@@ -50,7 +50,9 @@ def algorithmic_bytes(n, nnz):
 
 
 def load_traffic(workload, kernel_name):
-    """HBM bytes per launch from committed PMC profiles (profiles/*_pmc.json), or None."""
+    """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for this very
+    workload and kernel (committed under profiles/*_pmc.json with the calibration used), or None.
+    Counters cannot be read from inside the timed run, so this is the last profiled value."""
     pdir = os.path.join(ROOT, "profiles")
     best = None
     if os.path.isdir(pdir):
@@ -61,8 +63,8 @@ def load_traffic(workload, kernel_name):
                 except Exception:
                     continue
                 if d.get("workload") == workload and d.get("kernel") == kernel_name:
-                    best = d.get("hbm_bytes_per_launch")
-    return best
+                    best = (d.get("hbm_bytes_per_launch"), "profiles/" + f)
+    return best if best else (None, None)
 
 
 def cpu_baseline(p, c, v, x, seconds_budget=20.0):
@@ -282,7 +284,8 @@ def main():
     achieved = B / launch_s / 1e9
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=load_traffic(args.workload, kernel_name) if world == 1 else None,
+                    traffic=load_traffic(args.workload, kernel_name)[0] if world == 1 else None,
+                    traffic_source=load_traffic(args.workload, kernel_name)[1] if world == 1 else None,
                     kernel=kernel_name, algorithmic_bytes_per_launch=B, launch_us=round(launch_s * 1e6, 2),
                     timing="HIP events on the launch stream around the timed region / launches"
                            + (" (per-rank share incl. halo exchange; max over ranks)" if world > 1 else ""))

@@ -281,3 +281,37 @@ def test_rccl_plumbing_selftest():
     err = ctypes.c_double(-1.0)
     mpk.check(L.mi_comm_selftest(100_000, ctypes.byref(err)))
     assert err.value == 0.0
+
+
+def test_full_size_c4_and_c3():
+    """BASELINE configs at full size.  C4: 5 M rows / 75 M nnz single SpMV; C3: k = 4 matrix powers on the
+    1 M-row matrix.  Both bitwise against the oracle's fma chain, plus the size-independent
+    identities (A(ax1 + x2) = a A x1 + A x2 to rounding; y = A*1 equals the row sums)."""
+    n = 5_000_000
+    p, c, v = synth.rows("s15", n)
+    A = mpk.csrmatrix(n, p, c, v)
+    x1 = synth.x_sin(0, n)
+    d1 = dev(x1)
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(y, d1, A)
+    yo = O.spmv(p, c, v, x1)
+    assert_bit_equal(y.cpu().numpy(), yo, "C4")
+    assert O.rel_error(O.spmv(p, c, v, x1, "x87"), y.cpu().numpy()) <= 1e-15  # vs the reference's SpMV_CSR arithmetic
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
+    y1 = torch.empty_like(y)
+    mpk.SpMV_CSR(y1, ones, A)
+    assert O.rel_error(np.add.reduceat(v, p[:-1]), y1.cpu().numpy()) <= 1e-14
+    y12 = torch.empty_like(y)
+    mpk.SpMV_CSR(y12, 0.5 * d1 + ones, A)
+    assert O.rel_error((0.5 * y + y1).cpu().numpy(), y12.cpu().numpy()) <= 1e-14
+    A.close()
+    del p, c, v
+    n = 1_000_000
+    p, c, v = synth.rows("s15", n)
+    A = mpk.csrmatrix(n, p, c, v)
+    x = synth.x_ones(n)  # the reference harness's x (mpk/SpM2V.cpp:879)
+    ys = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(4)]
+    mpk.SpM4V(ys[3], ys[2], ys[1], ys[0], dev(x), A)
+    Y = O.spmk_chain(4, p, c, v, x)
+    for k in range(4):
+        assert_bit_equal(ys[k].cpu().numpy(), Y[k], f"C3 power {k + 1}")
