@@ -305,6 +305,16 @@ def main():
     if halo_info is not None:
         out["halo"] = halo_info
     out["setup_s"] = round(t_setup, 2)
+    if rank == 0 and world == 1 and not bcsr and k == 1 and not args.no_cpu_baseline:
+        # the reference's calling convention (host pointers): x H2D + kernel + y D2H per call; never `value`
+        xh, yh = x_host, np.empty(n)
+        mpk.SpMV_CSR(yh, xh, A)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            mpk.SpMV_CSR(yh, xh, A)
+        t1 = (time.perf_counter() - t1) / 3
+        out["pcie_inclusive"] = dict(gflops=round(2.0 * nnz_global / t1 / 1e9, 2), ms_per_call=round(t1 * 1e3, 3),
+                                     note="mi_spmv with host vectors (pageable numpy): x in, y out over PCIe every call")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(p, c, v, x_host)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -138,11 +138,15 @@ class DistCSR:
         if int(ok0) == 0:
             return False
         dist.broadcast(idt, src=0, group=self.group)
-        raw = bytes(idt.cpu().numpy().tobytes())
-        rc = L.mi_part_comm_init(self._h, _c.c_char_p(raw))  # collective inside RCCL
+        rc = self._native_init(bytes(idt.cpu().numpy().tobytes()))  # collective inside RCCL
         flag.fill_(1 if rc == 0 else 0)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag) == 1
+
+    def _native_init(self, id128):
+        """ncclCommInitRank for this partition from the 128-byte unique id (all ranks, collectively)."""
+        buf = _c.create_string_buffer(bytes(id128), 128)
+        return mpk.lib().mi_part_comm_init(self._h, buf)
 
     # -- host views of the two local pieces (CPU checks) -------------------------------------
     def local_piece(self, which):

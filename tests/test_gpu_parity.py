@@ -315,3 +315,27 @@ def test_full_size_c4_and_c3():
     Y = O.spmk_chain(4, p, c, v, x)
     for k in range(4):
         assert_bit_equal(ys[k].cpu().numpy(), Y[k], f"C3 power {k + 1}")
+
+
+def test_native_step_single_rank():
+    """mi_part_comm_init + mi_part_spmv_dev (the C++ step used for N > 1) on a 1-rank partition: the ctypes
+    argument path, RCCL communicator creation and the pack/interior/boundary sequence, bitwise vs the oracle."""
+    import ctypes
+    from navierstokes_amd import dist as D
+    L = mpk.lib()
+    if L.mi_comm_available() != 0:
+        pytest.skip("librccl not resolvable here")
+    n = 300_000
+    p, c, v = synth.rows("s15", n)
+    dc = D.DistCSR(np.array([0, n], np.int64), p, c, v)  # no process group: one rank
+    assert dc.nranks == 1 and dc.n_halo == 0 and dc.n_boundary == 0 and not dc.native
+    buf = ctypes.create_string_buffer(128)
+    mpk.check(L.mi_comm_unique_id(buf))
+    mpk.check(dc._native_init(buf.raw))
+    x = synth.x_sin(0, n)
+    x_ext = dc.new_x_ext()
+    x_ext[:n] = torch.from_numpy(x).cuda()
+    y = dc.new_y()
+    mpk.check(L.mi_part_spmv_dev(dc._h, ctypes.c_void_p(x_ext.data_ptr()), ctypes.c_void_p(y.data_ptr()), mpk._stream_ptr()))
+    torch.cuda.synchronize()
+    assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v, x), "native step, 1 rank")

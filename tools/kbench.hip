@@ -187,6 +187,46 @@ __global__ __launch_bounds__(256) void bg_writer_kernel(double* __restrict__ dst
     }
 }
 
+// "front order" variant of the pipelined stream: workgroup g takes blocks g, g+W, g+2W, ... so the whole
+// chip reads (and writes) one moving front instead of W private runs.  STORE: 0 none, 1 y-like (273 x 8 B per block)
+template <int T, int PER, int D, int STORE>
+__global__ __launch_bounds__(T) void astream_front_kernel(const double* __restrict__ coef, const unsigned* __restrict__ indcol,
+                                                          size_t nnz, double* __restrict__ sink, double* __restrict__ yout)
+{
+    const int W = gridDim.x;
+    const int nblk_total = (int)(nnz / ((size_t)T * PER));
+    const int mine = (nblk_total - (int)blockIdx.x + W - 1) / W; // blocks of this workgroup
+    double c[D][PER];
+    unsigned j[D][PER];
+    auto issue = [&](int it, int s) {
+        const int b = min((int)blockIdx.x + it * W, nblk_total - 1);
+        const size_t base = (size_t)b * T * PER;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            c[s][i] = coef[base + threadIdx.x + i * T];
+            j[s][i] = indcol[base + threadIdx.x + i * T];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    double acc = 0;
+    for (int g = 0; g < mine; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            double t = 0;
+#pragma unroll
+            for (int i = 0; i < PER; i++) t += c[s][i] * (double)j[s][i];
+            acc += t;
+            issue(g + s + D, s);
+            if (STORE == 1 && threadIdx.x < 273) {
+                const int b = min((int)blockIdx.x + (g + s) * W, nblk_total - 1);
+                yout[(size_t)b * 273 + threadIdx.x] = t;
+            }
+        }
+    }
+    if (acc == 123.456) sink[0] = acc;
+}
+
 int main(int argc, char** argv)
 {
     const int kind = argc > 1 ? atoi(argv[1]) : 0;
@@ -399,6 +439,10 @@ int main(int argc, char** argv)
         calib.push_back({"pipe 256x512 PER8 D2 +fresh 64KB burst / 32 blocks", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 4096>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +fresh, 512 thr x 8B (4 KB/blk)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 16384>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, d_a_as_y); }});
         calib.push_back({"pipe 256x512 PER8 D2 +fresh, 512 thr x 64B (32 KB/blk)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 8192>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, d_a_as_y); }});
+        calib.push_back({"front 256x512 PER8 D2 (one moving front)", [=](hipStream_t s) { hipLaunchKernelGGL((astream_front_kernel<512, 8, 2, 0>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"front 256x512 PER8 D2 + y-like stores in front order", [=](hipStream_t s) { hipLaunchKernelGGL((astream_front_kernel<512, 8, 2, 1>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"front 512x512 PER8 D2 + y-like stores in front order", [=](hipStream_t s) { hipLaunchKernelGGL((astream_front_kernel<512, 8, 2, 1>), dim3(512), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        calib.push_back({"front 256x512 PER8 D3 + y-like stores in front order", [=](hipStream_t s) { hipLaunchKernelGGL((astream_front_kernel<512, 8, 3, 1>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D3 +store", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 3, 2>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +ldsmeta+clamp", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 5>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +all", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 7>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});

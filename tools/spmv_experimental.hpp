@@ -1175,8 +1175,13 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __re
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int k = min(tid + i * T, last);
-            c[s][i] = A.coef[p0 + k];
-            j[s][i] = ucol[p0 + k];
+            if (ABL & 1024) { // non-temporal stream loads: do not let the matrix displace x / y / ptrow from L2 / Infinity Cache
+                c[s][i] = __builtin_nontemporal_load(&A.coef[p0 + k]);
+                j[s][i] = __builtin_nontemporal_load(&ucol[p0 + k]);
+            } else {
+                c[s][i] = A.coef[p0 + k];
+                j[s][i] = ucol[p0 + k];
+            }
         }
         const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
         if (ABL & 32) pr[s] = make_int2(p0, p0 + 15); else pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
@@ -1804,6 +1809,9 @@ inline void add_experimental_variants(std::vector<Variant>& vars, int n, const i
                 vars.push_back({"ALIGN" + std::to_string(al) + " ring5 full <512,4096,5120,D2>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 0>), dim3(wgs3), dim3(512), 0, s, V3, P3, OK3, d_x, d_y, bpw3); }});
                 vars.push_back({"ALIGN" + std::to_string(al) + " skeleton (7)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 7>), dim3(wgs3), dim3(512), 0, s, V3, P3, OK3, d_x, d_y, bpw3); }});
             }
+            vars.push_back({"NT ring5 full, nt loads of coef/indcol (1024)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 1024>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"NT skeleton (7) + nt loads", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 1031>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
+            vars.push_back({"NT skeleton no y stores (71) + nt loads", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 1095>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
             vars.push_back({"FIX y parked in LDS, flush per ~22 blocks (512)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 512>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
             vars.push_back({"FIX unconditional y store D2 (128)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 128>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
             vars.push_back({"FIX unconditional y store D3 (128)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 3, 160, 128>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
