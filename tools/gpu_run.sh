@@ -17,6 +17,7 @@ step() { # name timeout cmd...
 for s in "$@"; do
   case $s in
     kbench)   step kbench 300 ./tools/kbench 0 5000000 2000 5 50 ;;
+    rocsparse) step rocsparse_c4 300 ./tools/rocsparse_cmp 0 5000000 && step rocsparse_c2 200 ./tools/rocsparse_cmp 0 1000000 && step rocsparse_sfe 300 ./tools/rocsparse_cmp 2 1400000 ;;
     kbench_c2) step kbench_c2 200 ./tools/kbench 0 1000000 2000 5 100 ;;
     kbench_sfe) step kbench_sfe 300 ./tools/kbench 2 1400000 2000 5 50 ;;
     kbench_svar) step kbench_svar 300 ./tools/kbench 1 5000000 2000 5 50 ;;

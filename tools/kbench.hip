@@ -227,6 +227,45 @@ __global__ __launch_bounds__(T) void astream_front_kernel(const double* __restri
     if (acc == 123.456) sink[0] = acc;
 }
 
+// run-round-robin order: runs of R consecutive blocks dealt to the W workgroups in turn
+// (R = 1: one moving front; R = blocks/W: private contiguous runs).  STORE 1: y-like stores.
+template <int T, int PER, int D, int STORE>
+__global__ __launch_bounds__(T) void astream_rr_kernel(const double* __restrict__ coef, const unsigned* __restrict__ indcol,
+                                                       size_t nnz, double* __restrict__ sink, double* __restrict__ yout, int R)
+{
+    const int W = gridDim.x;
+    const int nblk_total = (int)(nnz / ((size_t)T * PER));
+    const int nruns = (nblk_total + R - 1) / R;
+    const int myruns = (nruns - (int)blockIdx.x + W - 1) / W;
+    const int mine = myruns * R;
+    double c[D][PER];
+    unsigned j[D][PER];
+    auto blk_of = [&](int it) { return min(((int)blockIdx.x + (it / R) * W) * R + (it % R), nblk_total - 1); };
+    auto issue = [&](int it, int s) {
+        const size_t base = (size_t)blk_of(it) * T * PER;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            c[s][i] = coef[base + threadIdx.x + i * T];
+            j[s][i] = indcol[base + threadIdx.x + i * T];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    double acc = 0;
+    for (int g = 0; g < mine; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            double t = 0;
+#pragma unroll
+            for (int i = 0; i < PER; i++) t += c[s][i] * (double)j[s][i];
+            acc += t;
+            issue(g + s + D, s);
+            if (STORE == 1 && threadIdx.x < (T * PER) / 15) yout[(size_t)blk_of(g + s) * ((T * PER) / 15) + threadIdx.x] = t;
+        }
+    }
+    if (acc == 123.456) sink[0] = acc;
+}
+
 int main(int argc, char** argv)
 {
     const int kind = argc > 1 ? atoi(argv[1]) : 0;
@@ -443,6 +482,16 @@ int main(int argc, char** argv)
         calib.push_back({"front 256x512 PER8 D2 + y-like stores in front order", [=](hipStream_t s) { hipLaunchKernelGGL((astream_front_kernel<512, 8, 2, 1>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"front 512x512 PER8 D2 + y-like stores in front order", [=](hipStream_t s) { hipLaunchKernelGGL((astream_front_kernel<512, 8, 2, 1>), dim3(512), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"front 256x512 PER8 D3 + y-like stores in front order", [=](hipStream_t s) { hipLaunchKernelGGL((astream_front_kernel<512, 8, 3, 1>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
+        for (int R : {1, 2, 4, 8, 16, 72}) {
+            calib.push_back({"rr 256x512 PER8 D2 R=" + std::to_string(R) + " no stores", [=](hipStream_t s) { hipLaunchKernelGGL((astream_rr_kernel<512, 8, 2, 0>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum, R); }});
+            calib.push_back({"rr 256x512 PER8 D2 R=" + std::to_string(R) + " + y-like stores", [=](hipStream_t s) { hipLaunchKernelGGL((astream_rr_kernel<512, 8, 2, 1>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum, R); }});
+        }
+#define RRV(T_, PER_, D_, W_, R_) \
+        calib.push_back({"rr W=" #W_ " T=" #T_ " PER" #PER_ " D" #D_ " R=" #R_ " no stores", [=](hipStream_t s) { hipLaunchKernelGGL((astream_rr_kernel<T_, PER_, D_, 0>), dim3(W_), dim3(T_), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum, R_); }}); \
+        calib.push_back({"rr W=" #W_ " T=" #T_ " PER" #PER_ " D" #D_ " R=" #R_ " + stores", [=](hipStream_t s) { hipLaunchKernelGGL((astream_rr_kernel<T_, PER_, D_, 1>), dim3(W_), dim3(T_), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum, R_); }});
+        RRV(512, 4, 2, 512, 8) RRV(512, 4, 2, 1024, 8) RRV(512, 4, 2, 1024, 1) RRV(512, 2, 2, 1024, 8) RRV(512, 2, 2, 2048, 8)
+        RRV(256, 4, 2, 2048, 8) RRV(256, 8, 2, 1024, 8) RRV(256, 8, 1, 2048, 8) RRV(512, 4, 1, 1024, 8) RRV(512, 4, 1, 2048, 1)
+        RRV(256, 4, 1, 4096, 1) RRV(256, 4, 1, 8192, 1)
         calib.push_back({"pipe 256x512 PER8 D3 +store", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 3, 2>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +ldsmeta+clamp", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 5>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
         calib.push_back({"pipe 256x512 PER8 D2 +all", [=](hipStream_t s) { hipLaunchKernelGGL((astream_pipe_kernel<512, 8, 2, 7>), dim3(256), dim3(512), 0, s, d_coef, ucol, (size_t)nnz, d_sink, ydum); }});
