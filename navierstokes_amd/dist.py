@@ -213,6 +213,23 @@ class DistCSR:
             self.compute(self, 1, x_ext, y_local)
         return y_local
 
+    # -- y_1..y_k = A x .. A^k x -----------------------------------------------------------------
+    def new_power_buffers(self, k):
+        """k buffers shaped like x_ext: the owned part of buffer i receives A^(i+1) x, its halo part the
+        ghosts of that power (needed by the next product)."""
+        return [self.new_x_ext() for _ in range(k)]
+
+    def spmk(self, x_ext, bufs, stream_ptr=None):
+        """The matrix-powers step across ranks: bufs[i][:n_local] = (A^(i+1) x)_local for i < len(bufs),
+        one halo exchange per power (SURVEY §8e "k exchanges").  Same vectors as the reference's fused
+        SpM2V_CSR / SpM3V / SpM4V return on one CPU (mpk/SpM2V.cpp:79-112, mpk/SpMVmulti0.cpp:132-221):
+        every row of every power is the same sequential fma chain.  Returns the owned views."""
+        src = x_ext
+        for b in bufs:
+            self.spmv(src, b[: self.n_local], stream_ptr)
+            src = b
+        return [b[: self.n_local] for b in bufs]
+
     def dot(self, a_local, b_local):
         """Global dot product: local fixed-tree reduction, then one all_reduce of a double."""
         if self.compute is None:

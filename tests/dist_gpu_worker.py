@@ -1,0 +1,51 @@
+"""Worker for test_gpu_parity.py::test_three_ranks_one_card: several ranks share cuda:0 (the dev box has
+one GPU; RCCL refuses two ranks on one device, so the halos travel over gloo, staged through host
+memory).  Everything else is the product path: planner, pack kernel, interior/boundary HIP kernels,
+fixed-tree dot.  Checks each rank's slice of A x, A^2 x, A^3 x bitwise against the oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from navierstokes_amd import dist as D  # noqa: E402
+from navierstokes_amd import synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402  (checker)
+
+
+def main():
+    kind, n, w = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    Pg, Cg, Vg = synth.rows(kind, n, w=w)
+    rs = D.balanced_row_starts(n, world, np.diff(Pg))
+    lo, hi = int(rs[rank]), int(rs[rank + 1])
+    p, c, v = synth.rows(kind, n, lo, hi, w=w)
+    ok = True
+    for kernel in (None, "ring", "stream"):
+        dc = D.DistCSR(rs, p, c, v, kernel=kernel)
+        assert not dc.native  # gloo: host-staged exchange
+        x_ext = dc.new_x_ext()
+        x_ext[: dc.n_local] = torch.from_numpy(synth.x_sin(lo, hi)).cuda()
+        ys = dc.spmk(x_ext, dc.new_power_buffers(3))
+        torch.cuda.synchronize()
+        Y = O.spmk_chain(3, Pg, Cg, Vg, synth.x_sin(0, n))
+        ok = ok and all(np.array_equal(ys[k].cpu().numpy().view(np.uint64), Y[k][lo:hi].view(np.uint64)) for k in range(3))
+        g = float(dc.dot(ys[0], ys[0]))
+        ref = float(np.dot(Y[0], Y[0]))
+        ok = ok and abs(g - ref) <= 1e-12 * ref
+        dc.close()
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(f"DIST_GPU_RESULT ok={int(flag)} world={world}")
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()

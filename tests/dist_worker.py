@@ -43,13 +43,8 @@ def main():
     y.fill_(float("nan"))
     dc.spmv(x_ext, y)
     # k = 3 chained distributed SpMVs (the k-exchange matrix-powers baseline)
-    ys = [y.clone()]
-    for _ in range(2):
-        xe = dc.new_x_ext()
-        xe[: dc.n_local] = ys[-1]
-        yy = dc.new_y()
-        dc.spmv(xe, yy)
-        ys.append(yy.clone())
+    ys = [t.clone() for t in dc.spmk(x_ext, dc.new_power_buffers(3))]
+    assert np.array_equal(ys[0].numpy().view(np.uint64), y.numpy().view(np.uint64))
     # global reference on every rank (small n)
     Pg, Cg, Vg = synth.rows(kind, n, w=w)
     Y = O.spmk_chain(3, Pg, Cg, Vg, synth.x_sin(0, n))

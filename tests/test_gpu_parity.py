@@ -339,3 +339,20 @@ def test_native_step_single_rank():
     mpk.check(L.mi_part_spmv_dev(dc._h, ctypes.c_void_p(x_ext.data_ptr()), ctypes.c_void_p(y.data_ptr()), mpk._stream_ptr()))
     torch.cuda.synchronize()
     assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v, x), "native step, 1 rank")
+
+
+@pytest.mark.parametrize("world,kind,n,w,port", [(3, "svar", 120_000, 2000, 29611), (2, "sfe", 60_000, 1500, 29612)])
+def test_ranks_sharing_one_card(world, kind, n, w, port):
+    """The N>1 pipeline on real HIP kernels: `world` ranks on cuda:0, halos over gloo (host-staged; RCCL
+    rejects duplicate devices), A x, A^2 x, A^3 x and a global dot, every rank's slice bitwise."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist_gpu_worker.py"), kind, str(n), str(w)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert any(ln.startswith("DIST_GPU_RESULT ok=1") for ln in r.stdout.splitlines()), r.stdout[-2000:]
