@@ -100,4 +100,27 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     }
 }
 
+// The 16-bit column stream of the ring kernel's C16 form: for block b, thread t, i < PER the
+// ring slot of nonzero k = t + i*T of the block (the last nonzero again for k >= nnz of the
+// block) at out[(b*T + t)*PER + i].  Blocks the ring does not serve get zeros (their runs take
+// the plain path, which reads indcol).
+inline void build_ring_slots(const RingPlanHost& P, const int* indcol, std::vector<unsigned short>& out)
+{
+    const int T = P.cfg.threads, per = P.cfg.nnzb / T, ring = P.cfg.ring;
+    out.assign((size_t)P.nblk * P.cfg.nnzb, 0);
+    for (int b = 0; b < P.nblk; b++) {
+        const int* Q = &P.plan[(size_t)8 * b];
+        const int p0 = Q[1], nn = Q[3], base = Q[6];
+        if (!Q[7] || nn <= 0 || nn > P.cfg.nnzb) continue;
+        unsigned short* o = &out[(size_t)b * P.cfg.nnzb];
+        for (int t = 0; t < T; t++)
+            for (int i = 0; i < per; i++) {
+                const int k = std::min(t + i * T, nn - 1);
+                int p = indcol[p0 + k] - base;
+                if (p >= ring) p -= ring;
+                o[t * per + i] = (unsigned short)p;
+            }
+    }
+}
+
 } // namespace mi355

@@ -88,13 +88,22 @@ __device__ __forceinline__ void ring_simple_block(const CsrView& A, const double
 // T threads, NNZB nonzeros per row block (PER = NNZB/T per thread), RING doubles of
 // x window, D blocks of prefetch, runs of at most MAXB blocks per workgroup.
 // LDS = 16 B * (NNZB + NNZB/32) staging + 8 B * RING + 32 B * (MAXB + 2D + 2) plan.
-template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED>
+//
+// C16: the column stream is read from `slots` instead of A.indcol — the ring slot of every
+// nonzero as a 16-bit number, precomputed with the plan (ring_plan.hpp: build_ring_slots) and
+// stored per block in thread order, so that one 2*PER-byte load hands a thread all its PER
+// slots.  The matrix stream shrinks from 12 to 10 bytes per nonzero and from 2*PER to PER+1
+// loads per thread and block; the arithmetic (and so every bit of y) is unchanged.
+template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool C16>
 __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __restrict__ plan,
                                                    const int* __restrict__ run_ok,
+                                                   const unsigned short* __restrict__ slots,
                                                    const double* __restrict__ x, double* __restrict__ y,
                                                    int bpw)
 {
     constexpr int PER = NNZB / T;
+    typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
+    static_assert(RING <= 65536, "ring slots are stored in 16 bits");
     constexpr int LDSN = NNZB + NNZB / 32 + 1;
     __shared__ double s_c[LDSN];
     __shared__ double s_x[LDSN];
@@ -133,7 +142,10 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     }
 
     double c[D][PER];
-    unsigned j[D][PER];
+    unsigned j[D][C16 ? 1 : PER];
+    SlotVec sl[D];
+    const SlotVec* slotv = reinterpret_cast<const SlotVec*>(slots);
+    const int bslot_last = A.nblk - 1;
     int2 pr[D];   // raw ptrow pair of this thread's row in the staged block
     double xr[D]; // the column this thread puts into the ring when the staged block becomes current
     int rm[D];    // rowmap[row] (MAPPED only)
@@ -146,8 +158,9 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
         for (int i = 0; i < PER; i++) {
             const int k = min(tid + i * T, last);
             c[s][i] = A.coef[p0 + k];
-            j[s][i] = ucol[p0 + k];
+            if (!C16) j[s][i] = ucol[p0 + k];
         }
+        if (C16) sl[s] = slotv[(size_t)min(b_begin + lb, bslot_last) * T + tid];
         const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
         pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
         if (MAPPED) rm[s] = A.rowmap[row];
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
             double xv[PER];
 #pragma unroll
             for (int i = 0; i < PER; i++) {
-                const unsigned pos = (unsigned)ring_slot<RING>((int)j[s][i], base);
+                const unsigned pos = C16 ? (unsigned)sl[s][i] : (unsigned)ring_slot<RING>((int)j[s][i], base);
                 xv[i] = s_ring[min(pos, (unsigned)(RING - 1))]; // clamp: sentinel blocks gather nothing meaningful
             }
 #pragma unroll

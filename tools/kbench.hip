@@ -363,20 +363,35 @@ int main(int argc, char** argv)
         const int nblk = (int)H.rows.size() - 1;
         int wgs = std::max(min_wgs, (nblk + maxb - 1) / maxb);
         wgs = ((wgs + 7) / 8) * 8;
-        const int bpw = (nblk + wgs - 1) / wgs;
-        std::vector<int4> plan(2 * (size_t)nblk);
+        int bpw = (nblk + wgs - 1) / wgs;
+        const int R = g_plan_rr; // > 0: runs of R consecutive blocks dealt round-robin to the workgroups
+        const int nruns = R ? (nblk + R - 1) / R : 0;
+        if (R) bpw = ((nruns + wgs - 1) / wgs) * R;
+        const size_t nslots = R ? (size_t)wgs * bpw : (size_t)nblk;
+        std::vector<int4> plan(2 * nslots);
         std::vector<int> ok(wgs, 1);
+        int nrestart = 0;
         for (int g = 0; g < wgs; g++) {
             int wlo = 0, whi = 0, base = 0;
             bool live = false;
-            const int b0 = g * bpw, b1 = std::min(nblk, (g + 1) * bpw), cnt = b1 - b0;
+            const int b0 = g * bpw, b1 = R ? b0 + bpw : std::min(nblk, (g + 1) * bpw), cnt = b1 - b0;
             if (cnt <= 0) continue;
             // processing order of the run: rotated by a per-run offset (stagger) so that the
             // workgroups do not all sit at the same phase of their equally long runs
             const int rot = g_stagger ? (int)(((long long)g * g_stagger) % cnt) : 0;
             for (int pos = 0; pos < cnt; pos++) {
-                const int b = b0 + (pos + rot) % cnt; // actual block
+                int b = b0 + (pos + rot) % cnt; // actual block
+                if (R) {
+                    const long long q = g + (long long)(pos / R) * wgs;
+                    b = q < nruns ? (int)(q * R + pos % R) : nblk;
+                    if (b > nblk) b = nblk;
+                }
                 const int slot = b0 + pos;             // where the kernel finds it
+                if (b >= nblk) { // padding: an empty block at the end of the matrix
+                    plan[2 * slot] = make_int4(H.rows[nblk], H.ptrs[nblk], 0, 0);
+                    plan[2 * slot + 1] = make_int4(0, 0, base, 0);
+                    continue;
+                }
                 const int nn = H.ptrs[b + 1] - H.ptrs[b], nrows = H.rows[b + 1] - H.rows[b];
                 plan[2 * slot] = make_int4(H.rows[b], H.ptrs[b], nrows, nn);
                 plan[2 * slot + 1] = make_int4(0, 0, base, 0);
@@ -390,7 +405,7 @@ int main(int argc, char** argv)
                     const int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
                     if (cmin < nlo) use = false;
                     else {
-                        if (restart) base = (lo / ring) * ring;
+                        if (restart) { base = (lo / ring) * ring; nrestart++; }
                         while (nlo - base >= ring) base += ring;
                         plan[2 * slot + 1] = make_int4(hi, nhi - hi, base, 1);
                         wlo = nlo; whi = nhi; live = true;
@@ -405,9 +420,9 @@ int main(int argc, char** argv)
         CK(hipMalloc(&dOK, sizeof(int) * ok.size()));
         CK(hipMemcpy(dOK, ok.data(), sizeof(int) * ok.size(), hipMemcpyHostToDevice));
         int nbad = 0; for (int v : ok) nbad += !v;
-        printf("plan row_align=%d stagger=%d nnzb=%d ring=%d: %d blocks, %d runs of <=%d blocks, %d runs not ring-able\n", g_row_align, g_stagger, nnzb, ring, nblk, wgs, bpw, nbad);
+        printf("plan row_align=%d stagger=%d rr=%d nnzb=%d ring=%d: %d blocks, %d runs of <=%d blocks, %d runs not ring-able, %d window restarts\n", g_row_align, g_stagger, R, nnzb, ring, nblk, wgs, bpw, nbad, nrestart);
         *P = dP; *OK = dOK; *wgs_out = wgs; *bpw_out = bpw;
-        g_last_plan_nblk = nblk;
+        g_last_plan_nblk = R ? (int)nslots : nblk;
     };
     std::vector<Variant> vars;
     auto grid8 = [](int nblk) { return dim3(kNXCD * ((nblk + kNXCD - 1) / kNXCD)); };

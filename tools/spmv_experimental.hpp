@@ -12,8 +12,10 @@
 
 #include "spmv_kernels.hpp"
 
+static int g_plan_rr = 0;        // kbench plan builder: round-robin run length (0: private contiguous runs)
+static int g_last_plan_nblk = 0; // slots of the last plan built
+
 static unsigned long long* g_prof_ptr = nullptr;
-static int g_last_plan_nblk = 0;
 
 struct Variant {
     std::string name;
@@ -1751,6 +1753,18 @@ inline void add_experimental_variants(std::vector<Variant>& vars, int n, const i
             make_plan(tab, ring, maxb, min_wgs, &P, &OK, &wgs, &bpw);
             return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, s, V, P, OK, d_x, d_y, bpw); };
         };
+        auto ring5_launch_rr = [=](auto kern, CsrView V, int tab, int ring, int threads, int wgsreq, int R) {
+            const int4* P; const int* OK; int wgs, bpw;
+            g_plan_rr = R;
+            make_plan(tab, ring, 1 << 20, wgsreq, &P, &OK, &wgs, &bpw);
+            g_plan_rr = 0;
+            V.nblk = g_last_plan_nblk;
+            return [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, s, V, P, OK, d_x, d_y, bpw); };
+        };
+        for (int R : {4, 8, 12, 24}) {
+            vars.push_back({"E13 ring5<512,4096,5120,D2> 256 WGs rr R=" + std::to_string(R), ring5_launch_rr(spmv_csr_ring5<512, 4096, 5120, 2, 160>, V4k, 4096, 5120, 512, 256, R)});
+            vars.push_back({"E13 ring5<512,2048,5120,D2> 512 WGs rr R=" + std::to_string(R), ring5_launch_rr(spmv_csr_ring5<512, 2048, 5120, 2, 160>, V2k, 2048, 5120, 512, 512, R)});
+        }
         vars.push_back({"E10 ring5<512,2048,5120,D2> 512 WGs", ring5_launch(spmv_csr_ring5<512, 2048, 5120, 2, 160>, V2k, 2048, 5120, 512, 160, 512)});
         vars.push_back({"E10 ring5<512,2048,5120,D3> 512 WGs", ring5_launch(spmv_csr_ring5<512, 2048, 5120, 3, 160>, V2k, 2048, 5120, 512, 160, 512)});
         vars.push_back({"E10 ring5<256,2048,5120,D2> 512 WGs", ring5_launch(spmv_csr_ring5<256, 2048, 5120, 2, 160>, V2k, 2048, 5120, 256, 160, 512)});
