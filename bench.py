@@ -313,10 +313,11 @@ def main():
                            half_bandwidth=synth.DEFAULT_W, partition=f"row-range x{world}", cold=bool(args.cold)),
                roofline=roofline, pct_hbm_roofline=round(100 * achieved / HBM_PEAK_GBS, 2))
     if world == 1 and not bcsr:
-        tr, ts = A.tune_info()
+        tune, nt = A.tune_detail()
         out["kernel_info"] = dict(kernel=kernel_name, ring_config=ring_cfg, runs=ring_runs, runs_on_plain_path=ring_bad,
-                                  nnz_fraction_ring=round(ring_frac, 4),
-                                  autotune_us=dict(ring=round(tr, 1), stream=round(ts, 1)))
+                                  nnz_fraction_ring=round(ring_frac, 4), nontemporal_values=nt,
+                                  matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else 12,
+                                  autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
     if parity is not None:
         out["parity"] = parity
     if halo_info is not None:

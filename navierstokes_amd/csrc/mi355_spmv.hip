@@ -81,6 +81,7 @@ struct RingTable {
     int* d_plan = nullptr; // 8 ints per block, read as two int4
     int* d_ok = nullptr;
     unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block; null: kernel reads indcol
+    bool nt = false;                   // non-temporal loads of the values (needs d_slots; chosen by measurement)
 };
 
 struct mi_csr_s {
@@ -96,7 +97,7 @@ struct mi_csr_s {
     RingTable ring;           // valid iff ring.d_plan != nullptr
     int kernel = MI_KERNEL_AUTO;
     int auto_kernel = MI_KERNEL_STREAM;
-    double tune_us_ring = 0.0, tune_us_stream = 0.0;
+    double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0;
     int n_out = 0; // length of the y a launch may write (n, or max rowmap + 1)
     // scratch for the host-pointer entry points
     double* d_x = nullptr;
@@ -328,6 +329,10 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         }
         A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     }
+    // default for the value loads when nothing is measured: non-temporal once the matrix stream
+    // (10 B per nonzero) no longer fits the 256 MB Infinity Cache with room for the vectors
+    A->ring.nt = A->ring.d_slots && 10.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
+    if (const char* e = getenv("MI355_RING_NT")) A->ring.nt = A->ring.d_slots && atoi(e) != 0;
     A->n_out = n;
     if (rowmap)
         for (int i = 0; i < n; i++) A->n_out = rowmap[i] + 1 > A->n_out ? rowmap[i] + 1 : A->n_out;
@@ -349,9 +354,16 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         TRY_OR_CLEAN(hipMemset(tx, 0, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
         TRY_OR_CLEAN(hipEventCreate(&e0));
         TRY_OR_CLEAN(hipEventCreate(&e1));
-        const int cand[2] = {MI_KERNEL_RING, MI_KERNEL_STREAM};
-        double us[2] = {0, 0};
-        for (int c = 0; c < 2; c++) {
+        // candidates: ring with temporal loads, ring with non-temporal loads, stream
+        const int cand[3] = {MI_KERNEL_RING, MI_KERNEL_RING, MI_KERNEL_STREAM};
+        double us[3] = {0, 0, 0};
+        const bool nt_forced = getenv("MI355_RING_NT") != nullptr;
+        for (int c = 0; c < 3; c++) {
+            if (c < 2) {
+                if (nt_forced && (c == 1) != A->ring.nt) continue;
+                if (c == 1 && !A->ring.d_slots) continue;
+                A->ring.nt = (c == 1);
+            }
             A->kernel = cand[c];
             for (int w = 0; w < 2; w++)
                 if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
@@ -366,8 +378,11 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         }
         A->kernel = MI_KERNEL_AUTO;
         A->tune_us_ring = us[0];
-        A->tune_us_stream = us[1];
-        if (us[1] > 0 && us[1] < us[0]) A->auto_kernel = MI_KERNEL_STREAM;
+        A->tune_us_ring_nt = us[1];
+        A->tune_us_stream = us[2];
+        A->ring.nt = us[1] > 0 && (us[0] <= 0 || us[1] < us[0]);
+        const double best_ring = A->ring.nt ? us[1] : us[0];
+        if (us[2] > 0 && us[2] < best_ring) A->auto_kernel = MI_KERNEL_STREAM;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         dfree(tx);
@@ -428,8 +443,20 @@ static int resolve_kernel(const mi_csr_s* A)
 extern "C" int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream)
 {
     CHECK_ARG(A, "null handle");
-    if (us_ring) *us_ring = A->tune_us_ring;
+    if (us_ring) *us_ring = A->ring.nt ? A->tune_us_ring_nt : A->tune_us_ring;
     if (us_stream) *us_stream = A->tune_us_stream;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[3], int* nt_chosen)
+{
+    CHECK_ARG(A, "null handle");
+    if (us) {
+        us[0] = A->tune_us_ring;
+        us[1] = A->tune_us_ring_nt;
+        us[2] = A->tune_us_stream;
+    }
+    if (nt_chosen) *nt_chosen = A->ring.nt ? 1 : 0;
     return MI_OK;
 }
 
@@ -466,8 +493,9 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     case MI_KERNEL_RING: { // the name rocprofv3 prints for the instantiation launch_ring picks
         static thread_local char nm[96];
         const RingConfig& c = A->ring.cfg;
-        snprintf(nm, sizeof nm, "spmv_csr_ring<%d, %d, %d, %d, %d, %s, %s>", c.threads, c.nnzb, c.ring, c.depth, kRingMaxB,
-                 A->d_rowmap ? "true" : "false", A->ring.d_slots ? "true" : "false");
+        snprintf(nm, sizeof nm, "spmv_csr_ring<%d, %d, %d, %d, %d, %s, %s, %s>", c.threads, c.nnzb, c.ring, c.depth, kRingMaxB,
+                 A->d_rowmap ? "true" : "false", A->ring.d_slots ? "true" : "false",
+                 A->ring.d_slots && A->ring.nt ? "true" : "false");
         return nm;
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
@@ -476,23 +504,26 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
 }
 
 // ---------------------------------------------------------------- SpMV launch
-template <int T, int NNZB, int RING, int D, bool MAPPED, bool C16>
+template <int T, int NNZB, int RING, int D, bool MAPPED, bool C16, bool NT>
 static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
 {
-    hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, C16>), dim3(A->ring.wgs), dim3(T), 0, s, V,
+    hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, C16, NT>), dim3(A->ring.wgs), dim3(T), 0, s, V,
                        reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, A->ring.bpw);
+}
+
+template <int T, int NNZB, int RING, int D, bool MAPPED>
+static void launch_ring1(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
+{
+    if (!A->ring.d_slots) launch_ring2<T, NNZB, RING, D, MAPPED, false, false>(A, V, d_x, d_y, s);
+    else if (A->ring.nt) launch_ring2<T, NNZB, RING, D, MAPPED, true, true>(A, V, d_x, d_y, s);
+    else launch_ring2<T, NNZB, RING, D, MAPPED, true, false>(A, V, d_x, d_y, s);
 }
 
 template <int T, int NNZB, int RING, int D>
 static void launch_ring(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
 {
-    if (A->d_rowmap) {
-        if (A->ring.d_slots) launch_ring2<T, NNZB, RING, D, true, true>(A, V, d_x, d_y, s);
-        else launch_ring2<T, NNZB, RING, D, true, false>(A, V, d_x, d_y, s);
-    } else {
-        if (A->ring.d_slots) launch_ring2<T, NNZB, RING, D, false, true>(A, V, d_x, d_y, s);
-        else launch_ring2<T, NNZB, RING, D, false, false>(A, V, d_x, d_y, s);
-    }
+    if (A->d_rowmap) launch_ring1<T, NNZB, RING, D, true>(A, V, d_x, d_y, s);
+    else launch_ring1<T, NNZB, RING, D, false>(A, V, d_x, d_y, s);
 }
 
 static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s)

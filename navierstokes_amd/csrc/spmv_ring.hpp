@@ -94,7 +94,13 @@ __device__ __forceinline__ void ring_simple_block(const CsrView& A, const double
 // stored per block in thread order, so that one 2*PER-byte load hands a thread all its PER
 // slots.  The matrix stream shrinks from 12 to 10 bytes per nonzero and from 2*PER to PER+1
 // loads per thread and block; the arithmetic (and so every bit of y) is unchanged.
-template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool C16>
+//
+// NT: the matrix values are loaded non-temporally.  A matrix much larger than the 256 MB Infinity
+// Cache is read once per product, and kept out of the L2 / Infinity Cache replacement it stops
+// displacing x, the plan and the y lines being written (C4: 190 -> 169 us).  A matrix that fits
+// the cache is better served by it across repeated products (C2: 38 us temporal, 44 us NT), so
+// mi_csr_create times both and keeps the faster.
+template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool C16, bool NT>
 __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __restrict__ plan,
                                                    const int* __restrict__ run_ok,
                                                    const unsigned short* __restrict__ slots,
@@ -157,7 +163,8 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int k = min(tid + i * T, last);
-            c[s][i] = A.coef[p0 + k];
+            if (NT) c[s][i] = __builtin_nontemporal_load(&A.coef[p0 + k]);
+            else c[s][i] = A.coef[p0 + k];
             if (!C16) j[s][i] = ucol[p0 + k];
         }
         if (C16) sl[s] = slotv[(size_t)min(b_begin + lb, bslot_last) * T + tid];

@@ -74,6 +74,7 @@ def lib():
         "mi_csr_get_kernel": [_vp, P(i)],
         "mi_csr_ring_info": [_vp, P(i), P(i), P(i), P(d)],
         "mi_csr_tune_info": [_vp, P(d), P(d)],
+        "mi_csr_tune_detail": [_vp, P(d), P(_c.c_int)],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_spmk": [_vp, i, _vp, _vp],
@@ -214,6 +215,13 @@ class csrmatrix:
         a, b = _c.c_double(), _c.c_double()
         check(lib().mi_csr_tune_info(self.handle, _c.byref(a), _c.byref(b)))
         return a.value, b.value
+
+    def tune_detail(self):
+        """({ring temporal, ring non-temporal, stream} us per launch at create time, nt chosen)."""
+        us = (_c.c_double * 3)()
+        nt = _c.c_int()
+        check(lib().mi_csr_tune_detail(self.handle, us, _c.byref(nt)))
+        return dict(ring=us[0], ring_nt=us[1], stream=us[2]), bool(nt.value)
 
     def drop_host_arrays(self):
         """Free the host copies of indcol/coef once the device handle exists (large benches)."""

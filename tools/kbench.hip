@@ -414,6 +414,25 @@ int main(int argc, char** argv)
                 if (!use) ok[g] = 0;
             }
         }
+        if (g_want_slots) { // 16-bit ring slots in thread order (the product's build_ring_slots, for this plan layout)
+            const int T = 512, per = nnzb / T;
+            std::vector<unsigned short> sl(nslots * nnzb, 0);
+            for (size_t b = 0; b < nslots; b++) {
+                const int4 m0 = plan[2 * b], m1 = plan[2 * b + 1];
+                if (!m1.w || m0.w <= 0 || m0.w > nnzb) continue;
+                for (int t = 0; t < T; t++)
+                    for (int i = 0; i < per; i++) {
+                        const int kk = std::min(t + i * T, m0.w - 1);
+                        int p = indcol[m0.y + kk] - m1.z;
+                        if (p >= ring) p -= ring;
+                        sl[b * nnzb + (size_t)t * per + i] = (unsigned short)p;
+                    }
+            }
+            unsigned short* dS;
+            CK(hipMalloc(&dS, sizeof(unsigned short) * sl.size()));
+            CK(hipMemcpy(dS, sl.data(), sizeof(unsigned short) * sl.size(), hipMemcpyHostToDevice));
+            g_last_slots = dS;
+        }
         int4* dP; int* dOK;
         CK(hipMalloc(&dP, sizeof(int4) * plan.size()));
         CK(hipMemcpy(dP, plan.data(), sizeof(int4) * plan.size(), hipMemcpyHostToDevice));

@@ -14,6 +14,8 @@
 
 static int g_plan_rr = 0;        // kbench plan builder: round-robin run length (0: private contiguous runs)
 static int g_last_plan_nblk = 0; // slots of the last plan built
+static int g_want_slots = 0;                          // make_plan also builds the 16-bit column stream
+static const unsigned short* g_last_slots = nullptr;  // ... and leaves it here
 
 static unsigned long long* g_prof_ptr = nullptr;
 
@@ -1124,9 +1126,11 @@ template <int T, int NNZB, int RING, int D, int MAXB, int ABL>
 __global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __restrict__ plan,
                                                     const int* __restrict__ run_ok,
                                                     const double* __restrict__ x, double* __restrict__ y,
-                                                    int bpw)
+                                                    int bpw, const unsigned short* __restrict__ slots = nullptr)
 {
     constexpr int PER = NNZB / T;
+    typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
+    constexpr bool C16 = (ABL & 2048) != 0;
     constexpr int LDSN = NNZB + NNZB / 32 + 1;
     __shared__ double s_c[LDSN];
     __shared__ double s_x[LDSN];
@@ -1165,7 +1169,8 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __re
     }
 
     double c[D][PER];
-    unsigned j[D][PER];
+    unsigned j[D][C16 ? 1 : PER];
+    SlotVec sl[D];
     int2 pr[D];
     double xr[D];
     double ysum = 0.0;
@@ -1179,11 +1184,15 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __re
             const int k = min(tid + i * T, last);
             if (ABL & 1024) { // non-temporal stream loads: do not let the matrix displace x / y / ptrow from L2 / Infinity Cache
                 c[s][i] = __builtin_nontemporal_load(&A.coef[p0 + k]);
-                j[s][i] = __builtin_nontemporal_load(&ucol[p0 + k]);
+                if (!C16) j[s][i] = __builtin_nontemporal_load(&ucol[p0 + k]);
             } else {
                 c[s][i] = A.coef[p0 + k];
-                j[s][i] = ucol[p0 + k];
+                if (!C16) j[s][i] = ucol[p0 + k];
             }
+        }
+        if (C16) {
+            const SlotVec* sp = &reinterpret_cast<const SlotVec*>(slots)[(size_t)min(b_begin + lb, A.nblk - 1) * T + tid];
+            if (ABL & 4096) sl[s] = __builtin_nontemporal_load(sp); else sl[s] = *sp;
         }
         const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
         if (ABL & 32) pr[s] = make_int2(p0, p0 + 15); else pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
@@ -1210,7 +1219,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __re
             double xv[PER];
 #pragma unroll
             for (int i = 0; i < PER; i++) {
-                const unsigned pos = (unsigned)ring_pos<RING>((int)j[s][i], base);
+                const unsigned pos = C16 ? (unsigned)sl[s][i] : (unsigned)ring_pos<RING>((int)j[s][i], base);
                 if (ABL & 2) xv[i] = (double)pos;
                 else xv[i] = s_ring[min(pos, (unsigned)(RING - 1))];
             }
@@ -1793,6 +1802,31 @@ inline void add_experimental_variants(std::vector<Variant>& vars, int n, const i
             const int4* P; const int* OK; int wgs, bpw;
             make_plan(4096, 5120, 160, 256, &P, &OK, &wgs, &bpw);
             CsrView V = V4k;
+            {
+                const int4* Pc; const int* OKc; int wgsc, bpwc;
+                g_want_slots = 1;
+                make_plan(4096, 5120, 160, 256, &Pc, &OKc, &wgsc, &bpwc);
+                g_want_slots = 0;
+                const unsigned short* SL = g_last_slots;
+#define C16V(name, abl) vars.push_back({name, [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 2048 | (abl)>), dim3(wgsc), dim3(512), 0, s, V, Pc, OKc, d_x, d_y, bpwc, SL); }});
+                C16V("C16 ring5a full", 0)
+                C16V("C16 no reduce (invalid)", 1)
+                C16V("C16 no gather (invalid)", 2)
+                C16V("C16 no stage writes (invalid)", 4)
+                C16V("C16 no reduce+gather+stage (invalid)", 7)
+                C16V("C16 full but NO y stores (invalid)", 64)
+                C16V("C16 skeleton no y stores (invalid)", 7 + 64)
+                C16V("C16 skeleton no barriers (invalid)", 15)
+                C16V("C16 skeleton no barr/xr/ptrow/stores (invalid)", 127)
+                C16V("C16 full, NT loads", 1024)
+                C16V("C16 full, NT coef + NT slots", 1024 + 4096)
+                C16V("C16 full, NT slots only", 4096)
+                C16V("C16 NT no y stores (invalid)", 1024 + 64)
+                C16V("C16 NT skeleton no y stores (invalid)", 1024 + 7 + 64)
+                C16V("C16 NT skeleton (invalid)", 1024 + 7)
+                C16V("C16 NT no reduce (invalid)", 1024 + 1)
+#undef C16V
+            }
             vars.push_back({"ABL ring5a full (ABL=0)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 0>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
             vars.push_back({"ABL ring5a no reduce (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 1>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
             vars.push_back({"ABL ring5a no gather (invalid)", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5a<512, 4096, 5120, 2, 160, 2>), dim3(wgs), dim3(512), 0, s, V, P, OK, d_x, d_y, bpw); }});
