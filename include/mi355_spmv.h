@@ -97,11 +97,12 @@ int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringab
  * Reports the measured microseconds per launch (0 = candidate not eligible / not timed).
  * MI355_SPMV_KERNEL=ring|stream|rowpar or MI355_SPMV_AUTOTUNE=0 skip the measurement. */
 int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
-/* The ring kernel is timed twice, with temporal and with non-temporal loads of the matrix values (a
- * matrix that fits the 256 MB Infinity Cache is faster temporal across repeated products, a larger
- * one non-temporal); us[0..2] = ring temporal, ring non-temporal, stream; *nt_chosen = 1 if the ring
- * kernel of this handle uses non-temporal loads.  MI355_RING_NT=0|1 forces the choice. */
-int mi_csr_tune_detail(mi_csr_t A, double us[3], int* nt_chosen);
+/* Each candidate is timed twice, with temporal and with non-temporal loads of the matrix (a matrix
+ * that fits the 256 MB Infinity Cache is faster temporal across repeated products, a larger one
+ * non-temporal); us[0..3] = ring, ring non-temporal, stream, stream non-temporal; *ring_nt / *stream_nt
+ * = 1 if that kernel of this handle uses non-temporal loads.  MI355_RING_NT / MI355_STREAM_NT = 0|1
+ * force the choice. */
+int mi_csr_tune_detail(mi_csr_t A, double us[4], int* ring_nt, int* stream_nt);
 int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
 /* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
 const char* mi_csr_kernel_name(mi_csr_t A);

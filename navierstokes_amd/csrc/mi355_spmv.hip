@@ -97,7 +97,8 @@ struct mi_csr_s {
     RingTable ring;           // valid iff ring.d_plan != nullptr
     int kernel = MI_KERNEL_AUTO;
     int auto_kernel = MI_KERNEL_STREAM;
-    double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0;
+    double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0, tune_us_stream_nt = 0.0;
+    bool stream_nt = false; // non-temporal matrix loads in the stream kernel
     int n_out = 0; // length of the y a launch may write (n, or max rowmap + 1)
     // scratch for the host-pointer entry points
     double* d_x = nullptr;
@@ -288,19 +289,19 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         TRY_OR_CLEAN(hipMemcpy(A->d_rowmap, rowmap, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     }
     // window plan of the ring kernel: first configuration (in preference order) that
-    // serves at least 90 % of the nonzeros; MI355_RING_CONFIG=1|2|3 forces one
+    // serves at least 90 % of the nonzeros; MI355_RING_CONFIG=1..4 forces one
     if (n > 0 && nnz > 0) {
-        int order[3] = {2, 3, 1};
+        const int* order = kRingConfigOrder;
         int forced = 0;
         if (const char* e = getenv("MI355_RING_CONFIG")) forced = atoi(e);
         RingPlanHost best;
         bool have = false;
-        for (int t = 0; t < 3 && !have; t++) {
-            const int id = forced >= 1 && forced <= 3 ? forced : order[t];
+        for (int t = 0; t < kNumRingConfigs && !have; t++) {
+            const int id = forced >= 1 && forced <= kNumRingConfigs ? forced : order[t];
             RingPlanHost P;
             build_ring_plan(kRingConfigs[id - 1], n, ptrow, row_min.data(), row_max.data(), P);
             const double okf = 1.0 - (double)P.bad_nnz / (double)nnz;
-            if (forced || okf >= 0.90 || (t == 2 && false)) {
+            if (forced || okf >= 0.90) {
                 best = std::move(P);
                 have = true;
             } else if (t == 0) {
@@ -333,6 +334,8 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
     // (10 B per nonzero) no longer fits the 256 MB Infinity Cache with room for the vectors
     A->ring.nt = A->ring.d_slots && 10.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
     if (const char* e = getenv("MI355_RING_NT")) A->ring.nt = A->ring.d_slots && atoi(e) != 0;
+    A->stream_nt = 12.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
+    if (const char* e = getenv("MI355_STREAM_NT")) A->stream_nt = atoi(e) != 0;
     A->n_out = n;
     if (rowmap)
         for (int i = 0; i < n; i++) A->n_out = rowmap[i] + 1 > A->n_out ? rowmap[i] + 1 : A->n_out;
@@ -345,8 +348,9 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         else forced_kernel = false;
     }
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
-    if (!forced_kernel && !(at && !strcmp(at, "0")) && A->auto_kernel == MI_KERNEL_RING && nnz >= 200000) {
-        // measure ring vs stream on this very matrix (x = 0: timing does not depend on the values)
+    if (!forced_kernel && !(at && !strcmp(at, "0")) && nnz >= 200000) {
+        // measure the candidates on this very matrix (x = 0: timing does not depend on the values):
+        // ring (if it serves the matrix) and stream, each with temporal and non-temporal matrix loads
         double *tx = nullptr, *ty = nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         TRY_OR_CLEAN(hipMalloc(&tx, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
@@ -354,35 +358,45 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         TRY_OR_CLEAN(hipMemset(tx, 0, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
         TRY_OR_CLEAN(hipEventCreate(&e0));
         TRY_OR_CLEAN(hipEventCreate(&e1));
-        // candidates: ring with temporal loads, ring with non-temporal loads, stream
-        const int cand[3] = {MI_KERNEL_RING, MI_KERNEL_RING, MI_KERNEL_STREAM};
-        double us[3] = {0, 0, 0};
-        const bool nt_forced = getenv("MI355_RING_NT") != nullptr;
-        for (int c = 0; c < 3; c++) {
+        const bool ring_ok = A->auto_kernel == MI_KERNEL_RING;
+        const bool ring_nt_forced = getenv("MI355_RING_NT") != nullptr, stream_nt_forced = getenv("MI355_STREAM_NT") != nullptr;
+        const bool ring_nt0 = A->ring.nt, stream_nt0 = A->stream_nt;
+        double us[4] = {0, 0, 0, 0}; // ring, ring nt, stream, stream nt
+        for (int c = 0; c < 4; c++) {
+            const bool nt = c & 1;
             if (c < 2) {
-                if (nt_forced && (c == 1) != A->ring.nt) continue;
-                if (c == 1 && !A->ring.d_slots) continue;
-                A->ring.nt = (c == 1);
+                if (!ring_ok || (nt && !A->ring.d_slots) || (ring_nt_forced && nt != ring_nt0)) continue;
+                A->ring.nt = nt;
+                A->kernel = MI_KERNEL_RING;
+            } else {
+                if (stream_nt_forced && nt != stream_nt0) continue;
+                A->stream_nt = nt;
+                A->kernel = MI_KERNEL_STREAM;
             }
-            A->kernel = cand[c];
-            for (int w = 0; w < 2; w++)
+            // warm launches first: a temporal candidate is judged with the Infinity Cache holding
+            // what it can of the matrix, as it would between the iterations of a solver
+            const int warm = 3, timed = nnz < 40000000 ? 12 : 6;
+            for (int w = 0; w < warm; w++)
                 if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
             TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
-            for (int w = 0; w < 5; w++)
+            for (int w = 0; w < timed; w++)
                 if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
             TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
             TRY_OR_CLEAN(hipEventSynchronize(e1));
             float ms = 0.f;
             TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
-            us[c] = ms * 1e3 / 5;
+            us[c] = ms * 1e3 / timed;
         }
         A->kernel = MI_KERNEL_AUTO;
         A->tune_us_ring = us[0];
         A->tune_us_ring_nt = us[1];
         A->tune_us_stream = us[2];
-        A->ring.nt = us[1] > 0 && (us[0] <= 0 || us[1] < us[0]);
-        const double best_ring = A->ring.nt ? us[1] : us[0];
-        if (us[2] > 0 && us[2] < best_ring) A->auto_kernel = MI_KERNEL_STREAM;
+        A->tune_us_stream_nt = us[3];
+        auto better = [](double a, double b) { return a > 0 && (b <= 0 || a < b); }; // a measured and faster than b
+        A->ring.nt = ring_ok ? better(us[1], us[0]) : ring_nt0;
+        A->stream_nt = better(us[3], us[2]);
+        const double best_ring = A->ring.nt ? us[1] : us[0], best_stream = A->stream_nt ? us[3] : us[2];
+        if (ring_ok && better(best_stream, best_ring)) A->auto_kernel = MI_KERNEL_STREAM;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         dfree(tx);
@@ -444,19 +458,21 @@ extern "C" int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream)
 {
     CHECK_ARG(A, "null handle");
     if (us_ring) *us_ring = A->ring.nt ? A->tune_us_ring_nt : A->tune_us_ring;
-    if (us_stream) *us_stream = A->tune_us_stream;
+    if (us_stream) *us_stream = A->stream_nt ? A->tune_us_stream_nt : A->tune_us_stream;
     return MI_OK;
 }
 
-extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[3], int* nt_chosen)
+extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[4], int* ring_nt, int* stream_nt)
 {
     CHECK_ARG(A, "null handle");
     if (us) {
         us[0] = A->tune_us_ring;
         us[1] = A->tune_us_ring_nt;
         us[2] = A->tune_us_stream;
+        us[3] = A->tune_us_stream_nt;
     }
-    if (nt_chosen) *nt_chosen = A->ring.nt ? 1 : 0;
+    if (ring_nt) *ring_nt = A->ring.nt ? 1 : 0;
+    if (stream_nt) *stream_nt = A->stream_nt ? 1 : 0;
     return MI_OK;
 }
 
@@ -489,7 +505,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
 {
     if (!A) return "";
     switch (resolve_kernel(A)) {
-    case MI_KERNEL_STREAM: return "spmv_csr_stream<1024>";
+    case MI_KERNEL_STREAM: return A->stream_nt ? "spmv_csr_stream<1024, true>" : "spmv_csr_stream<1024, false>";
     case MI_KERNEL_RING: { // the name rocprofv3 prints for the instantiation launch_ring picks
         static thread_local char nm[96];
         const RingConfig& c = A->ring.cfg;
@@ -547,7 +563,8 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
         switch (A->ring.cfg.id) {
         case 1: launch_ring<512, 2048, 5120, 2>(A, V, d_x, d_y, s); break;
         case 2: launch_ring<512, 4096, 5120, 2>(A, V, d_x, d_y, s); break;
-        default: launch_ring<512, 4096, 11264, 2>(A, V, d_x, d_y, s); break;
+        case 3: launch_ring<512, 4096, 11264, 2>(A, V, d_x, d_y, s); break;
+        default: launch_ring<256, 2048, 5120, 2>(A, V, d_x, d_y, s); break;
         }
     } else {
         BlockTable* T = nullptr;
@@ -556,7 +573,8 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
         V.blk = T->d_blk;
         V.nblk = T->nblk;
         const int grid = kNXCD * ((T->nblk + kNXCD - 1) / kNXCD);
-        hipLaunchKernelGGL((spmv_csr_stream<1024>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+        if (A->stream_nt) hipLaunchKernelGGL((spmv_csr_stream<1024, true>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+        else hipLaunchKernelGGL((spmv_csr_stream<1024, false>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;

@@ -22,11 +22,17 @@ constexpr int kRingMaxB = 160; // blocks per run (LDS plan capacity)
 
 // 1: two workgroups per CU (74 KB LDS each); 2: one per CU, bigger blocks (108 KB);
 // 3: one per CU with the widest window that still fits 160 KB (for wider bands).
-static const RingConfig kRingConfigs[3] = {
+// 4: like 1 with 256 threads (8 nonzeros per thread): two workgroups of 4 waves per CU.  With the
+//    16-bit column stream and non-temporal value loads this is the fastest shape measured on C4
+//    (tools/kbench "C16S" rows: 146-151 us against 152-159 for 1, 168-184 for 2), so it is tried first.
+constexpr int kNumRingConfigs = 4;
+static const RingConfig kRingConfigs[kNumRingConfigs] = {
     {1, 512, 2048, 5120, 2, 512},
     {2, 512, 4096, 5120, 2, 256},
     {3, 512, 4096, 11264, 2, 256},
+    {4, 256, 2048, 5120, 2, 512},
 };
+static const int kRingConfigOrder[kNumRingConfigs] = {4, 1, 2, 3};
 
 struct RingPlanHost {
     RingConfig cfg{};

@@ -85,7 +85,8 @@ __device__ __forceinline__ double row_chain(const double* s_c, const double* s_x
     return s;
 }
 
-template <int NNZB>
+// NT: matrix stream loaded non-temporally (see spmv_ring.hpp; chosen per matrix by mi_csr_create)
+template <int NNZB, bool NT = false>
 __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* __restrict__ x,
                                                        double* __restrict__ y)
 {
@@ -128,8 +129,13 @@ __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* 
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int k = min(tid + i * kWG, last);
-            c[i] = A.coef[p0 + k];
-            j[i] = ucol[p0 + k];
+            if (NT) {
+                c[i] = __builtin_nontemporal_load(&A.coef[p0 + k]);
+                j[i] = __builtin_nontemporal_load(&ucol[p0 + k]);
+            } else {
+                c[i] = A.coef[p0 + k];
+                j[i] = ucol[p0 + k];
+            }
         }
         // keep the three groups (stream loads | gathers | LDS stores) apart: left to
         // itself the scheduler re-fuses them into per-element load-wait-gather-wait-store
@@ -199,6 +205,8 @@ struct Bcsr4View {
     const double* coef; // 16 per block
 };
 
+// (non-temporal loads of the block values were measured and lose here: 1 235 -> 1 044 GFLOP/s on the
+// FE matrix — the 16-byte loads split in two)
 __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __restrict__ x,
                                                   double* __restrict__ y)
 {

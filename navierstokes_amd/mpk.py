@@ -74,7 +74,7 @@ def lib():
         "mi_csr_get_kernel": [_vp, P(i)],
         "mi_csr_ring_info": [_vp, P(i), P(i), P(i), P(d)],
         "mi_csr_tune_info": [_vp, P(d), P(d)],
-        "mi_csr_tune_detail": [_vp, P(d), P(_c.c_int)],
+        "mi_csr_tune_detail": [_vp, P(d), P(_c.c_int), P(_c.c_int)],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_spmk": [_vp, i, _vp, _vp],
@@ -217,11 +217,13 @@ class csrmatrix:
         return a.value, b.value
 
     def tune_detail(self):
-        """({ring temporal, ring non-temporal, stream} us per launch at create time, nt chosen)."""
-        us = (_c.c_double * 3)()
-        nt = _c.c_int()
-        check(lib().mi_csr_tune_detail(self.handle, us, _c.byref(nt)))
-        return dict(ring=us[0], ring_nt=us[1], stream=us[2]), bool(nt.value)
+        """(us per launch measured at create time for ring / stream, each with temporal and non-temporal
+        matrix loads; whether the kernel that AUTO resolves to uses non-temporal loads)."""
+        us = (_c.c_double * 4)()
+        rnt, snt = _c.c_int(), _c.c_int()
+        check(lib().mi_csr_tune_detail(self.handle, us, _c.byref(rnt), _c.byref(snt)))
+        nt = rnt.value if "ring" in self.kernel_name() else snt.value
+        return dict(ring=us[0], ring_nt=us[1], stream=us[2], stream_nt=us[3]), bool(nt)
 
     def drop_host_arrays(self):
         """Free the host copies of indcol/coef once the device handle exists (large benches)."""

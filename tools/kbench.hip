@@ -415,7 +415,7 @@ int main(int argc, char** argv)
             }
         }
         if (g_want_slots) { // 16-bit ring slots in thread order (the product's build_ring_slots, for this plan layout)
-            const int T = 512, per = nnzb / T;
+            const int T = g_want_slots > 1 ? g_want_slots : 512, per = nnzb / T;
             std::vector<unsigned short> sl(nslots * nnzb, 0);
             for (size_t b = 0; b < nslots; b++) {
                 const int4 m0 = plan[2 * b], m1 = plan[2 * b + 1];

@@ -1195,7 +1195,9 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __re
             if (ABL & 4096) sl[s] = __builtin_nontemporal_load(sp); else sl[s] = *sp;
         }
         const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
-        if (ABL & 32) pr[s] = make_int2(p0, p0 + 15); else pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
+        if (ABL & 32) pr[s] = make_int2(p0, p0 + 15);
+        else if (ABL & 16384) pr[s] = make_int2(__builtin_nontemporal_load(&A.ptrow[row]), __builtin_nontemporal_load(&A.ptrow[row + 1]));
+        else pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
         if (ABL & 16) xr[s] = 0.0; else xr[s] = x[min(m1.x + tid, clast)];
     };
 
@@ -1263,6 +1265,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __re
                 double* dst = tid < nrows ? &y[myrow] : &y[(size_t)A.n + (size_t)blockIdx.x * T + tid];
                 *dst = v;
             }
+            else if (ABL & 8192) { if (tid < nrows) __builtin_nontemporal_store(row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0), &y[myrow]); }
             else if (tid < nrows) y[myrow] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
             for (int r = myrow + T; r < r0 + nrows; r += T) {
                 const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
@@ -1819,6 +1822,39 @@ inline void add_experimental_variants(std::vector<Variant>& vars, int n, const i
                 C16V("C16 skeleton no barriers (invalid)", 15)
                 C16V("C16 skeleton no barr/xr/ptrow/stores (invalid)", 127)
                 C16V("C16 full, NT loads", 1024)
+                {
+                    auto shape = [&](const char* name, auto kern, CsrView VV, int tab, int ring, int T, int maxb, int wgsreq) {
+                        const int4* Pq; const int* OKq; int wgsq, bpwq;
+                        g_want_slots = T;
+                        make_plan(tab, ring, maxb, wgsreq, &Pq, &OKq, &wgsq, &bpwq);
+                        g_want_slots = 0;
+                        const unsigned short* SLq = g_last_slots;
+                        vars.push_back({name, [=](hipStream_t s) { hipLaunchKernelGGL(kern, dim3(wgsq), dim3(T), 0, s, VV, Pq, OKq, d_x, d_y, bpwq, SLq); }});
+                    };
+                    shape("C16S NT <512,2048,5120,D2> 512 WGs", spmv_csr_ring5a<512, 2048, 5120, 2, 160, 2048 + 1024>, V2k, 2048, 5120, 512, 160, 512);
+                    shape("C16S NT <512,2048,5120,D3> 512 WGs", spmv_csr_ring5a<512, 2048, 5120, 3, 160, 2048 + 1024>, V2k, 2048, 5120, 512, 160, 512);
+                    shape("C16S NT <256,2048,5120,D2> 512 WGs", spmv_csr_ring5a<256, 2048, 5120, 2, 160, 2048 + 1024>, V2k, 2048, 5120, 256, 160, 512);
+                    shape("C16S NT <256,2048,5120,D3> 512 WGs", spmv_csr_ring5a<256, 2048, 5120, 3, 160, 2048 + 1024>, V2k, 2048, 5120, 256, 160, 512);
+                    shape("C16S NT <256,2048,5120,D2> 1024 WGs", spmv_csr_ring5a<256, 2048, 5120, 2, 160, 2048 + 1024>, V2k, 2048, 5120, 256, 160, 1024);
+                    shape("C16S NT <128,2048,5120,D2> 512 WGs", spmv_csr_ring5a<128, 2048, 5120, 2, 160, 2048 + 1024>, V2k, 2048, 5120, 128, 160, 512);
+                    shape("C16S NT <128,1024,4224,D2> 768 WGs", spmv_csr_ring5a<128, 1024, 4224, 2, 96, 2048 + 1024>, V1k, 1024, 4224, 128, 96, 768);
+                    shape("C16S NT <256,4096,5120,D2> 256 WGs", spmv_csr_ring5a<256, 4096, 5120, 2, 160, 2048 + 1024>, V, 4096, 5120, 256, 160, 256);
+                    shape("C16S NT <256,2048,4224,D2> 512 WGs", spmv_csr_ring5a<256, 2048, 4224, 2, 160, 2048 + 1024>, V2k, 2048, 4224, 256, 160, 512);
+                    shape("C16S NT <256,2048,5120,D2> no y stores", spmv_csr_ring5a<256, 2048, 5120, 2, 160, 2048 + 1024 + 64>, V2k, 2048, 5120, 256, 160, 512);
+                    shape("C16S NT <256,2048,5120,D2> skeleton", spmv_csr_ring5a<256, 2048, 5120, 2, 160, 2048 + 1024 + 7>, V2k, 2048, 5120, 256, 160, 512);
+                    shape("C16S NT <256,2048,5120,D2> no reduce", spmv_csr_ring5a<256, 2048, 5120, 2, 160, 2048 + 1024 + 1>, V2k, 2048, 5120, 256, 160, 512);
+                    shape("C16S NT <256,1024,4224,D2> 768 WGs", spmv_csr_ring5a<256, 1024, 4224, 2, 96, 2048 + 1024>, V1k, 1024, 4224, 256, 96, 768);
+                    shape("C16S NT <256,1024,4224,D3> 768 WGs", spmv_csr_ring5a<256, 1024, 4224, 3, 96, 2048 + 1024>, V1k, 1024, 4224, 256, 96, 768);
+                    shape("C16S NT <512,1024,4224,D2> 768 WGs", spmv_csr_ring5a<512, 1024, 4224, 2, 96, 2048 + 1024>, V1k, 1024, 4224, 512, 96, 768);
+                    shape("C16S NT <512,4096,5120,D2> 256 WGs", spmv_csr_ring5a<512, 4096, 5120, 2, 160, 2048 + 1024>, V, 4096, 5120, 512, 160, 256);
+                    shape("C16S T  <512,2048,5120,D2> 512 WGs", spmv_csr_ring5a<512, 2048, 5120, 2, 160, 2048>, V2k, 2048, 5120, 512, 160, 512);
+                    shape("C16S NT <512,2048,5120,D2> no y stores", spmv_csr_ring5a<512, 2048, 5120, 2, 160, 2048 + 1024 + 64>, V2k, 2048, 5120, 512, 160, 512);
+                    shape("C16S NT <512,2048,5120,D2> skeleton", spmv_csr_ring5a<512, 2048, 5120, 2, 160, 2048 + 1024 + 7>, V2k, 2048, 5120, 512, 160, 512);
+                    shape("C16S NT <512,2048,5120,D2> no reduce", spmv_csr_ring5a<512, 2048, 5120, 2, 160, 2048 + 1024 + 1>, V2k, 2048, 5120, 512, 160, 512);
+                }
+                C16V("C16 full, NT coef + NT y store", 1024 + 8192)
+                C16V("C16 full, NT coef + NT ptrow", 1024 + 16384)
+                C16V("C16 full, NT coef + NT ptrow + NT y store", 1024 + 16384 + 8192)
                 C16V("C16 full, NT coef + NT slots", 1024 + 4096)
                 C16V("C16 full, NT slots only", 4096)
                 C16V("C16 NT no y stores (invalid)", 1024 + 64)
