@@ -316,7 +316,7 @@ def main():
         tune, nt = A.tune_detail()
         out["kernel_info"] = dict(kernel=kernel_name, ring_config=ring_cfg, runs=ring_runs, runs_on_plain_path=ring_bad,
                                   nnz_fraction_ring=round(ring_frac, 4), nontemporal_values=nt,
-                                  matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else 12,
+                                  matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else (8.25 if "bcsr4" in kernel_name else 12),
                                   autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
     if parity is not None:
         out["parity"] = parity

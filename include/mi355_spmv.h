@@ -59,7 +59,10 @@ enum {
     MI_KERNEL_AUTO = 0,    /* ring when the matrix's column window fits LDS, else stream */
     MI_KERNEL_STREAM = 1,  /* row-block CSR-stream, x gathered through L1/L2 (any matrix) */
     MI_KERNEL_RING = 2,    /* persistent workgroups, sliding x window in LDS, pipelined matrix stream */
-    MI_KERNEL_ROWPAR = 3   /* one thread per row straight from global memory (reference shape; slow) */
+    MI_KERNEL_ROWPAR = 3,  /* one thread per row straight from global memory (reference shape; slow) */
+    MI_KERNEL_BCSR4 = 4    /* the BCSR 4x4 kernel on a blocked copy made at mi_csr_create; available only when the
+                            * CSR matrix has exact 4x4 node-block structure (FE matrices), where it returns the
+                            * same bits from 8.25 instead of 12 matrix bytes per nonzero */
 };
 
 /* ---- library / device ------------------------------------------------- */
@@ -99,10 +102,11 @@ int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringab
 int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
 /* Each candidate is timed twice, with temporal and with non-temporal loads of the matrix (a matrix
  * that fits the 256 MB Infinity Cache is faster temporal across repeated products, a larger one
- * non-temporal); us[0..3] = ring, ring non-temporal, stream, stream non-temporal; *ring_nt / *stream_nt
- * = 1 if that kernel of this handle uses non-temporal loads.  MI355_RING_NT / MI355_STREAM_NT = 0|1
- * force the choice. */
-int mi_csr_tune_detail(mi_csr_t A, double us[4], int* ring_nt, int* stream_nt);
+ * non-temporal); us[0..4] = ring, ring non-temporal, stream, stream non-temporal, BCSR 4x4 on the
+ * blocked copy (0 = not eligible / not timed); *ring_nt / *stream_nt = 1 if that kernel of this
+ * handle uses non-temporal loads.  MI355_RING_NT / MI355_STREAM_NT = 0|1 force the choice,
+ * MI355_AUTO_BCSR=0 disables the blocked copy. */
+int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt);
 int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
 /* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
 const char* mi_csr_kernel_name(mi_csr_t A);

@@ -99,6 +99,8 @@ struct mi_csr_s {
     int auto_kernel = MI_KERNEL_STREAM;
     double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0, tune_us_stream_nt = 0.0;
     bool stream_nt = false; // non-temporal matrix loads in the stream kernel
+    mi_bcsr4_t blocked = nullptr; // BCSR 4x4 copy (exact 4x4 node-block structure only), else null
+    double tune_us_bcsr = 0.0;
     int n_out = 0; // length of the y a launch may write (n, or max rowmap + 1)
     // scratch for the host-pointer entry points
     double* d_x = nullptr;
@@ -330,12 +332,25 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         }
         A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     }
+    // FE matrices: a blocked copy for the BCSR 4x4 kernel (same bits, 8.25 instead of 12 B per nonzero)
+    if (!rowmap && n >= 4 && nnz >= 16 && ncols % 4 == 0 && !(getenv("MI355_AUTO_BCSR") && !strcmp(getenv("MI355_AUTO_BCSR"), "0"))) {
+        std::vector<int> bptr, bcol;
+        std::vector<double> bval;
+        if (csr_to_bcsr4_exact(n, ptrow, indcol, coef, bptr, bcol, bval)) {
+            const int rcb = mi_bcsr4_create(n / 4, ncols / 4, bptr.data(), bcol.data(), bval.data(), &A->blocked);
+            if (rcb != MI_OK) {
+                mi_csr_destroy(A);
+                return rcb;
+            }
+        }
+    }
     // default for the value loads when nothing is measured: non-temporal once the matrix stream
     // (10 B per nonzero) no longer fits the 256 MB Infinity Cache with room for the vectors
     A->ring.nt = A->ring.d_slots && 10.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
     if (const char* e = getenv("MI355_RING_NT")) A->ring.nt = A->ring.d_slots && atoi(e) != 0;
     A->stream_nt = 12.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
     if (const char* e = getenv("MI355_STREAM_NT")) A->stream_nt = atoi(e) != 0;
+    if (A->blocked) A->auto_kernel = MI_KERNEL_BCSR4; // unless measured otherwise below
     A->n_out = n;
     if (rowmap)
         for (int i = 0; i < n; i++) A->n_out = rowmap[i] + 1 > A->n_out ? rowmap[i] + 1 : A->n_out;
@@ -345,6 +360,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         if (!strcmp(e, "stream")) A->auto_kernel = MI_KERNEL_STREAM;
         else if (!strcmp(e, "ring") && A->ring.d_plan) A->auto_kernel = MI_KERNEL_RING;
         else if (!strcmp(e, "rowpar")) A->auto_kernel = MI_KERNEL_ROWPAR;
+        else if (!strcmp(e, "bcsr4") && A->blocked) A->auto_kernel = MI_KERNEL_BCSR4;
         else forced_kernel = false;
     }
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
@@ -397,6 +413,22 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         A->stream_nt = better(us[3], us[2]);
         const double best_ring = A->ring.nt ? us[1] : us[0], best_stream = A->stream_nt ? us[3] : us[2];
         if (ring_ok && better(best_stream, best_ring)) A->auto_kernel = MI_KERNEL_STREAM;
+        if (A->blocked) { // the blocked copy against the best CSR kernel
+            A->kernel = MI_KERNEL_BCSR4;
+            for (int w = 0; w < 3; w++)
+                if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+            TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+            for (int w = 0; w < 6; w++)
+                if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+            TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+            TRY_OR_CLEAN(hipEventSynchronize(e1));
+            float ms = 0.f;
+            TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+            A->tune_us_bcsr = ms * 1e3 / 6;
+            A->kernel = MI_KERNEL_AUTO;
+            const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : best_stream;
+            if (better(A->tune_us_bcsr, best_csr)) A->auto_kernel = MI_KERNEL_BCSR4;
+        }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         dfree(tx);
@@ -434,6 +466,7 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->ring.d_plan);
     dfree(A->ring.d_ok);
     dfree(A->ring.d_slots);
+    mi_bcsr4_destroy(A->blocked);
     delete A;
     return MI_OK;
 }
@@ -451,6 +484,7 @@ static int resolve_kernel(const mi_csr_s* A)
 {
     int k = A->kernel != MI_KERNEL_AUTO ? A->kernel : A->auto_kernel;
     if (k == MI_KERNEL_RING && !A->ring.d_plan) k = MI_KERNEL_STREAM; // empty matrix: nothing to plan
+    if (k == MI_KERNEL_BCSR4 && !A->blocked) k = MI_KERNEL_STREAM;
     return k;
 }
 
@@ -462,7 +496,7 @@ extern "C" int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream)
     return MI_OK;
 }
 
-extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[4], int* ring_nt, int* stream_nt)
+extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt)
 {
     CHECK_ARG(A, "null handle");
     if (us) {
@@ -470,6 +504,7 @@ extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[4], int* ring_nt, int* s
         us[1] = A->tune_us_ring_nt;
         us[2] = A->tune_us_stream;
         us[3] = A->tune_us_stream_nt;
+        us[4] = A->tune_us_bcsr;
     }
     if (ring_nt) *ring_nt = A->ring.nt ? 1 : 0;
     if (stream_nt) *stream_nt = A->stream_nt ? 1 : 0;
@@ -489,7 +524,9 @@ extern "C" int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs
 extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
 {
     CHECK_ARG(A, "null handle");
-    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_ROWPAR, "unknown kernel id");
+    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_BCSR4, "unknown kernel id");
+    if (kernel_id == MI_KERNEL_BCSR4 && !A->blocked)
+        return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_BCSR4: this matrix has no exact 4x4 block structure (or is row-mapped)");
     A->kernel = kernel_id;
     return MI_OK;
 }
@@ -515,6 +552,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
         return nm;
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
+    case MI_KERNEL_BCSR4: return "spmv_bcsr4";
     default: return "";
     }
 }
@@ -556,6 +594,18 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
     V.blk = nullptr;
     V.blk_span = nullptr;
     V.nblk = 0;
+    if (kid == MI_KERNEL_BCSR4 && (((uintptr_t)d_x) & 15) == 0) return mi_bcsr4_spmv_dev(A->blocked, d_x, d_y, (mi_stream_t)s);
+    if (kid == MI_KERNEL_BCSR4) { // x not 16-byte aligned: the blocked kernel's paired loads cannot be used
+        BlockTable* T = nullptr;
+        int rc = get_table(A, 1024, &T);
+        if (rc) return rc;
+        V.blk = T->d_blk;
+        V.nblk = T->nblk;
+        const int grid = kNXCD * ((T->nblk + kNXCD - 1) / kNXCD);
+        hipLaunchKernelGGL((spmv_csr_stream<1024, false>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
     if (kid == MI_KERNEL_ROWPAR) {
         hipLaunchKernelGGL(spmv_csr_rowpar, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y);
     } else if (kid == MI_KERNEL_RING) {

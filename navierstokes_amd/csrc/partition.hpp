@@ -161,4 +161,55 @@ inline void build_row_blocks(int n, const int* ptrow, int nnzb, int max_rows, st
     out_ptr.push_back(n > 0 ? ptrow[n] : 0);
 }
 
+// CSR with 4x4 node-block structure (what the reference's FE assembly produces:
+// src/benchmark_spmv.c:104-118 inserts whole 4x4 blocks) -> BCSR 4x4 with row-major blocks
+// (mpk/SpMV.h:26-33).  Succeeds only if the conversion loses nothing and keeps every row's
+// nonzeros in the same order: n % 4 == 0, the four rows of a block row hold the same columns, and
+// these come in aligned groups {4j, 4j+1, 4j+2, 4j+3}.  Then a BCSR row chain visits exactly the
+// CSR row's terms in CSR order, so the two kernels return the same bits.
+inline bool csr_to_bcsr4_exact(int n, const int* ptrow, const int* indcol, const double* coef, std::vector<int>& bptr,
+                               std::vector<int>& bcol, std::vector<double>& bval)
+{
+    bptr.clear();
+    bcol.clear();
+    bval.clear();
+    if (n <= 0 || n % 4 != 0) return false;
+    const int nb = n / 4;
+    bptr.resize((size_t)nb + 1);
+    bptr[0] = 0;
+    for (int b = 0; b < nb; b++) {
+        const int p0 = ptrow[4 * b], len = ptrow[4 * b + 1] - p0;
+        if (len % 4 != 0) return false;
+        for (int r = 1; r < 4; r++)
+            if (ptrow[4 * b + r + 1] - ptrow[4 * b + r] != len) return false;
+        for (int g = 0; g < len; g += 4) {
+            const int c0 = indcol[p0 + g];
+            if (c0 % 4 != 0) return false;
+            for (int k = 1; k < 4; k++)
+                if (indcol[p0 + g + k] != c0 + k) return false;
+        }
+        for (int r = 1; r < 4; r++) {
+            const int pr = ptrow[4 * b + r];
+            for (int k = 0; k < len; k++)
+                if (indcol[pr + k] != indcol[p0 + k]) return false;
+        }
+        bptr[b + 1] = bptr[b] + len / 4;
+    }
+    const size_t nblk = (size_t)bptr[nb];
+    bcol.resize(nblk);
+    bval.resize(16 * nblk);
+    for (int b = 0; b < nb; b++) {
+        const int p0 = ptrow[4 * b], nbk = bptr[b + 1] - bptr[b];
+        for (int g = 0; g < nbk; g++) {
+            const size_t blk = (size_t)bptr[b] + g;
+            bcol[blk] = indcol[p0 + 4 * g] / 4;
+            for (int r = 0; r < 4; r++) {
+                const int pr = ptrow[4 * b + r] + 4 * g;
+                for (int k = 0; k < 4; k++) bval[16 * blk + 4 * r + k] = coef[pr + k];
+            }
+        }
+    }
+    return true;
+}
+
 } // namespace mi355

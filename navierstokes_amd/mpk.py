@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmi355spmv.so")
 
 MI_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_RING, KERNEL_ROWPAR = 0, 1, 2, 3
-KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3}
+KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3, "bcsr4": 4}
 
 _c = ctypes
 _vp = ctypes.c_void_p
@@ -219,11 +219,11 @@ class csrmatrix:
     def tune_detail(self):
         """(us per launch measured at create time for ring / stream, each with temporal and non-temporal
         matrix loads; whether the kernel that AUTO resolves to uses non-temporal loads)."""
-        us = (_c.c_double * 4)()
+        us = (_c.c_double * 5)()
         rnt, snt = _c.c_int(), _c.c_int()
         check(lib().mi_csr_tune_detail(self.handle, us, _c.byref(rnt), _c.byref(snt)))
         nt = rnt.value if "ring" in self.kernel_name() else snt.value
-        return dict(ring=us[0], ring_nt=us[1], stream=us[2], stream_nt=us[3]), bool(nt)
+        return dict(ring=us[0], ring_nt=us[1], stream=us[2], stream_nt=us[3], bcsr4=us[4]), bool(nt)
 
     def drop_host_arrays(self):
         """Free the host copies of indcol/coef once the device handle exists (large benches)."""

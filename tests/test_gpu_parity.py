@@ -356,3 +356,42 @@ def test_ranks_sharing_one_card(world, kind, n, w, port):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert any(ln.startswith("DIST_GPU_RESULT ok=1") for ln in r.stdout.splitlines()), r.stdout[-2000:]
+
+
+def test_fe_matrix_takes_the_blocked_kernel_with_identical_bits():
+    """An FE matrix handed over as plain CSR (the reference's assemble_ns_matrix layout, src/benchmark_spmv.c:76-123)
+    has exact 4x4 node-block structure: mi_csr_create keeps a BCSR copy and AUTO may run the BCSR kernel on it.
+    Same terms in the same order per row, so the bits are those of the CSR fma chain."""
+    p, c, v = synth.fe_matrix(14)
+    n = len(p) - 1
+    x = synth.x_sin(0, n)
+    yr = O.spmv(p, c, v, x)
+    A = mpk.csrmatrix(n, p, c, v)
+    tune, _ = A.tune_detail()
+    assert tune["bcsr4"] > 0.0, "blocked copy was not built / timed"
+    for kernel in ("bcsr4", "stream", "auto"):
+        A.set_kernel(kernel)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(y, dev(x), A)
+        assert_bit_equal(y.cpu().numpy(), yr, f"FE matrix, {kernel} -> {A.kernel_name()}")
+    A.set_kernel("bcsr4")
+    assert A.kernel_name() == "spmv_bcsr4"
+    # an x that is only 8-byte aligned cannot feed the blocked kernel's paired loads: the CSR kernel steps in
+    xo = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+    xo[1:] = dev(x)
+    assert xo[1:].data_ptr() % 16 == 8
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(y, xo[1:], A)
+    assert_bit_equal(y.cpu().numpy(), yr, "FE matrix, bcsr4 requested, misaligned x")
+    # powers through the blocked kernel
+    ys = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    mpk.SpMkV(ys, dev(x), A)
+    Y = O.spmk_chain(3, p, c, v, x)
+    for k in range(3):
+        assert_bit_equal(ys[k].cpu().numpy(), Y[k], f"FE power {k + 1} via bcsr4")
+    # a matrix without the structure refuses the request loudly
+    p2, c2, v2 = synth.rows("s15", 4000)
+    B = mpk.csrmatrix(4000, p2, c2, v2)
+    _ = B.handle
+    with pytest.raises(mpk.MiError):
+        B.set_kernel("bcsr4")
