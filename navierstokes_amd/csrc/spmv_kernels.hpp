@@ -205,11 +205,15 @@ struct Bcsr4View {
     const double* coef; // 16 per block
 };
 
-// (non-temporal loads of the block values were measured and lose here: 1 235 -> 1 044 GFLOP/s on the
-// FE matrix — the 16-byte loads split in two)
+// Three-stage software pipeline per lane: block column two blocks ahead, block values and x one
+// block ahead, so the dependent x gather (column -> address -> L2) of block ia+1 is in flight while
+// block ia's four fmas run (indices clamped, loads unconditional).  Measured on the FE matrix:
+// 1 240 GFLOP/s with x fetched on demand, 1 260 like this.  Non-temporal loads of the block values
+// lose badly here (870 GFLOP/s): a lane's two 16-byte loads touch the same 128-byte line twice.
 __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __restrict__ x,
                                                   double* __restrict__ y)
 {
+    // (an XCD-aware block-row order was measured and changes nothing here: 1 264 vs 1 266 GFLOP/s)
     const int g = blockIdx.x * kWG + threadIdx.x;
     const int bi = g >> 2, q = g & 3;
     if (bi >= A.nbrows) return;
@@ -217,25 +221,29 @@ __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __r
     const int ia0 = A.ptrow[bi], ia1 = A.ptrow[bi + 1];
     double s = 0.0;
     if (ia0 < ia1) {
-        // two-deep software pipeline: block ia+1's coefficients and column are requested before
-        // block ia's x values are consumed (indices clamped, loads unconditional)
+        const int last = ia1 - 1;
         const double2* row = reinterpret_cast<const double2*>(A.coef + 16 * (size_t)ia0 + 4 * q);
         double2 a01 = row[0], a23 = row[1];
-        unsigned bj = ucol[ia0];
+        const unsigned bj = ucol[ia0];
+        unsigned bj2 = ucol[min(ia0 + 1, last)]; // column of block ia+1
+        const double2* xb = reinterpret_cast<const double2*>(x + 4 * (size_t)bj);
+        double2 x01 = xb[0], x23 = xb[1];
         for (int ia = ia0; ia < ia1; ia++) {
-            const int nx = min(ia + 1, ia1 - 1);
-            const double2* nrow = reinterpret_cast<const double2*>(A.coef + 16 * (size_t)nx + 4 * q);
+            const int n1 = min(ia + 1, last), n2 = min(ia + 2, last);
+            const double2* nrow = reinterpret_cast<const double2*>(A.coef + 16 * (size_t)n1 + 4 * q);
             const double2 n01 = nrow[0], n23 = nrow[1];
-            const unsigned nbj = ucol[nx];
-            const double2* xb = reinterpret_cast<const double2*>(x + 4 * (size_t)bj);
-            const double2 x01 = xb[0], x23 = xb[1];
+            const double2* nxb = reinterpret_cast<const double2*>(x + 4 * (size_t)bj2);
+            const double2 nx01 = nxb[0], nx23 = nxb[1];
+            const unsigned nbj2 = ucol[n2];
             s = fma(a01.x, x01.x, s);
             s = fma(a01.y, x01.y, s);
             s = fma(a23.x, x23.x, s);
             s = fma(a23.y, x23.y, s);
             a01 = n01;
             a23 = n23;
-            bj = nbj;
+            x01 = nx01;
+            x23 = nx23;
+            bj2 = nbj2;
         }
     }
     y[4 * (size_t)bi + q] = s;
