@@ -107,6 +107,8 @@ int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
  * handle uses non-temporal loads.  MI355_RING_NT / MI355_STREAM_NT = 0|1 force the choice,
  * MI355_AUTO_BCSR=0 disables the blocked copy. */
 int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt);
+/* override the measured choice: 1 = non-temporal matrix loads, 0 = temporal, -1 = leave as is */
+int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt);
 int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
 /* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
 const char* mi_csr_kernel_name(mi_csr_t A);

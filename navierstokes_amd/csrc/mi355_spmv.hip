@@ -378,31 +378,37 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         const bool ring_nt_forced = getenv("MI355_RING_NT") != nullptr, stream_nt_forced = getenv("MI355_STREAM_NT") != nullptr;
         const bool ring_nt0 = A->ring.nt, stream_nt0 = A->stream_nt;
         double us[4] = {0, 0, 0, 0}; // ring, ring nt, stream, stream nt
-        for (int c = 0; c < 4; c++) {
-            const bool nt = c & 1;
-            if (c < 2) {
-                if (!ring_ok || (nt && !A->ring.d_slots) || (ring_nt_forced && nt != ring_nt0)) continue;
-                A->ring.nt = nt;
-                A->kernel = MI_KERNEL_RING;
-            } else {
-                if (stream_nt_forced && nt != stream_nt0) continue;
-                A->stream_nt = nt;
-                A->kernel = MI_KERNEL_STREAM;
+        // two interleaved rounds, the faster of the two counts: one round is not enough to tell two
+        // candidates 5 % apart from each other (clock ramps, what the previous candidate left in the caches)
+        for (int round = 0; round < 2; round++)
+            for (int c = 0; c < 4; c++) {
+                const bool nt = c & 1;
+                if (c < 2) {
+                    if (!ring_ok || (nt && !A->ring.d_slots) || (ring_nt_forced && nt != ring_nt0)) continue;
+                    A->ring.nt = nt;
+                    A->kernel = MI_KERNEL_RING;
+                } else {
+                    if (stream_nt_forced && nt != stream_nt0) continue;
+                    if (round == 1 && ring_ok && us[c] > 1.25 * std::min(us[0] > 0 ? us[0] : us[1], us[1] > 0 ? us[1] : us[0]))
+                        continue; // stream is out of the race already
+                    A->stream_nt = nt;
+                    A->kernel = MI_KERNEL_STREAM;
+                }
+                // warm launches first: a temporal candidate is judged with the Infinity Cache holding
+                // what it can of the matrix, as it would between the iterations of a solver
+                const int warm = 3, timed = nnz < 40000000 ? 12 : 6;
+                for (int w = 0; w < warm; w++)
+                    if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+                TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+                for (int w = 0; w < timed; w++)
+                    if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+                TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+                TRY_OR_CLEAN(hipEventSynchronize(e1));
+                float ms = 0.f;
+                TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+                const double t = ms * 1e3 / timed;
+                us[c] = us[c] > 0 ? std::min(us[c], t) : t;
             }
-            // warm launches first: a temporal candidate is judged with the Infinity Cache holding
-            // what it can of the matrix, as it would between the iterations of a solver
-            const int warm = 3, timed = nnz < 40000000 ? 12 : 6;
-            for (int w = 0; w < warm; w++)
-                if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
-            TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
-            for (int w = 0; w < timed; w++)
-                if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
-            TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
-            TRY_OR_CLEAN(hipEventSynchronize(e1));
-            float ms = 0.f;
-            TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
-            us[c] = ms * 1e3 / timed;
-        }
         A->kernel = MI_KERNEL_AUTO;
         A->tune_us_ring = us[0];
         A->tune_us_ring_nt = us[1];
@@ -508,6 +514,14 @@ extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* s
     }
     if (ring_nt) *ring_nt = A->ring.nt ? 1 : 0;
     if (stream_nt) *stream_nt = A->stream_nt ? 1 : 0;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt)
+{
+    CHECK_ARG(A, "null handle");
+    if (ring_nt >= 0) A->ring.nt = ring_nt != 0 && A->ring.d_slots;
+    if (stream_nt >= 0) A->stream_nt = stream_nt != 0;
     return MI_OK;
 }
 
