@@ -979,9 +979,16 @@ static bool rccl_load()
     if (R.tried) return R.ok;
     R.tried = true;
     void* h = nullptr;
+    // MI355_RCCL_LIBRARY: a specific RCCL build (or the tests' in-process stand-in, tests/fake_rccl)
+    if (const char* e = getenv("MI355_RCCL_LIBRARY")) {
+        if (!(h = dlopen(e, RTLD_NOW | RTLD_LOCAL))) {
+            R.why = std::string("dlopen(") + e + "): " + (dlerror() ? dlerror() : "failed");
+            return false;
+        }
+    }
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* nm : names)
-        if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (h || (h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!h) {
         R.why = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found");
         return false;

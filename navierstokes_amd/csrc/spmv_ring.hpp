@@ -176,9 +176,18 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
 
 #pragma unroll
     for (int s = 0; s < D; s++) issue(s, s);
-    { // the whole first window (more than T columns): synchronous fill
+    { // the whole first window (more than T columns): synchronous fill, 8 loads in flight per thread
+      // (one load per round trip costs ~10 us per run: a quarter of a C2-sized launch)
         const int4 q = s_plan[1];
-        for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_slot<RING>(cc, q.z)] = x[cc];
+        const int cend = q.x + q.y;
+        for (int c0 = q.x + tid; c0 < cend; c0 += 8 * T) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = x[min(c0 + u * T, clast)];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (c0 + u * T < cend) s_ring[ring_slot<RING>(c0 + u * T, q.z)] = v[u];
+        }
     }
 
     for (int g = 0; g < nb; g += D) {

@@ -395,3 +395,21 @@ def test_fe_matrix_takes_the_blocked_kernel_with_identical_bits():
     _ = B.handle
     with pytest.raises(mpk.MiError):
         B.set_kernel("bcsr4")
+
+
+@pytest.mark.parametrize("kind,n,w,ranks", [("s15", 240_000, 2000, 4), ("svar", 90_000, 2000, 3), ("sfe", 64_000, 1500, 2)])
+def test_native_step_multirank_threads(kind, n, w, ranks):
+    """The library's native multi-rank step (C++: pack + exchange on a comm stream, interior beside, boundary
+    behind) with `ranks` ranks as threads on this one GPU and tests/fake_rccl in place of librccl, which refuses
+    two ranks per device.  Bitwise for 4 chained powers and for 40 unsynchronised repetitions of one step."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(fake), "run __graft_entry__.build() first (it builds tests/fake_rccl)"
+    env = dict(os.environ, MI355_RCCL_LIBRARY=fake, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native_threads_worker.py"), kind, str(n), str(w), str(ranks)],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "NATIVE_THREADS_RESULT" in r.stdout

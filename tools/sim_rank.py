@@ -45,6 +45,17 @@ t0 = time.perf_counter(); e0.record()
 for _ in range(500): step()
 e1.record(); torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / 500 * 1e6
+def only(fn, name):
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(500): fn()
+    b.record(); torch.cuda.synchronize()
+    print(f"    {name}: {a.elapsed_time(b) / 500 * 1e3:.1f} us back-to-back")
+only(lambda: mpk.check(L.mi_part_pack_dev(h, vp(x_ext.data_ptr()), vp(send.data_ptr()), sp)), "pack")
+only(lambda: mpk.check(L.mi_part_spmv_interior_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp)), "interior")
+only(lambda: mpk.check(L.mi_part_spmv_boundary_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp)), "boundary")
 cl = np.where((c >= lo) & (c < hi), c - lo, nl.value + np.searchsorted(halo_ids, c)).astype(np.int32)
 ok = np.array_equal(O.spmv(p, cl, v, xe).view(np.uint64), y.cpu().numpy().view(np.uint64))
 print(f"N={N} rank={rank} rows={nl.value} halo={nh.value} interior={ni.value} boundary={nb.value}: "
