@@ -80,8 +80,9 @@ struct RingTable {
     double ok_fraction = 0.0; // share of the nonzeros in ring-served runs
     int* d_plan = nullptr; // 8 ints per block, read as two int4
     int* d_ok = nullptr;
-    unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block; null: kernel reads indcol
-    bool nt = false;                   // non-temporal loads of the values (needs d_slots; chosen by measurement)
+    unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block
+    bool nt = false;                   // non-temporal loads of the values (chosen by measurement)
+    bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
 };
 
 struct mi_csr_s {
@@ -322,13 +323,21 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
             TRY_OR_CLEAN(hipMalloc(&A->ring.d_ok, sizeof(int) * best.run_ok.size()));
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
-            const char* c16 = getenv("MI355_RING_C16"); // development knob: 0 keeps the 32-bit column stream
-            if (!(c16 && !strcmp(c16, "0"))) {
+            {
                 std::vector<unsigned short> slots;
                 build_ring_slots(best, indcol, slots);
                 TRY_OR_CLEAN(hipMalloc(&A->ring.d_slots, sizeof(unsigned short) * slots.size()));
                 TRY_OR_CLEAN(hipMemcpy(A->ring.d_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice));
             }
+            // staging layout of the row chains: plain unless more than a tenth of the rows have a length
+            // that is a multiple of 8 (their LDS segments would start on the same two banks)
+            long long mult8 = 0;
+            for (int i = 0; i < n; i++) {
+                const int len = ptrow[i + 1] - ptrow[i];
+                mult8 += len > 0 && len % 8 == 0;
+            }
+            A->ring.skew = 10 * mult8 > n;
+            if (const char* e = getenv("MI355_RING_SKEW")) A->ring.skew = atoi(e) != 0;
         }
         A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     }
@@ -561,8 +570,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
         static thread_local char nm[96];
         const RingConfig& c = A->ring.cfg;
         snprintf(nm, sizeof nm, "spmv_csr_ring<%d, %d, %d, %d, %d, %s, %s, %s>", c.threads, c.nnzb, c.ring, c.depth, kRingMaxB,
-                 A->d_rowmap ? "true" : "false", A->ring.d_slots ? "true" : "false",
-                 A->ring.d_slots && A->ring.nt ? "true" : "false");
+                 A->d_rowmap ? "true" : "false", A->ring.nt ? "true" : "false", A->ring.skew ? "true" : "false");
         return nm;
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
@@ -572,19 +580,23 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
 }
 
 // ---------------------------------------------------------------- SpMV launch
-template <int T, int NNZB, int RING, int D, bool MAPPED, bool C16, bool NT>
+template <int T, int NNZB, int RING, int D, bool MAPPED, bool NT, bool SKEW>
 static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
 {
-    hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, C16, NT>), dim3(A->ring.wgs), dim3(T), 0, s, V,
+    hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW>), dim3(A->ring.wgs), dim3(T), 0, s, V,
                        reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, A->ring.bpw);
 }
 
 template <int T, int NNZB, int RING, int D, bool MAPPED>
 static void launch_ring1(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
 {
-    if (!A->ring.d_slots) launch_ring2<T, NNZB, RING, D, MAPPED, false, false>(A, V, d_x, d_y, s);
-    else if (A->ring.nt) launch_ring2<T, NNZB, RING, D, MAPPED, true, true>(A, V, d_x, d_y, s);
-    else launch_ring2<T, NNZB, RING, D, MAPPED, true, false>(A, V, d_x, d_y, s);
+    if (A->ring.nt) {
+        if (A->ring.skew) launch_ring2<T, NNZB, RING, D, MAPPED, true, true>(A, V, d_x, d_y, s);
+        else launch_ring2<T, NNZB, RING, D, MAPPED, true, false>(A, V, d_x, d_y, s);
+    } else {
+        if (A->ring.skew) launch_ring2<T, NNZB, RING, D, MAPPED, false, true>(A, V, d_x, d_y, s);
+        else launch_ring2<T, NNZB, RING, D, MAPPED, false, false>(A, V, d_x, d_y, s);
+    }
 }
 
 template <int T, int NNZB, int RING, int D>

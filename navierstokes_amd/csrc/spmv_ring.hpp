@@ -85,22 +85,60 @@ __device__ __forceinline__ void ring_simple_block(const CsrView& A, const double
     }
 }
 
+// Row chain over the staged {coef, x} of one row, operands fetched U at a time.  SKEW: the
+// staging arrays carry one pad slot per 32 entries (sk(), spmv_kernels.hpp) — needed when many
+// rows have a length that is a multiple of 8 (neighbouring lanes' segments then start a multiple of
+// 64 B apart and pile onto two LDS banks), at the price of index arithmetic per term.  Without it a
+// row is a plain contiguous segment: full batches of U are read with immediate offsets and run
+// unpredicated, only the tail (< U terms) tests against the row end; reads past the row end stay
+// inside the (padded) staging array and are never used.  (S15 rows, ISA of the chain phase:
+// ~170 VALU instructions per row with the skewed form, ~45 without.)
+template <int U, bool SKEW>
+__device__ __forceinline__ double ring_row_chain(const double* s_c, const double* s_x, int ra, int re)
+{
+    if (SKEW) return row_chain<U>(s_c, s_x, ra, re);
+    double s = 0.0;
+    int k = ra;
+    for (; k + U <= re; k += U) {
+        double cc[U], xx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            cc[u] = s_c[k + u];
+            xx[u] = s_x[k + u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) s = fma(cc[u], xx[u], s);
+    }
+    if (k < re) {
+        double cc[U], xx[U];
+#pragma unroll
+        for (int u = 0; u < U - 1; u++) {
+            cc[u] = s_c[k + u];
+            xx[u] = s_x[k + u];
+        }
+#pragma unroll
+        for (int u = 0; u < U - 1; u++)
+            if (k + u < re) s = fma(cc[u], xx[u], s);
+    }
+    return s;
+}
+
 // T threads, NNZB nonzeros per row block (PER = NNZB/T per thread), RING doubles of
 // x window, D blocks of prefetch, runs of at most MAXB blocks per workgroup.
 // LDS = 16 B * (NNZB + NNZB/32) staging + 8 B * RING + 32 B * (MAXB + 2D + 2) plan.
 //
-// C16: the column stream is read from `slots` instead of A.indcol — the ring slot of every
-// nonzero as a 16-bit number, precomputed with the plan (ring_plan.hpp: build_ring_slots) and
-// stored per block in thread order, so that one 2*PER-byte load hands a thread all its PER
-// slots.  The matrix stream shrinks from 12 to 10 bytes per nonzero and from 2*PER to PER+1
-// loads per thread and block; the arithmetic (and so every bit of y) is unchanged.
+// The column stream is read from `slots`, not from A.indcol: the ring slot of every nonzero as a
+// 16-bit number, precomputed with the plan (ring_plan.hpp: build_ring_slots) and stored per
+// block in thread order, so that one 2*PER-byte load hands a thread all its PER slots.  The
+// matrix stream is 10 instead of 12 bytes per nonzero and PER+1 instead of 2*PER loads per
+// thread and block; the arithmetic (and so every bit of y) is that of the CSR arrays.
 //
 // NT: the matrix values are loaded non-temporally.  A matrix much larger than the 256 MB Infinity
 // Cache is read once per product, and kept out of the L2 / Infinity Cache replacement it stops
 // displacing x, the plan and the y lines being written (C4: 190 -> 169 us).  A matrix that fits
 // the cache is better served by it across repeated products (C2: 38 us temporal, 44 us NT), so
 // mi_csr_create times both and keeps the faster.
-template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool C16, bool NT>
+template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool NT, bool SKEW>
 __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __restrict__ plan,
                                                    const int* __restrict__ run_ok,
                                                    const unsigned short* __restrict__ slots,
@@ -123,8 +161,10 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     const int b_begin = gw * bpw;
     const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
     if (nb <= 0) return;
-    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
     const int nlast = A.n - 1, clast = A.ncols - 1;
+    // the plan is read back from LDS at a uniform address: tell the compiler so (SGPRs, scalar
+    // address arithmetic for the stream loads instead of 64-bit vector adds per load)
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
     for (int i = tid; i < 2 * nb; i += T) s_plan[i] = plan[2 * b_begin + i];
     __syncthreads();
@@ -148,7 +188,6 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     }
 
     double c[D][PER];
-    unsigned j[D][C16 ? 1 : PER];
     SlotVec sl[D];
     const SlotVec* slotv = reinterpret_cast<const SlotVec*>(slots);
     const int bslot_last = A.nblk - 1;
@@ -158,20 +197,20 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
 
     auto issue = [&](int lb, int s) {
         const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
-        const int p0 = m0.y;
-        const int last = max(m0.w - 1, 0);
+        const int p0 = uni(m0.y);
+        const int last = max(uni(m0.w) - 1, 0);
+        const double* cb = A.coef + p0;
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int k = min(tid + i * T, last);
-            if (NT) c[s][i] = __builtin_nontemporal_load(&A.coef[p0 + k]);
-            else c[s][i] = A.coef[p0 + k];
-            if (!C16) j[s][i] = ucol[p0 + k];
+            if (NT) c[s][i] = __builtin_nontemporal_load(&cb[k]);
+            else c[s][i] = cb[k];
         }
-        if (C16) sl[s] = slotv[(size_t)min(b_begin + lb, bslot_last) * T + tid];
-        const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
+        sl[s] = (slotv + (size_t)min(b_begin + lb, bslot_last) * T)[tid];
+        const int row = min(uni(m0.x) + min(tid, max(uni(m0.z) - 1, 0)), nlast);
         pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
         if (MAPPED) rm[s] = A.rowmap[row];
-        xr[s] = x[min(m1.x + tid, clast)];
+        xr[s] = x[min(uni(m1.x) + tid, clast)];
     };
 
 #pragma unroll
@@ -194,21 +233,18 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
 #pragma unroll
         for (int s = 0; s < D; s++) {
             const int lb = g + s; // lb >= nb: an empty sentinel block
-            const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
-            const int r0 = m0.x, p0 = m0.y, nrows = m0.z, nn = m0.w;
-            const int base = m1.z;
+            const int4 m0 = s_plan[2 * lb];
+            const int r0 = uni(m0.x), p0 = uni(m0.y), nrows = uni(m0.z);
             __syncthreads(); // ring holds block lb's window; staging is free again
-            // ---- gather from the ring, park {coef, x} in the staging arrays
-            const int last = max(nn - 1, 0);
+            // ---- gather from the ring, park {coef, x} in the staging arrays.  Every thread writes
+            // its PER fixed slots; slots past the block's last nonzero receive copies of that
+            // nonzero (the clamped loads) and are never read by a row chain.
             double xv[PER];
 #pragma unroll
-            for (int i = 0; i < PER; i++) {
-                const unsigned pos = C16 ? (unsigned)sl[s][i] : (unsigned)ring_slot<RING>((int)j[s][i], base);
-                xv[i] = s_ring[min(pos, (unsigned)(RING - 1))]; // clamp: sentinel blocks gather nothing meaningful
-            }
+            for (int i = 0; i < PER; i++) xv[i] = s_ring[min((unsigned)sl[s][i], (unsigned)(RING - 1))]; // slots are < RING by construction
 #pragma unroll
             for (int i = 0; i < PER; i++) {
-                const int k = sk(min(tid + i * T, last));
+                const int k = SKEW ? sk(tid + i * T) : tid + i * T;
                 s_c[k] = c[s][i];
                 s_x[k] = xv[i];
             }
@@ -220,19 +256,20 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
             // ---- ring entries of block lb + 1 (requested D blocks ago into stage (s+1)%D).
             // They overwrite only columns behind lb+1's window, which lb's gather is done with.
             {
-                const int4 q = s_plan[2 * (lb + 1) + 1];
+                const int4 q4 = s_plan[2 * (lb + 1) + 1];
+                const int qx = uni(q4.x), qy = uni(q4.y), qz = uni(q4.z);
                 const double xn = xr[(s + 1) % D];
-                if (q.y <= T) {
-                    if (tid < q.y) s_ring[ring_slot<RING>(q.x + tid, q.z)] = xn;
+                if (qy <= T) {
+                    if (tid < qy) s_ring[ring_slot<RING>(qx + tid, qz)] = xn;
                 } else { // the window restarts inside the run (a jump in the column range)
-                    for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_slot<RING>(cc, q.z)] = x[cc];
+                    for (int cc = qx + tid; cc < qx + qy; cc += T) s_ring[ring_slot<RING>(cc, qz)] = x[cc];
                 }
             }
             // ---- row chains
-            if (tid < nrows) y[MAPPED ? rms : r0 + tid] = row_chain<8>(s_c, s_x, prs.x - p0, prs.y - p0);
+            if (tid < nrows) y[MAPPED ? rms : r0 + tid] = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
             for (int r = r0 + tid + T; r < r0 + nrows; r += T) { // blocks of very short rows
                 const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
-                y[MAPPED ? A.rowmap[r] : r] = row_chain<8>(s_c, s_x, a, e);
+                y[MAPPED ? A.rowmap[r] : r] = ring_row_chain<8, SKEW>(s_c, s_x, a, e);
             }
         }
     }

@@ -620,6 +620,18 @@ int main(int argc, char** argv)
             printf("\n");
         }
     }
+    if (g_prof_ptr2) {
+        unsigned long long h[16];
+        CK(hipMemcpy(h, g_prof_ptr2, sizeof h, hipMemcpyDeviceToHost));
+        const char* names[6] = {"wait barrier1", "gather+stage", "issue loads", "wait barrier2", "ringwrite+reduce+store", "launch-to-loop"};
+        for (int w = 0; w < 2; w++) {
+            double tot = 0;
+            for (int i = 0; i < 6; i++) tot += (double)h[w * 8 + i];
+            printf("ring5t C16NT <256,2048> phase shares, %s wave:", w == 0 ? "first" : "last");
+            for (int i = 0; i < 6; i++) printf("  %s %.1f%%", names[i], 100.0 * h[w * 8 + i] / tot);
+            printf("   [clock64 ticks per workgroup-wave over all launches: %.0f]\n", tot / g_prof2_wgs);
+        }
+    }
     for (auto& v : calib) {
         const double us = med(v.ms) * 1e3;
         printf("%-44s %9.1f %9.1f %10.1f %8.1f\n", v.name.c_str(), us, mn(v.ms) * 1e3, 12.0 * nnz / us / 1e3, 12.0 * nnz / us / 1e3 / 80.0);

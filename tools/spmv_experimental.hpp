@@ -18,6 +18,8 @@ static int g_want_slots = 0;                          // make_plan also builds t
 static const unsigned short* g_last_slots = nullptr;  // ... and leaves it here
 
 static unsigned long long* g_prof_ptr = nullptr;
+static unsigned long long* g_prof_ptr2 = nullptr;
+static int g_prof2_wgs = 0;
 
 struct Variant {
     std::string name;
@@ -1279,13 +1281,15 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5a(CsrView A, const int4* __re
 
 
 // diagnostic copy of ring5 with s_memtime stamps (shares of the block loop per phase)
-template <int T, int NNZB, int RING, int D, int MAXB>
+template <int T, int NNZB, int RING, int D, int MAXB, bool C16NT = false>
 __global__ __launch_bounds__(T) void spmv_csr_ring5t(CsrView A, const int4* __restrict__ plan, unsigned long long* __restrict__ prof,
                                                     const int* __restrict__ run_ok,
                                                     const double* __restrict__ x, double* __restrict__ y,
-                                                    int bpw)
+                                                    int bpw, const unsigned short* __restrict__ slots = nullptr)
 {
+    const long long t_start = clock64();
     constexpr int PER = NNZB / T;
+    typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
     constexpr int LDSN = NNZB + NNZB / 32 + 1;
     __shared__ double s_c[LDSN];
     __shared__ double s_x[LDSN];
@@ -1321,7 +1325,8 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5t(CsrView A, const int4* __re
     }
 
     double c[D][PER];
-    unsigned j[D][PER];
+    unsigned j[D][C16NT ? 1 : PER];
+    SlotVec sl[D];
     int2 pr[D];
     double xr[D];
     long long acc[6] = {0, 0, 0, 0, 0, 0};
@@ -1335,9 +1340,13 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5t(CsrView A, const int4* __re
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int k = min(tid + i * T, last);
-            c[s][i] = A.coef[p0 + k];
-            j[s][i] = ucol[p0 + k];
+            if (C16NT) c[s][i] = __builtin_nontemporal_load(&A.coef[p0 + k]);
+            else {
+                c[s][i] = A.coef[p0 + k];
+                j[s][i] = ucol[p0 + k];
+            }
         }
+        if (C16NT) sl[s] = reinterpret_cast<const SlotVec*>(slots)[(size_t)min(b_begin + lb, A.nblk - 1) * T + tid];
         const int row = min(m0.x + min(tid, max(m0.z - 1, 0)), nlast);
         pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
         xr[s] = x[min(m1.x + tid, clast)]; // the column this thread will put into the ring for block lb
@@ -1350,6 +1359,8 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5t(CsrView A, const int4* __re
         for (int cc = q.x + tid; cc < q.x + q.y; cc += T) s_ring[ring_pos<RING>(cc, q.z)] = x[cc];
     }
 
+    t0 = clock64();
+    acc[5] = t0 - t_start; // launch-to-loop: plan load, barriers, prologue issue, first window
     for (int g = 0; g < nb; g += D) {
 #pragma unroll
         for (int s = 0; s < D; s++) {
@@ -1365,7 +1376,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5t(CsrView A, const int4* __re
             double xv[PER];
 #pragma unroll
             for (int i = 0; i < PER; i++) {
-                const unsigned pos = (unsigned)ring_pos<RING>((int)j[s][i], base);
+                const unsigned pos = C16NT ? (unsigned)sl[s][i] : (unsigned)ring_pos<RING>((int)j[s][i], base);
                 xv[i] = s_ring[min(pos, (unsigned)(RING - 1))]; // clamp: sentinel blocks gather nothing meaningful
             }
 #pragma unroll
@@ -1404,7 +1415,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring5t(CsrView A, const int4* __re
     if ((tid & 63) == 0) {
         const int w = (tid >> 6) == 0 ? 0 : ((tid >> 6) == (T / 64 - 1) ? 1 : 2);
         if (w < 2)
-            for (int i = 0; i < 5; i++) atomicAdd(&prof[w * 8 + i], (unsigned long long)acc[i]);
+            for (int i = 0; i < 6; i++) atomicAdd(&prof[w * 8 + i], (unsigned long long)acc[i]);
     }
 #undef STAMP
 }
@@ -1792,6 +1803,20 @@ inline void add_experimental_variants(std::vector<Variant>& vars, int n, const i
             (void)hipMemset(prof, 0, 16 * sizeof(unsigned long long));
             g_prof_ptr = prof;
             CsrView V = V4k;
+            {
+                const int4* Pd; const int* OKd; int wgsd, bpwd;
+                g_want_slots = 256;
+                make_plan(2048, 5120, 160, 512, &Pd, &OKd, &wgsd, &bpwd);
+                g_want_slots = 0;
+                const unsigned short* SLd = g_last_slots;
+                unsigned long long* prof2 = nullptr;
+                (void)hipMalloc(&prof2, 16 * sizeof(unsigned long long));
+                (void)hipMemset(prof2, 0, 16 * sizeof(unsigned long long));
+                g_prof_ptr2 = prof2;
+                g_prof2_wgs = wgsd;
+                CsrView Vd = V2k;
+                vars.push_back({"DIAG2 ring5t C16 NT <256,2048,5120,D2>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5t<256, 2048, 5120, 2, 160, true>), dim3(wgsd), dim3(256), 0, s, Vd, Pd, prof2, OKd, d_x, d_y, bpwd, SLd); }});
+            }
             vars.push_back({"DIAG ring5t stamps <512,4096,5120,D2>", [=](hipStream_t s) { hipLaunchKernelGGL((spmv_csr_ring5t<512, 4096, 5120, 2, 160>), dim3(wgs), dim3(512), 0, s, V, P, prof, OK, d_x, d_y, bpw); }});
         }
     }
