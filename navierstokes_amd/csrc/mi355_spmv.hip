@@ -264,8 +264,8 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
     A->nnz = nnz;
     A->h_ptrow.assign(ptrow, ptrow + n + 1);
     hipError_t e = hipGetDevice(&A->device);
-    // +8 entries of zero padding behind indcol/coef: vector loads may touch them
-    const size_t pad = 8;
+    // zero padding behind the arrays: the kernels' unclamped / vector loads may touch it (ring_plan.hpp)
+    const size_t pad = 8, padv = kRingPadNnz, padr = kRingPadRows;
     auto cleanup = [&]() { mi_csr_destroy(A); };
 #define TRY_OR_CLEAN(expr)                                                          \
     do {                                                                            \
@@ -277,18 +277,20 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         }                                                                           \
     } while (0)
     TRY_OR_CLEAN(e);
-    TRY_OR_CLEAN(hipMalloc(&A->d_ptrow, sizeof(int) * ((size_t)n + 1)));
+    TRY_OR_CLEAN(hipMalloc(&A->d_ptrow, sizeof(int) * ((size_t)n + 1 + padr)));
     TRY_OR_CLEAN(hipMalloc(&A->d_indcol, sizeof(int) * ((size_t)nnz + pad)));
-    TRY_OR_CLEAN(hipMalloc(&A->d_coef, sizeof(double) * ((size_t)nnz + pad)));
+    TRY_OR_CLEAN(hipMalloc(&A->d_coef, sizeof(double) * ((size_t)nnz + padv)));
+    TRY_OR_CLEAN(hipMemset(A->d_ptrow + n + 1, 0, sizeof(int) * padr));
     TRY_OR_CLEAN(hipMemset(A->d_indcol + nnz, 0, sizeof(int) * pad));
-    TRY_OR_CLEAN(hipMemset(A->d_coef + nnz, 0, sizeof(double) * pad));
+    TRY_OR_CLEAN(hipMemset(A->d_coef + nnz, 0, sizeof(double) * padv));
     TRY_OR_CLEAN(hipMemcpy(A->d_ptrow, ptrow, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
     if (nnz) {
         TRY_OR_CLEAN(hipMemcpy(A->d_indcol, indcol, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
         TRY_OR_CLEAN(hipMemcpy(A->d_coef, coef, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     if (rowmap && n > 0) {
-        TRY_OR_CLEAN(hipMalloc(&A->d_rowmap, sizeof(int) * (size_t)n));
+        TRY_OR_CLEAN(hipMalloc(&A->d_rowmap, sizeof(int) * ((size_t)n + padr)));
+        TRY_OR_CLEAN(hipMemset(A->d_rowmap + n, 0, sizeof(int) * padr));
         TRY_OR_CLEAN(hipMemcpy(A->d_rowmap, rowmap, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     }
     // window plan of the ring kernel: first configuration (in preference order) that
@@ -602,6 +604,7 @@ static void launch_ring1(const mi_csr_s* A, const CsrView& V, const double* d_x,
 template <int T, int NNZB, int RING, int D>
 static void launch_ring(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
 {
+    static_assert(NNZB <= kRingPadNnz && 2 * T + 1 <= kRingPadRows, "device arrays are padded for the kernel's unclamped loads");
     if (A->d_rowmap) launch_ring1<T, NNZB, RING, D, true>(A, V, d_x, d_y, s);
     else launch_ring1<T, NNZB, RING, D, false>(A, V, d_x, d_y, s);
 }

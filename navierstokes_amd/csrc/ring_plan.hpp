@@ -19,6 +19,11 @@ struct RingConfig {
 };
 
 constexpr int kRingMaxB = 160; // blocks per run (LDS plan capacity)
+// The ring kernel addresses the value stream, ptrow and rowmap with plain tid-strided indices: lanes
+// past a block's last nonzero / last row read what lies behind (never used) instead of clamping
+// every index.  The device copies therefore carry this much initialised padding at the end:
+constexpr int kRingPadNnz = 4096;      // >= the largest NNZB of kRingConfigs
+constexpr int kRingPadRows = 1024 + 1; // >= the largest 2*T, plus the row-end entry
 
 // 1: two workgroups per CU (74 KB LDS each); 2: one per CU, bigger blocks (108 KB);
 // 3: one per CU with the widest window that still fits 160 KB (for wider bands).

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     const int b_begin = gw * bpw;
     const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
     if (nb <= 0) return;
-    const int nlast = A.n - 1, clast = A.ncols - 1;
+    const int clast = A.ncols - 1;
     // the plan is read back from LDS at a uniform address: tell the compiler so (SGPRs, scalar
     // address arithmetic for the stream loads instead of 64-bit vector adds per load)
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -197,19 +197,19 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
 
     auto issue = [&](int lb, int s) {
         const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
-        const int p0 = uni(m0.y);
-        const int last = max(uni(m0.w) - 1, 0);
-        const double* cb = A.coef + p0;
+        // plain tid-strided addresses, no clamps: lanes past the block's last nonzero / last row
+        // read what lies behind it (initialised padding at the very end, ring_plan.hpp:
+        // kRingPadNnz / kRingPadRows) and their values are never used
+        const double* cb = A.coef + uni(m0.y) + tid;
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const int k = min(tid + i * T, last);
-            if (NT) c[s][i] = __builtin_nontemporal_load(&cb[k]);
-            else c[s][i] = cb[k];
+            if (NT) c[s][i] = __builtin_nontemporal_load(&cb[i * T]);
+            else c[s][i] = cb[i * T];
         }
         sl[s] = (slotv + (size_t)min(b_begin + lb, bslot_last) * T)[tid];
-        const int row = min(uni(m0.x) + min(tid, max(uni(m0.z) - 1, 0)), nlast);
-        pr[s] = make_int2(A.ptrow[row], A.ptrow[row + 1]);
-        if (MAPPED) rm[s] = A.rowmap[row];
+        const int* rp = A.ptrow + uni(m0.x) + tid;
+        pr[s] = make_int2(rp[0], rp[1]);
+        if (MAPPED) rm[s] = (A.rowmap + uni(m0.x))[tid];
         xr[s] = x[min(uni(m1.x) + tid, clast)];
     };
 
