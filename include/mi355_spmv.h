@@ -109,6 +109,8 @@ int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
 int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt);
 /* override the measured choice: 1 = non-temporal matrix loads, 0 = temporal, -1 = leave as is */
 int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt);
+/* diagnostic: host_out[b] = XCD (HW_REG_XCC_ID) that workgroup b of a `wgs`-workgroup launch ran on */
+int mi_debug_xcc_map(int wgs, int* host_out);
 int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
 /* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
 const char* mi_csr_kernel_name(mi_csr_t A);

@@ -528,6 +528,28 @@ extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* s
     return MI_OK;
 }
 
+// diagnostic: which XCD each workgroup of a launch shaped like the ring kernel's lands on
+__global__ __launch_bounds__(256) void xcc_probe_kernel(int* out)
+{
+    __shared__ double hog[9000]; // ~70 KB: two workgroups per CU, like ring configuration 4
+    hog[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; // HW_REG_XCC_ID[3:0]
+    if (hog[threadIdx.x] != 0.0) out[blockIdx.x] = -1;
+}
+
+extern "C" int mi_debug_xcc_map(int wgs, int* host_out)
+{
+    CHECK_ARG(wgs > 0 && host_out, "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    int* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(int) * wgs));
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(wgs), dim3(256), 0, nullptr, d);
+    HIP_TRY(hipMemcpy(host_out, d, sizeof(int) * wgs, hipMemcpyDeviceToHost));
+    dfree(d);
+    return MI_OK;
+}
+
 extern "C" int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt)
 {
     CHECK_ARG(A, "null handle");

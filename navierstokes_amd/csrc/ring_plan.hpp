@@ -30,6 +30,8 @@ constexpr int kRingPadRows = 1024 + 1; // >= the largest 2*T, plus the row-end e
 // 4: like 1 with 256 threads (8 nonzeros per thread): two workgroups of 4 waves per CU.  With the
 //    16-bit column stream and non-temporal value loads this is the fastest shape measured on C4
 //    (tools/kbench "C16S" rows: 146-151 us against 152-159 for 1, 168-184 for 2), so it is tried first.
+//    (In-process A/B of the final kernel, tools/cfg_ab.py, C4: 4 = 151.4 us, 1 = 158.1, 2 = 160.0; the same
+//    shape with D = 3 or with a 4352-entry ring: 152.4 / 151.3 — no gain, not kept.  C2: all within 2 %.)
 constexpr int kNumRingConfigs = 4;
 static const RingConfig kRingConfigs[kNumRingConfigs] = {
     {1, 512, 2048, 5120, 2, 512},
