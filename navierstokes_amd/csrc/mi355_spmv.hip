@@ -242,6 +242,8 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
     for (int i = 0; i < n; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
     const long long nnz = ptrow[n];
     CHECK_ARG(nnz == 0 || (indcol && coef), "indcol/coef is null");
+    // 32-bit element offsets inside the kernels, padding included (ring_plan.hpp)
+    CHECK_ARG(nnz <= 0x7fffffffLL - 2 * kRingPadNnz && n <= 0x7fffffff - 2 * kRingPadRows, "matrix too large for 32-bit offsets: partition it (mi_part_*)");
     std::vector<int> row_min((size_t)n), row_max((size_t)n);
     for (int i = 0; i < n; i++) {
         int lo = 0x7fffffff, hi = -1;

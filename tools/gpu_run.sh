@@ -47,8 +47,8 @@ for s in "$@"; do
     bench_cold) step bench_cold 400 python bench.py --cold --steps 30 --warmup 3 --no-cpu-baseline ;;
     bench_gloo3) MI355_FORCE_DEVICE=0 MI355_BENCH_BACKEND=gloo step bench_gloo3 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 3 --workload c3 --steps 3 --warmup 1 --no-cpu-baseline ;;
     prof)     rm -rf gpurun_out/prof; step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity ;;
-    pmc_fetch) rm -rf gpurun_out/pmc_fetch; step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
-    pmc_write) rm -rf gpurun_out/pmc_write; step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
+    pmc_fetch) rm -rf gpurun_out/pmc_fetch; MI355_SPMV_AUTOTUNE=0 step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
+    pmc_write) rm -rf gpurun_out/pmc_write; MI355_SPMV_AUTOTUNE=0 step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
     *) echo "unknown step $s"; exit 1 ;;
   esac
 done
