@@ -413,3 +413,27 @@ def test_native_step_multirank_threads(kind, n, w, ranks):
                        env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "NATIVE_THREADS_RESULT" in r.stdout
+
+
+@pytest.mark.parametrize("kind,n", [("s15", 300_000), ("svar", 250_000)])
+def test_ring_variants_are_bit_identical(kind, n, monkeypatch):
+    """Every instantiation of the ring kernel mi_csr_create may pick — temporal / non-temporal value loads,
+    plain / padded staging layout, the four block shapes — returns the same bits as the oracle's fma chain."""
+    import ctypes
+    p, c, v = synth.rows(kind, n)
+    x = synth.x_sin(0, n)
+    yr = O.spmv(p, c, v, x)
+    L = mpk.lib()
+    seen = set()
+    for cfg in ("4", "1", "2", "3"):
+        for skew in ("0", "1"):
+            monkeypatch.setenv("MI355_RING_CONFIG", cfg)
+            monkeypatch.setenv("MI355_RING_SKEW", skew)
+            A = mpk.csrmatrix(n, p, c, v).set_kernel("ring")
+            for nt in (0, 1):
+                mpk.check(L.mi_csr_set_nontemporal(A.handle, nt, -1))
+                y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+                mpk.SpMV_CSR(y, dev(x), A)
+                assert_bit_equal(y.cpu().numpy(), yr, f"{kind} cfg {cfg} skew {skew} nt {nt}: {A.kernel_name()}")
+                seen.add(A.kernel_name())
+    assert len(seen) == 16, seen
