@@ -113,7 +113,7 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     }
 }
 
-// The 16-bit column stream of the ring kernel's C16 form: for block b, thread t, i < PER the
+// The 16-bit column stream of the ring kernel: for block b, thread t, i < PER the
 // ring slot of nonzero k = t + i*T of the block (the last nonzero again for k >= nnz of the
 // block) at out[(b*T + t)*PER + i].  Blocks the ring does not serve get zeros (their runs take
 // the plain path, which reads indcol).

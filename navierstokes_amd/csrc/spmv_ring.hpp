@@ -217,18 +217,18 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
 
 #pragma unroll
     for (int s = 0; s < D; s++) issue(s, s);
-    { // the whole first window (more than T columns): synchronous fill, 8 loads in flight per thread
-      // (one load per round trip costs ~10 us per run: a quarter of a C2-sized launch)
+    { // the whole first window (up to RING columns): all of a thread's loads in flight at once — one
+      // round trip instead of one per T columns, which at ~1 us each is a visible share of a short
+      // run (a 1 M-row matrix gives each workgroup 14 blocks, ~30 us in all)
+        constexpr int FILL = (RING + T - 1) / T;
         const int4 q = s_plan[1];
-        const int cend = q.x + q.y;
-        for (int c0 = q.x + tid; c0 < cend; c0 += 8 * T) {
-            double v[8];
+        const int c0 = uni(q.x) + tid, cend = uni(q.x) + uni(q.y), qz = uni(q.z);
+        double v[FILL];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = x[min(c0 + u * T, clast)];
+        for (int u = 0; u < FILL; u++) v[u] = x[min(c0 + u * T, clast)];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (c0 + u * T < cend) s_ring[ring_slot<RING>(c0 + u * T, q.z)] = v[u];
-        }
+        for (int u = 0; u < FILL; u++)
+            if (c0 + u * T < cend) s_ring[ring_slot<RING>(c0 + u * T, qz)] = v[u];
     }
 
     for (int g = 0; g < nb; g += D) {

@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmi355spmv.so")
+LIB_PATH = os.environ.get("MI355_SPMV_LIBRARY") or os.path.join(_HERE, "csrc", "libmi355spmv.so")  # env: A/B of two builds (tools/)
 
 MI_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_RING, KERNEL_ROWPAR = 0, 1, 2, 3
