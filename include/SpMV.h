@@ -108,6 +108,14 @@ void SpM2V_CSR_OPT(double* z, double* y, double* x, csrmatrix& A, std::vector<in
 void SpM2V_CSR_FMA(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& ptrowend1);
 void SpM2V_CSR_AVX2(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& ptrowend1);
 
+// mpk/SpM2V.cpp:28-46 and :375-801: the same on the blocked matrix (first-touch table of block rows;
+// y = A x, z = A (A x)).
+void Generate1stlayer_BCSR4(std::vector<int>& ptrowendB, const bcsr4x4_matrix& A);
+void SpM2V_BCSR(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& ptrowendB);
+void SpM2V_BCSR_OPT(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& ptrowendB);
+void SpM2V_BCSR_FMA(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& ptrowendB);
+void SpM2V_BCSR_AVX2(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& ptrowendB);
+
 // mpk/SpMVmulti0.cpp:132-155 and :189-221: all intermediate powers are returned
 // (y = A x, z = A^2 x, w = A^3 x, v = A^4 x).  The nested first-touch tables are
 // accepted for signature parity and ignored.

@@ -154,6 +154,10 @@ int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol,
 int mi_bcsr4_destroy(mi_bcsr4_t A);
 int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y);
 int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s);
+/* y_out[p] = A^(p+1) x for p < k on the blocked matrix: what SpM2V_BCSR{,_OPT,_FMA,_AVX2}(z, y, x, A, ptrowend1)
+ * (mpk/SpM2V.cpp:375-801) return for k = 2 (y_out = {y, z}); k chained launches, each row one fma chain. */
+int mi_bcsr4_spmk(mi_bcsr4_t A, int k, const double* x, double* const* y_out);
+int mi_bcsr4_spmk_dev(mi_bcsr4_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s);
 
 /* ---- row-range partition of one matrix over the GPUs of a node ----------
  * New design (the reference has no distributed code).  Rank r

@@ -118,6 +118,7 @@ struct mi_bcsr4_s {
     double* d_coef = nullptr;
     double* d_x = nullptr;
     double* d_y = nullptr;
+    std::vector<double*> d_pow;
 };
 
 struct mi_part_s {
@@ -958,6 +959,7 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     dfree(A->d_coef);
     dfree(A->d_x);
     dfree(A->d_y);
+    for (double* p : A->d_pow) dfree(p);
     delete A;
     return MI_OK;
 }
@@ -986,6 +988,46 @@ extern "C" int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y)
     int rc = mi_bcsr4_spmv_dev(A, A->d_x, A->d_y, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(y, A->d_y, sizeof(double) * 4 * (size_t)A->nbrows, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmk_dev(mi_bcsr4_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(A->nbrows == A->nbcols, "matrix powers need a square matrix");
+    CHECK_ARG(d_y_out, "null output array");
+    const double* src = d_x;
+    for (int p = 0; p < k; p++) {
+        CHECK_ARG(A->nbrows == 0 || d_y_out[p], "null output vector");
+        int rc = mi_bcsr4_spmv_dev(A, src, d_y_out[p], s);
+        if (rc) return rc;
+        src = d_y_out[p];
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmk(mi_bcsr4_t A, int k, const double* x, double* const* y_out)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(A->nbrows == A->nbcols, "matrix powers need a square matrix");
+    if (A->nbrows == 0) return MI_OK;
+    CHECK_ARG(x && y_out, "null vector");
+    const size_t n = 4 * (size_t)A->nbrows;
+    if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * n));
+    while ((int)A->d_pow.size() < k) {
+        double* p = nullptr;
+        HIP_TRY(hipMalloc(&p, sizeof(double) * n));
+        A->d_pow.push_back(p);
+    }
+    HIP_TRY(hipMemcpy(A->d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = mi_bcsr4_spmk_dev(A, k, A->d_x, A->d_pow.data(), nullptr);
+    if (rc) return rc;
+    for (int p = 0; p < k; p++) {
+        CHECK_ARG(y_out[p], "null output vector");
+        HIP_TRY(hipMemcpy(y_out[p], A->d_pow[p], sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
     return MI_OK;
 }
 

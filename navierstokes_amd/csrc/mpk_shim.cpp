@@ -152,6 +152,29 @@ void SpM2V_CSR_OPT(double* z, double* y, double* x, csrmatrix& A, std::vector<in
 void SpM2V_CSR_FMA(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& t) { SpM2V_CSR(z, y, x, A, t); }
 void SpM2V_CSR_AVX2(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& t) { SpM2V_CSR(z, y, x, A, t); }
 
+// first-touch table of block rows, filled as the reference fills it (mpk/SpM2V.cpp:28-46): the
+// block row of a block column's first appearance gets its full range, later appearances an empty one
+void Generate1stlayer_BCSR4(std::vector<int>& ptrowendB, const bcsr4x4_matrix& A)
+{
+    std::vector<char> seen((size_t)A.nrows, 0);
+    ptrowendB.resize(A.indcol.size());
+    for (int bi = 0; bi < A.nrows; bi++)
+        for (int m = A.ptrow[bi]; m < A.ptrow[bi + 1]; m++) {
+            const int bj = A.indcol[m];
+            ptrowendB[m] = seen[bj] ? A.ptrow[bj] : A.ptrow[bj + 1];
+            seen[bj] = 1;
+        }
+}
+
+void SpM2V_BCSR(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>&)
+{
+    double* outs[2] = {y, z};
+    MI_CALL(mi_bcsr4_spmk(device_bcsr(A), 2, x, outs));
+}
+void SpM2V_BCSR_OPT(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& t) { SpM2V_BCSR(z, y, x, A, t); }
+void SpM2V_BCSR_FMA(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& t) { SpM2V_BCSR(z, y, x, A, t); }
+void SpM2V_BCSR_AVX2(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& t) { SpM2V_BCSR(z, y, x, A, t); }
+
 void SpM3V(double* w, double* z, double* y, double* x, csrmatrix& A, std::vector<int>&,
            std::vector<std::vector<int> >&)
 {

@@ -96,6 +96,8 @@ def lib():
         "mi_bcsr4_destroy": [_vp],
         "mi_bcsr4_spmv": [_vp, _vp, _vp],
         "mi_bcsr4_spmv_dev": [_vp, _vp, _vp, _vp],
+        "mi_bcsr4_spmk": [_vp, i, _vp, _vp],
+        "mi_bcsr4_spmk_dev": [_vp, i, _vp, _vp, _vp],
         "mi_part_create": [i, i, _vp, _vp, _vp, _vp, P(_vp)],
         "mi_part_destroy": [_vp],
         "mi_part_sizes": [_vp, P(i), P(i), P(i), P(i)],
@@ -384,6 +386,25 @@ def SpM4V(v, w, z, y, x, A, ptrowend1=None, ptrowend2=None, ptrowend3=None):
     """y=Ax, z=A^2x, w=A^3x, v=A^4x — SpM4V(v, w, z, y, x, A, ...), mpk/SpMVmulti0.cpp:189-221."""
     SpMkV([y, z, w, v], x, A)
     return v, w, z, y
+
+
+def SpM2V_BCSR(z, y, x, A, ptrowend1=None):
+    """y = A x, z = A (A x) on a bcsr4x4_matrix — SpM2V_BCSR{,_OPT,_FMA,_AVX2}(z, y, x, A, ptrowend1),
+    mpk/SpM2V.cpp:375-801 (square matrices)."""
+    n = 4 * A.nrows
+    if _is_torch(x):
+        ptrs = (_vp * 2)(_dev_ptr(y, n, "y").value, _dev_ptr(z, n, "z").value)
+        check(lib().mi_bcsr4_spmk_dev(A.handle, 2, _dev_ptr(x, n, "x"), ptrs, _stream_ptr()))
+    else:
+        yy, zz = _host_f64(y, n, "y", writable=True), _host_f64(z, n, "z", writable=True)
+        ptrs = (_vp * 2)(yy.ctypes.data, zz.ctypes.data)
+        check(lib().mi_bcsr4_spmk(A.handle, 2, _host_f64(x, n, "x").ctypes.data, ptrs))
+    return z, y
+
+
+SpM2V_BCSR_OPT = SpM2V_BCSR
+SpM2V_BCSR_FMA = SpM2V_BCSR
+SpM2V_BCSR_AVX2 = SpM2V_BCSR
 
 
 # ------------------------------------------------------------------- BLAS-1

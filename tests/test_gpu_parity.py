@@ -437,3 +437,25 @@ def test_ring_variants_are_bit_identical(kind, n, monkeypatch):
                 assert_bit_equal(y.cpu().numpy(), yr, f"{kind} cfg {cfg} skew {skew} nt {nt}: {A.kernel_name()}")
                 seen.add(A.kernel_name())
     assert len(seen) == 16, seen
+
+
+def test_bcsr_matrix_powers():
+    """SpM2V_BCSR (mpk/SpM2V.cpp:375-801) on the blocked FE matrix: y = A x, z = A^2 x, device and host entry
+    points, bitwise against two oracle BCSR products (= two CSR fma-chain products of the same matrix)."""
+    p, c, v = synth.fe_matrix(10)
+    n = len(p) - 1
+    bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+    A = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
+    x = synth.x_sin(0, n)
+    Y = O.spmk_chain(2, p, c, v, x)
+    yb = O.spmv_bcsr4(bp, bc, bv, x)
+    assert_bit_equal(yb, Y[0], "oracle BCSR product == oracle CSR product on the blocked matrix")
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    z = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpM2V_BCSR(z, y, dev(x), A)
+    assert_bit_equal(y.cpu().numpy(), Y[0], "SpM2V_BCSR y (device)")
+    assert_bit_equal(z.cpu().numpy(), Y[1], "SpM2V_BCSR z (device)")
+    yh, zh = np.full(n, np.nan), np.full(n, np.nan)
+    mpk.SpM2V_BCSR_FMA(zh, yh, x, A)
+    assert_bit_equal(yh, Y[0], "SpM2V_BCSR y (host)")
+    assert_bit_equal(zh, Y[1], "SpM2V_BCSR z (host)")
