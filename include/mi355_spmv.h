@@ -107,6 +107,10 @@ int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
  * handle uses non-temporal loads.  MI355_RING_NT / MI355_STREAM_NT = 0|1 force the choice,
  * MI355_AUTO_BCSR=0 disables the blocked copy. */
 int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt);
+/* host-only: does this CSR pattern have the exact 4x4 node-block structure mi_csr_create looks for (n % 4 == 0,
+ * the four rows of a block row hold the same columns, in aligned groups {4j..4j+3}) — i.e. will a blocked copy be
+ * built and the BCSR kernel become an AUTO candidate?  *nblocks = number of 4x4 blocks if so. */
+int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_blocked, long long* nblocks);
 /* override the measured choice: 1 = non-temporal matrix loads, 0 = temporal, -1 = leave as is */
 int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt);
 /* diagnostic: host_out[b] = XCD (HW_REG_XCC_ID) that workgroup b of a `wgs`-workgroup launch ran on */

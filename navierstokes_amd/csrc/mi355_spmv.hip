@@ -553,6 +553,20 @@ extern "C" int mi_debug_xcc_map(int wgs, int* host_out)
     return MI_OK;
 }
 
+extern "C" int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_blocked, long long* nblocks)
+{
+    CHECK_ARG(n >= 0 && ptrow && is_blocked, "bad argument");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    // values are irrelevant to the structure test: hand the converter a dummy array of the right length
+    std::vector<double> dummy((size_t)ptrow[n], 0.0);
+    std::vector<int> bptr, bcol;
+    std::vector<double> bval;
+    const bool ok = csr_to_bcsr4_exact(n, ptrow, indcol, dummy.data(), bptr, bcol, bval);
+    *is_blocked = ok ? 1 : 0;
+    if (nblocks) *nblocks = ok ? (long long)bcol.size() : 0;
+    return MI_OK;
+}
+
 extern "C" int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt)
 {
     CHECK_ARG(A, "null handle");

@@ -76,6 +76,7 @@ def lib():
         "mi_csr_tune_info": [_vp, P(d), P(d)],
         "mi_csr_tune_detail": [_vp, P(d), P(_c.c_int), P(_c.c_int)],
         "mi_csr_set_nontemporal": [_vp, i, i],
+        "mi_csr_block4_structure": [i, _vp, _vp, P(i), P(_c.c_longlong)],
         "mi_debug_xcc_map": [i, _vp],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],

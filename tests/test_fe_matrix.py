@@ -155,3 +155,43 @@ def test_fe_matrix_gpu_parity():
     mpk.SpM3V(ys[2], ys[1], ys[0], dx, A)
     for k in range(3):
         assert_bit_equal(ys[k].cpu().numpy(), Y[k], f"FE matrix, A^{k + 1} x")
+
+
+def test_block4_structure_detection():
+    """mi_csr_block4_structure (host-only; the test mi_csr_create applies before it keeps a BCSR copy): FE matrices
+    qualify, and every way of breaking the structure is noticed."""
+    import ctypes
+    from navierstokes_amd import mpk
+    L = mpk.lib()
+
+    def blocked(p, c):
+        flag, nb = ctypes.c_int(-1), ctypes.c_longlong(-1)
+        p = np.ascontiguousarray(p, np.int32)
+        c = np.ascontiguousarray(c, np.int32)
+        mpk.check(L.mi_csr_block4_structure(len(p) - 1, p.ctypes.data, c.ctypes.data, ctypes.byref(flag), ctypes.byref(nb)))
+        return flag.value, nb.value
+
+    p, c, v = synth.fe_matrix(4)
+    assert blocked(p, c) == (1, len(c) // 16)
+    bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+    assert len(bc) == len(c) // 16
+    for kind in ("s15", "svar"):
+        ps, cs, _ = synth.rows(kind, 400)
+        assert blocked(ps, cs)[0] == 0
+    ps, cs, _ = synth.rows("sfe", 400)  # the synthetic FE-like generator is blocked too
+    assert blocked(ps, cs)[0] == 1
+    # one row of a block row loses its last entry -> lengths differ
+    keep = np.ones(len(c), bool)
+    keep[p[6] - 1] = False
+    p2 = p.copy()
+    p2[6:] -= 1
+    assert blocked(p2, c[keep])[0] == 0
+    # same lengths, but one column moved out of its aligned group
+    c3 = c.copy()
+    c3[p[5] + 1] = c3[p[5] + 1] + 4 if c3[p[5] + 1] + 4 < len(p) - 1 else c3[p[5] + 1] - 4
+    assert blocked(p, c3)[0] == 0
+    # n not a multiple of 4
+    assert blocked(p[:-1], c[: p[-2]])[0] == 0
+    # empty matrix and a single dense block
+    assert blocked(np.zeros(5, np.int32), np.zeros(0, np.int32)) == (1, 0)
+    assert blocked(np.array([0, 4, 8, 12, 16], np.int32), np.tile(np.arange(4, dtype=np.int32), 4)) == (1, 1)
