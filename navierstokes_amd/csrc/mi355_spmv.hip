@@ -615,7 +615,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
         return nm;
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
-    case MI_KERNEL_BCSR4: return "spmv_bcsr4";
+    case MI_KERNEL_BCSR4: return "spmv_bcsr4<2>";
     default: return "";
     }
 }
@@ -986,7 +986,7 @@ extern "C" int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, m
     CHECK_ARG((((uintptr_t)d_x) & 15) == 0, "x must be 16-byte aligned");
     Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef};
     const long long threads = 4LL * A->nbrows;
-    hipLaunchKernelGGL(spmv_bcsr4, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y);
+    hipLaunchKernelGGL(spmv_bcsr4<kBcsrDepth>, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }

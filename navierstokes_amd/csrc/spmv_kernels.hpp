@@ -205,15 +205,22 @@ struct Bcsr4View {
     const double* coef; // 16 per block
 };
 
-// Three-stage software pipeline per lane: block column two blocks ahead, block values and x one
-// block ahead, so the dependent x gather (column -> address -> L2) of block ia+1 is in flight while
-// block ia's four fmas run (indices clamped, loads unconditional).  Measured on the FE matrix:
-// 1 240 GFLOP/s with x fetched on demand, 1 260 like this.  Non-temporal loads of the block values
-// lose badly here (870 GFLOP/s): a lane's two 16-byte loads touch the same 128-byte line twice.
+// Software pipeline per lane, P blocks deep: while block ia's four fmas run, the values and x
+// entries of blocks ia+1 .. ia+P are in flight and the block columns of ia+P+1 .. ia+2P are being
+// fetched (x[4*col] cannot be requested before col has arrived, so columns run one round ahead of
+// values and x).  Indices are clamped to the row's last block and loads are unconditional; only
+// the fmas test against the row end.  A lane's lifetime is (blocks per row) x (memory latency) / P:
+// measured on the FE matrix (one box): P = 1 1 177 GFLOP/s, P = 2 1 256, P = 3 1 263, P = 4 1 083
+// (registers cost occupancy); kBcsrDepth = 2 is what mi_bcsr4_spmv* launches.
+// Tried and dropped: an XCD-aware block-row order (each XCD's L2 gets a contiguous eighth of the
+// rows) cuts the HBM reads from 771 to 673 MB per product (minimum 660) but not the time — it is
+// 2-3 % SLOWER at every depth, so the kernel is not traffic-bound; non-temporal loads of the block
+// values lose badly (870 GFLOP/s: a lane's two 16-byte loads touch the same 128-byte line twice).
+constexpr int kBcsrDepth = 2;
+template <int P>
 __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __restrict__ x,
                                                   double* __restrict__ y)
 {
-    // (an XCD-aware block-row order was measured and changes nothing here: 1 264 vs 1 266 GFLOP/s)
     const int g = blockIdx.x * kWG + threadIdx.x;
     const int bi = g >> 2, q = g & 3;
     if (bi >= A.nbrows) return;
@@ -222,28 +229,46 @@ __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __r
     double s = 0.0;
     if (ia0 < ia1) {
         const int last = ia1 - 1;
-        const double2* row = reinterpret_cast<const double2*>(A.coef + 16 * (size_t)ia0 + 4 * q);
-        double2 a01 = row[0], a23 = row[1];
-        const unsigned bj = ucol[ia0];
-        unsigned bj2 = ucol[min(ia0 + 1, last)]; // column of block ia+1
-        const double2* xb = reinterpret_cast<const double2*>(x + 4 * (size_t)bj);
-        double2 x01 = xb[0], x23 = xb[1];
-        for (int ia = ia0; ia < ia1; ia++) {
-            const int n1 = min(ia + 1, last), n2 = min(ia + 2, last);
-            const double2* nrow = reinterpret_cast<const double2*>(A.coef + 16 * (size_t)n1 + 4 * q);
-            const double2 n01 = nrow[0], n23 = nrow[1];
-            const double2* nxb = reinterpret_cast<const double2*>(x + 4 * (size_t)bj2);
-            const double2 nx01 = nxb[0], nx23 = nxb[1];
-            const unsigned nbj2 = ucol[n2];
-            s = fma(a01.x, x01.x, s);
-            s = fma(a01.y, x01.y, s);
-            s = fma(a23.x, x23.x, s);
-            s = fma(a23.y, x23.y, s);
-            a01 = n01;
-            a23 = n23;
-            x01 = nx01;
-            x23 = nx23;
-            bj2 = nbj2;
+        const double* cq = A.coef + 4 * q;
+        double2 a01[P], a23[P], x01[P], x23[P];
+        unsigned cn[P]; // columns of blocks ia+P+t
+#pragma unroll
+        for (int t = 0; t < P; t++) {
+            const int blk = min(ia0 + t, last);
+            const double2* row = reinterpret_cast<const double2*>(cq + 16 * (size_t)blk);
+            a01[t] = row[0];
+            a23[t] = row[1];
+            cn[t] = ucol[blk];
+        }
+#pragma unroll
+        for (int t = 0; t < P; t++) {
+            const double2* xb = reinterpret_cast<const double2*>(x + 4 * (size_t)cn[t]);
+            x01[t] = xb[0];
+            x23[t] = xb[1];
+        }
+#pragma unroll
+        for (int t = 0; t < P; t++) cn[t] = ucol[min(ia0 + P + t, last)];
+        for (int ia = ia0; ia < ia1; ia += P) {
+#pragma unroll
+            for (int t = 0; t < P; t++) {
+                const double2 c01 = a01[t], c23 = a23[t], v01 = x01[t], v23 = x23[t];
+                // refill stage t with block ia+t+P (its column arrived a round ago), then ask for
+                // the column of block ia+t+2P
+                const int nb = min(ia + t + P, last);
+                const double2* nrow = reinterpret_cast<const double2*>(cq + 16 * (size_t)nb);
+                a01[t] = nrow[0];
+                a23[t] = nrow[1];
+                const double2* nxb = reinterpret_cast<const double2*>(x + 4 * (size_t)cn[t]);
+                x01[t] = nxb[0];
+                x23[t] = nxb[1];
+                cn[t] = ucol[min(ia + t + 2 * P, last)];
+                if (ia + t < ia1) {
+                    s = fma(c01.x, v01.x, s);
+                    s = fma(c01.y, v01.y, s);
+                    s = fma(c23.x, v23.x, s);
+                    s = fma(c23.y, v23.y, s);
+                }
+            }
         }
     }
     y[4 * (size_t)bi + q] = s;

@@ -375,7 +375,7 @@ def test_fe_matrix_takes_the_blocked_kernel_with_identical_bits():
         mpk.SpMV_CSR(y, dev(x), A)
         assert_bit_equal(y.cpu().numpy(), yr, f"FE matrix, {kernel} -> {A.kernel_name()}")
     A.set_kernel("bcsr4")
-    assert A.kernel_name() == "spmv_bcsr4"
+    assert A.kernel_name() == "spmv_bcsr4<2>"
     # an x that is only 8-byte aligned cannot feed the blocked kernel's paired loads: the CSR kernel steps in
     xo = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
     xo[1:] = dev(x)
