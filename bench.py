@@ -62,7 +62,11 @@ def load_traffic(workload, kernel_name):
                     d = json.load(open(os.path.join(pdir, f)))
                 except Exception:
                     continue
-                if d.get("workload") == workload and d.get("kernel") == kernel_name:
+                # the temporal / non-temporal instantiations of one kernel move the same bytes (measured:
+                # 408.9 vs 410.4 thousand KB fetched), so a profile of either describes both
+                same = lambda a, b: a == b or (a.startswith("spmv_csr_ring<") and a.split(",")[:5] == b.split(",")[:5]
+                                               and a.split(",")[7:] == b.split(",")[7:])
+                if d.get("workload") == workload and same(d.get("kernel", ""), kernel_name):
                     best = (d.get("hbm_bytes_per_launch"), "profiles/" + f)
     return best if best else (None, None)
 
