@@ -13,6 +13,28 @@
 namespace mi355 {
 
 constexpr int kRedWG = 256;
+// NT: stream the vectors past the caches (non-temporal loads / stores).  Between two SpMVs of a
+// Krylov step the dot + update touch 160 MB of vectors at C4 size; left temporal they push the ring
+// kernel's 16-bit column stream and x out of the Infinity Cache and each SpMV of the pipeline costs
+// 167 us instead of 152 (tools/bench_pipeline.py: 368 -> 350 us per SpMV-orthogonalize-SpMV pass with
+// NT).  Small vectors live in the caches anyway and stay temporal (kBlas1NtMin).
+constexpr int kBlas1NtMin = 2000000;
+typedef double d2v_ __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 ld2_stream(const double* p)
+{
+    if (NT) {
+        const d2v_ v = __builtin_nontemporal_load(reinterpret_cast<const d2v_*>(p));
+        return make_double2(v.x, v.y);
+    }
+    return *reinterpret_cast<const double2*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ double ld1_stream(const double* p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
 constexpr int kMaxPartials = 1024; // = 4 per thread of the finishing workgroup
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -38,7 +60,7 @@ __device__ __forceinline__ double block_sum(double v, double* s_part /* [4] */)
 // MODE 0: sum a_i b_i     MODE 1: sum (a_i-b_i)^2 and sum a_i^2 (rel_error)
 // Workgroup g owns the contiguous segment [g*seg, (g+1)*seg); seg is a multiple
 // of 2*kRedWG so every lane's double2 is 16-byte aligned when the bases are.
-template <int MODE>
+template <int MODE, bool NT>
 __global__ __launch_bounds__(kRedWG) void reduce_stage1(int n, int seg, const double* __restrict__ a,
                                                         const double* __restrict__ b,
                                                         double* __restrict__ partial,
@@ -51,8 +73,8 @@ __global__ __launch_bounds__(kRedWG) void reduce_stage1(int n, int seg, const do
     const bool aligned = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
     if (aligned) {
         for (long long i = lo + 2 * threadIdx.x; i + 1 < hi; i += 2 * kRedWG) {
-            const double2 av = *reinterpret_cast<const double2*>(a + i);
-            const double2 bv = *reinterpret_cast<const double2*>(b + i);
+            const double2 av = ld2_stream<NT>(a + i);
+            const double2 bv = ld2_stream<NT>(b + i);
             if (MODE == 0) {
                 s = fma(av.x, bv.x, s);
                 s = fma(av.y, bv.y, s);
@@ -133,6 +155,7 @@ __global__ __launch_bounds__(256) void axpy_kernel(int n, double a, const double
 // round trip between the dot and the update): the AXPY half of orthogonalize,
 // evaluated exactly as the reference writes it (mpk/SpMVmulti.cpp:149:
 // x1[i] - alpha * beta * b[i], i.e. ((alpha*beta)*b[i]) subtracted, no fma).
+template <bool NT>
 __global__ __launch_bounds__(256) void ortho_update_kernel(int n, double alpha, const double* __restrict__ beta,
                                                            const double* __restrict__ b,
                                                            const double* __restrict__ x1,
@@ -141,7 +164,11 @@ __global__ __launch_bounds__(256) void ortho_update_kernel(int n, double alpha, 
     const double ab = alpha * beta[0];
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = __dsub_rn(x1[i], __dmul_rn(ab, b[i]));
+    {
+        const double v = __dsub_rn(ld1_stream<NT>(x1 + i), __dmul_rn(ab, ld1_stream<NT>(b + i)));
+        if (NT) __builtin_nontemporal_store(v, out + i);
+        else out[i] = v;
+    }
 }
 
 // dst[i] = src[idx[i]]

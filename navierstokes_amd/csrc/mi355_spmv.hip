@@ -762,6 +762,13 @@ extern "C" int mi_spmk(mi_csr_t A, int k, const double* x, double* const* y_out)
 }
 
 // ---------------------------------------------------------------- BLAS-1
+// large vectors are streamed past the caches (blas1_kernels.hpp); MI355_BLAS1_NT=0|1 forces the choice
+static bool blas1_nt(int n)
+{
+    static const int forced = getenv("MI355_BLAS1_NT") ? atoi(getenv("MI355_BLAS1_NT")) : -1;
+    return forced >= 0 ? forced != 0 : n >= kBlas1NtMin;
+}
+
 static int red_geometry(int n, int* np, int* seg)
 {
     // segments of a multiple of 2*kRedWG elements, at most kMaxPartials of them
@@ -785,7 +792,8 @@ static int reduce_dev(int n, const double* a, const double* b, double* d_out, hi
     if (rc) return rc;
     int np, seg;
     red_geometry(n, &np, &seg);
-    hipLaunchKernelGGL((reduce_stage1<MODE>), dim3(np), dim3(kRedWG), 0, s, n, seg, a, b, ws, ws + kMaxPartials);
+    if (blas1_nt(n)) hipLaunchKernelGGL((reduce_stage1<MODE, true>), dim3(np), dim3(kRedWG), 0, s, n, seg, a, b, ws, ws + kMaxPartials);
+    else hipLaunchKernelGGL((reduce_stage1<MODE, false>), dim3(np), dim3(kRedWG), 0, s, n, seg, a, b, ws, ws + kMaxPartials);
     hipLaunchKernelGGL((reduce_stage2<FIN>), dim3(1), dim3(kRedWG), 0, s, np, ws, ws + kMaxPartials, d_out);
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -846,7 +854,8 @@ extern "C" int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1
     CHECK_ARG(d_x3, "null output");
     int grid = (n + 255) / 256;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(ortho_update_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, n, alpha, d_beta_out, d_b, d_x1, d_x3);
+    if (blas1_nt(n)) hipLaunchKernelGGL(ortho_update_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)s, n, alpha, d_beta_out, d_b, d_x1, d_x3);
+    else hipLaunchKernelGGL(ortho_update_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)s, n, alpha, d_beta_out, d_b, d_x1, d_x3);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
