@@ -56,7 +56,7 @@ typedef void* mi_stream_t;           /* hipStream_t; NULL = the default stream *
 
 /* kernel ids for mi_csr_set_kernel (all produce the same bits) */
 enum {
-    MI_KERNEL_AUTO = 0,    /* ring when the matrix's column window fits LDS, else stream */
+    MI_KERNEL_AUTO = 0,    /* the fastest eligible kernel, measured on the handle at mi_csr_create (mi_csr_tune_detail) */
     MI_KERNEL_STREAM = 1,  /* row-block CSR-stream, x gathered through L1/L2 (any matrix) */
     MI_KERNEL_RING = 2,    /* persistent workgroups, sliding x window in LDS, pipelined matrix stream */
     MI_KERNEL_ROWPAR = 3,  /* one thread per row straight from global memory (reference shape; slow) */
@@ -95,10 +95,12 @@ int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz);
 int mi_csr_set_kernel(mi_csr_t A, int kernel_id);
 int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable);
 /* MI_KERNEL_AUTO is decided by measurement: mi_csr_create times the candidate kernels (ring if
- * >= 90 % of the nonzeros are ring-served, stream) on the new handle, a few launches each, and
- * keeps the faster.  All kernels produce the same bits, so the choice never changes a result.
- * Reports the measured microseconds per launch (0 = candidate not eligible / not timed).
- * MI355_SPMV_KERNEL=ring|stream|rowpar or MI355_SPMV_AUTOTUNE=0 skip the measurement. */
+ * >= 90 % of the nonzeros are ring-served, stream, BCSR 4x4 if a blocked copy exists) on the new
+ * handle, two interleaved rounds of a few launches each, and keeps the fastest.  All kernels produce
+ * the same bits, so the choice never changes a result.  Reports the measured microseconds per launch
+ * of the chosen temporal / non-temporal form (0 = candidate not eligible / not timed).
+ * MI355_SPMV_KERNEL=ring|stream|rowpar|bcsr4 or MI355_SPMV_AUTOTUNE=0 skip the measurement (then: ring
+ * if eligible else stream, BCSR 4x4 if blocked; non-temporal loads for matrices beyond the Infinity Cache). */
 int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
 /* Each candidate is timed twice, with temporal and with non-temporal loads of the matrix (a matrix
  * that fits the 256 MB Infinity Cache is faster temporal across repeated products, a larger one
