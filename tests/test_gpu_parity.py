@@ -459,3 +459,59 @@ def test_bcsr_matrix_powers():
     mpk.SpM2V_BCSR_FMA(zh, yh, x, A)
     assert_bit_equal(yh, Y[0], "SpM2V_BCSR y (host)")
     assert_bit_equal(zh, Y[1], "SpM2V_BCSR z (host)")
+
+
+def _random_banded(rng, n, ncols, mean_len, band, len_mode):
+    """Seeded CSR with a chosen row-length law and column band (columns ascending per row)."""
+    if len_mode == "mult8":
+        lens = 8 * rng.integers(0, max(2, mean_len // 4), n)
+    elif len_mode == "const":
+        lens = np.full(n, mean_len)
+    elif len_mode == "spiky":
+        lens = rng.integers(0, 2 * mean_len, n)
+        lens[rng.integers(0, n, 3)] = rng.integers(2048, 5000, 3)   # rows longer than a block
+    else:
+        lens = rng.integers(0, 2 * mean_len + 1, n)
+    lens = np.minimum(lens, min(ncols, 2 * band + 1)).astype(np.int64)
+    cols, centre = [], np.linspace(0, ncols - 1, n).astype(np.int64)
+    for i in range(n):
+        lo, hi = max(0, centre[i] - band), min(ncols, centre[i] + band + 1)
+        cols.append(np.sort(rng.choice(np.arange(lo, hi), int(min(lens[i], hi - lo)), replace=False)))
+        lens[i] = len(cols[-1])
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    c = (np.concatenate(cols) if p[-1] else np.zeros(0)).astype(np.int32)
+    return p, c, rng.uniform(-1, 1, int(p[-1]))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_all_kernels_and_layouts(seed, monkeypatch):
+    """Seeded sweep over shapes the tid-strided (unclamped) loads and the padded arrays must survive: sizes that are
+    multiples of nothing, rectangular matrices, row lengths that are multiples of 8 (padded staging layout),
+    rows longer than a block, narrow and wide bands, row-mapped pieces — every kernel, temporal and non-temporal,
+    bitwise against the oracle."""
+    import ctypes
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 40000))
+    ncols = n if seed % 2 == 0 else int(rng.integers(max(1, n // 2), 2 * n + 2))
+    mode = ["uniform", "mult8", "const", "spiky", "uniform", "mult8"][seed]
+    band = [300, 2000, 50, 1500, 30000, 6000][seed]
+    p, c, v = _random_banded(rng, n, ncols, int(rng.integers(3, 30)), band, mode)
+    x = rng.uniform(-1, 1, ncols)
+    yr = O.spmv(p, c, v, x)
+    L = mpk.lib()
+    rowmap = rng.permutation(n + 7)[:n].astype(np.int32)
+    for cfg in ("4", "2"):
+        monkeypatch.setenv("MI355_RING_CONFIG", cfg)
+        for mapped in (False, True):
+            A = mpk.csrmatrix(n, p, c, v, ncols=ncols, rowmap=rowmap if mapped else None)
+            for kernel in ("ring", "stream", "rowpar", "auto"):
+                A.set_kernel(kernel)
+                for nt in (0, 1):
+                    mpk.check(L.mi_csr_set_nontemporal(A.handle, nt, nt))
+                    y = torch.full((n + 7,), float("nan"), dtype=torch.float64, device="cuda")
+                    mpk.SpMV_CSR(y, dev(x), A)
+                    got = y.cpu().numpy()
+                    got = got[rowmap] if mapped else got[:n]
+                    assert_bit_equal(got, yr, f"seed {seed} n={n} ncols={ncols} {mode} band={band} cfg={cfg} mapped={mapped} {kernel} nt={nt}")
+                    if not mapped:
+                        assert np.isnan(y.cpu().numpy()[n:]).all(), "wrote past y"
