@@ -93,6 +93,8 @@ struct mi_csr_s {
     int* d_indcol = nullptr;
     double* d_coef = nullptr;
     int* d_rowmap = nullptr;
+    bool mapped = false;  // created with a rowmap (device-only entry points, no powers)
+    int y_offset = 0;     // a rowmap that is just "row r -> y[r + offset]" is applied as a pointer offset, not as a gather
     std::vector<int> h_ptrow; // kept to (re)build row-block tables
     std::map<int, BlockTable> tables;
     RingTable ring;           // valid iff ring.d_plan != nullptr
@@ -291,7 +293,11 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         TRY_OR_CLEAN(hipMemcpy(A->d_indcol, indcol, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
         TRY_OR_CLEAN(hipMemcpy(A->d_coef, coef, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
     }
-    if (rowmap && n > 0) {
+    A->mapped = rowmap != nullptr;
+    bool offset_only = rowmap != nullptr && n > 0;
+    for (int i = 1; offset_only && i < n; i++) offset_only = rowmap[i] == rowmap[0] + i;
+    if (offset_only) A->y_offset = rowmap[0]; // e.g. the interior rows of a banded partition: one contiguous range
+    if (rowmap && n > 0 && !offset_only) {
         TRY_OR_CLEAN(hipMalloc(&A->d_rowmap, sizeof(int) * ((size_t)n + padr)));
         TRY_OR_CLEAN(hipMemset(A->d_rowmap + n, 0, sizeof(int) * padr));
         TRY_OR_CLEAN(hipMemcpy(A->d_rowmap, rowmap, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
@@ -347,7 +353,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     }
     // FE matrices: a blocked copy for the BCSR 4x4 kernel (same bits, 8.25 instead of 12 B per nonzero)
-    if (!rowmap && n >= 4 && nnz >= 16 && ncols % 4 == 0 && !(getenv("MI355_AUTO_BCSR") && !strcmp(getenv("MI355_AUTO_BCSR"), "0"))) {
+    if ((!rowmap || offset_only) && n >= 4 && nnz >= 16 && ncols % 4 == 0 && !(getenv("MI355_AUTO_BCSR") && !strcmp(getenv("MI355_AUTO_BCSR"), "0"))) {
         std::vector<int> bptr, bcol;
         std::vector<double> bval;
         if (csr_to_bcsr4_exact(n, ptrow, indcol, coef, bptr, bcol, bval)) {
@@ -652,6 +658,7 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
 {
     if (A->n == 0) return MI_OK;
     const int kid = resolve_kernel(A);
+    d_y += A->y_offset;
     CsrView V;
     V.n = A->n;
     V.ncols = A->ncols;
@@ -709,7 +716,7 @@ extern "C" int mi_spmv(mi_csr_t A, const double* x, double* y)
 {
     CHECK_ARG(A, "null handle");
     CHECK_ARG(A->n == 0 || (x && y), "null vector");
-    if (A->d_rowmap) return fail(MI_ERR_UNSUPPORTED, "mapped matrices are device-only (use mi_spmv_dev)");
+    if (A->mapped) return fail(MI_ERR_UNSUPPORTED, "mapped matrices are device-only (use mi_spmv_dev)");
     if (A->n == 0) return MI_OK;
     if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * (size_t)(A->ncols > 0 ? A->ncols : 1)));
     if (!A->d_y) HIP_TRY(hipMalloc(&A->d_y, sizeof(double) * (size_t)A->n));
@@ -726,7 +733,7 @@ extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* 
     CHECK_ARG(A, "null handle");
     if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
     CHECK_ARG(A->n == A->ncols, "matrix powers need a square matrix");
-    CHECK_ARG(!A->d_rowmap, "matrix powers need an unmapped matrix");
+    CHECK_ARG(!A->mapped, "matrix powers need an unmapped matrix");
     CHECK_ARG(d_y_out, "null output array");
     const double* src = d_x;
     for (int p = 0; p < k; p++) {

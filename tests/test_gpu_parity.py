@@ -499,10 +499,11 @@ def test_random_shapes_all_kernels_and_layouts(seed, monkeypatch):
     x = rng.uniform(-1, 1, ncols)
     yr = O.spmv(p, c, v, x)
     L = mpk.lib()
-    rowmap = rng.permutation(n + 7)[:n].astype(np.int32)
     for cfg in ("4", "2"):
         monkeypatch.setenv("MI355_RING_CONFIG", cfg)
-        for mapped in (False, True):
+        for mapped in (False, True, "offset"):
+            # a scattered rowmap (gather per row) and a contiguous one (applied as a pointer offset)
+            rowmap = (np.arange(n) + 5).astype(np.int32) if mapped == "offset" else rng.permutation(n + 7)[:n].astype(np.int32)
             A = mpk.csrmatrix(n, p, c, v, ncols=ncols, rowmap=rowmap if mapped else None)
             for kernel in ("ring", "stream", "rowpar", "auto"):
                 A.set_kernel(kernel)
