@@ -1,0 +1,21 @@
+"""Create / use / destroy handles in a loop; device memory in use must return to where it started."""
+import os, sys, gc
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from navierstokes_amd import mpk, synth, dist as D
+torch.cuda.init()
+def used(): torch.cuda.synchronize(); f, t = torch.cuda.mem_get_info(); return (t - f) / 2**20
+p, c, v = synth.rows("s15", 400_000)
+pf, cf, vf = synth.fe_matrix(12)
+x = torch.from_numpy(synth.x_sin(0, 400_000)).cuda(); y = torch.empty(400_000, dtype=torch.float64, device="cuda")
+xf = torch.from_numpy(synth.x_sin(0, len(pf) - 1)).cuda(); yf = torch.empty(len(pf) - 1, dtype=torch.float64, device="cuda")
+def once():
+    A = mpk.csrmatrix(400_000, p, c, v); mpk.SpMV_CSR(y, x, A); mpk.SpMkV([y.clone(), y.clone()], x, A)
+    yh = np.empty(400_000); mpk.SpMV_CSR(yh, synth.x_sin(0, 400_000), A); A.close() if hasattr(A, "close") else None
+    B = mpk.csrmatrix(len(pf) - 1, pf, cf, vf); mpk.SpMV_CSR(yf, xf, B); del A, B
+    dc = D.DistCSR(np.array([0, 400_000], np.int64), p, c, v); xe = dc.new_x_ext(); yy = dc.new_y(); dc.spmv(xe, yy); dc.close(); del dc
+    gc.collect()
+once(); base = used()
+for i in range(30): once()
+torch.cuda.empty_cache()
+print(f"LEAK base {base:.1f} MiB, after 30 more rounds {used():.1f} MiB")
