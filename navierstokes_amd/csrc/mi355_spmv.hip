@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <new>
@@ -1208,6 +1209,33 @@ extern "C" int mi_comm_selftest(int count, double* max_abs_err)
     double m = 0.0;
     for (int i = 0; i < count; i++) m = std::max(m, std::fabs(back[i] - h[i]));
     *max_abs_err = m;
+    if (const char* e = getenv("MI355_COMM_SELFTEST_TIMING")) { // development: host / device cost of the per-step exchange calls
+        const int steps = atoi(e) > 0 ? atoi(e) : 1000;
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        HIP_TRY(hipEventCreate(&t0));
+        HIP_TRY(hipEventCreate(&t1));
+        for (int rep = 0; rep < 2; rep++) {
+            HIP_TRY(hipStreamSynchronize(s0));
+            const auto w0 = std::chrono::steady_clock::now();
+            HIP_TRY(hipEventRecord(t0, s0));
+            for (int i = 0; i < steps; i++) { // the call sequence of mi_part_spmv_dev without its three kernels
+                HIP_TRY(hipEventRecord(e0, s0));
+                HIP_TRY(hipStreamWaitEvent(cs, e0, 0));
+                if ((rc = enqueue_exchange(pl, comm, d_src, d_dst, cs))) return rc;
+                HIP_TRY(hipEventRecord(e1, cs));
+                HIP_TRY(hipStreamWaitEvent(s0, e1, 0));
+            }
+            HIP_TRY(hipEventRecord(t1, s0));
+            const auto w1 = std::chrono::steady_clock::now();
+            HIP_TRY(hipStreamSynchronize(s0));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+            fprintf(stderr, "mi_comm_selftest timing: %d steps, host %.1f us/step to enqueue, device %.1f us/step (self send/recv of %d doubles)\n",
+                    steps, std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps, count);
+        }
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+    }
     g_rccl.CommDestroy(comm);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
