@@ -109,6 +109,11 @@ int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
  * handle uses non-temporal loads.  MI355_RING_NT / MI355_STREAM_NT = 0|1 force the choice,
  * MI355_AUTO_BCSR=0 disables the blocked copy. */
 int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt);
+/* host-only: build the ring kernel's window plan and 16-bit column stream for configuration config_id (1..4,
+ * ring_plan.hpp) exactly as mi_csr_create would, verify their invariants (MI_ERR_STATE names the first
+ * violation) and report what the ring would serve.  Lets the planner be tested without a GPU. */
+int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, int config_id, int* nblk, int* runs,
+                       int* runs_not_ringable, double* nnz_fraction_ringable, int* max_slot);
 /* host-only: does this CSR pattern have the exact 4x4 node-block structure mi_csr_create looks for (n % 4 == 0,
  * the four rows of a block row hold the same columns, in aligned groups {4j..4j+3}) — i.e. will a blocked copy be
  * built and the BCSR kernel become an AUTO candidate?  *nblocks = number of 4x4 blocks if so. */

@@ -560,6 +560,68 @@ extern "C" int mi_debug_xcc_map(int wgs, int* host_out)
     return MI_OK;
 }
 
+// host-only: build the ring plan and the 16-bit column stream for one configuration exactly as
+// mi_csr_create would, and check their invariants (every block of a served run keeps its columns
+// inside one window of at most RING entries, distinct columns of a block get distinct slots, slots
+// are < RING, rows/nonzeros are covered once and in order).  For CPU-side tests of the planner.
+extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, int config_id, int* nblk, int* runs,
+                                  int* runs_not_ringable, double* nnz_fraction_ringable, int* max_slot)
+{
+    CHECK_ARG(n >= 0 && ptrow && config_id >= 1 && config_id <= kNumRingConfigs, "bad argument");
+    const long long nnz = ptrow[n];
+    CHECK_ARG(nnz == 0 || indcol, "indcol is null");
+    std::vector<int> row_min((size_t)n), row_max((size_t)n);
+    for (int i = 0; i < n; i++) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) {
+            lo = std::min(lo, indcol[k]);
+            hi = std::max(hi, indcol[k]);
+        }
+        row_min[i] = lo;
+        row_max[i] = hi;
+    }
+    RingPlanHost P;
+    build_ring_plan(kRingConfigs[config_id - 1], n, ptrow, row_min.data(), row_max.data(), P);
+    std::vector<unsigned short> slots;
+    if (P.nblk > 0) build_ring_slots(P, indcol, slots);
+    const RingConfig& c = P.cfg;
+    const int T = c.threads, per = c.nnzb / T;
+    int next_row = 0, mslot = -1;
+    long long next_nz = 0;
+    for (int b = 0; b < P.nblk; b++) {
+        const int* Q = &P.plan[(size_t)8 * b];
+        if (Q[0] != next_row || Q[1] != next_nz) return fail(MI_ERR_STATE, "plan does not cover rows / nonzeros in order");
+        next_row += Q[2];
+        next_nz += Q[3];
+        if (Q[3] != ptrow[Q[0] + Q[2]] - ptrow[Q[0]]) return fail(MI_ERR_STATE, "block nonzero count disagrees with ptrow");
+        const int run = b / (P.bpw > 0 ? P.bpw : 1);
+        if (!P.run_ok[run] || Q[3] == 0) continue;
+        if (!Q[7] || Q[3] > c.nnzb || Q[2] > 2 * T) return fail(MI_ERR_STATE, "a served run holds a block the kernel cannot take");
+        int cmin = 0x7fffffff, cmax = -1;
+        for (long long k = Q[1]; k < (long long)Q[1] + Q[3]; k++) {
+            cmin = std::min(cmin, indcol[k]);
+            cmax = std::max(cmax, indcol[k]);
+        }
+        if (cmax - cmin + 1 > c.ring) return fail(MI_ERR_STATE, "block window wider than the ring");
+        if (cmin - Q[6] < 0 || cmax - Q[6] >= 2 * c.ring) return fail(MI_ERR_STATE, "ring base out of range for the block's columns");
+        if (Q[4] + Q[5] < cmax + 1) return fail(MI_ERR_STATE, "window does not reach the block's last column");
+        for (int k = 0; k < Q[3]; k++) { // slot of nonzero k as the kernel's thread (k % T), element k / T reads it
+            const int slot = slots[(size_t)b * c.nnzb + (size_t)(k % T) * per + k / T];
+            int want = indcol[Q[1] + k] - Q[6];
+            if (want >= c.ring) want -= c.ring;
+            if (slot != want || slot < 0 || slot >= c.ring) return fail(MI_ERR_STATE, "16-bit slot disagrees with the column");
+            mslot = std::max(mslot, slot);
+        }
+    }
+    if (next_row != n || next_nz != nnz) return fail(MI_ERR_STATE, "plan does not cover the matrix");
+    if (nblk) *nblk = P.nblk;
+    if (runs) *runs = P.wgs;
+    if (runs_not_ringable) *runs_not_ringable = P.bad_runs;
+    if (nnz_fraction_ringable) *nnz_fraction_ringable = nnz ? 1.0 - (double)P.bad_nnz / (double)nnz : 0.0;
+    if (max_slot) *max_slot = mslot;
+    return MI_OK;
+}
+
 extern "C" int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_blocked, long long* nblocks)
 {
     CHECK_ARG(n >= 0 && ptrow && is_blocked, "bad argument");

@@ -77,6 +77,7 @@ def lib():
         "mi_csr_tune_detail": [_vp, P(d), P(_c.c_int), P(_c.c_int)],
         "mi_csr_set_nontemporal": [_vp, i, i],
         "mi_csr_block4_structure": [i, _vp, _vp, P(i), P(_c.c_longlong)],
+        "mi_ring_plan_probe": [i, _vp, _vp, i, P(i), P(i), P(i), P(d), P(i)],
         "mi_debug_xcc_map": [i, _vp],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],

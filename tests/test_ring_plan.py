@@ -1,0 +1,65 @@
+"""The ring kernel's host-side planner (navierstokes_amd/csrc/ring_plan.hpp) without a GPU: mi_ring_plan_probe
+builds the window plan and the 16-bit column stream exactly as mi_csr_create does and checks their invariants
+in C++ (rows / nonzeros covered once and in order, every served block inside one window of <= RING columns,
+slots agree with the columns and are < RING); here: what each configuration serves on the benchmark families."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from navierstokes_amd import mpk, synth
+
+
+def probe(p, c, cfg):
+    L = mpk.lib()
+    p = np.ascontiguousarray(p, np.int32)
+    c = np.ascontiguousarray(c, np.int32)
+    nblk, runs, bad, mslot = (ctypes.c_int() for _ in range(4))
+    frac = ctypes.c_double()
+    mpk.check(L.mi_ring_plan_probe(len(p) - 1, p.ctypes.data, c.ctypes.data, cfg, ctypes.byref(nblk), ctypes.byref(runs),
+                                   ctypes.byref(bad), ctypes.byref(frac), ctypes.byref(mslot)))
+    return nblk.value, runs.value, bad.value, frac.value, mslot.value
+
+
+RING = {1: 5120, 2: 5120, 3: 11264, 4: 5120}
+NNZB = {1: 2048, 2: 4096, 3: 4096, 4: 2048}
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("kind,n,w", [("s15", 60_000, 2000), ("svar", 50_000, 2000), ("s15", 30_001, 300)])
+def test_banded_families_are_fully_served(cfg, kind, n, w):
+    p, c, _ = synth.rows(kind, n, w=w)
+    nblk, runs, bad, frac, mslot = probe(p, c, cfg)
+    assert bad == 0 and frac == 1.0
+    assert 0 <= mslot < RING[cfg]
+    assert nblk >= int(p[-1]) // NNZB[cfg] and runs % 8 == 0      # runs are dealt to the 8 XCDs
+
+
+def test_wider_band_needs_the_wide_ring():
+    p, c, _ = synth.rows("s15", 60_000, w=4500)                   # window ~9000 columns
+    assert probe(p, c, 4)[3] < 0.05 and probe(p, c, 2)[3] < 0.05  # 5120-entry rings hold only the truncated corners
+    assert probe(p, c, 3)[2:4] == (0, 1.0)                        # the 11264-entry ring can
+
+
+def test_window_wider_than_any_ring_is_left_to_the_stream_kernel():
+    p, c, _ = synth.rows("s15", 80_000, w=30_000)
+    for cfg in (1, 2, 3, 4):
+        assert probe(p, c, cfg)[3] < 0.6   # only the truncated corners of the band fit a window
+
+
+def test_fe_matrix_and_degenerate_shapes():
+    p, c, _ = synth.fe_matrix(6)                                   # 3-D mesh in natural order: partly served at best
+    for cfg in (1, 2, 3, 4):
+        nblk, runs, bad, frac, mslot = probe(p, c, cfg)
+        assert 0.0 <= frac <= 1.0 and mslot < RING[cfg]
+    # empty matrix, all-empty rows, one dense row longer than a block, a single entry
+    assert probe(np.zeros(1, np.int32), np.zeros(0, np.int32), 4)[0] == 0
+    assert probe(np.zeros(9, np.int32), np.zeros(0, np.int32), 4)[3] == 0.0
+    n = 3000
+    lens = np.ones(n, np.int64)
+    lens[17] = 2500                                                # longer than NNZB of configuration 4
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    c = np.concatenate([np.arange(l) if l > 1 else [i] for i, l in enumerate(lens)]).astype(np.int32)
+    nblk, runs, bad, frac, _ = probe(p, c, 4)
+    assert bad >= 1 and frac < 1.0                                 # that run takes the plain path
+    assert probe(np.array([0, 1], np.int32), np.array([0], np.int32), 4)[2:4] == (0, 1.0)
