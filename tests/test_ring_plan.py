@@ -63,3 +63,23 @@ def test_fe_matrix_and_degenerate_shapes():
     nblk, runs, bad, frac, _ = probe(p, c, 4)
     assert bad >= 1 and frac < 1.0                                 # that run takes the plain path
     assert probe(np.array([0, 1], np.int32), np.array([0], np.int32), 4)[2:4] == (0, 1.0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_plan_invariants_hold_on_random_matrices(seed):
+    """Whatever the matrix — random row lengths (with empty and over-long rows), random bands, columns unsorted and
+    repeated, rectangular — the plan and the 16-bit stream pass the C++ invariant checks for every configuration."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 6000))
+    ncols = int(rng.integers(1, 9000))
+    band = int(rng.choice([5, 200, 3000, 20000]))
+    lens = rng.integers(0, int(rng.choice([4, 20, 70])), n)
+    if n > 3:
+        lens[rng.integers(0, n, 2)] = rng.integers(2000, 4500, 2)
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    centre = np.linspace(0, ncols - 1, n)
+    c = np.concatenate([np.clip(rng.integers(-band, band + 1, l) + int(centre[i]), 0, ncols - 1) for i, l in enumerate(lens)]
+                       + [np.zeros(0, np.int64)]).astype(np.int32)
+    for cfg in (1, 2, 3, 4):
+        nblk, runs, bad, frac, mslot = probe(p, c, cfg)
+        assert 0.0 <= frac <= 1.0 and mslot < RING[cfg]
