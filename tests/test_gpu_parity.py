@@ -516,3 +516,21 @@ def test_random_shapes_all_kernels_and_layouts(seed, monkeypatch):
                     assert_bit_equal(got, yr, f"seed {seed} n={n} ncols={ncols} {mode} band={band} cfg={cfg} mapped={mapped} {kernel} nt={nt}")
                     if not mapped:
                         assert np.isnan(y.cpu().numpy()[n:]).all(), "wrote past y"
+
+
+def test_unsorted_and_repeated_columns():
+    """CSR rows whose columns are neither ascending nor unique (generate_CSR never produces them, a caller's arrays
+    might): every kernel still evaluates the row's terms in storage order, like the reference's loop."""
+    rng = np.random.default_rng(77)
+    n, ncols, band = 30_000, 30_000, 1500
+    lens = rng.integers(0, 24, n)
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    c = np.concatenate([np.clip(rng.integers(-band, band + 1, l) + i, 0, ncols - 1) for i, l in enumerate(lens)]).astype(np.int32)
+    v = rng.uniform(-1, 1, int(p[-1]))
+    x = rng.uniform(-1, 1, ncols)
+    yr = O.spmv(p, c, v, x)
+    for kernel in KERNELS + ["auto"]:
+        A = mpk.csrmatrix(n, p, c, v).set_kernel(kernel)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(y, dev(x), A)
+        assert_bit_equal(y.cpu().numpy(), yr, f"unsorted/repeated columns, {kernel} -> {A.kernel_name()}")
