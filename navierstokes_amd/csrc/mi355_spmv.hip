@@ -1142,6 +1142,7 @@ struct Rccl {
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t) = nullptr; // optional
 };
 } // namespace
 static Rccl g_rccl;
@@ -1180,6 +1181,7 @@ static bool rccl_load()
     R.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
     R.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
     R.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    R.AllToAllv = (int (*)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t))dlsym(h, "ncclAllToAllv");
     R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv && R.GetErrorString;
     return R.ok;
 }
@@ -1294,6 +1296,28 @@ extern "C" int mi_comm_selftest(int count, double* max_abs_err)
             HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
             fprintf(stderr, "mi_comm_selftest timing: %d steps, host %.1f us/step to enqueue, device %.1f us/step (self send/recv of %d doubles)\n",
                     steps, std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps, count);
+        }
+        if (g_rccl.AllToAllv) { // the same exchange as ONE ncclAllToAllv call
+            const size_t sc[1] = {(size_t)count}, sd[1] = {0};
+            for (int rep = 0; rep < 2; rep++) {
+                HIP_TRY(hipStreamSynchronize(s0));
+                const auto w0 = std::chrono::steady_clock::now();
+                HIP_TRY(hipEventRecord(t0, s0));
+                for (int i = 0; i < steps; i++) {
+                    HIP_TRY(hipEventRecord(e0, s0));
+                    HIP_TRY(hipStreamWaitEvent(cs, e0, 0));
+                    NCCL_TRY(g_rccl.AllToAllv(d_src, sc, sd, d_dst, sc, sd, kNcclDouble, comm, cs));
+                    HIP_TRY(hipEventRecord(e1, cs));
+                    HIP_TRY(hipStreamWaitEvent(s0, e1, 0));
+                }
+                HIP_TRY(hipEventRecord(t1, s0));
+                const auto w1 = std::chrono::steady_clock::now();
+                HIP_TRY(hipStreamSynchronize(s0));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+                fprintf(stderr, "mi_comm_selftest timing (ncclAllToAllv): host %.1f us/step, device %.1f us/step\n",
+                        std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps);
+            }
         }
         (void)hipEventDestroy(t0);
         (void)hipEventDestroy(t1);
