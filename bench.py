@@ -88,6 +88,9 @@ def cpu_baseline(p, c, v, x, seconds_budget=20.0):
         for var in ("opt", "fma"):
             tv, _ = O.ref_time_spmv(p, c, v, x, var, reps=2, flush=True)
             extra[f"SpMV_CSR_{var.upper()}"] = round(2 * nnz / tv / 1e9, 4)
+        # the same arithmetic written as a plain C loop (oracle/cpu_ref.c): what one core of this host can do
+        tp, _ = O.time_spmv(p, c, v, x, reps=2, flush=True)
+        extra["oracle_fma_chain_port_1_thread"] = round(2 * nnz / tp / 1e9, 4)
         out["other_variants_gflops"] = extra
     else:
         t, _ = O.time_spmv(p, c, v, x, reps=reps, flush=True)
