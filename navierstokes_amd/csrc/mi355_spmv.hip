@@ -1297,6 +1297,29 @@ extern "C" int mi_comm_selftest(int count, double* max_abs_err)
             fprintf(stderr, "mi_comm_selftest timing: %d steps, host %.1f us/step to enqueue, device %.1f us/step (self send/recv of %d doubles)\n",
                     steps, std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps, count);
         }
+        for (int variant = 0; variant < 2; variant++) { // the hand-offs alone / the exchange alone on one stream
+            HIP_TRY(hipStreamSynchronize(s0));
+            HIP_TRY(hipStreamSynchronize(cs));
+            const auto w0 = std::chrono::steady_clock::now();
+            HIP_TRY(hipEventRecord(t0, variant == 0 ? s0 : cs));
+            for (int i = 0; i < steps; i++) {
+                if (variant == 0) {
+                    HIP_TRY(hipEventRecord(e0, s0));
+                    HIP_TRY(hipStreamWaitEvent(cs, e0, 0));
+                    HIP_TRY(hipEventRecord(e1, cs));
+                    HIP_TRY(hipStreamWaitEvent(s0, e1, 0));
+                } else if ((rc = enqueue_exchange(pl, comm, d_src, d_dst, cs))) return rc;
+            }
+            HIP_TRY(hipEventRecord(t1, variant == 0 ? s0 : cs));
+            const auto w1 = std::chrono::steady_clock::now();
+            HIP_TRY(hipStreamSynchronize(s0));
+            HIP_TRY(hipStreamSynchronize(cs));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+            fprintf(stderr, "mi_comm_selftest timing (%s): host %.1f us/step, device %.1f us/step\n",
+                    variant == 0 ? "two event hand-offs only" : "grouped send/recv only, one stream",
+                    std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps);
+        }
         if (g_rccl.AllToAllv) { // the same exchange as ONE ncclAllToAllv call
             const size_t sc[1] = {(size_t)count}, sd[1] = {0};
             for (int rep = 0; rep < 2; rep++) {
