@@ -1219,12 +1219,17 @@ extern "C" int mi_comm_unique_id(void* id128)
 
 // the exchange of one step, enqueued on cs: send my packed entries to every peer that
 // needs some, receive my ghosts straight into x_ext's halo region (contiguous per owner)
-static int enqueue_exchange(const PartPlan& pl, void* comm, const double* d_sendbuf, double* d_halo, hipStream_t cs)
+// d_x_direct != nullptr: every send list is a contiguous slice of the owned x (PartPlan::sends_contiguous) and is
+// sent from there, no packed copy
+static int enqueue_exchange(const PartPlan& pl, void* comm, const double* d_sendbuf, double* d_halo, hipStream_t cs,
+                            const double* d_x_direct = nullptr)
 {
     NCCL_TRY(g_rccl.GroupStart());
     for (int p = 0; p < pl.nranks; p++) {
-        if (pl.send_counts[p])
-            NCCL_TRY(g_rccl.Send(d_sendbuf + pl.send_offsets[p], (size_t)pl.send_counts[p], kNcclDouble, p, comm, cs));
+        if (pl.send_counts[p]) {
+            const double* src = d_x_direct ? d_x_direct + pl.send_lists[p][0] : d_sendbuf + pl.send_offsets[p];
+            NCCL_TRY(g_rccl.Send(src, (size_t)pl.send_counts[p], kNcclDouble, p, comm, cs));
+        }
         if (pl.recv_counts[p])
             NCCL_TRY(g_rccl.Recv(d_halo + pl.recv_offsets[p], (size_t)pl.recv_counts[p], kNcclDouble, p, comm, cs));
     }
@@ -1509,8 +1514,12 @@ extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local,
     // latency) and the pack (~4 us) thus hide behind the interior kernel (~22 us) with the exchange.
     HIP_TRY(hipEventRecord(P->ev_pack, s));
     HIP_TRY(hipStreamWaitEvent(P->comm_stream, P->ev_pack, 0));
-    if ((rc = mi_gather_dev((int)pl.send_idx.size(), P->d_send_idx, d_x_ext, P->d_sendbuf, P->comm_stream))) return rc;
-    if ((rc = enqueue_exchange(pl, P->comm, P->d_sendbuf, d_x_ext + pl.n_local, P->comm_stream))) return rc;
+    if (pl.sends_contiguous) { // banded partitions: the neighbours' ghosts are slices of x, sent in place
+        if ((rc = enqueue_exchange(pl, P->comm, nullptr, d_x_ext + pl.n_local, P->comm_stream, d_x_ext))) return rc;
+    } else {
+        if ((rc = mi_gather_dev((int)pl.send_idx.size(), P->d_send_idx, d_x_ext, P->d_sendbuf, P->comm_stream))) return rc;
+        if ((rc = enqueue_exchange(pl, P->comm, P->d_sendbuf, d_x_ext + pl.n_local, P->comm_stream))) return rc;
+    }
     if ((rc = mi_spmv_dev(P->piece[1], d_x_ext, d_y_local, P->comm_stream))) return rc;
     HIP_TRY(hipEventRecord(P->ev_comm, P->comm_stream));
     if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;

@@ -11,6 +11,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,7 @@ struct PartPlan {
     std::vector<int> send_idx;                  // concatenated by peer
     LocalPiece piece[2];               // 0 interior, 1 boundary
     bool sends_set = false;
+    bool sends_contiguous = false;     // every non-empty send list is a run of consecutive local ids: no pack needed
 
     // returns "" or an error message
     std::string build(int nranks_, int rank_, const long long* rs, const int* ptrow, const int* indcol,
@@ -63,6 +65,28 @@ struct PartPlan {
         }
         std::sort(ghosts.begin(), ghosts.end());
         ghosts.erase(std::unique(ghosts.begin(), ghosts.end()), ghosts.end());
+        // Where the ghosts of one owner nearly fill a range (banded matrices: the rows just across the
+        // partition boundary), take the WHOLE range: the owner can then send a contiguous slice of its x
+        // without a pack kernel, at the price of a few unused entries.  Column relabelling below only
+        // needs the list to be ascending, so nothing else changes.
+        const char* dense_env = getenv("MI355_PART_DENSE_HALO"); // 0: keep the exact ghost sets (tests of the packed path)
+        if (!(dense_env && dense_env[0] == '0')) {
+            std::vector<long long> dense;
+            size_t i = 0;
+            while (i < ghosts.size()) {
+                int p = 0;
+                while (ghosts[i] >= rs[p + 1]) p++;
+                size_t j = i;
+                while (j < ghosts.size() && ghosts[j] < rs[p + 1]) j++;
+                const long long gmin = ghosts[i], gmax = ghosts[j - 1], cnt = (long long)(j - i);
+                if (gmax - gmin + 1 <= cnt + cnt / 2 + 64)
+                    for (long long g = gmin; g <= gmax; g++) dense.push_back(g);
+                else
+                    dense.insert(dense.end(), ghosts.begin() + i, ghosts.begin() + j);
+                i = j;
+            }
+            ghosts.swap(dense);
+        }
         halo_ids.swap(ghosts);
         n_halo = (int)halo_ids.size();
         if ((long long)n_local + n_halo > INT32_MAX) return "n_local + n_halo exceeds int32";
@@ -129,6 +153,10 @@ struct PartPlan {
             send_idx.insert(send_idx.end(), send_lists[p].begin(), send_lists[p].end());
         }
         sends_set = true;
+        sends_contiguous = true;
+        for (int p = 0; p < nranks && sends_contiguous; p++)
+            for (size_t i = 1; i < send_lists[p].size(); i++)
+                if (send_lists[p][i] != send_lists[p][0] + (int)i) { sends_contiguous = false; break; }
         return "";
     }
 };

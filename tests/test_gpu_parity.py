@@ -397,8 +397,9 @@ def test_fe_matrix_takes_the_blocked_kernel_with_identical_bits():
         B.set_kernel("bcsr4")
 
 
-@pytest.mark.parametrize("kind,n,w,ranks", [("s15", 240_000, 2000, 4), ("svar", 90_000, 2000, 3), ("sfe", 64_000, 1500, 2)])
-def test_native_step_multirank_threads(kind, n, w, ranks):
+@pytest.mark.parametrize("kind,n,w,ranks,dense", [("s15", 240_000, 2000, 4, "1"), ("svar", 90_000, 2000, 3, "1"),
+                                                    ("sfe", 64_000, 1500, 2, "1"), ("s15", 150_000, 2000, 3, "0")])
+def test_native_step_multirank_threads(kind, n, w, ranks, dense):
     """The library's native multi-rank step (C++: pack + exchange on a comm stream, interior beside, boundary
     behind) with `ranks` ranks as threads on this one GPU and tests/fake_rccl in place of librccl, which refuses
     two ranks per device.  Bitwise for 4 chained powers and for 40 unsynchronised repetitions of one step."""
@@ -408,7 +409,8 @@ def test_native_step_multirank_threads(kind, n, w, ranks):
     from conftest import ROOT
     fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
     assert os.path.exists(fake), "run __graft_entry__.build() first (it builds tests/fake_rccl)"
-    env = dict(os.environ, MI355_RCCL_LIBRARY=fake, OMP_NUM_THREADS="1")
+    # dense = "1": ghost ranges, contiguous slices of x sent in place; "0": exact ghost sets, pack kernel + send buffer
+    env = dict(os.environ, MI355_RCCL_LIBRARY=fake, OMP_NUM_THREADS="1", MI355_PART_DENSE_HALO=dense)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native_threads_worker.py"), kind, str(n), str(w), str(ranks)],
                        env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
