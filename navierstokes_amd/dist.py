@@ -113,6 +113,11 @@ class DistCSR:
             self._send_idx = (np.ctypeslib.as_array(_c.cast(ptr, _c.POINTER(_c.c_int)), shape=(tot.value,)).copy()
                               if tot.value else np.zeros(0, np.int32))
         self.sendbuf = torch.empty(max(self.n_send, 1), dtype=torch.float64, device=self.device)
+        import os
+        if self.native and not self._native_selfcheck():
+            self.native = False  # collective decision: every rank falls back to the torch.distributed exchange
+        elif not self.native and compute is None and self.nranks > 1 and os.environ.get("MI355_DIST_FORCE_SELFCHECK") == "1":
+            assert self._native_selfcheck()  # tests: run the check's own code on a backend without RCCL
 
     def _try_native_exchange(self):
         """Set up the C++/RCCL step (mi_part_spmv_dev).  Every decision is collective: either all
@@ -140,6 +145,32 @@ class DistCSR:
         dist.broadcast(idt, src=0, group=self.group)
         rc = self._native_init(bytes(idt.cpu().numpy().tobytes()))  # collective inside RCCL
         flag.fill_(1 if rc == 0 else 0)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag) == 1
+
+    def _native_selfcheck(self):
+        """One product through the native C++ step and one through the torch.distributed exchange on the same
+        (seeded) vector: the two must agree bit for bit on every rank, or nobody uses the native step."""
+        ok = 1
+        try:
+            g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+            x_ext = self.new_x_ext()
+            x_ext[: self.n_local] = torch.rand(self.n_local, generator=g, dtype=torch.float64).to(self.device)
+            y_native = self.new_y()
+            self.spmv(x_ext, y_native)
+            torch.cuda.synchronize()
+            halo_native = x_ext[self.n_local:].clone()
+            x_ext[self.n_local:] = float("nan")
+            was_native, self.native = self.native, False
+            y_torch = self.new_y()
+            self.spmv(x_ext, y_torch)
+            torch.cuda.synchronize()
+            self.native = was_native
+            if not (torch.equal(y_native, y_torch) and torch.equal(halo_native, x_ext[self.n_local:])):
+                ok = 0
+        except Exception:  # noqa: BLE001 - any failure means: do not use it
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if self._nccl else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag) == 1
 

@@ -349,7 +349,7 @@ def test_ranks_sharing_one_card(world, kind, n, w, port):
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MI355_DIST_FORCE_SELFCHECK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_gpu_worker.py"), kind, str(n), str(w)]
