@@ -107,6 +107,14 @@ __global__ __launch_bounds__(kRedWG) void reduce_stage1(int n, int seg, const do
     }
 }
 
+// The finishing tree over the per-workgroup partials, fixed order; valid in thread 0 (kRedWG threads).
+__device__ __forceinline__ double finish_sum(int np, const double* __restrict__ partial, double* s_part)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += kRedWG) s += partial[i];
+    return block_sum(s, s_part);
+}
+
 // FIN 0: out = sum   FIN 1: out = sqrt(sum)   FIN 2: out = sqrt(sum)/sqrt(sum2)
 template <int FIN>
 __global__ __launch_bounds__(kRedWG) void reduce_stage2(int np, const double* __restrict__ partial,
@@ -114,12 +122,10 @@ __global__ __launch_bounds__(kRedWG) void reduce_stage2(int np, const double* __
                                                         double* __restrict__ out)
 {
     __shared__ double s_part[4];
-    double s = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < np; i += kRedWG) {
-        s += partial[i];
-        if (FIN == 2) s2 += partial2[i];
-    }
-    const double t = block_sum(s, s_part);
+    double s2 = 0.0;
+    if (FIN == 2)
+        for (int i = threadIdx.x; i < np; i += kRedWG) s2 += partial2[i];
+    const double t = finish_sum(np, partial, s_part);
     double t2 = 0.0;
     if (FIN == 2) t2 = block_sum(s2, s_part);
     if (threadIdx.x == 0) {
@@ -156,15 +162,23 @@ __global__ __launch_bounds__(256) void axpy_kernel(int n, double a, const double
 // evaluated exactly as the reference writes it (mpk/SpMVmulti.cpp:149:
 // x1[i] - alpha * beta * b[i], i.e. ((alpha*beta)*b[i]) subtracted, no fma).
 template <bool NT>
-__global__ __launch_bounds__(256) void ortho_update_kernel(int n, double alpha, const double* __restrict__ beta,
-                                                           const double* __restrict__ b,
-                                                           const double* __restrict__ x1,
-                                                           double* __restrict__ out)
+__global__ __launch_bounds__(kRedWG) void ortho_update_kernel(int n, double alpha, int np, const double* __restrict__ partial,
+                                                              double* __restrict__ beta_out, const double* __restrict__ b,
+                                                              const double* __restrict__ x1, double* __restrict__ out)
 {
-    const double ab = alpha * beta[0];
+    // every workgroup finishes the dot itself — the same fixed tree over the same <= 1024 partials (8 KB, in L2),
+    // hence the same bits everywhere — instead of waiting for a one-workgroup kernel to publish beta
+    __shared__ double s_part[4];
+    __shared__ double s_beta;
+    const double t = finish_sum(np, partial, s_part);
+    if (threadIdx.x == 0) {
+        s_beta = t;
+        if (blockIdx.x == 0) beta_out[0] = t;
+    }
+    __syncthreads();
+    const double ab = alpha * s_beta;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double v = __dsub_rn(ld1_stream<NT>(x1 + i), __dmul_rn(ab, ld1_stream<NT>(b + i)));
         if (NT) __builtin_nontemporal_store(v, out + i);
         else out[i] = v;

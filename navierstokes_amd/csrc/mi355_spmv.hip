@@ -915,17 +915,28 @@ extern "C" int mi_axpy_dev(int n, double a, const double* d_x, double* d_y, mi_s
 }
 
 extern "C" int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1, double* d_x3, double alpha,
-                                    double* d_beta_out, mi_stream_t s)
+                                    double* d_beta_out, mi_stream_t s_)
 {
     CHECK_ARG(d_beta_out, "null beta");
-    int rc = reduce_dev<0, 0>(n, d_b, d_x1, d_beta_out, (hipStream_t)s);
+    CHECK_ARG(n >= 0, "negative n");
+    hipStream_t s = (hipStream_t)s_;
+    if (n == 0) return reduce_dev<0, 0>(n, d_b, d_x1, d_beta_out, s); // beta = 0
+    CHECK_ARG(d_b && d_x1 && d_x3, "null vector");
+    // two kernels: per-workgroup partials of b.x1, then the update, whose workgroups each finish the dot themselves
+    double* ws = nullptr;
+    int rc = get_ws(&ws);
     if (rc) return rc;
-    if (n == 0) return MI_OK;
-    CHECK_ARG(d_x3, "null output");
-    int grid = (n + 255) / 256;
+    int np, seg;
+    red_geometry(n, &np, &seg);
+    int grid = (n + kRedWG - 1) / kRedWG;
     if (grid > 2048) grid = 2048;
-    if (blas1_nt(n)) hipLaunchKernelGGL(ortho_update_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)s, n, alpha, d_beta_out, d_b, d_x1, d_x3);
-    else hipLaunchKernelGGL(ortho_update_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)s, n, alpha, d_beta_out, d_b, d_x1, d_x3);
+    if (blas1_nt(n)) {
+        hipLaunchKernelGGL((reduce_stage1<0, true>), dim3(np), dim3(kRedWG), 0, s, n, seg, d_b, d_x1, ws, ws + kMaxPartials);
+        hipLaunchKernelGGL(ortho_update_kernel<true>, dim3(grid), dim3(kRedWG), 0, s, n, alpha, np, ws, d_beta_out, d_b, d_x1, d_x3);
+    } else {
+        hipLaunchKernelGGL((reduce_stage1<0, false>), dim3(np), dim3(kRedWG), 0, s, n, seg, d_b, d_x1, ws, ws + kMaxPartials);
+        hipLaunchKernelGGL(ortho_update_kernel<false>, dim3(grid), dim3(kRedWG), 0, s, n, alpha, np, ws, d_beta_out, d_b, d_x1, d_x3);
+    }
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
