@@ -11,8 +11,8 @@ from navierstokes_amd import synth
 from oracle import oracle as O
 
 
-def build_plans(kind, n, w, nranks, balanced=True):
-    P, C, V = synth.rows(kind, n, w=w)
+def build_plans(kind, n, w, nranks, balanced=True, matrix=None):
+    P, C, V = matrix if matrix is not None else synth.rows(kind, n, w=w)
     rs = D.balanced_row_starts(n, nranks, np.diff(P) if balanced else None)
     plans = []
     for r in range(nranks):
@@ -72,10 +72,34 @@ class _Plan(D.DistCSR):
         return sc
 
 
+def _band_plus_far_couplings(n, w, seed):
+    """A banded matrix (dense ghost ranges towards the neighbours) with a few far couplings (sparse ghost sets towards
+    ranks that are not neighbours): both halo forms of the planner in one partition."""
+    rng = np.random.default_rng(seed)
+    P, C, V = synth.rows("s15", n, w=w)
+    rows = [C[P[i]:P[i + 1]].astype(np.int64) for i in range(n)]
+    vals = [V[P[i]:P[i + 1]] for i in range(n)]
+    for i in rng.choice(n, 40, replace=False):
+        far = np.setdiff1d(rng.integers(0, n, 3), rows[i])
+        rows[i] = np.concatenate([rows[i], far])
+        vals[i] = np.concatenate([vals[i], rng.uniform(-1, 1, len(far))])
+    lens = np.array([len(r) for r in rows])
+    return (np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), np.concatenate(rows).astype(np.int32), np.concatenate(vals))
+
+
 @pytest.mark.parametrize("kind,n,w,nranks", [("s15", 6000, 300, 1), ("s15", 6000, 300, 2), ("svar", 5000, 200, 3),
-                                              ("sfe", 4000, 240, 4), ("s15", 3000, 2000, 8)])
-def test_partitioned_spmv_equals_global_bitwise(kind, n, w, nranks):
-    (P, C, V), rs, plans = build_plans(kind, n, w, nranks)
+                                              ("sfe", 4000, 240, 4), ("s15", 3000, 2000, 8), ("far", 6000, 150, 5),
+                                              ("far-exact", 6000, 150, 5)])
+def test_partitioned_spmv_equals_global_bitwise(kind, n, w, nranks, monkeypatch):
+    matrix = None
+    if kind.startswith("far"):
+        matrix = _band_plus_far_couplings(n, w, 5)
+        monkeypatch.setenv("MI355_PART_DENSE_HALO", "0" if kind == "far-exact" else "1")
+    (P, C, V), rs, plans = build_plans(kind, n, w, nranks, matrix=matrix)
+    if kind == "far":      # dense ranges towards neighbours made the halo larger than the exact ghost set ...
+        monkeypatch.setenv("MI355_PART_DENSE_HALO", "0")
+        exact = build_plans(kind, n, w, nranks, matrix=matrix)[2]
+        assert all(pl.n_halo >= ex.n_halo for pl, ex in zip(plans, exact))
     x = synth.x_sin(0, n)
     y_ref = O.spmv(P, C, V, x)
     # exchange the id lists by hand: what q needs from r becomes r's send list to q
@@ -113,6 +137,27 @@ def test_partitioned_spmv_equals_global_bitwise(kind, n, w, nranks):
         assert_bit_equal(y_loc, y_ref[lo:hi], f"rank {r}/{nranks}")
         if nranks == 1:
             assert pl.n_halo == 0 and pl.n_boundary == 0
+
+
+def test_dense_halo_ranges(monkeypatch):
+    """Banded partition: the ghosts of a neighbour nearly fill a range, the planner takes the whole range so that the
+    neighbour's send list is one contiguous slice of its x (sent in place, no pack kernel)."""
+    sizes = {}
+    for dense in ("1", "0"):
+        monkeypatch.setenv("MI355_PART_DENSE_HALO", dense)
+        _, rs, plans = build_plans("s15", 30000, 2000, 2)
+        for r in range(2):
+            plans[r].set_send(1 - r, plans[1 - r].recv_ids[r])
+        sizes[dense] = [pl.n_halo for pl in plans]
+        for pl in plans:
+            idx = pl.send_index()
+            contiguous = bool((np.diff(idx) == 1).all())
+            assert contiguous == (dense == "1")
+            for ids in pl.recv_ids:
+                assert (np.diff(ids) > 0).all()                      # ascending, unique
+                if dense == "1" and len(ids):
+                    assert ids[-1] - ids[0] + 1 == len(ids)          # a full range
+    assert all(d > e and d <= 1.5 * e + 64 for d, e in zip(sizes["1"], sizes["0"]))
 
 
 def test_balanced_row_starts():
