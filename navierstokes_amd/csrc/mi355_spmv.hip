@@ -135,6 +135,9 @@ struct mi_part_s {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
     double* d_sendbuf = nullptr;
+    unsigned* d_flags = nullptr; // [0] "x ready" (set on the caller's stream), [1] "halo rows done" (set on the comm stream), [2] spin time-outs
+    unsigned step_no = 0;
+    bool flag_handoff = true;    // hand-offs between the two streams by flag kernels instead of HIP events
 };
 
 static void part_comm_release(mi_part_s* P);
@@ -536,6 +539,31 @@ extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* s
     if (ring_nt) *ring_nt = A->ring.nt ? 1 : 0;
     if (stream_nt) *stream_nt = A->stream_nt ? 1 : 0;
     return MI_OK;
+}
+
+// Cross-stream hand-off by a flag in device memory instead of a HIP event.  An event record + wait between two
+// HIP streams costs ~10 us of latency on this runtime (mi_comm_selftest, MI355_COMM_SELFTEST_TIMING); a one-wave
+// kernel that sets a counter on one stream and a one-wave kernel that spins on it on the other cost a launch each.
+// Data visibility does not rest on the flag: the producer's kernels completed before flag_set_kernel started
+// (stream order, end-of-kernel release) and the consumer's kernels start after flag_wait_kernel finished
+// (stream order, start-of-kernel acquire); the flag only carries "has happened".  The spin gives up only after
+// minutes and counts the time-out (checked every 1024 steps) rather than hang the GPU for good.
+__global__ void flag_set_kernel(unsigned* flag, unsigned value)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_kernel(const unsigned* flag, unsigned value, unsigned* timeouts)
+{
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
+            // poll fast at first (the usual wait is a few microseconds), then back off; give up only after
+            // minutes (a peer may be busy setting up its RCCL channels on the first steps) — never hang for good
+            if (spins < 4096) __builtin_amdgcn_s_sleep(2);
+            else __builtin_amdgcn_s_sleep(127);
+            if (++spins > (1u << 26)) { atomicAdd(timeouts, 1u); break; }
+        }
+    }
 }
 
 // diagnostic: which XCD each workgroup of a launch shaped like the ring kernel's lands on
@@ -1212,6 +1240,10 @@ static void part_comm_release(mi_part_s* P)
     if (P->ev_comm) (void)hipEventDestroy(P->ev_comm);
     P->comm_stream = nullptr;
     P->ev_pack = P->ev_comm = nullptr;
+    if (P->d_sendbuf) dfree(P->d_sendbuf);
+    if (P->d_flags) dfree(P->d_flags);
+    P->d_sendbuf = nullptr;
+    P->d_flags = nullptr;
 }
 
 extern "C" int mi_comm_available(void)
@@ -1336,6 +1368,37 @@ extern "C" int mi_comm_selftest(int count, double* max_abs_err)
                     variant == 0 ? "two event hand-offs only" : "grouped send/recv only, one stream",
                     std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps);
         }
+        { // hand-offs by flag kernels: s0 sets flag A, cs waits for it, exchange, cs sets flag B, s0 waits for it
+            unsigned* fl = nullptr;
+            HIP_TRY(hipMalloc(&fl, 4 * sizeof(unsigned)));
+            HIP_TRY(hipMemset(fl, 0, 4 * sizeof(unsigned)));
+            for (int variant = 0; variant < 2; variant++) { // 0: hand-offs only, 1: with the exchange
+                HIP_TRY(hipStreamSynchronize(s0));
+                HIP_TRY(hipStreamSynchronize(cs));
+                HIP_TRY(hipMemset(fl, 0, 4 * sizeof(unsigned)));
+                const auto w0 = std::chrono::steady_clock::now();
+                HIP_TRY(hipEventRecord(t0, s0));
+                for (int i = 0; i < steps; i++) {
+                    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, s0, fl, (unsigned)(i + 1));
+                    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, cs, fl, (unsigned)(i + 1), fl + 2);
+                    if (variant == 1 && (rc = enqueue_exchange(pl, comm, d_src, d_dst, cs))) return rc;
+                    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, cs, fl + 1, (unsigned)(i + 1));
+                    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s0, fl + 1, (unsigned)(i + 1), fl + 2);
+                }
+                HIP_TRY(hipEventRecord(t1, s0));
+                const auto w1 = std::chrono::steady_clock::now();
+                HIP_TRY(hipStreamSynchronize(s0));
+                HIP_TRY(hipStreamSynchronize(cs));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+                unsigned to = 0;
+                HIP_TRY(hipMemcpy(&to, fl + 2, sizeof to, hipMemcpyDeviceToHost));
+                fprintf(stderr, "mi_comm_selftest timing (flag-kernel hand-offs%s): host %.1f us/step, device %.1f us/step, %u spin timeouts\n",
+                        variant ? " + grouped send/recv" : " only", std::chrono::duration<double, std::micro>(w1 - w0).count() / steps,
+                        ms * 1e3 / steps, to);
+            }
+            (void)hipFree(fl);
+        }
         if (g_rccl.AllToAllv) { // the same exchange as ONE ncclAllToAllv call
             const size_t sc[1] = {(size_t)count}, sd[1] = {0};
             for (int rep = 0; rep < 2; rep++) {
@@ -1394,6 +1457,7 @@ extern "C" int mi_part_destroy(mi_part_t P)
     mi_csr_destroy(P->piece[0]);
     mi_csr_destroy(P->piece[1]);
     if (P->d_send_idx) dfree(P->d_send_idx);
+    part_comm_release(P);
     delete P;
     return MI_OK;
 }
@@ -1500,6 +1564,10 @@ extern "C" int mi_part_comm_init(mi_part_t P, const void* id128)
     HIP_TRY(hipEventCreateWithFlags(&P->ev_comm, hipEventDisableTiming));
     const size_t ns = P->plan.send_idx.size();
     HIP_TRY(hipMalloc(&P->d_sendbuf, sizeof(double) * (ns ? ns : 1)));
+    HIP_TRY(hipMalloc(&P->d_flags, 4 * sizeof(unsigned)));
+    HIP_TRY(hipMemset(P->d_flags, 0, 4 * sizeof(unsigned)));
+    P->step_no = 0;
+    if (const char* e = getenv("MI355_PART_HANDOFF")) P->flag_handoff = strcmp(e, "events") != 0;
     return MI_OK;
 }
 
@@ -1518,13 +1586,25 @@ extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local,
     // Two concurrent chains:
     //   comm stream:      pack -> exchange -> boundary rows (they need the halo, nothing else)
     //   caller's stream:  interior rows (they need only owned x)
-    // joined by an event at the end.  The first event orders the comm chain behind everything
-    // already queued on s: the producer of x, and the previous step (whose boundary rows read the
-    // halo region this exchange overwrites, and which joined s with its own closing event).  The
-    // two row sets are disjoint in y.  On an 8-rank piece the boundary kernel (~4 us, mostly launch
-    // latency) and the pack (~4 us) thus hide behind the interior kernel (~22 us) with the exchange.
-    HIP_TRY(hipEventRecord(P->ev_pack, s));
-    HIP_TRY(hipStreamWaitEvent(P->comm_stream, P->ev_pack, 0));
+    // joined at the end.  The first hand-off orders the comm chain behind everything already queued
+    // on s: the producer of x, and the previous step (whose boundary rows read the halo region this
+    // exchange overwrites, and which joined s with its own closing hand-off).  The two row sets are
+    // disjoint in y.  On an 8-rank piece the boundary kernel (~4 us, mostly launch latency) and the
+    // exchange (~7 us) thus hide behind the interior kernel (~23 us).  The hand-offs are flag kernels
+    // (see flag_set_kernel) unless MI355_PART_HANDOFF=events.
+    const unsigned step = ++P->step_no;
+    if (P->flag_handoff) {
+        if ((step & 1023u) == 1u && step > 1) { // now and then: did a spin ever give up?
+            unsigned timeouts = 0;
+            HIP_TRY(hipMemcpy(&timeouts, P->d_flags + 2, sizeof timeouts, hipMemcpyDeviceToHost));
+            if (timeouts) return fail(MI_ERR_HIP, "mi_part_spmv_dev: a stream hand-off timed out (results since then are invalid)");
+        }
+        hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, s, P->d_flags, step);
+        hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, P->comm_stream, P->d_flags, step, P->d_flags + 2);
+    } else {
+        HIP_TRY(hipEventRecord(P->ev_pack, s));
+        HIP_TRY(hipStreamWaitEvent(P->comm_stream, P->ev_pack, 0));
+    }
     if (pl.sends_contiguous) { // banded partitions: the neighbours' ghosts are slices of x, sent in place
         if ((rc = enqueue_exchange(pl, P->comm, nullptr, d_x_ext + pl.n_local, P->comm_stream, d_x_ext))) return rc;
     } else {
@@ -1532,9 +1612,12 @@ extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local,
         if ((rc = enqueue_exchange(pl, P->comm, P->d_sendbuf, d_x_ext + pl.n_local, P->comm_stream))) return rc;
     }
     if ((rc = mi_spmv_dev(P->piece[1], d_x_ext, d_y_local, P->comm_stream))) return rc;
-    HIP_TRY(hipEventRecord(P->ev_comm, P->comm_stream));
+    if (P->flag_handoff) hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, P->comm_stream, P->d_flags + 1, step);
+    else HIP_TRY(hipEventRecord(P->ev_comm, P->comm_stream));
     if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;
-    HIP_TRY(hipStreamWaitEvent(s, P->ev_comm, 0));
+    if (P->flag_handoff) hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s, P->d_flags + 1, step, P->d_flags + 2);
+    else HIP_TRY(hipStreamWaitEvent(s, P->ev_comm, 0));
+    HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
