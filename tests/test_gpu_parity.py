@@ -398,7 +398,8 @@ def test_fe_matrix_takes_the_blocked_kernel_with_identical_bits():
 
 
 @pytest.mark.parametrize("kind,n,w,ranks,dense", [("s15", 240_000, 2000, 4, "1"), ("svar", 90_000, 2000, 3, "1"),
-                                                    ("sfe", 64_000, 1500, 2, "1"), ("s15", 150_000, 2000, 3, "0")])
+                                                    ("sfe", 64_000, 1500, 2, "1"), ("s15", 150_000, 2000, 3, "0"),
+                                                    ("s15", 480_000, 2000, 8, "1")])
 def test_native_step_multirank_threads(kind, n, w, ranks, dense):
     """The library's native multi-rank step (C++: pack + exchange on a comm stream, interior beside, boundary
     behind) with `ranks` ranks as threads on this one GPU and tests/fake_rccl in place of librccl, which refuses
