@@ -8,7 +8,8 @@
 // against libmpk_mi355.so instead of mpk/SpMV.cpp + mpk/utils.cpp without a
 // source change.  The bodies live in navierstokes_amd/csrc/mpk_shim.cpp and
 // forward to the C-ABI of include/mi355_spmv.h; a device copy of each matrix is
-// created on first use and cached.
+// created on first use, cached, and checked against the caller's live arrays
+// (full content hash) before every product.
 //
 // Behavioural contract kept from the reference:
 //   * all functions return void and do not validate (mpk/SpMV.h:52-66); a
@@ -116,6 +117,17 @@ void SpM2V_BCSR_OPT(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vec
 void SpM2V_BCSR_FMA(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& ptrowendB);
 void SpM2V_BCSR_AVX2(double* z, double* y, double* x, bcsr4x4_matrix& A, std::vector<int>& ptrowendB);
 
+// mpk/SpMVmulti0.cpp:106-130 and :157-187: the nested first-touch tables of the k = 3, 4 CPU
+// traversals, filled exactly as the reference fills them (the GPU kernels do not need them).
+void Generate2ndlayer(std::vector<std::vector<int> >& ptrowend2, csrmatrix& A, std::vector<int>& ptrowend1);
+void Generate3rdlayer(std::vector<std::vector<std::vector<int> > >& ptrowend3, csrmatrix& A,
+                      std::vector<int>& ptrowend1, std::vector<std::vector<int> >& ptrowend2);
+
+// mpk/SpMVmulti0.cpp:223-236, :44-61, :65-104: that file's own names for y = A x and the k = 2 kernel
+void SpMV(double* y, double* x, csrmatrix& A);
+void SpM2V0(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& ptrowend1);
+void SpM2V(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& ptrowend1);
+
 // mpk/SpMVmulti0.cpp:132-155 and :189-221: all intermediate powers are returned
 // (y = A x, z = A^2 x, w = A^3 x, v = A^4 x).  The nested first-touch tables are
 // accepted for signature parity and ignored.
@@ -125,10 +137,27 @@ void SpM4V(double* v, double* w, double* z, double* y, double* x, csrmatrix& A,
            std::vector<int>& ptrowend1, std::vector<std::vector<int> >& ptrowend2,
            std::vector<std::vector<std::vector<int> > >& ptrowend3);
 
+// mpk/SpMVmulti-1.cpp:434-493: y1 = A x ... y4 = A^4 x (outputs in descending order of power)
+void SpM4V_AVX2(double* y4, double* y3, double* y2, double* y1, const double* x, const csrmatrix& A,
+                const std::vector<int>& ptrowend1, const std::vector<std::vector<int> >& ptrowend2,
+                const std::vector<std::vector<std::vector<int> > >& ptrowend3);
+
 // mpk/SpMVmulti.cpp:146-151: x3 = x1 - alpha * (b . x1) * b.
 void orthogonalize(int nrow, const std::vector<double>& b, const std::vector<double>& x1,
                    std::vector<double>& x3, double alpha = 1e-8);
 // mpk/2SpMV.cpp:3-11: y -= alpha * (x . y) * x, in place.
 void orthogonalize(int nrow, const std::vector<double>& x, std::vector<double>& y, double alpha = 1e-8);
+// mpk/2SpMV.cpp:13-28: for each basis vector in turn y -= (y . v) v, on the y updated so far; like the
+// reference nothing is normalised (its norm is computed and dropped).
+void orthonormalize_against_basis(int nrow, std::vector<std::vector<double> >& basis, std::vector<double>& y);
+
+// ---- extensions (not in the reference) ----------------------------------------
+// The device copy of a matrix is keyed on the addresses of its three arrays and checked against a hash
+// of their FULL content before every product, so in-place edits of coefficients or pattern are always
+// seen (same pattern + new coefficients = one upload of the values, anything else = a new device
+// copy).  A caller whose matrices stay fixed between explicit invalidations can skip the hash:
+void mi355_assume_unchanged(bool on);          // on: trust the cached copy until mi355_invalidate
+void mi355_invalidate(csrmatrix& A);           // drop A's device copy (next call uploads again)
+void mi355_invalidate(const bcsr4x4_matrix& A);
 
 #endif // MI355_MPK_SPMV_H

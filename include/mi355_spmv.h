@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 100 /* 0.1.0 */
+#define MI355_SPMV_VERSION 200 /* 0.2.0 */
 
 enum {
     MI_OK = 0,
@@ -89,6 +89,16 @@ int mi_csr_create(int n, int ncols, const int* ptrow, const int* indcol, const d
 int mi_csr_create_mapped(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
                          const int* rowmap, mi_csr_t* out);
 int mi_csr_destroy(mi_csr_t A);
+/* New coefficients for an UNCHANGED sparsity pattern: coef has the nnz values in the order of the
+ * arrays given to mi_csr_create.  The reference's functions read the caller's live arrays on every
+ * call; a handle holds a device copy, so a caller that rewrites its coefficients in place — the
+ * Newton loop does that to the Jacobian every iteration, src/solve_newton.c:1245-1247 (MatCopy +
+ * add_nonlinear_jacobian_terms + MatZeroRows), before KSPSolve :1265 — refreshes the copy with this
+ * call: one transfer of the values; row blocks, ring plan, column stream and kernel choice depend on
+ * the pattern only and are kept, the blocked copy's values are regenerated on the device.  The
+ * mpk/SpMV.h shim (libmpk_mi355.so) detects such changes by itself (full content hash) and calls this. */
+int mi_csr_update_values(mi_csr_t A, const double* coef);                          /* host values; synchronous */
+int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_stream_t s);     /* device values; asynchronous on s */
 int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz);
 /* MI_KERNEL_RING on a matrix whose window does not fit is still correct (its runs take the
  * per-block path); mi_csr_ring_info reports how much of the matrix the ring serves. */
@@ -147,10 +157,19 @@ int mi_dot_dev(int n, const double* d_x, const double* d_y, double* d_out, mi_st
 int mi_axpy(int n, double a, const double* x, double* y);
 int mi_axpy_dev(int n, double a, const double* d_x, double* d_y, mi_stream_t s);
 /* x3 = x1 - alpha * (b . x1) * b ; *beta_out = b . x1
- * (orthogonalize, mpk/SpMVmulti.cpp:146-151; in-place twin mpk/2SpMV.cpp:3-11) */
+ * (orthogonalize, mpk/SpMVmulti.cpp:146-151; in-place twin mpk/2SpMV.cpp:3-11: pass x3 == x1).
+ * The update is evaluated as the reference's object code does it: x3[i] = fma(-(alpha*beta), b[i], x1[i]).
+ * Reductions enqueued on different streams use separate workspaces and may run concurrently. */
 int mi_orthogonalize(int n, const double* b, const double* x1, double* x3, double alpha, double* beta_out);
 int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1, double* d_x3, double alpha,
                          double* d_beta_out, mi_stream_t s);
+/* orthonormalize_against_basis(nrow, basis, y), mpk/2SpMV.cpp:13-28: for each of the m basis vectors IN TURN
+ * dots[j] = y . v_j (on the y updated so far), y <- fma(-dots[j], v_j, y).  Like the reference nothing is
+ * normalised (its norm is computed and dropped).  basis: HOST array of m pointers (host resp. device vectors).
+ * m + 1 launches: each update also accumulates the next vector's dot. */
+int mi_orthonormalize_against_basis(int n, int m, const double* const* basis, double* y, double* dots_out /* [m] or NULL */);
+int mi_orthonormalize_against_basis_dev(int n, int m, const double* const* d_basis, double* d_y, double* d_dots /* [m] */,
+                                        mi_stream_t s);
 /* sqrt(sum x^2) (norm2, mpk/utils.cpp:131-136) and ||ref-test||/||ref|| (rel_error, :138-143) */
 int mi_norm2(int n, const double* x, double* out);
 int mi_norm2_dev(int n, const double* d_x, double* d_out, mi_stream_t s);
@@ -163,6 +182,9 @@ int mi_gather_dev(int m, const int* d_idx, const double* d_src, double* d_dst, m
 int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
                     mi_bcsr4_t* out);
 int mi_bcsr4_destroy(mi_bcsr4_t A);
+/* new block values (16 per block, row-major) for an unchanged block pattern; see mi_csr_update_values */
+int mi_bcsr4_update_values(mi_bcsr4_t A, const double* coef);
+int mi_bcsr4_update_values_dev(mi_bcsr4_t A, const double* d_coef, mi_stream_t s);
 int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y);
 int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s);
 /* y_out[p] = A^(p+1) x for p < k on the blocked matrix: what SpM2V_BCSR{,_OPT,_FMA,_AVX2}(z, y, x, A, ptrowend1)
@@ -213,10 +235,16 @@ int mi_part_spmv_boundary_dev(mi_part_t P, const double* d_x_ext, double* d_y_lo
 int mi_comm_available(void); /* MI_OK iff librccl could be resolved in this process */
 int mi_comm_unique_id(void* id128);
 int mi_part_comm_init(mi_part_t P, const void* id128);
-/* y_local = (A x)_local: d_x_ext = [x_local | halo], the halo part is overwritten */
+/* y_local = (A x)_local: d_x_ext = [x_local | halo], the halo part is overwritten.
+ * Cross-stream hand-offs are HIP events; MI355_PART_HANDOFF=flags selects one-wave flag kernels instead
+ * (cheaper, but a wait on a stalled peer then spins on the GPU: it gives up after minutes and the give-up is
+ * sticky — this call, mi_part_status and mi_part_destroy return MI_ERR_HIP from then on). */
 int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s);
+/* MI_OK, or MI_ERR_HIP once a hand-off wait has given up (call after synchronising; no GPU work, no copy) */
+int mi_part_status(mi_part_t P);
 /* development check of the RCCL plumbing on ONE GPU: a communicator of size 1 sends
- * `count` doubles to itself through the same send/recv/stream/event code path */
+ * `count` doubles to itself through the same send/recv/stream/event code path
+ * (the per-step cost measurements of this path live in tools/comm_timing.hip) */
 int mi_comm_selftest(int count, double* max_abs_err);
 
 #ifdef __cplusplus

@@ -157,14 +157,15 @@ __global__ __launch_bounds__(256) void axpy_kernel(int n, double a, const double
     }
 }
 
-// out = x1 - (alpha * beta) * b with beta read from device memory (no host
-// round trip between the dot and the update): the AXPY half of orthogonalize,
-// evaluated exactly as the reference writes it (mpk/SpMVmulti.cpp:149:
-// x1[i] - alpha * beta * b[i], i.e. ((alpha*beta)*b[i]) subtracted, no fma).
+// out = x1 - (alpha * beta) * b with beta read from device memory (no host round trip between the
+// dot and the update): the AXPY half of orthogonalize.  Evaluated as the reference's object code
+// evaluates it (g++ -O3 on an FMA target contracts x1[i] - (alpha*beta)*b[i], mpk/SpMVmulti.cpp:149 and
+// mpk/2SpMV.cpp:10, into ONE vfnmadd per element behind a rounded alpha*beta): out = fma(-(alpha*beta), b, x1)
+// — pinned by tests/golden/blas1_*.npz.  out may alias x1 (the in-place form of mpk/2SpMV.cpp:3-11).
 template <bool NT>
 __global__ __launch_bounds__(kRedWG) void ortho_update_kernel(int n, double alpha, int np, const double* __restrict__ partial,
                                                               double* __restrict__ beta_out, const double* __restrict__ b,
-                                                              const double* __restrict__ x1, double* __restrict__ out)
+                                                              const double* x1, double* out)
 {
     // every workgroup finishes the dot itself — the same fixed tree over the same <= 1024 partials (8 KB, in L2),
     // hence the same bits everywhere — instead of waiting for a one-workgroup kernel to publish beta
@@ -176,12 +177,50 @@ __global__ __launch_bounds__(kRedWG) void ortho_update_kernel(int n, double alph
         if (blockIdx.x == 0) beta_out[0] = t;
     }
     __syncthreads();
-    const double ab = alpha * s_beta;
+    const double nab = -__dmul_rn(alpha, s_beta);
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double v = __dsub_rn(ld1_stream<NT>(x1 + i), __dmul_rn(ab, ld1_stream<NT>(b + i)));
+        const double v = fma(nab, ld1_stream<NT>(b + i), ld1_stream<NT>(x1 + i));
         if (NT) __builtin_nontemporal_store(v, out + i);
         else out[i] = v;
+    }
+}
+
+// One step of orthonormalize_against_basis (mpk/2SpMV.cpp:13-28), fused with the NEXT step's dot:
+//   d = sum of partial_in (fixed tree) = y . v;  y <- fma(-d, v, y);  partial_out[g] = (y_new . v_next) over segment g
+// so that a sweep against m vectors is m + 1 launches and reads y once per vector instead of twice
+// (32 instead of 40 bytes per element and vector).  Workgroup g owns the same segment as in
+// reduce_stage1 (grid = np workgroups).  Every workgroup finishes d itself from the same partials in the
+// same order, hence the same bits everywhere.  v_next == nullptr: last vector, no further dot.
+// Like the reference each projection uses the y updated by the previous ones (the loop is sequential:
+// modified Gram-Schmidt in effect), which is why the dots cannot be batched.
+template <bool NT>
+__global__ __launch_bounds__(kRedWG) void mgs_step_kernel(int n, int seg, int np, const double* __restrict__ partial_in,
+                                                          double* __restrict__ dot_out, const double* __restrict__ v,
+                                                          const double* __restrict__ v_next, double* __restrict__ y,
+                                                          double* __restrict__ partial_out)
+{
+    __shared__ double s_part[4];
+    __shared__ double s_d;
+    const double t = finish_sum(np, partial_in, s_part);
+    if (threadIdx.x == 0) {
+        s_d = t;
+        if (blockIdx.x == 0) dot_out[0] = t;
+    }
+    __syncthreads();
+    const double nd = -s_d;
+    const long long lo = (long long)blockIdx.x * seg;
+    const long long hi = (lo + seg < n) ? lo + seg : n;
+    double s = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += kRedWG) {
+        const double yn = fma(nd, ld1_stream<NT>(v + i), ld1_stream<NT>(y + i));
+        if (NT) __builtin_nontemporal_store(yn, y + i);
+        else y[i] = yn;
+        if (v_next) s = fma(yn, ld1_stream<NT>(v_next + i), s);
+    }
+    if (v_next) { // uniform branch
+        const double p = block_sum(s, s_part);
+        if (threadIdx.x == 0) partial_out[blockIdx.x] = p;
     }
 }
 

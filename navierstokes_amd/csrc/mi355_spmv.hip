@@ -8,20 +8,21 @@
 
 #include <hip/hip_runtime.h>
 
-#include <dlfcn.h>
-
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "blas1_kernels.hpp"
+#include "handoff_kernels.hpp"
 #include "partition.hpp"
+#include "rccl_loader.hpp"
 #include "ring_plan.hpp"
 #include "spmv_kernels.hpp"
 #include "spmv_ring.hpp"
@@ -135,26 +136,35 @@ struct mi_part_s {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
     double* d_sendbuf = nullptr;
-    unsigned* d_flags = nullptr; // [0] "x ready" (set on the caller's stream), [1] "halo rows done" (set on the comm stream), [2] spin time-outs
+    unsigned* d_flags = nullptr; // [0] "x ready" (set on the caller's stream), [1] "halo rows done" (set on the comm stream)
+    unsigned* h_timeouts = nullptr; // pinned, device-mapped: hand-off waits that gave up (read by the host at every entry point)
+    unsigned* d_timeouts = nullptr; // the device address of h_timeouts
     unsigned step_no = 0;
-    bool flag_handoff = true;    // hand-offs between the two streams by flag kernels instead of HIP events
+    // Hand-offs between the two streams: HIP events by default.  Flag kernels (handoff_kernels.hpp) are ~8 us per
+    // step cheaper in the one-GPU harness but have not run against real multi-GPU RCCL yet: opt in with
+    // MI355_PART_HANDOFF=flags.
+    bool flag_handoff = false;
 };
 
 static void part_comm_release(mi_part_s* P);
 
-// per-device reduction workspace (2 * kMaxPartials partials + 1 scalar)
-struct RedWs {
-    double* d = nullptr;
-};
-static std::map<int, RedWs> g_ws;
+// Reduction workspace: partials of the two-stage reductions, one per (device, stream) so that
+// reductions enqueued on different streams (or by different rank threads of one process) never share
+// partials.  4 * kMaxPartials doubles: [0, 2K) the two partial arrays of a reduction (or the
+// ping-pong pair of the Gram-Schmidt sweep), the rest spare.  32 KB per stream that ever reduced; a
+// destroyed stream's slot is simply reused if the runtime hands the same handle out again.
+// g_mu guards every process-wide table of this file (workspaces, flush buffers).
+static std::mutex g_mu;
+static std::map<std::pair<int, hipStream_t>, double*> g_ws;
 
-static int get_ws(double** out)
+static int get_ws(hipStream_t s, double** out)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    RedWs& w = g_ws[dev];
-    if (!w.d) HIP_TRY(hipMalloc(&w.d, sizeof(double) * (2 * kMaxPartials + 8)));
-    *out = w.d;
+    std::lock_guard<std::mutex> lock(g_mu);
+    double*& w = g_ws[std::make_pair(dev, s)];
+    if (!w) HIP_TRY(hipMalloc(&w, sizeof(double) * (4 * kMaxPartials + 8)));
+    *out = w;
     return MI_OK;
 }
 
@@ -211,8 +221,13 @@ extern "C" int mi_flush_cache(void)
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const size_t bytes = (size_t)512 << 20;
-    void*& buf = g_flush[dev];
-    if (!buf) HIP_TRY(hipMalloc(&buf, bytes));
+    void* buf = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        void*& slot = g_flush[dev];
+        if (!slot) HIP_TRY(hipMalloc(&slot, bytes));
+        buf = slot;
+    }
     HIP_TRY(hipMemsetAsync(buf, 1, bytes, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     return MI_OK;
@@ -391,8 +406,19 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
     if (!forced_kernel && !(at && !strcmp(at, "0")) && nnz >= 200000) {
         // measure the candidates on this very matrix (x = 0: timing does not depend on the values):
         // ring (if it serves the matrix) and stream, each with temporal and non-temporal matrix loads
-        double *tx = nullptr, *ty = nullptr;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+        struct TuneScratch { // released on every exit path, the early error returns of TRY_OR_CLEAN included
+            double *tx = nullptr, *ty = nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~TuneScratch()
+            {
+                dfree(tx);
+                dfree(ty);
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+            }
+        } ts;
+        double *&tx = ts.tx, *&ty = ts.ty;
+        hipEvent_t &e0 = ts.e0, &e1 = ts.e1;
         TRY_OR_CLEAN(hipMalloc(&tx, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
         TRY_OR_CLEAN(hipMalloc(&ty, sizeof(double) * (size_t)(A->n_out > 0 ? A->n_out : 1)));
         TRY_OR_CLEAN(hipMemset(tx, 0, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
@@ -459,10 +485,6 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : best_stream;
             if (better(A->tune_us_bcsr, best_csr)) A->auto_kernel = MI_KERNEL_BCSR4;
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        dfree(tx);
-        dfree(ty);
     }
 #undef TRY_OR_CLEAN
     *out = A;
@@ -498,6 +520,60 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->ring.d_slots);
     mi_bcsr4_destroy(A->blocked);
     delete A;
+    return MI_OK;
+}
+
+// Blocked copy's values from the CSR values already on the device: lane q of block row bi copies its
+// row's four coefficients of every block (32 B per lane and block; setup-time traffic).
+__global__ __launch_bounds__(kWG) void bcsr4_values_from_csr_kernel(int nbrows, const int* __restrict__ csr_ptrow,
+                                                                     const double* __restrict__ csr_coef,
+                                                                     const int* __restrict__ bptr, double* __restrict__ bval)
+{
+    const int g = blockIdx.x * kWG + threadIdx.x;
+    const int bi = g >> 2, q = g & 3;
+    if (bi >= nbrows) return;
+    const double* src = csr_coef + csr_ptrow[4 * bi + q];
+    const int b0 = bptr[bi], b1 = bptr[bi + 1];
+    for (int blk = b0; blk < b1; blk++) {
+        double* dst = bval + 16 * (size_t)blk + 4 * q;
+        const double* sp = src + 4 * (size_t)(blk - b0);
+        dst[0] = sp[0]; dst[1] = sp[1]; dst[2] = sp[2]; dst[3] = sp[3];
+    }
+}
+
+static int refresh_blocked_values(mi_csr_t A, hipStream_t s)
+{
+    if (!A->blocked || A->blocked->nbrows == 0) return MI_OK;
+    const long long threads = 4LL * A->blocked->nbrows;
+    hipLaunchKernelGGL(bcsr4_values_from_csr_kernel, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, s,
+                       A->blocked->nbrows, A->d_ptrow, A->d_coef, A->blocked->d_ptrow, A->blocked->d_coef);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// New coefficients for an unchanged sparsity pattern (what a Newton loop does to its Jacobian every
+// iteration, src/solve_newton.c:1245-1247): only the value array is replaced.  Row-block tables, the
+// ring plan, the 16-bit column stream and the kernel choice depend on the pattern alone and are kept;
+// the blocked copy's values are regenerated on the device.
+extern "C" int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_stream_t s_)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nnz == 0) return MI_OK;
+    CHECK_ARG(d_coef, "null coef");
+    hipStream_t s = (hipStream_t)s_;
+    HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
+    return refresh_blocked_values(A, s);
+}
+
+extern "C" int mi_csr_update_values(mi_csr_t A, const double* coef)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nnz == 0) return MI_OK;
+    CHECK_ARG(coef, "null coef");
+    HIP_TRY(hipMemcpy(A->d_coef, coef, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice));
+    int rc = refresh_blocked_values(A, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return MI_OK;
 }
 
@@ -539,31 +615,6 @@ extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* s
     if (ring_nt) *ring_nt = A->ring.nt ? 1 : 0;
     if (stream_nt) *stream_nt = A->stream_nt ? 1 : 0;
     return MI_OK;
-}
-
-// Cross-stream hand-off by a flag in device memory instead of a HIP event.  An event record + wait between two
-// HIP streams costs ~10 us of latency on this runtime (mi_comm_selftest, MI355_COMM_SELFTEST_TIMING); a one-wave
-// kernel that sets a counter on one stream and a one-wave kernel that spins on it on the other cost a launch each.
-// Data visibility does not rest on the flag: the producer's kernels completed before flag_set_kernel started
-// (stream order, end-of-kernel release) and the consumer's kernels start after flag_wait_kernel finished
-// (stream order, start-of-kernel acquire); the flag only carries "has happened".  The spin gives up only after
-// minutes and counts the time-out (checked every 1024 steps) rather than hang the GPU for good.
-__global__ void flag_set_kernel(unsigned* flag, unsigned value)
-{
-    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void flag_wait_kernel(const unsigned* flag, unsigned value, unsigned* timeouts)
-{
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
-            // poll fast at first (the usual wait is a few microseconds), then back off; give up only after
-            // minutes (a peer may be busy setting up its RCCL channels on the first steps) — never hang for good
-            if (spins < 4096) __builtin_amdgcn_s_sleep(2);
-            else __builtin_amdgcn_s_sleep(127);
-            if (++spins > (1u << 26)) { atomicAdd(timeouts, 1u); break; }
-        }
-    }
 }
 
 // diagnostic: which XCD each workgroup of a launch shaped like the ring kernel's lands on
@@ -886,7 +937,7 @@ static int reduce_dev(int n, const double* a, const double* b, double* d_out, hi
     CHECK_ARG(n >= 0, "negative n");
     CHECK_ARG(d_out && (n == 0 || (a && b)), "null vector");
     double* ws = nullptr;
-    int rc = get_ws(&ws);
+    int rc = get_ws(s, &ws);
     if (rc) return rc;
     int np, seg;
     red_geometry(n, &np, &seg);
@@ -952,7 +1003,7 @@ extern "C" int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1
     CHECK_ARG(d_b && d_x1 && d_x3, "null vector");
     // two kernels: per-workgroup partials of b.x1, then the update, whose workgroups each finish the dot themselves
     double* ws = nullptr;
-    int rc = get_ws(&ws);
+    int rc = get_ws(s, &ws);
     if (rc) return rc;
     int np, seg;
     red_geometry(n, &np, &seg);
@@ -964,6 +1015,38 @@ extern "C" int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1
     } else {
         hipLaunchKernelGGL((reduce_stage1<0, false>), dim3(np), dim3(kRedWG), 0, s, n, seg, d_b, d_x1, ws, ws + kMaxPartials);
         hipLaunchKernelGGL(ortho_update_kernel<false>, dim3(grid), dim3(kRedWG), 0, s, n, alpha, np, ws, d_beta_out, d_b, d_x1, d_x3);
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_orthonormalize_against_basis_dev(int n, int m, const double* const* d_basis, double* d_y, double* d_dots,
+                                                    mi_stream_t s_)
+{
+    CHECK_ARG(n >= 0 && m >= 0, "negative size");
+    if (m == 0) return MI_OK;
+    CHECK_ARG(d_basis && d_dots, "null basis / dots");
+    hipStream_t s = (hipStream_t)s_;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_dots, 0, sizeof(double) * (size_t)m, s));
+        return MI_OK;
+    }
+    CHECK_ARG(d_y, "null y");
+    for (int j = 0; j < m; j++) CHECK_ARG(d_basis[j], "null basis vector");
+    double* ws = nullptr;
+    int rc = get_ws(s, &ws);
+    if (rc) return rc;
+    int np, seg;
+    red_geometry(n, &np, &seg);
+    double* part[2] = {ws, ws + kMaxPartials};
+    const bool nt = blas1_nt(n);
+    // dot of the first vector, then one launch per vector: finish dot j, update y, partials of dot j+1
+    if (nt) hipLaunchKernelGGL((reduce_stage1<0, true>), dim3(np), dim3(kRedWG), 0, s, n, seg, d_y, d_basis[0], part[0], part[1]);
+    else hipLaunchKernelGGL((reduce_stage1<0, false>), dim3(np), dim3(kRedWG), 0, s, n, seg, d_y, d_basis[0], part[0], part[1]);
+    for (int j = 0; j < m; j++) {
+        const double* vn = j + 1 < m ? d_basis[j + 1] : nullptr;
+        if (nt) hipLaunchKernelGGL(mgs_step_kernel<true>, dim3(np), dim3(kRedWG), 0, s, n, seg, np, part[j & 1], d_dots + j, d_basis[j], vn, d_y, part[(j + 1) & 1]);
+        else hipLaunchKernelGGL(mgs_step_kernel<false>, dim3(np), dim3(kRedWG), 0, s, n, seg, np, part[j & 1], d_dots + j, d_basis[j], vn, d_y, part[(j + 1) & 1]);
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -1050,6 +1133,29 @@ extern "C" int mi_orthogonalize(int n, const double* b, const double* x1, double
     return MI_OK;
 }
 
+extern "C" int mi_orthonormalize_against_basis(int n, int m, const double* const* basis, double* y, double* dots_out)
+{
+    CHECK_ARG(n >= 0 && m >= 0 && (m == 0 || basis) && (n == 0 || y), "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    if (m == 0) return MI_OK;
+    Scratch S;
+    std::vector<const double*> dv((size_t)m);
+    double *dy = nullptr, *dd = nullptr;
+    for (int j = 0; j < m; j++) {
+        CHECK_ARG(n == 0 || basis[j], "null basis vector");
+        double* p = nullptr;
+        if ((rc = S.up(basis[j], n, &p))) return rc;
+        dv[j] = p;
+    }
+    if ((rc = S.up(y, n, &dy)) || (rc = S.up(nullptr, m, &dd))) return rc;
+    if ((rc = mi_orthonormalize_against_basis_dev(n, m, dv.data(), dy, dd, nullptr))) return rc;
+    if (n) HIP_TRY(hipMemcpy(y, dy, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    if (dots_out) HIP_TRY(hipMemcpy(dots_out, dd, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost));
+    else HIP_TRY(hipDeviceSynchronize());
+    return MI_OK;
+}
+
 // ---------------------------------------------------------------- BCSR 4x4
 extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
                                mi_bcsr4_t* out)
@@ -1080,6 +1186,25 @@ extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const i
         return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 upload: ") + hipGetErrorString(e));
     }
     *out = A;
+    return MI_OK;
+}
+
+// new block values (16 per block, row-major) for an unchanged block pattern
+extern "C" int mi_bcsr4_update_values(mi_bcsr4_t A, const double* coef)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nblocks == 0) return MI_OK;
+    CHECK_ARG(coef, "null coef");
+    HIP_TRY(hipMemcpy(A->d_coef, coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyHostToDevice));
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_update_values_dev(mi_bcsr4_t A, const double* d_coef, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nblocks == 0) return MI_OK;
+    CHECK_ARG(d_coef, "null coef");
+    HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyDeviceToDevice, (hipStream_t)s));
     return MI_OK;
 }
 
@@ -1163,67 +1288,9 @@ extern "C" int mi_bcsr4_spmk(mi_bcsr4_t A, int k, const double* x, double* const
     return MI_OK;
 }
 
-// ---------------------------------------------------------------- RCCL, resolved at run time
-// No link-time dependency: the library must load (and plan partitions) on machines
-// without RCCL.  dlopen picks up the copy already in the process (torch's) if any.
-struct IdByValue { // ncclUniqueId, passed BY VALUE to ncclCommInitRank
-    char internal[MI_COMM_ID_BYTES];
-};
-namespace {
-struct Rccl {
-    bool tried = false, ok = false;
-    std::string why;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, IdByValue, int) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    int (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t) = nullptr; // optional
-};
-} // namespace
-static Rccl g_rccl;
-static const int kNcclDouble = 8; // ncclFloat64 (rccl.h)
-
-static bool rccl_load()
-{
-    Rccl& R = g_rccl;
-    if (R.tried) return R.ok;
-    R.tried = true;
-    void* h = nullptr;
-    // MI355_RCCL_LIBRARY: a specific RCCL build (or the tests' in-process stand-in, tests/fake_rccl)
-    if (const char* e = getenv("MI355_RCCL_LIBRARY")) {
-        if (!(h = dlopen(e, RTLD_NOW | RTLD_LOCAL))) {
-            R.why = std::string("dlopen(") + e + "): " + (dlerror() ? dlerror() : "failed");
-            return false;
-        }
-    }
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names)
-        if (h || (h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) {
-        R.why = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found");
-        return false;
-    }
-    auto sym = [&](const char* nm) -> void* {
-        void* p = dlsym(h, nm);
-        if (!p) R.why = std::string("dlsym ") + nm + " failed";
-        return p;
-    };
-    R.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
-    R.CommInitRank = (int (*)(void**, int, IdByValue, int))sym("ncclCommInitRank");
-    R.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
-    R.GroupStart = (int (*)())sym("ncclGroupStart");
-    R.GroupEnd = (int (*)())sym("ncclGroupEnd");
-    R.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
-    R.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
-    R.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
-    R.AllToAllv = (int (*)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t))dlsym(h, "ncclAllToAllv");
-    R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv && R.GetErrorString;
-    return R.ok;
-}
+// ---------------------------------------------------------------- RCCL, resolved at run time (rccl_loader.hpp)
+static Rccl& g_rccl = rccl_state();
+static_assert(MI_COMM_ID_BYTES == kCommIdBytes, "id size");
 
 #define NCCL_TRY(expr)                                                                                  \
     do {                                                                                                \
@@ -1242,8 +1309,24 @@ static void part_comm_release(mi_part_s* P)
     P->ev_pack = P->ev_comm = nullptr;
     if (P->d_sendbuf) dfree(P->d_sendbuf);
     if (P->d_flags) dfree(P->d_flags);
+    if (P->h_timeouts) (void)hipHostFree(P->h_timeouts);
     P->d_sendbuf = nullptr;
     P->d_flags = nullptr;
+    P->h_timeouts = P->d_timeouts = nullptr;
+}
+
+// A hand-off wait that gave up means every result since is invalid: sticky, reported by every later call.
+static int part_handoff_status(const mi_part_s* P)
+{
+    if (P->h_timeouts && __atomic_load_n(P->h_timeouts, __ATOMIC_ACQUIRE) != 0)
+        return fail(MI_ERR_HIP, "mi_part: a stream hand-off timed out (a peer rank stalled or died); results since then are invalid");
+    return MI_OK;
+}
+
+extern "C" int mi_part_status(mi_part_t P)
+{
+    CHECK_ARG(P, "null handle");
+    return part_handoff_status(P);
 }
 
 extern "C" int mi_comm_available(void)
@@ -1321,109 +1404,6 @@ extern "C" int mi_comm_selftest(int count, double* max_abs_err)
     double m = 0.0;
     for (int i = 0; i < count; i++) m = std::max(m, std::fabs(back[i] - h[i]));
     *max_abs_err = m;
-    if (const char* e = getenv("MI355_COMM_SELFTEST_TIMING")) { // development: host / device cost of the per-step exchange calls
-        const int steps = atoi(e) > 0 ? atoi(e) : 1000;
-        hipEvent_t t0 = nullptr, t1 = nullptr;
-        HIP_TRY(hipEventCreate(&t0));
-        HIP_TRY(hipEventCreate(&t1));
-        for (int rep = 0; rep < 2; rep++) {
-            HIP_TRY(hipStreamSynchronize(s0));
-            const auto w0 = std::chrono::steady_clock::now();
-            HIP_TRY(hipEventRecord(t0, s0));
-            for (int i = 0; i < steps; i++) { // the call sequence of mi_part_spmv_dev without its three kernels
-                HIP_TRY(hipEventRecord(e0, s0));
-                HIP_TRY(hipStreamWaitEvent(cs, e0, 0));
-                if ((rc = enqueue_exchange(pl, comm, d_src, d_dst, cs))) return rc;
-                HIP_TRY(hipEventRecord(e1, cs));
-                HIP_TRY(hipStreamWaitEvent(s0, e1, 0));
-            }
-            HIP_TRY(hipEventRecord(t1, s0));
-            const auto w1 = std::chrono::steady_clock::now();
-            HIP_TRY(hipStreamSynchronize(s0));
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
-            fprintf(stderr, "mi_comm_selftest timing: %d steps, host %.1f us/step to enqueue, device %.1f us/step (self send/recv of %d doubles)\n",
-                    steps, std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps, count);
-        }
-        for (int variant = 0; variant < 2; variant++) { // the hand-offs alone / the exchange alone on one stream
-            HIP_TRY(hipStreamSynchronize(s0));
-            HIP_TRY(hipStreamSynchronize(cs));
-            const auto w0 = std::chrono::steady_clock::now();
-            HIP_TRY(hipEventRecord(t0, variant == 0 ? s0 : cs));
-            for (int i = 0; i < steps; i++) {
-                if (variant == 0) {
-                    HIP_TRY(hipEventRecord(e0, s0));
-                    HIP_TRY(hipStreamWaitEvent(cs, e0, 0));
-                    HIP_TRY(hipEventRecord(e1, cs));
-                    HIP_TRY(hipStreamWaitEvent(s0, e1, 0));
-                } else if ((rc = enqueue_exchange(pl, comm, d_src, d_dst, cs))) return rc;
-            }
-            HIP_TRY(hipEventRecord(t1, variant == 0 ? s0 : cs));
-            const auto w1 = std::chrono::steady_clock::now();
-            HIP_TRY(hipStreamSynchronize(s0));
-            HIP_TRY(hipStreamSynchronize(cs));
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
-            fprintf(stderr, "mi_comm_selftest timing (%s): host %.1f us/step, device %.1f us/step\n",
-                    variant == 0 ? "two event hand-offs only" : "grouped send/recv only, one stream",
-                    std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps);
-        }
-        { // hand-offs by flag kernels: s0 sets flag A, cs waits for it, exchange, cs sets flag B, s0 waits for it
-            unsigned* fl = nullptr;
-            HIP_TRY(hipMalloc(&fl, 4 * sizeof(unsigned)));
-            HIP_TRY(hipMemset(fl, 0, 4 * sizeof(unsigned)));
-            for (int variant = 0; variant < 2; variant++) { // 0: hand-offs only, 1: with the exchange
-                HIP_TRY(hipStreamSynchronize(s0));
-                HIP_TRY(hipStreamSynchronize(cs));
-                HIP_TRY(hipMemset(fl, 0, 4 * sizeof(unsigned)));
-                const auto w0 = std::chrono::steady_clock::now();
-                HIP_TRY(hipEventRecord(t0, s0));
-                for (int i = 0; i < steps; i++) {
-                    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, s0, fl, (unsigned)(i + 1));
-                    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, cs, fl, (unsigned)(i + 1), fl + 2);
-                    if (variant == 1 && (rc = enqueue_exchange(pl, comm, d_src, d_dst, cs))) return rc;
-                    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, cs, fl + 1, (unsigned)(i + 1));
-                    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s0, fl + 1, (unsigned)(i + 1), fl + 2);
-                }
-                HIP_TRY(hipEventRecord(t1, s0));
-                const auto w1 = std::chrono::steady_clock::now();
-                HIP_TRY(hipStreamSynchronize(s0));
-                HIP_TRY(hipStreamSynchronize(cs));
-                float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
-                unsigned to = 0;
-                HIP_TRY(hipMemcpy(&to, fl + 2, sizeof to, hipMemcpyDeviceToHost));
-                fprintf(stderr, "mi_comm_selftest timing (flag-kernel hand-offs%s): host %.1f us/step, device %.1f us/step, %u spin timeouts\n",
-                        variant ? " + grouped send/recv" : " only", std::chrono::duration<double, std::micro>(w1 - w0).count() / steps,
-                        ms * 1e3 / steps, to);
-            }
-            (void)hipFree(fl);
-        }
-        if (g_rccl.AllToAllv) { // the same exchange as ONE ncclAllToAllv call
-            const size_t sc[1] = {(size_t)count}, sd[1] = {0};
-            for (int rep = 0; rep < 2; rep++) {
-                HIP_TRY(hipStreamSynchronize(s0));
-                const auto w0 = std::chrono::steady_clock::now();
-                HIP_TRY(hipEventRecord(t0, s0));
-                for (int i = 0; i < steps; i++) {
-                    HIP_TRY(hipEventRecord(e0, s0));
-                    HIP_TRY(hipStreamWaitEvent(cs, e0, 0));
-                    NCCL_TRY(g_rccl.AllToAllv(d_src, sc, sd, d_dst, sc, sd, kNcclDouble, comm, cs));
-                    HIP_TRY(hipEventRecord(e1, cs));
-                    HIP_TRY(hipStreamWaitEvent(s0, e1, 0));
-                }
-                HIP_TRY(hipEventRecord(t1, s0));
-                const auto w1 = std::chrono::steady_clock::now();
-                HIP_TRY(hipStreamSynchronize(s0));
-                float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
-                fprintf(stderr, "mi_comm_selftest timing (ncclAllToAllv): host %.1f us/step, device %.1f us/step\n",
-                        std::chrono::duration<double, std::micro>(w1 - w0).count() / steps, ms * 1e3 / steps);
-            }
-        }
-        (void)hipEventDestroy(t0);
-        (void)hipEventDestroy(t1);
-    }
     g_rccl.CommDestroy(comm);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1454,12 +1434,17 @@ extern "C" int mi_part_create(int nranks, int rank, const long long* row_starts,
 extern "C" int mi_part_destroy(mi_part_t P)
 {
     if (!P) return MI_OK;
+    int status = MI_OK;
+    if (P->comm_stream) { // let queued steps finish, then report a hand-off that gave up during them
+        (void)hipStreamSynchronize(P->comm_stream);
+        status = part_handoff_status(P);
+    }
     mi_csr_destroy(P->piece[0]);
     mi_csr_destroy(P->piece[1]);
     if (P->d_send_idx) dfree(P->d_send_idx);
     part_comm_release(P);
     delete P;
-    return MI_OK;
+    return status;
 }
 
 extern "C" int mi_part_sizes(mi_part_t P, int* n_local, int* n_halo, int* n_interior_rows, int* n_boundary_rows)
@@ -1566,8 +1551,11 @@ extern "C" int mi_part_comm_init(mi_part_t P, const void* id128)
     HIP_TRY(hipMalloc(&P->d_sendbuf, sizeof(double) * (ns ? ns : 1)));
     HIP_TRY(hipMalloc(&P->d_flags, 4 * sizeof(unsigned)));
     HIP_TRY(hipMemset(P->d_flags, 0, 4 * sizeof(unsigned)));
+    HIP_TRY(hipHostMalloc((void**)&P->h_timeouts, sizeof(unsigned), hipHostMallocMapped));
+    *P->h_timeouts = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&P->d_timeouts, P->h_timeouts, 0));
     P->step_no = 0;
-    if (const char* e = getenv("MI355_PART_HANDOFF")) P->flag_handoff = strcmp(e, "events") != 0;
+    if (const char* e = getenv("MI355_PART_HANDOFF")) P->flag_handoff = strcmp(e, "flags") == 0;
     return MI_OK;
 }
 
@@ -1590,17 +1578,13 @@ extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local,
     // on s: the producer of x, and the previous step (whose boundary rows read the halo region this
     // exchange overwrites, and which joined s with its own closing hand-off).  The two row sets are
     // disjoint in y.  On an 8-rank piece the boundary kernel (~4 us, mostly launch latency) and the
-    // exchange (~7 us) thus hide behind the interior kernel (~23 us).  The hand-offs are flag kernels
-    // (see flag_set_kernel) unless MI355_PART_HANDOFF=events.
+    // exchange (~7 us) thus hide behind the interior kernel (~23 us).  The hand-offs are HIP events, or flag
+    // kernels (handoff_kernels.hpp) with MI355_PART_HANDOFF=flags.
+    if ((rc = part_handoff_status(P))) return rc; // a plain load of pinned memory: no copy, no synchronisation
     const unsigned step = ++P->step_no;
     if (P->flag_handoff) {
-        if ((step & 1023u) == 1u && step > 1) { // now and then: did a spin ever give up?
-            unsigned timeouts = 0;
-            HIP_TRY(hipMemcpy(&timeouts, P->d_flags + 2, sizeof timeouts, hipMemcpyDeviceToHost));
-            if (timeouts) return fail(MI_ERR_HIP, "mi_part_spmv_dev: a stream hand-off timed out (results since then are invalid)");
-        }
         hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, s, P->d_flags, step);
-        hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, P->comm_stream, P->d_flags, step, P->d_flags + 2);
+        hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, P->comm_stream, P->d_flags, step, P->d_timeouts);
     } else {
         HIP_TRY(hipEventRecord(P->ev_pack, s));
         HIP_TRY(hipStreamWaitEvent(P->comm_stream, P->ev_pack, 0));
@@ -1615,7 +1599,7 @@ extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local,
     if (P->flag_handoff) hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, P->comm_stream, P->d_flags + 1, step);
     else HIP_TRY(hipEventRecord(P->ev_comm, P->comm_stream));
     if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;
-    if (P->flag_handoff) hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s, P->d_flags + 1, step, P->d_flags + 2);
+    if (P->flag_handoff) hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s, P->d_flags + 1, step, P->d_timeouts);
     else HIP_TRY(hipStreamWaitEvent(s, P->ev_comm, 0));
     HIP_TRY(hipGetLastError());
     return MI_OK;

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <map>
+#include <thread>
 
 #include "mi355_spmv.h"
 
@@ -27,24 +28,61 @@ namespace {
         if (st_ != MI_OK) die(#expr, st_); \
     } while (0)
 
-// Cheap content fingerprint so that a matrix rebuilt in the same storage is
-// re-uploaded: size, extent and up to 64 evenly spaced (column, value) samples.
-uint64_t fingerprint(int n, const int* ptrow, const int* indcol, const double* coef, size_t per_entry)
+// Content hashes of the caller's arrays.  The reference's functions read the live arrays on every
+// call; this library computes from a device copy, so before every product the shim must know whether
+// the caller changed anything since the copy was made — including in-place edits of a few
+// coefficients (boundary-condition rows, the Newton loop's Jacobian update,
+// src/solve_newton.c:1245-1247).  EVERY byte is hashed (a sampled fingerprint would miss exactly
+// those edits): 8 independent multiply-xor lanes per 4 MiB chunk, chunks hashed by a few threads and
+// combined in order, so the value does not depend on the thread count.  ~10 ms for the 920 MB of a
+// 75 M-nonzero matrix, against 190 ms+ for the reference's CPU product of that size; callers that keep
+// their matrix fixed can switch the check off (mi355_assume_unchanged).
+uint64_t hash_chunk(const unsigned char* p, size_t bytes)
 {
+    static const uint64_t K[8] = {0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull, 0xd6e8feb86659fd93ull,
+                                  0xca5a826395121157ull, 0x9fb21c651e98df25ull, 0xa0761d6478bd642full, 0xe7037ed1a0b428dbull};
+    uint64_t lane[8];
+    for (int i = 0; i < 8; i++) lane[i] = K[i] ^ (uint64_t)bytes;
+    size_t k = 0;
+    for (; k + 64 <= bytes; k += 64) {
+        uint64_t w[8];
+        std::memcpy(w, p + k, 64);
+        for (int i = 0; i < 8; i++) lane[i] = (lane[i] ^ w[i]) * K[i] + (lane[i] >> 29);
+    }
+    uint64_t tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::memcpy(tail, p + k, bytes - k);
     uint64_t h = 0xcbf29ce484222325ull;
-    auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; };
-    const long long m = n > 0 ? ptrow[n] : 0;
-    mix((uint64_t)n);
-    mix((uint64_t)m);
-    const long long step = m > 64 ? m / 64 : 1;
-    for (long long k = 0; k < m; k += step) {
-        mix((uint64_t)indcol[k]);
-        uint64_t bits;
-        std::memcpy(&bits, coef + (size_t)k * per_entry, sizeof bits);
-        mix(bits);
+    for (int i = 0; i < 8; i++) {
+        lane[i] = (lane[i] ^ tail[i]) * K[i] + (lane[i] >> 29);
+        h = (h ^ lane[i]) * 0x100000001b3ull + (h >> 31);
     }
     return h;
 }
+
+uint64_t hash_bytes(const void* data, size_t bytes)
+{
+    const size_t chunk = (size_t)4 << 20;
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    std::vector<uint64_t> part(nchunks ? nchunks : 1, 0);
+    auto work = [&](size_t c0, size_t c1) {
+        for (size_t c = c0; c < c1; c++) part[c] = hash_chunk(p + c * chunk, std::min(chunk, bytes - c * chunk));
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+    if (nchunks < 4 || nt == 1) work(0, nchunks);
+    else {
+        if (nt > nchunks) nt = (unsigned)nchunks;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, nchunks * t / nt, nchunks * (t + 1) / nt);
+        for (std::thread& t : th) t.join();
+    }
+    uint64_t h = 0x84222325cbf29ce4ull ^ (uint64_t)bytes;
+    for (size_t c = 0; c < nchunks; c++) h = (h ^ part[c]) * 0x100000001b3ull + (h >> 31);
+    return h;
+}
+
+bool g_assume_unchanged = false; // mi355_assume_unchanged(true): the caller promises to call mi355_invalidate after edits
 
 struct Key {
     const void* p0;
@@ -61,52 +99,72 @@ struct Key {
 template <class H>
 struct Slot {
     H handle;
-    uint64_t fp;
+    int n;
+    long long stored;     // ptrow[n] when the copy was made
+    uint64_t pattern_fp;  // ptrow + indcol
+    uint64_t values_fp;   // coef
 };
 
 std::map<Key, Slot<mi_csr_t>> g_csr;
 std::map<Key, Slot<mi_bcsr4_t>> g_bcsr;
 
+// the device copy of A, brought up to date with the caller's arrays
+template <class H, class Create, class Update, class Destroy>
+H device_copy(std::map<Key, Slot<H>>& cache, const Key& k, int n, const int* ptrow, const int* indcol, const double* coef,
+              size_t per_entry, Create create, Update update, Destroy destroy)
+{
+    const long long stored = n > 0 ? ptrow[n] : 0;
+    typename std::map<Key, Slot<H>>::iterator it = cache.find(k);
+    const bool cached = it != cache.end() && it->second.n == n && it->second.stored == stored;
+    if (cached && g_assume_unchanged) return it->second.handle;
+    const uint64_t pfp = hash_bytes(ptrow, sizeof(int) * ((size_t)n + 1)) ^ (hash_bytes(indcol, sizeof(int) * (size_t)stored) * 3);
+    const uint64_t vfp = hash_bytes(coef, sizeof(double) * per_entry * (size_t)stored);
+    if (cached && it->second.pattern_fp == pfp) {
+        if (it->second.values_fp != vfp) { // same pattern, new coefficients: refresh the values only
+            update(it->second.handle);
+            it->second.values_fp = vfp;
+        }
+        return it->second.handle;
+    }
+    if (it != cache.end()) {
+        destroy(it->second.handle);
+        cache.erase(it);
+    }
+    if (cache.size() >= 16) { // bounded: drop everything rather than grow without limit
+        for (typename std::map<Key, Slot<H>>::iterator q = cache.begin(); q != cache.end(); ++q) destroy(q->second.handle);
+        cache.clear();
+    }
+    H h = create();
+    cache[k] = Slot<H>{h, n, stored, pfp, vfp};
+    return h;
+}
+
 mi_csr_t device_csr(csrmatrix& A)
 {
     const Key k{A.ptrow.data(), A.indcol.data(), A.coef.data()};
-    const uint64_t fp = fingerprint(A.n, A.ptrow.data(), A.indcol.data(), A.coef.data(), 1);
-    auto it = g_csr.find(k);
-    if (it != g_csr.end() && it->second.fp == fp) return it->second.handle;
-    if (it != g_csr.end()) {
-        mi_csr_destroy(it->second.handle);
-        g_csr.erase(it);
-    }
-    if (g_csr.size() >= 16) { // bounded: drop everything rather than grow without limit
-        for (auto& kv : g_csr) mi_csr_destroy(kv.second.handle);
-        g_csr.clear();
-    }
-    mi_csr_t h = nullptr;
-    MI_CALL(mi_csr_create(A.n, A.n, A.ptrow.data(), A.indcol.data(), A.coef.data(), &h));
-    g_csr[k] = Slot<mi_csr_t>{h, fp};
-    return h;
+    return device_copy<mi_csr_t>(
+        g_csr, k, A.n, A.ptrow.data(), A.indcol.data(), A.coef.data(), 1,
+        [&]() {
+            mi_csr_t h = nullptr;
+            MI_CALL(mi_csr_create(A.n, A.n, A.ptrow.data(), A.indcol.data(), A.coef.data(), &h));
+            return h;
+        },
+        [&](mi_csr_t h) { MI_CALL(mi_csr_update_values(h, A.coef.data())); }, [](mi_csr_t h) { mi_csr_destroy(h); });
 }
 
 mi_bcsr4_t device_bcsr(const bcsr4x4_matrix& A)
 {
     const Key k{A.ptrow.data(), A.indcol.data(), A.coef.data()};
-    const uint64_t fp = fingerprint(A.nrows, A.ptrow.data(), A.indcol.data(), A.coef.data(), 16);
-    auto it = g_bcsr.find(k);
-    if (it != g_bcsr.end() && it->second.fp == fp) return it->second.handle;
-    if (it != g_bcsr.end()) {
-        mi_bcsr4_destroy(it->second.handle);
-        g_bcsr.erase(it);
-    }
-    if (g_bcsr.size() >= 16) {
-        for (auto& kv : g_bcsr) mi_bcsr4_destroy(kv.second.handle);
-        g_bcsr.clear();
-    }
     // x is indexed by block column; the reference's callers pass vectors of
     // 4*nrows entries, so that is how much of x is transferred.
-    mi_bcsr4_t h = nullptr;
-    MI_CALL(mi_bcsr4_create(A.nrows, A.nrows, A.ptrow.data(), A.indcol.data(), A.coef.data(), &h));
-    g_bcsr[k] = Slot<mi_bcsr4_t>{h, fp};
-    return h;
+    return device_copy<mi_bcsr4_t>(
+        g_bcsr, k, A.nrows, A.ptrow.data(), A.indcol.data(), A.coef.data(), 16,
+        [&]() {
+            mi_bcsr4_t h = nullptr;
+            MI_CALL(mi_bcsr4_create(A.nrows, A.nrows, A.ptrow.data(), A.indcol.data(), A.coef.data(), &h));
+            return h;
+        },
+        [&](mi_bcsr4_t h) { MI_CALL(mi_bcsr4_update_values(h, A.coef.data())); }, [](mi_bcsr4_t h) { mi_bcsr4_destroy(h); });
 }
 
 void powers(int k, double* const* outs, double* x, csrmatrix& A)
@@ -116,12 +174,35 @@ void powers(int k, double* const* outs, double* x, csrmatrix& A)
 
 } // namespace
 
+// ---- device-copy cache control (extensions; see include/SpMV.h) ---------------------------------
+
+void mi355_assume_unchanged(bool on) { g_assume_unchanged = on; }
+
+void mi355_invalidate(csrmatrix& A)
+{
+    std::map<Key, Slot<mi_csr_t> >::iterator it = g_csr.find(Key{A.ptrow.data(), A.indcol.data(), A.coef.data()});
+    if (it != g_csr.end()) {
+        mi_csr_destroy(it->second.handle);
+        g_csr.erase(it);
+    }
+}
+
+void mi355_invalidate(const bcsr4x4_matrix& A)
+{
+    std::map<Key, Slot<mi_bcsr4_t> >::iterator it = g_bcsr.find(Key{A.ptrow.data(), A.indcol.data(), A.coef.data()});
+    if (it != g_bcsr.end()) {
+        mi_bcsr4_destroy(it->second.handle);
+        g_bcsr.erase(it);
+    }
+}
+
 // ---- y = A x ------------------------------------------------------------------
 
 void SpMV_CSR(double* y, double* x, csrmatrix& A) { MI_CALL(mi_spmv(device_csr(A), x, y)); }
 void SpMV_CSR_OPT(double* y, double* x, csrmatrix& A) { SpMV_CSR(y, x, A); }
 void SpMV_CSR_FMA(double* y, double* x, csrmatrix& A) { SpMV_CSR(y, x, A); }
 void SpMV_CSR_AVX2(double* y, double* x, csrmatrix& A) { SpMV_CSR(y, x, A); }
+void SpMV(double* y, double* x, csrmatrix& A) { SpMV_CSR(y, x, A); } // the name in mpk/SpMVmulti0.cpp:223-236
 
 void SpMV_BCSR(double* y, const double* x, const bcsr4x4_matrix& A) { MI_CALL(mi_bcsr4_spmv(device_bcsr(A), x, y)); }
 void SpMV_BCSR_OPT(double* y, const double* x, const bcsr4x4_matrix& A) { SpMV_BCSR(y, x, A); }
@@ -135,7 +216,7 @@ void Generate1stlayer(std::vector<int>& ptrowend1, csrmatrix& A)
     // entry ia=(i,j): whole row j on the first meeting of column j, empty range afterwards
     std::vector<char> met((size_t)(A.n > 0 ? A.n : 0), 0);
     const int stored = A.n > 0 ? A.ptrow[A.n] : 0;
-    ptrowend1.assign((size_t)std::max(A.nnz, stored), 0);
+    ptrowend1.resize((size_t)std::max(A.nnz, stored)); // resize(A.nnz) in the reference: entries behind ptrow[n] keep their content
     for (int ia = 0; ia < stored; ia++) {
         const int j = A.indcol[ia];
         ptrowend1[ia] = met[j] ? A.ptrow[j] : A.ptrow[j + 1];
@@ -189,6 +270,64 @@ void SpM4V(double* v, double* w, double* z, double* y, double* x, csrmatrix& A, 
     powers(4, outs, x, A);
 }
 
+// Nested first-touch tables of the k = 3, 4 CPU traversals (mpk/SpMVmulti0.cpp:106-130, :157-187).
+// The GPU kernels do not use them; they are filled exactly as the reference fills them for callers
+// that build, print or reuse them.  Level L has its own "already met" set, updated in the order in
+// which the level-L loop of the traversal reaches an index.
+void Generate2ndlayer(std::vector<std::vector<int> >& ptrowend2, csrmatrix& A, std::vector<int>& ptrowend1)
+{
+    std::vector<char> met((size_t)(A.n > 0 ? A.n : 0), 0);
+    const int stored = A.n > 0 ? A.ptrow[A.n] : 0;
+    ptrowend2.resize((size_t)std::max(A.nnz, stored));
+    for (int ia = 0; ia < stored; ia++) {
+        const int first = A.ptrow[A.indcol[ia]], last = ptrowend1[ia];
+        std::vector<int>& t = ptrowend2[ia];
+        t.resize((size_t)(last - first));
+        for (int jb = first; jb < last; jb++) {
+            const int k = A.indcol[jb];
+            t[jb - first] = met[k] ? A.ptrow[k] : A.ptrow[k + 1];
+            met[k] = 1;
+        }
+    }
+}
+
+void Generate3rdlayer(std::vector<std::vector<std::vector<int> > >& ptrowend3, csrmatrix& A, std::vector<int>& ptrowend1,
+                      std::vector<std::vector<int> >& ptrowend2)
+{
+    std::vector<char> met((size_t)(A.n > 0 ? A.n : 0), 0);
+    const int stored = A.n > 0 ? A.ptrow[A.n] : 0;
+    ptrowend3.resize((size_t)std::max(A.nnz, stored));
+    for (int ia = 0; ia < stored; ia++) {
+        const int first = A.ptrow[A.indcol[ia]], last = ptrowend1[ia];
+        std::vector<std::vector<int> >& t2 = ptrowend3[ia];
+        t2.resize((size_t)(last - first));
+        for (int jb = first; jb < last; jb++) {
+            const int k = A.indcol[jb];
+            const int kfirst = A.ptrow[k], klast = ptrowend2[ia][jb - first];
+            if (klast <= kfirst) continue; // the reference sizes this level inside its (empty) kc loop
+            std::vector<int>& t3 = t2[jb - first];
+            t3.resize((size_t)(klast - kfirst));
+            for (int kc = kfirst; kc < klast; kc++) {
+                const int l = A.indcol[kc];
+                t3[kc - kfirst] = met[l] ? A.ptrow[l] : A.ptrow[l + 1];
+                met[l] = 1;
+            }
+        }
+    }
+}
+
+// mpk/SpMVmulti0.cpp:44-61 (SpM2V0) and :65-104 (SpM2V): the k = 2 kernels under their other names
+void SpM2V0(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& t) { SpM2V_CSR(z, y, x, A, t); }
+void SpM2V(double* z, double* y, double* x, csrmatrix& A, std::vector<int>& t) { SpM2V_CSR(z, y, x, A, t); }
+
+// mpk/SpMVmulti-1.cpp:434-493: outputs first (y4 = A^4 x ... y1 = A x), const inputs
+void SpM4V_AVX2(double* y4, double* y3, double* y2, double* y1, const double* x, const csrmatrix& A, const std::vector<int>&,
+                const std::vector<std::vector<int> >&, const std::vector<std::vector<std::vector<int> > >&)
+{
+    double* outs[4] = {y1, y2, y3, y4};
+    powers(4, outs, const_cast<double*>(x), const_cast<csrmatrix&>(A));
+}
+
 // ---- BLAS-1 ----------------------------------------------------------------------
 
 void orthogonalize(int nrow, const std::vector<double>& b, const std::vector<double>& x1,
@@ -201,9 +340,14 @@ void orthogonalize(int nrow, const std::vector<double>& b, const std::vector<dou
 void orthogonalize(int nrow, const std::vector<double>& x, std::vector<double>& y, double alpha)
 {
     double beta = 0.0;
-    std::vector<double> out((size_t)nrow);
-    MI_CALL(mi_orthogonalize(nrow, x.data(), y.data(), out.data(), alpha, &beta));
-    std::copy(out.begin(), out.end(), y.begin());
+    MI_CALL(mi_orthogonalize(nrow, x.data(), y.data(), y.data(), alpha, &beta)); // in place: x3 == x1
+}
+
+void orthonormalize_against_basis(int nrow, std::vector<std::vector<double> >& basis, std::vector<double>& y)
+{
+    std::vector<const double*> ptrs(basis.size());
+    for (size_t j = 0; j < basis.size(); j++) ptrs[j] = basis[j].data();
+    MI_CALL(mi_orthonormalize_against_basis(nrow, (int)basis.size(), ptrs.data(), y.data(), nullptr));
 }
 
 double norm2(const std::vector<double>& x)

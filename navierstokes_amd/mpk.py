@@ -69,6 +69,13 @@ def lib():
         "mi_csr_create": [i, i, _vp, _vp, _vp, P(_vp)],
         "mi_csr_create_mapped": [i, i, _vp, _vp, _vp, _vp, P(_vp)],
         "mi_csr_destroy": [_vp],
+        "mi_csr_update_values": [_vp, _vp],
+        "mi_csr_update_values_dev": [_vp, _vp, _vp],
+        "mi_bcsr4_update_values": [_vp, _vp],
+        "mi_bcsr4_update_values_dev": [_vp, _vp, _vp],
+        "mi_orthonormalize_against_basis": [i, i, _vp, _vp, _vp],
+        "mi_orthonormalize_against_basis_dev": [i, i, _vp, _vp, _vp, _vp],
+        "mi_part_status": [_vp],
         "mi_csr_dims": [_vp, P(i), P(i), P(ll)],
         "mi_csr_set_kernel": [_vp, i],
         "mi_csr_get_kernel": [_vp, P(i)],
@@ -231,6 +238,15 @@ class csrmatrix:
         nt = rnt.value if "ring" in self.kernel_name() else snt.value
         return dict(ring=us[0], ring_nt=us[1], stream=us[2], stream_nt=us[3], bcsr4=us[4]), bool(nt)
 
+    def update_values(self, coef):
+        """New coefficients for the same pattern (mi_csr_update_values): numpy array (host) or CUDA tensor."""
+        if _is_torch(coef):
+            check(lib().mi_csr_update_values_dev(self.handle, _dev_ptr(coef, self.nnz, "coef"), _stream_ptr()))
+        else:
+            self.coef = _host_f64(coef, self.nnz, "coef")
+            check(lib().mi_csr_update_values(self.handle, self.coef.ctypes.data))
+        return self
+
     def drop_host_arrays(self):
         """Free the host copies of indcol/coef once the device handle exists (large benches)."""
         _ = self.handle
@@ -361,9 +377,17 @@ def SpMkV(ys, x, A):
 
 
 def Generate1stlayer(ptrowend1, A):
-    """Kept for signature parity with mpk/SpM2V.cpp:5-26.  The first-touch table
-    drives the CPU's serial traversal; the GPU path needs no table (each power is
-    a full row-parallel sweep), so this is a no-op that returns its argument."""
+    """mpk/SpM2V.cpp:5-26: ptrowend1[ia] = ptrow[j + 1] the first time column j = indcol[ia] is met in
+    CSR traversal order, else ptrow[j].  The table drives the CPU's serial traversal; the GPU path does
+    not need it (each power is a full row-parallel sweep) but callers may inspect it, so it is filled
+    as the reference fills it.  ptrowend1: int32 array of >= nnz entries (or None: a new one)."""
+    nnz = A.nnz
+    if ptrowend1 is None:
+        ptrowend1 = np.zeros(nnz, np.int32)
+    cols = A.indcol[:nnz].astype(np.int64)
+    ptrowend1[:nnz] = A.ptrow[cols]
+    _, first = np.unique(cols, return_index=True)
+    ptrowend1[first] = A.ptrow[cols[first] + 1]
     return ptrowend1
 
 
@@ -453,6 +477,28 @@ def orthogonalize(nrow, b, x1, x3, alpha=1e-8):
     check(lib().mi_orthogonalize(nrow, _host_f64(b, nrow).ctypes.data, _host_f64(x1, nrow).ctypes.data,
                                  x3h.ctypes.data, float(alpha), _c.byref(out)))
     return out.value
+
+
+def orthonormalize_against_basis(basis, y):
+    """orthonormalize_against_basis(nrow, basis, y), mpk/2SpMV.cpp:13-28: for each basis vector in turn
+    y -= (y . v) v on the y updated so far (nothing is normalised, like the reference).  y is updated in
+    place; returns the m coefficients (numpy array, or a device tensor for device inputs).
+    basis: sequence of m vectors (numpy rows or CUDA tensors)."""
+    m = len(basis)
+    if _is_torch(y):
+        import torch
+        n = int(y.numel())
+        dots = torch.empty(max(m, 1), dtype=torch.float64, device=y.device)
+        ptrs = (_vp * max(m, 1))(*[_dev_ptr(b, n, f"basis[{j}]").value for j, b in enumerate(basis)])
+        check(lib().mi_orthonormalize_against_basis_dev(n, m, ptrs, _dev_ptr(y), _dev_ptr(dots), _stream_ptr()))
+        return dots[:m]
+    yy = _host_f64(y, None, "y", writable=True)
+    n = yy.size
+    rows = [_host_f64(b, n, f"basis[{j}]") for j, b in enumerate(basis)]
+    ptrs = (_vp * max(m, 1))(*[r.ctypes.data for r in rows])
+    dots = np.zeros(m)
+    check(lib().mi_orthonormalize_against_basis(n, m, ptrs, yy.ctypes.data, dots.ctypes.data if m else None))
+    return dots
 
 
 def norm2(x):

@@ -17,7 +17,12 @@
  *   - orc_spmv_csr_x87     bit-equal to SpMV_CSR (x87 build, per-term rounding)
  *   - orc_spm2v_fused      bit-equal to SpM2V_CSR_OPT, = 2 chained fma SpMVs
  *   - orc_spmkv_fused      k<=4 first-touch traversal; arith fma bit-equal to
- *                          SpM3V, arith x87 bit-equal to SpM2V0 / SpM4V
+ *                          SpM3V, arith x87 bit-equal to SpM2V0 / SpM4V, arith
+ *                          avx2row bit-equal to SpM4V_AVX2 (mpk/SpMVmulti-1.cpp)
+ *   - orc_gen_layers       bit-equal to Generate1st/2nd/3rdlayer (nested tables)
+ *   - orc_orthogonalize    bit-equal to orthogonalize of mpk/old/SpMVmulti.cpp:164-169
+ *   - orc_orthogonalize_inplace  bit-equal to orthogonalize of mpk/2SpMV.cpp:3-11
+ *   - orc_mgs              bit-equal to orthonormalize_against_basis, mpk/2SpMV.cpp:13-28
  *
  * All citations are relative to /root/reference/.
  */
@@ -71,11 +76,15 @@ void orc_spmv_csr_muladd(int n, const int *ptrow, const int *indcol, const doubl
  *                on x86-64 Linux.  Verified bit-for-bit against the reference's
  *                object code in tests/test_oracle_vs_reference.py.
  *   ARITH_MULADD IEEE double multiply, then add (an SSE2 build without FMA). */
-enum { ARITH_FMA = 0, ARITH_X87 = 1, ARITH_MULADD = 2 };
+enum { ARITH_FMA = 0, ARITH_X87 = 1, ARITH_MULADD = 2, ARITH_AVX2ROW = 3 };
+/* ARITH_AVX2ROW (orc_spmkv_fused only): SpM4V_AVX2, mpk/SpMVmulti-1.cpp:434-493 — the innermost
+ * row sum runs four interleaved fma chains (one per AVX lane) over the groups of four terms, folds
+ * them as (l0 + l2) + (l1 + l3), continues with a scalar fma chain over the <4 remainder and is
+ * then ADDED to y1[l] (0.0 at first touch); the upper levels are plain fma updates. */
 
 static inline double acc_term(int arith, double c, double x, double s)
 {
-    if (arith == ARITH_FMA) return fma(c, x, s);
+    if (arith == ARITH_FMA || arith == ARITH_AVX2ROW) return fma(c, x, s);
     if (arith == ARITH_X87) return (double)((long double)s + (long double)c * (long double)x);
     volatile double p = c * x;
     volatile double r = s + p;
@@ -177,6 +186,18 @@ static void level_visit(int arith, int depth, int k, int row, const int *ptrow, 
 {
     /* computes Y[depth][row] assuming it is visited for the first time */
     double *out = Y + (size_t)depth * n;
+    if (depth == 0 && arith == ARITH_AVX2ROW) {
+        double l[4] = {0.0, 0.0, 0.0, 0.0};
+        int ld = ptrow[row];
+        const int end = ptrow[row + 1];
+        for (; ld <= end - 4; ld += 4)
+            for (int t = 0; t < 4; t++) l[t] = fma(coef[ld + t], x[indcol[ld + t]], l[t]);
+        double sum = 0.0;
+        sum += (l[0] + l[2]) + (l[1] + l[3]);
+        for (; ld < end; ld++) sum = fma(coef[ld], x[indcol[ld]], sum);
+        out[row] += sum;
+        return;
+    }
     for (int ia = ptrow[row]; ia < ptrow[row + 1]; ia++) {
         int j = indcol[ia];
         if (depth == 0) {
@@ -192,13 +213,70 @@ static void level_visit(int arith, int depth, int k, int row, const int *ptrow, 
     }
 }
 
-/* arith: 0 fma (SpM2V_CSR_OPT, SpM3V), 1 x87 (SpM2V_CSR, SpM2V0, SpM4V), 2 mul+add */
+/* arith: 0 fma (SpM2V_CSR_OPT, SpM3V), 1 x87 (SpM2V_CSR, SpM2V0, SpM4V), 2 mul+add, 3 SpM4V_AVX2 */
 void orc_spmkv_fused(int arith, int k, int n, const int *ptrow, const int *indcol, const double *coef,
                      const double *x, double *Y)
 {
     memset(Y, 0, (size_t)k * n * sizeof(double));
     unsigned char *seen = (unsigned char *)calloc((size_t)(k > 1 ? k - 1 : 1) * (n > 0 ? n : 1), 1);
     for (int i = 0; i < n; i++) level_visit(arith, k - 1, k, i, ptrow, indcol, coef, x, Y, n, seen);
+    free(seen);
+}
+
+/* The nested first-touch tables of the k = 3, 4 traversals, mpk/SpMVmulti0.cpp:106-130
+ * (Generate2ndlayer) and :157-187 (Generate3rdlayer), flattened in traversal order:
+ *   e1[ia]                               (Generate1stlayer, :22-40)
+ *   len2[ia] = size of ptrowend2[ia] = e1[ia] - ptrow[j];  e2 = their concatenation
+ *   len3[q]  = size of ptrowend3[ia][jjb], q over (ia, jjb) in order; e3 = their concatenation
+ * Each level keeps its own mask: an index is "first met" at level L the first time the level-L
+ * loop of THIS traversal reaches it.  Two-pass: buffers may be NULL to obtain *n2 (entries of e2)
+ * and *n3 (entries of e3). */
+void orc_gen_layers(int n, const int *ptrow, const int *indcol, int *e1, int *len2, int *e2, int *len3,
+                    int *e3, long long *n2, long long *n3)
+{
+    unsigned char *m1 = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    unsigned char *m2 = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    unsigned char *m3 = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    long long c2 = 0, c3 = 0;
+    for (int i = 0; i < n; i++)
+        for (int ia = ptrow[i]; ia < ptrow[i + 1]; ia++) {
+            const int j = indcol[ia];
+            int end1 = ptrow[j];
+            if (!m1[j]) { end1 = ptrow[j + 1]; m1[j] = 1; }
+            if (e1) e1[ia] = end1;
+            if (len2) len2[ia] = end1 - ptrow[j];
+            for (int jb = ptrow[j]; jb < end1; jb++) {
+                const int k = indcol[jb];
+                int end2 = ptrow[k];
+                if (!m2[k]) { end2 = ptrow[k + 1]; m2[k] = 1; }
+                if (e2) e2[c2] = end2;
+                if (len3) len3[c2] = end2 - ptrow[k];
+                c2++;
+                for (int kc = ptrow[k]; kc < end2; kc++) {
+                    const int l = indcol[kc];
+                    int end3 = ptrow[l];
+                    if (!m3[l]) { end3 = ptrow[l + 1]; m3[l] = 1; }
+                    if (e3) e3[c3] = end3;
+                    c3++;
+                }
+            }
+        }
+    if (n2) *n2 = c2;
+    if (n3) *n3 = c3;
+    free(m1); free(m2); free(m3);
+}
+
+/* First-touch table of block rows, mpk/SpM2V.cpp:28-46 (Generate1stlayer_BCSR4): block m = (bi, bj)
+ * gets the full block row bj the first time block column bj is met, an empty range afterwards. */
+void orc_gen_layer1_bcsr4(int nbrows, const int *ptrow, const int *indcol, int *endB)
+{
+    unsigned char *seen = (unsigned char *)calloc((size_t)(nbrows > 0 ? nbrows : 1), 1);
+    for (int bi = 0; bi < nbrows; bi++)
+        for (int m = ptrow[bi]; m < ptrow[bi + 1]; m++) {
+            const int bj = indcol[m];
+            if (seen[bj]) endB[m] = ptrow[bj];
+            else { endB[m] = ptrow[bj + 1]; seen[bj] = 1; }
+        }
     free(seen);
 }
 
@@ -242,7 +320,8 @@ double orc_rel_error(int n, const double *ref, const double *test)
     return sqrt(s) / orc_norm2(n, ref);
 }
 
-/* sequential dot, std::inner_product order — mpk/SpMVmulti.cpp:147 */
+/* sequential fma dot: beta = fma(a[i], b[i], beta) — what the volatile accumulation loop of
+ * mpk/2SpMV.cpp:5-7 compiles to (g++ 11.4 -O3, FMA target: one vfmadd231sd per element) */
 double orc_dot(int n, const double *a, const double *b)
 {
     double s = 0.0;
@@ -250,13 +329,66 @@ double orc_dot(int n, const double *a, const double *b)
     return s;
 }
 
-/* out = x1 - alpha*beta*b with beta = b.x1 — mpk/SpMVmulti.cpp:146-151;
- * returns beta.  (In-place twin: mpk/2SpMV.cpp:3-11, y -= alpha*(x.y)*x.) */
+/* std::inner_product(b, x1) of mpk/SpMVmulti.cpp:147 (= mpk/old/SpMVmulti.cpp:165) and the dot loops of
+ * orthonormalize_against_basis, mpk/2SpMV.cpp:15-17, as g++ 11.4 -O3 vectorises them for an FMA
+ * target: the PRODUCTS are formed four at a time and rounded (vmulpd), then added to the running sum
+ * one by one in index order (an in-order reduction: no reassociation without -ffast-math); a
+ * remaining pair is handled the same way, and a last odd element by one scalar fma.  Pinned bitwise
+ * against the reference's object code (tests/golden/blas1_*.npz). */
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off")
+double orc_dot_gccvec(int n, const double *a, const double *b)
+{
+    volatile double s = 0.0;
+    int i = 0;
+    for (; i + 4 <= n; i += 4)
+        for (int t = 0; t < 4; t++) { volatile double p = a[i + t] * b[i + t]; s = s + p; }
+    if (n - i >= 2) {
+        for (int t = 0; t < 2; t++) { volatile double p = a[i + t] * b[i + t]; s = s + p; }
+        i += 2;
+    }
+    double r = s;
+    if (i < n) r = fma(a[i], b[i], r);
+    return r;
+}
+#pragma GCC pop_options
+
+/* out[i] = fma(-ab, b[i], x1[i]): the update half of both orthogonalize forms as compiled
+ * (vmulsd alpha*beta once per element, then vfnmadd132sd: mpk/2SpMV.cpp:9-10, mpk/SpMVmulti.cpp:148-150) */
+void orc_ortho_update(int n, double ab, const double *b, const double *x1, double *out)
+{
+    for (int i = 0; i < n; i++) out[i] = fma(-ab, b[i], x1[i]);
+}
+
+/* out = x1 - alpha*beta*b with beta = b.x1 — orthogonalize(nrow, b, x1, x3, alpha),
+ * mpk/SpMVmulti.cpp:146-151 (compilable copy: mpk/old/SpMVmulti.cpp:164-169); returns beta. */
 double orc_orthogonalize(int n, const double *b, const double *x1, double *out, double alpha)
 {
-    double beta = orc_dot(n, b, x1);
-    for (int i = 0; i < n; i++) out[i] = x1[i] - alpha * beta * b[i];
+    double beta = orc_dot_gccvec(n, b, x1);
+    orc_ortho_update(n, alpha * beta, b, x1, out);
     return beta;
+}
+
+/* y -= alpha*(x.y)*x in place — orthogonalize(nrow, x, y, alpha), mpk/2SpMV.cpp:3-11; returns beta. */
+double orc_orthogonalize_inplace(int n, const double *x, double *y, double alpha)
+{
+    double beta = orc_dot(n, x, y);
+    orc_ortho_update(n, alpha * beta, x, y, y);
+    return beta;
+}
+
+/* orthonormalize_against_basis(nrow, basis, y), mpk/2SpMV.cpp:13-28: for each basis vector in turn
+ * dot = y.v (on the y updated so far), y -= dot*v (compiled to vfnmadd: y = fma(-dot, v, y)); the
+ * norm computed at the end is discarded by the reference and nothing is normalised.  basis = m
+ * contiguous vectors of n; dots (may be NULL) receives the m coefficients. */
+void orc_mgs(int n, int m, const double *basis, double *y, double *dots)
+{
+    for (int j = 0; j < m; j++) {
+        const double *v = basis + (size_t)j * n;
+        const double d = orc_dot_gccvec(n, y, v);
+        orc_ortho_update(n, d, v, y, y);
+        if (dots) dots[j] = d;
+    }
 }
 
 /* y += a x */

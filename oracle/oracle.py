@@ -56,6 +56,14 @@ def cpu():
         L.orc_dot.restype = _c.c_double
         L.orc_orthogonalize.argtypes = [_c.c_int, _f64, _f64, _f64, _c.c_double]
         L.orc_orthogonalize.restype = _c.c_double
+        L.orc_dot_gccvec.argtypes = [_c.c_int, _f64, _f64]
+        L.orc_dot_gccvec.restype = _c.c_double
+        L.orc_ortho_update.argtypes = [_c.c_int, _c.c_double, _f64, _f64, _f64]
+        L.orc_orthogonalize_inplace.argtypes = [_c.c_int, _f64, _f64, _c.c_double]
+        L.orc_orthogonalize_inplace.restype = _c.c_double
+        L.orc_mgs.argtypes = [_c.c_int, _c.c_int, _f64, _f64, _c.c_void_p]
+        L.orc_gen_layers.argtypes = [_c.c_int, _i32, _i32] + [_c.c_void_p] * 5 + [_c.POINTER(_c.c_longlong)] * 2
+        L.orc_gen_layer1_bcsr4.argtypes = [_c.c_int, _i32, _i32, _i32]
         L.orc_axpy.argtypes = [_c.c_int, _c.c_double, _f64, _f64]
         L.orc_coo2csr.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _f64, _i32, _i32, _f64]
         L.orc_coo2csr.restype = _c.c_int
@@ -118,7 +126,7 @@ def spm2v_fused(ptrow, indcol, coef, x, arith="fma"):
     return y, z
 
 
-ARITH = {"fma": 0, "x87": 1, "muladd": 2}
+ARITH = {"fma": 0, "x87": 1, "muladd": 2, "avx2row": 3}
 
 
 def spmkv_fused(k, ptrow, indcol, coef, x, arith="fma"):
@@ -160,6 +168,64 @@ def orthogonalize(b, x1, alpha=1e-8):
     out = np.empty_like(x1)
     beta = cpu().orc_orthogonalize(len(b), b, x1, out, alpha)
     return beta, out
+
+
+def dot_gccvec(a, b):
+    """std::inner_product as the reference's object code evaluates it (rounded products, in-order sum)."""
+    a, b = _as_f64(a), _as_f64(b)
+    return cpu().orc_dot_gccvec(len(a), a, b)
+
+
+def ortho_update(ab, b, x1):
+    """fma(-ab, b, x1) elementwise: the update half of orthogonalize given alpha*beta."""
+    b, x1 = _as_f64(b), _as_f64(x1)
+    out = np.empty_like(x1)
+    cpu().orc_ortho_update(len(b), float(ab), b, x1, out)
+    return out
+
+
+def orthogonalize_inplace(x, y, alpha=1e-8):
+    """(beta, y') with y' = y - alpha*(x.y)*x — the in-place form of mpk/2SpMV.cpp:3-11."""
+    x, y = _as_f64(x), _as_f64(y).copy()
+    beta = cpu().orc_orthogonalize_inplace(len(x), x, y, alpha)
+    return beta, y
+
+
+def mgs(basis, y):
+    """orthonormalize_against_basis (mpk/2SpMV.cpp:13-28): (y', dots) for basis of shape (m, n)."""
+    basis = _as_f64(basis)
+    m, n = basis.shape
+    y = _as_f64(y).copy()
+    dots = np.empty(m, np.float64)
+    cpu().orc_mgs(n, m, basis.reshape(-1), y, dots.ctypes.data)
+    return y, dots
+
+
+def _layers(fn, n, ptrow, indcol, nnz):
+    n2, n3 = _c.c_longlong(0), _c.c_longlong(0)
+    fn(None, None, None, None, None, _c.byref(n2), _c.byref(n3))
+    e1 = np.empty(nnz, np.int32)
+    len2 = np.empty(nnz, np.int32)
+    e2 = np.empty(max(n2.value, 1), np.int32)
+    len3 = np.empty(max(n2.value, 1), np.int32)
+    e3 = np.empty(max(n3.value, 1), np.int32)
+    fn(e1.ctypes.data, len2.ctypes.data, e2.ctypes.data, len3.ctypes.data, e3.ctypes.data, _c.byref(n2), _c.byref(n3))
+    return dict(e1=e1, len2=len2, e2=e2[: n2.value].copy(), len3=len3[: n2.value].copy(), e3=e3[: n3.value].copy())
+
+
+def gen_layers(ptrow, indcol):
+    """Flattened Generate1st/2nd/3rdlayer tables (see orc_gen_layers)."""
+    ptrow, indcol = _as_i32(ptrow), _as_i32(indcol)
+    n = len(ptrow) - 1
+    L = cpu()
+    return _layers(lambda *a: L.orc_gen_layers(n, ptrow, indcol, *a), n, ptrow, indcol, len(indcol))
+
+
+def gen_layer1_bcsr4(ptrow, indcol):
+    ptrow, indcol = _as_i32(ptrow), _as_i32(indcol)
+    out = np.empty(len(indcol), np.int32)
+    cpu().orc_gen_layer1_bcsr4(len(ptrow) - 1, ptrow, indcol, out)
+    return out
 
 
 def axpy(a, x, y):
@@ -217,7 +283,8 @@ def time_spmv(ptrow, indcol, coef, x, reps=3, flush=True):
 # ------------------------------------------------ the real reference (if built)
 
 def have_ref():
-    return all(os.path.exists(os.path.join(_HERE, "_ref", f"libref_{s}.so")) for s in ("spmv", "spm2v", "multi0"))
+    return all(os.path.exists(os.path.join(_HERE, "_ref", f"libref_{s}.so"))
+               for s in ("spmv", "spm2v", "multi0", "2spmv", "multiold", "multi1"))
 
 
 def ref(which):
@@ -241,8 +308,17 @@ def ref(which):
             L.ref_gen_layer1.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _i32]
             L.ref_spm2v_csr.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64, _f64]
             L.ref_spm2v_bcsr.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64, _f64]
+            L.ref_gen_layer1_bcsr4.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _i32]
         elif which == "multi0":
             L.ref_multi0_powers.argtypes = [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64]
+            L.ref_multi0_layers.argtypes = [_c.c_int, _c.c_int, _i32, _i32] + [_c.c_void_p] * 5 + [_c.POINTER(_c.c_longlong)] * 2
+        elif which == "2spmv":
+            L.ref_orthogonalize_inplace.argtypes = [_c.c_int, _f64, _f64, _c.c_double]
+            L.ref_orthonormalize_against_basis.argtypes = [_c.c_int, _c.c_int, _f64, _f64]
+        elif which == "multiold":
+            L.ref_orthogonalize3.argtypes = [_c.c_int, _f64, _f64, _f64, _c.c_double]
+        elif which == "multi1":
+            L.ref_multi1_spm4v_avx2.argtypes = [_c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64]
         _REF[which] = L
     return _REF[which]
 
@@ -332,3 +408,48 @@ def ref_time_spmv(ptrow, indcol, coef, x, variant="scalar", reps=3, flush=True):
     t = ref("spmv").ref_time_spmv_csr(REF_VARIANTS[variant], n, len(indcol), ptrow, indcol, coef, x, y, reps,
                                       1 if flush else 0)
     return t, y
+
+
+def ref_gen_layers(ptrow, indcol):
+    ptrow, indcol = _as_i32(ptrow), _as_i32(indcol)
+    n, nnz = len(ptrow) - 1, len(indcol)
+    L = ref("multi0")
+    return _layers(lambda *a: L.ref_multi0_layers(n, nnz, ptrow, indcol, *a), n, ptrow, indcol, nnz)
+
+
+def ref_gen_layer1_bcsr4(ptrow, indcol):
+    ptrow, indcol = _as_i32(ptrow), _as_i32(indcol)
+    out = np.empty(len(indcol), np.int32)
+    rc = ref("spm2v").ref_gen_layer1_bcsr4(len(ptrow) - 1, len(indcol), ptrow, indcol, out)
+    assert rc == 0
+    return out
+
+
+def ref_orthogonalize3(b, x1, alpha=1e-8):
+    b, x1 = _as_f64(b), _as_f64(x1)
+    out = np.full(len(b), np.nan)
+    ref("multiold").ref_orthogonalize3(len(b), b, x1, out, alpha)
+    return out
+
+
+def ref_orthogonalize_inplace(x, y, alpha=1e-8):
+    x, y = _as_f64(x), _as_f64(y).copy()
+    ref("2spmv").ref_orthogonalize_inplace(len(x), x, y, alpha)
+    return y
+
+
+def ref_mgs(basis, y):
+    basis = _as_f64(basis)
+    m, n = basis.shape
+    y = _as_f64(y).copy()
+    ref("2spmv").ref_orthonormalize_against_basis(n, m, basis.reshape(-1), y)
+    return y
+
+
+def ref_spm4v_avx2(ptrow, indcol, coef, x):
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    Y = np.full((4, n), np.nan)
+    rc = ref("multi1").ref_multi1_spm4v_avx2(n, len(indcol), ptrow, indcol, coef, x, Y.reshape(-1))
+    assert rc == 0
+    return Y

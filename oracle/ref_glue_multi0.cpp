@@ -69,4 +69,47 @@ int ref_multi0_powers(int fused, int k, int n, int nnz, const int* ptrow, const 
     return 0;
 }
 
+// The nested first-touch tables of Generate1st/2nd/3rdlayer (mpk/SpMVmulti0.cpp:22-40, :106-130,
+// :157-187), flattened in traversal order so that Python can compare them:
+//   e1[ia]                                   nnz entries
+//   len2[ia] = ptrowend2[ia].size(), e2 = concatenation over ia
+//   len3[q]  = ptrowend3[ia][jjb].size() for q running over (ia, jjb) in order, e3 = concatenation
+// Two-pass: call with e2 == NULL to get the counts (*n2 = total e2 entries = number of (ia,jjb)
+// pairs, *n3 = total e3 entries), then again with buffers.
+int ref_multi0_layers(int n, int nnz, const int* ptrow, const int* indcol, int* e1, int* len2, int* e2,
+                      int* len3, int* e3, long long* n2, long long* n3)
+{
+    csrmatrix a;
+    a.n = n;
+    a.nnz = nnz;
+    a.ptrow.assign(ptrow, ptrow + n + 1);
+    a.indcol.assign(indcol, indcol + nnz);
+    a.coef.assign((size_t)nnz, 0.0);
+    std::vector<int> t1(nnz);
+    std::vector<std::vector<int>> t2(nnz);
+    std::vector<std::vector<std::vector<int>>> t3(nnz);
+    Generate1stlayer(t1, a);
+    Generate2ndlayer(t2, a, t1);
+    Generate3rdlayer(t3, a, t1, t2);
+    long long c2 = 0, c3 = 0;
+    for (int ia = 0; ia < nnz; ia++) {
+        if (e1) e1[ia] = t1[ia];
+        if (len2) len2[ia] = (int)t2[ia].size();
+        for (size_t jjb = 0; jjb < t2[ia].size(); jjb++) {
+            if (e2) e2[c2] = t2[ia][jjb];
+            const std::vector<int>* v3 = jjb < t3[ia].size() ? &t3[ia][jjb] : nullptr;
+            if (len3) len3[c2] = v3 ? (int)v3->size() : 0;
+            c2++;
+            if (v3)
+                for (size_t kkc = 0; kkc < v3->size(); kkc++) {
+                    if (e3) e3[c3] = (*v3)[kkc];
+                    c3++;
+                }
+        }
+    }
+    if (n2) *n2 = c2;
+    if (n3) *n3 = c3;
+    return 0;
+}
+
 } // extern "C"

@@ -78,4 +78,19 @@ int ref_spm2v_bcsr(int variant, int nbrows, int nblocks, const int* ptrow, const
     return 0;
 }
 
+// first-touch table of block rows (mpk/SpM2V.cpp:28-46); endB has nblocks entries
+int ref_gen_layer1_bcsr4(int nbrows, int nblocks, const int* ptrow, const int* indcol, int* endB)
+{
+    bcsr4x4_matrix a;
+    a.nrows = nbrows;
+    a.nblocks = nblocks;
+    a.ptrow.assign(ptrow, ptrow + nbrows + 1);
+    a.indcol.assign(indcol, indcol + nblocks);
+    std::vector<int> t;
+    Generate1stlayer_BCSR4(t, a);
+    if ((int)t.size() < nblocks) return -1;
+    for (int k = 0; k < nblocks; k++) endB[k] = t[k];
+    return 0;
+}
+
 } // extern "C"

@@ -42,6 +42,13 @@ def csr_case(name, kind, n, w, xkind):
     d["pow_fused2"] = O.ref_powers(2, p, c, v, x, fused=True)
     d["pow_fused3"] = O.ref_powers(3, p, c, v, x, fused=True)
     d["pow_fused4"] = O.ref_powers(4, p, c, v, x, fused=True)
+    # mpk/SpMVmulti0.cpp:106-130, :157-187: the nested first-touch tables, flattened in traversal order
+    lay = O.ref_gen_layers(p, c)
+    assert np.array_equal(lay["e1"], d["end1"])
+    for key in ("len2", "e2", "len3", "e3"):
+        d["lay_" + key] = lay[key]
+    # mpk/SpMVmulti-1.cpp:434-493: SpM4V_AVX2 (y1..y4)
+    d["pow_avx2_4"] = O.ref_spm4v_avx2(p, c, v, x)
     # mpk/utils.cpp: the parity metric on a perturbed vector
     pert = d["y_scalar"] * (1.0 + 1e-9 * np.cos(np.arange(n)))
     d["pert"] = pert
@@ -59,6 +66,9 @@ def coo_case(name, nrow, irow, jcol, val, x):
     d["y_fma"] = O.ref_spmv(p, c, v, x, "fma")
     bp, bc, bv = O.ref_coo2bcsr4(nrow, irow, jcol, val)
     d["bcsr_ptrow"], d["bcsr_indcol"], d["bcsr_coef"] = bp, bc, bv
+    d["end1"] = O.ref_gen_layer1(p, c)                      # mpk/SpM2V.cpp:5-26 on the duplicate-dropped CSR
+    if nrow % 4 == 0:                                        # block columns must be block rows too
+        d["bcsr_end1"] = O.ref_gen_layer1_bcsr4(bp, bc)     # mpk/SpM2V.cpp:28-46
     xb = x[: 4 * (nrow // 4)] if nrow % 4 else x
     # BCSR kernels index x by block column: pad x so that a block column that
     # straddles nrow stays in bounds (the reference would read past the vector)
@@ -74,12 +84,29 @@ def coo_case(name, nrow, irow, jcol, val, x):
     print(name, "nrow", nrow, "coo", len(irow), "csr", len(c), "blocks", len(bc))
 
 
+def blas1_case(name, n, m, alpha, seed):
+    """dot + AXPY helpers between the SpMVs: orthogonalize (both forms) and orthonormalize_against_basis."""
+    rng = np.random.default_rng(seed)
+    b = rng.uniform(-1, 1, n)
+    x1 = rng.uniform(-1, 1, n)
+    basis = np.sin(0.001 * np.arange(n)[None, :] + np.arange(m)[:, None])  # v_i[j] = sin(0.001 j + i), mpk/2SpMV.cpp:110-116
+    d = dict(n=n, m=m, alpha=alpha, b=b, x1=x1, basis=basis)
+    d["x3_ortho3"] = O.ref_orthogonalize3(b, x1, alpha)              # mpk/old/SpMVmulti.cpp:164-169 (= mpk/SpMVmulti.cpp:146-151)
+    d["y_ortho_inplace"] = O.ref_orthogonalize_inplace(b, x1, alpha)  # mpk/2SpMV.cpp:3-11
+    d["y_mgs"] = O.ref_mgs(basis, x1)                               # mpk/2SpMV.cpp:13-28
+    np.savez(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "n", n, "m", m)
+
+
 def main():
     if not O.have_ref():
         sys.exit("oracle/_ref is not built: run `make -C oracle` where /root/reference exists")
     csr_case("s15_n512", "s15", 512, 40, "sin")
     csr_case("svar_n400", "svar", 400, 30, "sin")
     csr_case("sfe_n268", "sfe", 268, 40, "ones")  # 268 rows = mat/matrix1 (mpk/log/log_SPMV.txt:1)
+
+    blas1_case("blas1_n1003", 1003, 6, 1e-8, 7)    # odd length: exercises the vectorised dot's pair + single tails
+    blas1_case("blas1_n2000", 2000, 50, 0.25, 8)   # 50 basis vectors as the reference's harness builds; alpha large enough to matter
 
     # COO edge cases: duplicates (first-wins in CSR, last-wins in BCSR4), empty
     # rows, missing diagonal, unsorted input, nrow not a multiple of 4

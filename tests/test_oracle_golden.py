@@ -129,3 +129,44 @@ def test_orthogonalize_and_axpy():
     assert abs(beta - float(np.dot(b, x1))) <= 1e-12 * np.abs(b * x1).sum()
     assert np.allclose(x3, x1 - 1e-8 * beta * b, rtol=0, atol=1e-18)
     assert np.allclose(O.axpy(0.5, b, x1), x1 + 0.5 * b, rtol=1e-15)
+
+
+@pytest.mark.parametrize("name", ["blas1_n1003", "blas1_n2000"])
+def test_blas1_pinned_to_reference_object_code(golden, name):
+    """orthogonalize (both forms) and orthonormalize_against_basis, bit for bit."""
+    g = golden(name)
+    b, x1, alpha = g["b"], g["x1"], float(g["alpha"])
+    beta, x3 = O.orthogonalize(b, x1, alpha)              # mpk/SpMVmulti.cpp:146-151
+    assert_bit_equal(x3, g["x3_ortho3"], "orthogonalize(nrow, b, x1, x3, alpha)")
+    assert beta == O.dot_gccvec(b, x1)
+    beta2, y = O.orthogonalize_inplace(b, x1, alpha)      # mpk/2SpMV.cpp:3-11
+    assert_bit_equal(y, g["y_ortho_inplace"], "orthogonalize(nrow, x, y, alpha) in place")
+    assert beta2 == O.dot(b, x1)
+    ym, dots = O.mgs(g["basis"], x1)                      # mpk/2SpMV.cpp:13-28
+    assert_bit_equal(ym, g["y_mgs"], "orthonormalize_against_basis")
+    assert len(dots) == int(g["m"])
+    # the two dot orders agree to rounding: what licenses a tolerance (not bits) for the GPU's tree reduction
+    assert abs(beta - beta2) <= 1e-13 * np.abs(b * x1).sum()
+
+
+@pytest.mark.parametrize("name", CSR_CASES)
+def test_nested_layer_tables_and_spm4v_avx2(golden, name):
+    g = golden(name)
+    p, c, v, x = g["ptrow"], g["indcol"], g["coef"], g["x"]
+    lay = O.gen_layers(p, c)  # Generate2ndlayer / Generate3rdlayer, mpk/SpMVmulti0.cpp:106-130, :157-187
+    assert np.array_equal(lay["e1"], g["end1"])
+    for key in ("len2", "e2", "len3", "e3"):
+        assert np.array_equal(lay[key], g["lay_" + key]), key
+    # SpM4V_AVX2 (mpk/SpMVmulti-1.cpp:434-493): bitwise with its lane-interleaved row sums, 1e-15 from the fma chain
+    assert_bit_equal(O.spmkv_fused(4, p, c, v, x, "avx2row"), g["pow_avx2_4"], "SpM4V_AVX2")
+    Y = O.spmk_chain(4, p, c, v, x)
+    for k in range(4):
+        assert O.rel_error(g["pow_avx2_4"][k], Y[k]) <= 1e-15
+
+
+@pytest.mark.parametrize("name", ["edge_coo_n37", "edge_coo_n40"])
+def test_first_touch_tables_of_coo_built_matrices(golden, name):
+    g = golden(name)
+    assert np.array_equal(O.gen_layer1(g["csr_ptrow"], g["csr_indcol"]), g["end1"])
+    if "bcsr_end1" in g:
+        assert np.array_equal(O.gen_layer1_bcsr4(g["bcsr_ptrow"], g["bcsr_indcol"]), g["bcsr_end1"])

@@ -49,3 +49,24 @@ def test_coo_rules_random():
         a = O.coo2bcsr4(nrow, ir, jc, va)
         b = O.ref_coo2bcsr4(nrow, ir, jc, va)
         assert all(np.array_equal(s, t) for s, t in zip(a, b))
+
+
+def test_blas1_random_lengths():
+    """orthogonalize (3-vector and in-place) and orthonormalize_against_basis, live object code, every tail length."""
+    rng = np.random.default_rng(11)
+    for n in list(range(1, 13)) + [255, 1000, 4099]:
+        b, x1 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        assert_bit_equal(O.orthogonalize(b, x1, 0.37)[1], O.ref_orthogonalize3(b, x1, 0.37), f"orthogonalize3 n={n}")
+        assert_bit_equal(O.orthogonalize_inplace(b, x1, 0.37)[1], O.ref_orthogonalize_inplace(b, x1, 0.37), f"in place n={n}")
+        B = rng.uniform(-1, 1, (5, n))
+        assert_bit_equal(O.mgs(B, x1)[0], O.ref_mgs(B, x1), f"mgs n={n}")
+
+
+@pytest.mark.parametrize("kind,n,w", [("s15", 3000, 200), ("svar", 2500, 80), ("sfe", 1200, 60)])
+def test_layer_tables_and_avx2_powers(kind, n, w):
+    p, c, v = synth.rows(kind, n, w=w)
+    a, b = O.gen_layers(p, c), O.ref_gen_layers(p, c)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    x = synth.x_sin(0, n)
+    assert_bit_equal(O.spmkv_fused(4, p, c, v, x, "avx2row"), O.ref_spm4v_avx2(p, c, v, x), "SpM4V_AVX2")
