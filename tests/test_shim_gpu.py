@@ -181,3 +181,85 @@ def test_update_values_through_the_c_abi():
         assert A.kernel_name() == k0
         mpk.SpMV_CSR(y, x, A)
         assert_bit_equal(y, O.spmv(p, c, v2, x), "after mi_csr_update_values (" + k0 + ")")
+
+
+# ---- the reference's matrix-powers DRIVERS, unmodified, routed to the GPU (oracle/driver_main.cpp) ----------------
+
+REFDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+
+
+def _write_mtx(path, n, p, c, v):
+    """PETSc-style MatrixMarket as the reference's readers expect it (mpk/SpM2V.cpp:815-852)."""
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (n, n, len(c)))
+        for i in range(n):
+            for k in range(p[i], p[i + 1]):
+                f.write("%d %d %.9g\n" % (i + 1, c[k] + 1, v[k]))
+
+
+def _run(exe, mtx, **env):
+    import subprocess
+    e = dict(os.environ)
+    e.update(env)
+    return subprocess.run([os.path.join(REFDIR, exe), mtx], capture_output=True, text=True, timeout=300, env=e)
+
+
+def _bound_to_shim(stderr, wanted):
+    """LD_DEBUG=bindings lines 'binding file <driver.so> to <lib>: normal symbol `X'': which library each wanted symbol bound to."""
+    out = {}
+    for ln in stderr.splitlines():
+        if "binding file" in ln and "libdrv_" in ln.split(" to ")[0] and "symbol `" in ln:
+            sym = ln.split("symbol `")[1].split("'")[0]
+            for w in wanted:
+                if w in sym:
+                    out[w] = os.path.basename(ln.split(" to ")[1].split(" ")[0].rstrip(":"))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "spm2v_mi355")), reason="oracle/_ref/spm2v_mi355 not built")
+def test_reference_SpM2V_driver_routed_to_the_gpu(tmp_path):
+    """mpk/SpM2V.cpp's own main (:804-987), compiled where it lies and bound to the shim: its seven rel-err columns."""
+    from navierstokes_amd import synth
+    for kind, n, w in (("sfe", 268, 40), ("sfe", 20000, 300)):
+        p, c, v = synth.rows(kind, n, w=w)
+        mtx = str(tmp_path / f"{kind}{n}.mtx")
+        _write_mtx(mtx, n, p, c, v)
+        r = _run("spm2v_mi355", mtx, LD_DEBUG="bindings")
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("SpM2V")]
+        assert len(lines) == 8, r.stdout
+        errs = [float(ln.split("rel err =")[1]) for ln in lines[1:]]
+        assert len(errs) == 7 and max(errs) <= 1e-15, lines
+        b = _bound_to_shim(r.stderr, ["9SpM2V_CSR", "13SpM2V_CSR_OPT", "14SpM2V_CSR_AVX2", "10SpM2V_BCSR", "15SpM2V_BCSR_AVX2",
+                                      "16Generate1stlayer", "22Generate1stlayer_BCSR4", "7COO2CSR", "14generate_BCSR4", "9rel_error"])
+        assert b and all(lib == "libmpk_mi355.so" for lib in b.values()), b
+        assert len(b) == 10, b
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(REFDIR, "multi0_mi355")) and os.path.exists(os.path.join(REFDIR, "multi0_ref"))),
+                    reason="oracle/_ref/multi0_* not built")
+def test_reference_SpMVmulti0_driver_routed_to_the_gpu(tmp_path):
+    """mpk/SpMVmulti0.cpp's own main (:317-418): prints the SpMV chain x_k beside the fused y_k for k = 1..4.  The
+    routed driver's columns must equal each other and the CPU reference driver's columns (printed with %g)."""
+    from navierstokes_amd import synth
+    n = 268
+    p, c, v = synth.rows("sfe", n, w=40)
+    mtx = str(tmp_path / "sfe268.mtx")
+    _write_mtx(mtx, n, p, c, v)
+
+    def table(stderr):
+        rows = [ln for ln in stderr.splitlines() if ln.startswith(":: ")]
+        assert len(rows) == n
+        return np.array([[float(t) for t in ln.replace(":", " ").split()[1:]] for ln in rows])  # x1 y1 x2 y2 x3 y3 x4 y4
+
+    g = _run("multi0_mi355", mtx, LD_DEBUG="bindings")
+    assert g.returncode == 0, g.stderr[-2000:]
+    b = _bound_to_shim(g.stderr, ["4SpMV", "5SpM2V", "5SpM3V", "5SpM4V", "16Generate1stlayer", "16Generate2ndlayer", "16Generate3rdlayer", "7COO2CSR"])
+    assert len(b) == 8 and all(lib == "libmpk_mi355.so" for lib in b.values()), b
+    T = table(g.stderr)
+    for k in range(4):
+        assert np.array_equal(T[:, 2 * k], T[:, 2 * k + 1]), f"chain vs fused, power {k + 1}"
+    cpu = _run("multi0_ref", mtx)
+    assert cpu.returncode == 0
+    R = table(cpu.stderr)
+    assert np.allclose(T, R, rtol=2e-6, atol=1e-300), np.abs(T - R).max()  # six printed digits
