@@ -155,13 +155,18 @@ mi_csr_t device_csr(csrmatrix& A)
 mi_bcsr4_t device_bcsr(const bcsr4x4_matrix& A)
 {
     const Key k{A.ptrow.data(), A.indcol.data(), A.coef.data()};
-    // x is indexed by block column; the reference's callers pass vectors of
-    // 4*nrows entries, so that is how much of x is transferred.
+    // x is indexed by block column: the reference reads x[4*bj .. 4*bj+3] for every block column bj that
+    // occurs (mpk/SpMV.cpp:104-113), which for a matrix whose row count is not a multiple of 4 reaches one
+    // block past 4*nrows (generate_BCSR4 truncates the ROWS only, mpk/utils.cpp:49).  The same range of the
+    // caller's x is transferred here: 4 * (largest block column + 1) entries, at least 4*nrows.
     return device_copy<mi_bcsr4_t>(
         g_bcsr, k, A.nrows, A.ptrow.data(), A.indcol.data(), A.coef.data(), 16,
         [&]() {
+            int nbcols = A.nrows;
+            const int nb = A.nrows > 0 ? A.ptrow[A.nrows] : 0;
+            for (int m = 0; m < nb; m++) nbcols = std::max(nbcols, A.indcol[m] + 1);
             mi_bcsr4_t h = nullptr;
-            MI_CALL(mi_bcsr4_create(A.nrows, A.nrows, A.ptrow.data(), A.indcol.data(), A.coef.data(), &h));
+            MI_CALL(mi_bcsr4_create(A.nrows, nbcols, A.ptrow.data(), A.indcol.data(), A.coef.data(), &h));
             return h;
         },
         [&](mi_bcsr4_t h) { MI_CALL(mi_bcsr4_update_values(h, A.coef.data())); }, [](mi_bcsr4_t h) { mi_bcsr4_destroy(h); });
