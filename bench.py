@@ -40,6 +40,10 @@ WORKLOADS = {
     "tiny": dict(kind="s15", n=200_000, k=1, desc="S15 synthetic CSR 200,000 rows x 15 nnz/row (plumbing checks only)"),
     # the reference's own matrix family: NS FE matrix, 4 dofs/node, <=60 nnz/row, 68^3 cells
     "fe": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, desc="NS P1-P1 FE matrix (src/integration.c + benchmark_spmv.c block rule) on a 68^3-cell Kuhn box: 1,314,036 rows, CSR, y=Ax"),
+    # the same FE matrix under a seeded RANDOM node numbering (4 dofs of a node kept together) — what an unstructured gmsh
+    # mesh delivers (src/solve_newton.c:91-197): mi_csr_create relabels it behind the API (reorder.hpp), bits unchanged
+    "fe_perm": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, perm_block=4, desc="the fe matrix under a random node numbering (unstructured-mesh order), CSR, y=Ax"),
+    "c2_perm": dict(kind="s15", n=1_000_000, k=1, perm_block=1, desc="the c2 matrix under a random row/column numbering, CSR, y=Ax"),
     "fe_bcsr": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, bcsr=True, desc="same FE matrix as BCSR 4x4 (SpMV_BCSR path, mpk/SpMV.cpp:90-219), y=Ax"),
 }
 
@@ -98,6 +102,22 @@ def cpu_baseline(p, c, v, x, seconds_budget=20.0):
                    sample=f"full workload ({n} rows, {nnz} nnz), oracle/cpu_ref.c fma chain, 1 thread, "
                           f"best of {reps} cold calls after a 300 MiB flush")
     out["value"] = round(out["value"], 4)
+    # all host cores this process may use (SURVEY.md §8d "CPU baseline" (2)): the same fma chain, rows split
+    # over OpenMP threads (oracle/cpu_ref.c: orc_spmv_csr_fma_omp), warm, best of 5.  Not something the
+    # reference ships (mpk/ is single-threaded): the fair upper bound for its algorithm on this host.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    nthreads = int(os.environ.get("MI355_BENCH_CPU_THREADS", "0")) or min(avail, 64)
+    best = None
+    for nt in sorted({nthreads, max(1, nthreads // 2), min(nthreads, 16)}):
+        ta, _ = O.time_spmv_omp(p, c, v, x, nt, reps=5)
+        if best is None or ta < best[0]:
+            best = (ta, nt)
+    out["all_cores"] = dict(value=round(2 * nnz / best[0] / 1e9, 3), unit="GFLOP/s", cores=best[1], kind="port",
+                            sample=f"full workload, oracle fma chain row-parallel over OpenMP threads (best of "
+                                   f"{sorted({nthreads, max(1, nthreads // 2), min(nthreads, 16)})} threads; {avail} usable by this process), warm, best of 5")
     try:
         out["host_cpu"] = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
         out["host_cores_available"] = os.cpu_count()
@@ -116,6 +136,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cold single-shot and in-pipeline measurements")
     args = ap.parse_args()
 
     import torch
@@ -157,6 +178,10 @@ def main():
     rs = D.balanced_row_starts(n, world)  # S15 rows all hold 15 nnz: equal rows == equal nnz
     lo, hi = int(rs[rank]), int(rs[rank + 1])
     p, c, v = synth.fe_matrix(W["cells"]) if is_fe else synth.rows(kind, n, lo, hi)
+    if W.get("perm_block"):
+        if world > 1:
+            sys.exit("the permuted workloads are 1-GPU configurations")
+        p, c, v, _ = synth.permute_nodes(p, c, v, block=W["perm_block"], seed=synth.DEFAULT_SEED)
     x_host = synth.x_sin(lo, hi)
     bcsr = bool(W.get("bcsr"))
     if world == 1 and bcsr:
@@ -241,6 +266,50 @@ def main():
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
     barrier()
+    # ---- the same kernel in two other regimes (N = 1, y = A x workloads only; never `value`) -------------------
+    extra = {}
+    if world == 1 and k == 1 and not args.cold and not args.no_extras:
+        # (1) cold single shot: L2s and the 256 MiB Infinity Cache evicted before EVERY launch (the reference's own
+        #     protocol: flush_cache() before each timed call, mpk/SpM2V.cpp:895-904)
+        ms = 0.0
+        ncold = 12
+        for _ in range(ncold):
+            mpk.flush_cache()
+            ev0.record()
+            step()
+            ev1.record()
+            torch.cuda.synchronize()
+            ms += ev0.elapsed_time(ev1)
+        extra["cold_us"] = ms * 1e3 / ncold
+        # (2) inside the Krylov-step pipeline SpMV -> dot + AXPY (orthogonalize) -> SpMV of mpk/SpMVmulti.cpp:559-574:
+        #     the vector kernels between two products compete with the matrix stream for the caches
+        if not bcsr:
+            bvec = torch.cos(0.002 * torch.arange(n, dtype=torch.float64, device="cuda"))
+            x3 = torch.empty_like(ys[0])
+            z = torch.empty_like(ys[0])
+
+            def pipe():
+                mpk.SpMV_CSR(ys[0], x, A)
+                mpk.orthogonalize(n, bvec, ys[0], x3, 1e-8)
+                mpk.SpMV_CSR(z, x3, A)
+
+            def timed(fn, reps):
+                for _ in range(5):
+                    fn()
+                ev0.record()
+                for _ in range(reps):
+                    fn()
+                ev1.record()
+                torch.cuda.synchronize()
+                return ev0.elapsed_time(ev1) * 1e3 / reps
+            t_pipe = timed(pipe, 50)
+            t_orth = timed(lambda: mpk.orthogonalize(n, bvec, ys[0], x3, 1e-8), 50)
+            extra["pipeline_pass_us"] = t_pipe
+            extra["pipeline_orthogonalize_us"] = t_orth
+            extra["pipeline_spmv_us"] = (t_pipe - t_orth) / 2
+            step()  # leave ys[0] = A x for the parity check below
+            torch.cuda.synchronize()
+            del bvec, x3, z
     red_dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     if world > 1:
         tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=red_dev)
@@ -299,25 +368,50 @@ def main():
     flops = 2.0 * nnz_global * k * args.steps
     value = flops / wall / 1e9
     launches = args.steps * k
-    if bcsr:  # 16 values + 1 block column per block, block-row pointers, x once, y once
-        nblk = nnz_global // 16
-        B = 132 * nblk + 4 * (n // 4 + 1) + 16 * n
-    else:
-        B = algorithmic_bytes(n, nnz_global) if world == 1 else algorithmic_bytes(hi - lo, len(c))
+    n_loc, nnz_loc = (n, nnz_global) if world == 1 else (hi - lo, len(c))
+    B_csr = algorithmic_bytes(n_loc, nnz_loc)  # the reference's own model, CSR arrays
+    # bytes of the format the launched kernel actually reads (what `frac` is priced on, so it can never exceed 1):
+    # 16 values + 1 block column per block, block-row pointers, x once, y once for the BCSR kernel
+    runs_blocked = bcsr or (world == 1 and "bcsr4" in kernel_name)
+    B_exec = (132 * (nnz_loc // 16) + 4 * (n_loc // 4 + 1) + 16 * n_loc) if runs_blocked else B_csr
     launch_s = ev_ms / 1e3 / launches
-    achieved = B / launch_s / 1e9
+    achieved = B_exec / launch_s / 1e9
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=load_traffic(args.workload, kernel_name)[0] if world == 1 else None,
                     traffic_source=load_traffic(args.workload, kernel_name)[1] if world == 1 else None,
-                    kernel=kernel_name, algorithmic_bytes_per_launch=B, launch_us=round(launch_s * 1e6, 2),
+                    kernel=kernel_name, algorithmic_bytes_per_launch=B_exec, launch_us=round(launch_s * 1e6, 2),
+                    bytes_model=("BCSR 4x4: 132 B per block + 4 B per block row + 16 B per row (the format the kernel reads)" if runs_blocked
+                                 else "CSR: 12 B per nonzero + 4 B per row pointer + 16 B per row (SURVEY.md §8d)"),
                     timing="HIP events on the launch stream around the timed region / launches"
                            + (" (per-rank share incl. halo exchange; max over ranks)" if world > 1 else ""))
-    if world == 1 and not bcsr and "bcsr4" in kernel_name:
-        roofline["note"] = ("algorithmic bytes are those of the CSR arrays the caller handed over (12 B per nonzero); AUTO runs the "
-                            "BCSR kernel on a blocked copy (8.25 B per nonzero, same bits), so frac may exceed 1: against the "
-                            "blocked format's own 132 B/block model the same launch is " +
-                            str(round((132.0 * (nnz_global // 16) + 4 * (n // 4 + 1) + 16 * n) / launch_s / 1e9 / HBM_PEAK_GBS, 4)))
+    if runs_blocked and not bcsr:
+        # the caller handed over CSR arrays; AUTO runs the BCSR kernel on a blocked copy (same bits, 8.25 instead of 12 B per
+        # nonzero).  Priced in the CSR bytes the caller's format would have cost, the same launch reads "faster than HBM":
+        roofline["csr_equivalent"] = dict(bytes_per_launch=B_csr, gbs=round(B_csr / launch_s / 1e9, 1),
+                                          of_peak=round(B_csr / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                                          note="NOT a roofline fraction: CSR-model bytes over the time of a kernel that reads the blocked copy")
+    if k > 1 and world == 1:
+        # matrix powers: `frac` above prices each of the k launches at the un-fused traffic k*B; a fused kernel that
+        # read the matrix once would need B_fused = 12 nnz + 4 (n+1) + 8 n (1 + k) for the whole step
+        B_fused = 12 * nnz_loc + 4 * (n_loc + 1) + 8 * n_loc * (1 + k)
+        step_s = ev_ms / 1e3 / args.steps
+        roofline["fused_lower_bound"] = dict(bytes_per_step=B_fused, unfused_bytes_per_step=k * B_csr,
+                                             step_us=round(step_s * 1e6, 2),
+                                             frac_of_peak_if_fused_bytes=round(B_fused / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                             note="time of the whole k-step over the bytes a perfectly fused kernel would move; "
+                                                  "the gap to `frac` is what fusing the k sweeps could still buy")
+    if extra:
+        if "cold_us" in extra:
+            roofline["cold_single_shot"] = dict(launch_us=round(extra["cold_us"], 2),
+                                                frac=round(B_exec / (extra["cold_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                protocol="mi_flush_cache() (512 MiB device fill) before every launch, 12 launches, HIP events")
+        if "pipeline_spmv_us" in extra:
+            roofline["in_pipeline"] = dict(spmv_us=round(extra["pipeline_spmv_us"], 2),
+                                           frac=round(B_exec / (extra["pipeline_spmv_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                           pass_us=round(extra["pipeline_pass_us"], 2), orthogonalize_us=round(extra["pipeline_orthogonalize_us"], 2),
+                                           protocol="SpMV -> orthogonalize (dot + AXPY) -> SpMV, mpk/SpMVmulti.cpp:559-574, device-resident, 50 passes; "
+                                                    "spmv_us = (pass - orthogonalize alone) / 2")
     out = dict(metric="fp64 CSR SpMV GFLOP/s & % HBM roofline @ nnz; 1/2/4/8 GPU", value=round(value, 2), unit="GFLOP/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(wall * 1e3 / args.steps, 5),
                higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
@@ -330,6 +424,9 @@ def main():
                                   nnz_fraction_ring=round(ring_frac, 4), nontemporal_values=nt,
                                   matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else (8.25 if "bcsr4" in kernel_name else 12),
                                   autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
+        ri = A.reorder_info()
+        if ri["reordered"] or ri["block"]:
+            out["reorder"] = {k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in ri.items()}
     if parity is not None:
         out["parity"] = parity
     if halo_info is not None:
@@ -348,6 +445,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(p, c, v, x_host)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        out["gpu_over_cpu_all_cores"] = round(value / out["cpu_baseline"]["all_cores"]["value"], 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

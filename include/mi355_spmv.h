@@ -100,6 +100,22 @@ int mi_csr_destroy(mi_csr_t A);
 int mi_csr_update_values(mi_csr_t A, const double* coef);                          /* host values; synchronous */
 int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_stream_t s);     /* device values; asynchronous on s */
 int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz);
+/* Locality reordering.  The reference's matrices come from unstructured gmsh meshes (src/solve_newton.c:91-197,
+ * src/benchmark_spmv.c:76-123) whose node numbering scatters a row's columns over all of x.  For a square matrix
+ * that is not already served by the ring kernel and whose nonzeros lie far from the diagonal for its size,
+ * mi_csr_create computes a reverse Cuthill-McKee relabelling of the NODE graph (4x4 node blocks stay together),
+ * builds A' = P A P^T with every row's nonzeros in the caller's order, and keeps it if it measures faster.  The
+ * permutation never shows: x is gathered into the new numbering before a product and y is written back through a
+ * row map, and since a row's terms keep their order every bit of y equals the unreordered kernels' (and the
+ * reference's SpMV_CSR_FMA).  A reordered handle owns one gather buffer: issue its products on one stream at a time.
+ * MI355_REORDER=0 disables, =1 forces.  *reordered = 1 if the handle computes through the relabelled twin; block = 4
+ * if nodes of four rows were moved, 1 if single rows; spread = mean |column - row| in nodes before / after;
+ * us_* = measured launch time of the natural-order choice and of the twin incl. its gather (0 if not measured). */
+int mi_csr_reorder_info(mi_csr_t A, int* reordered, int* block, double* spread_before, double* spread_after,
+                        double* us_natural, double* us_reordered);
+/* host-only: the relabelling mi_csr_create would compute; perm[old] = new (n entries) */
+int mi_reorder_probe(int n, const int* ptrow, const int* indcol, int* block, int* perm, double* spread_before,
+                     double* spread_after);
 /* MI_KERNEL_RING on a matrix whose window does not fit is still correct (its runs take the
  * per-block path); mi_csr_ring_info reports how much of the matrix the ring serves. */
 int mi_csr_set_kernel(mi_csr_t A, int kernel_id);

@@ -23,6 +23,7 @@
 #include "handoff_kernels.hpp"
 #include "partition.hpp"
 #include "rccl_loader.hpp"
+#include "reorder.hpp"
 #include "ring_plan.hpp"
 #include "spmv_kernels.hpp"
 #include "spmv_ring.hpp"
@@ -107,6 +108,17 @@ struct mi_csr_s {
     mi_bcsr4_t blocked = nullptr; // BCSR 4x4 copy (exact 4x4 node-block structure only), else null
     double tune_us_bcsr = 0.0;
     int n_out = 0; // length of the y a launch may write (n, or max rowmap + 1)
+    // Locality reordering (reorder.hpp): when `inner` is set, this handle is a front for A' = P A P^T, a row-mapped
+    // handle in the new numbering; products gather x into d_xp (new numbering) and inner writes y through its row
+    // map straight into the caller's numbering.  The natural-order device arrays are released then.
+    mi_csr_t inner = nullptr;
+    int* d_iperm = nullptr;     // [n] caller's index of new row / column
+    int* d_src_start = nullptr; // [n] offset of new row r' in the caller's coef (values refresh)
+    double* d_xp = nullptr;     // x in the new numbering (one product at a time per handle)
+    std::vector<double*> d_pp;  // powers in the new numbering
+    double* d_vtmp = nullptr;   // staging for mi_csr_update_values (host values)
+    double spread_before = 0.0, spread_after = 0.0, us_natural = 0.0, us_reordered = 0.0;
+    int reorder_block = 0;      // 0: no reordering attempted
     // scratch for the host-pointer entry points
     double* d_x = nullptr;
     double* d_y = nullptr;
@@ -120,6 +132,7 @@ struct mi_bcsr4_s {
     int* d_ptrow = nullptr;
     int* d_indcol = nullptr;
     double* d_coef = nullptr;
+    int* d_browmap = nullptr; // block-row map of a reordered matrix's blocked copy, else null
     double* d_x = nullptr;
     double* d_y = nullptr;
     std::vector<double*> d_pow;
@@ -251,7 +264,9 @@ static int get_table(mi_csr_t A, int nnzb, BlockTable** out)
     return MI_OK;
 }
 
-static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s);
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true);
+static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);
+static int resolve_kernel(const mi_csr_s* A);
 
 static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
                            const int* rowmap, mi_csr_t* out)
@@ -372,7 +387,12 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     }
     // FE matrices: a blocked copy for the BCSR 4x4 kernel (same bits, 8.25 instead of 12 B per nonzero)
-    if ((!rowmap || offset_only) && n >= 4 && nnz >= 16 && ncols % 4 == 0 && !(getenv("MI355_AUTO_BCSR") && !strcmp(getenv("MI355_AUTO_BCSR"), "0"))) {
+    // (a row map that moves whole nodes — rowmap[4b + q] = rowmap[4b] + q, 4-aligned — becomes a block-row map)
+    bool node_map = rowmap != nullptr && !offset_only && n % 4 == 0;
+    for (int b = 0; node_map && b < n / 4; b++)
+        node_map = rowmap[4 * b] % 4 == 0 && rowmap[4 * b + 1] == rowmap[4 * b] + 1 && rowmap[4 * b + 2] == rowmap[4 * b] + 2 &&
+                   rowmap[4 * b + 3] == rowmap[4 * b] + 3;
+    if ((!rowmap || offset_only || node_map) && n >= 4 && nnz >= 16 && ncols % 4 == 0 && !(getenv("MI355_AUTO_BCSR") && !strcmp(getenv("MI355_AUTO_BCSR"), "0"))) {
         std::vector<int> bptr, bcol;
         std::vector<double> bval;
         if (csr_to_bcsr4_exact(n, ptrow, indcol, coef, bptr, bcol, bval)) {
@@ -380,6 +400,12 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             if (rcb != MI_OK) {
                 mi_csr_destroy(A);
                 return rcb;
+            }
+            if (node_map) {
+                std::vector<int> bmap((size_t)n / 4);
+                for (int b = 0; b < n / 4; b++) bmap[b] = rowmap[4 * b] / 4;
+                TRY_OR_CLEAN(hipMalloc(&A->blocked->d_browmap, sizeof(int) * bmap.size()));
+                TRY_OR_CLEAN(hipMemcpy(A->blocked->d_browmap, bmap.data(), sizeof(int) * bmap.size(), hipMemcpyHostToDevice));
             }
         }
     }
@@ -491,9 +517,162 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
     return MI_OK;
 }
 
+// mean launch time of A's current choice over `timed` launches after `warm` (x = 0: timing does not depend on values)
+static int time_handle(mi_csr_t A, int warm, int timed, double* us)
+{
+    struct Scratch2 {
+        double *tx = nullptr, *ty = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scratch2()
+        {
+            dfree(tx);
+            dfree(ty);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } t;
+    const size_t nx = (size_t)(A->ncols > 0 ? A->ncols : 1), ny = (size_t)(A->n_out > 0 ? A->n_out : 1);
+    HIP_TRY(hipMalloc(&t.tx, sizeof(double) * nx));
+    HIP_TRY(hipMalloc(&t.ty, sizeof(double) * ny));
+    HIP_TRY(hipMemset(t.tx, 0, sizeof(double) * nx));
+    HIP_TRY(hipEventCreate(&t.e0));
+    HIP_TRY(hipEventCreate(&t.e1));
+    int rc;
+    for (int w = 0; w < warm; w++)
+        if ((rc = launch_spmv(A, t.tx, t.ty, nullptr))) return rc;
+    HIP_TRY(hipEventRecord(t.e0, nullptr));
+    for (int w = 0; w < timed; w++)
+        if ((rc = launch_spmv(A, t.tx, t.ty, nullptr))) return rc;
+    HIP_TRY(hipEventRecord(t.e1, nullptr));
+    HIP_TRY(hipEventSynchronize(t.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t.e0, t.e1));
+    *us = ms * 1e3 / timed;
+    return MI_OK;
+}
+
+static void release_natural_arrays(mi_csr_t A)
+{
+    dfree(A->d_ptrow);
+    dfree(A->d_indcol);
+    dfree(A->d_coef);
+    A->d_ptrow = A->d_indcol = nullptr;
+    A->d_coef = nullptr;
+    for (auto& kv : A->tables) dfree(kv.second.d_blk);
+    A->tables.clear();
+    dfree(A->ring.d_plan);
+    dfree(A->ring.d_ok);
+    dfree(A->ring.d_slots);
+    A->ring = RingTable();
+    mi_bcsr4_destroy(A->blocked);
+    A->blocked = nullptr;
+}
+
+// Locality reordering at create time (reorder.hpp).  Tried when the matrix is square, not row-mapped, large enough
+// to matter, NOT already served by the ring kernel, and its nonzeros lie far from the diagonal for its size (an
+// unstructured node numbering); kept when the reordered twin — x gather included — measures faster.
+// MI355_REORDER=0 never, =1 always try and keep (tests), unset: as described.
+static int maybe_reorder(mi_csr_t A, const int* ptrow, const int* indcol, const double* coef)
+{
+    const char* env = getenv("MI355_REORDER");
+    const bool force = env && !strcmp(env, "1");
+    if (env && !strcmp(env, "0")) return MI_OK;
+    const int n = A->n;
+    if (A->mapped || n != A->ncols || n < 8 || A->nnz == 0) return MI_OK;
+    if (!force && (n < 100000 || resolve_kernel(A) == MI_KERNEL_RING)) return MI_OK;
+    const int block = csr_has_block4_pattern(n, ptrow, indcol) ? 4 : 1;
+    const double nn = (double)n / block;
+    const double spread = mean_column_distance(n, ptrow, indcol, block);
+    A->spread_before = spread;
+    // a mesh of nn nodes in d >= 2 dimensions cannot be numbered with a mean distance much below nn^(1 - 1/d);
+    // far above the 3-D figure means the numbering, not the mesh, spreads the columns
+    if (!force && spread < 2.0 * std::pow(nn, 2.0 / 3.0)) return MI_OK;
+    Reorder R;
+    rcm_reorder(n, ptrow, indcol, block, R);
+    A->reorder_block = block;
+    A->spread_after = R.spread_after;
+    if (!force && R.spread_after > 0.5 * spread) return MI_OK; // nothing gained
+    std::vector<int> p2, c2, src_start;
+    std::vector<double> v2;
+    permute_csr(n, ptrow, indcol, coef, R, p2, c2, v2, src_start);
+    mi_csr_t inner = nullptr;
+    int rc = csr_create_impl(n, n, p2.data(), c2.data(), v2.data(), R.iperm.data(), &inner);
+    if (rc) return rc;
+    A->inner = inner; // from here on launch_spmv(A) goes through the twin; destroy releases it
+    hipError_t e;
+    if ((e = hipMalloc(&A->d_iperm, sizeof(int) * (size_t)n)) != hipSuccess ||
+        (e = hipMalloc(&A->d_src_start, sizeof(int) * (size_t)n)) != hipSuccess ||
+        (e = hipMalloc(&A->d_xp, sizeof(double) * (size_t)n)) != hipSuccess ||
+        (e = hipMemcpy(A->d_iperm, R.iperm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(A->d_src_start, src_start.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("reorder upload: ") + hipGetErrorString(e));
+    const char* at = getenv("MI355_SPMV_AUTOTUNE");
+    bool keep = true;
+    if (!force && !(at && !strcmp(at, "0"))) { // measure: natural choice against the twin (gather included)
+        const int timed = A->nnz < 40000000 ? 12 : 6;
+        A->inner = nullptr;
+        rc = time_handle(A, 3, timed, &A->us_natural);
+        A->inner = inner;
+        if (rc) return rc;
+        if ((rc = time_handle(A, 3, timed, &A->us_reordered))) return rc;
+        keep = A->us_reordered < 0.97 * A->us_natural;
+    }
+    if (!keep) {
+        mi_csr_destroy(A->inner);
+        A->inner = nullptr;
+        dfree(A->d_iperm);
+        dfree(A->d_src_start);
+        dfree(A->d_xp);
+        A->d_iperm = A->d_src_start = nullptr;
+        A->d_xp = nullptr;
+        return MI_OK;
+    }
+    release_natural_arrays(A);
+    return MI_OK;
+}
+
 extern "C" int mi_csr_create(int n, int ncols, const int* ptrow, const int* indcol, const double* coef, mi_csr_t* out)
 {
-    return csr_create_impl(n, ncols, ptrow, indcol, coef, nullptr, out);
+    int rc = csr_create_impl(n, ncols, ptrow, indcol, coef, nullptr, out);
+    if (rc) return rc;
+    if ((rc = maybe_reorder(*out, ptrow, indcol, coef))) {
+        mi_csr_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+// host-only: the relabelling maybe_reorder would compute (reverse Cuthill-McKee on the node graph), for CPU tests
+extern "C" int mi_reorder_probe(int n, const int* ptrow, const int* indcol, int* block, int* perm, double* spread_before,
+                                double* spread_after)
+{
+    CHECK_ARG(n >= 0 && ptrow && (ptrow[n] == 0 || indcol), "bad argument");
+    for (int i = 0; i < n; i++) {
+        CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) CHECK_ARG(indcol[k] >= 0 && indcol[k] < n, "column index outside [0, n)");
+    }
+    const int b = csr_has_block4_pattern(n, ptrow, indcol) ? 4 : 1;
+    Reorder R;
+    rcm_reorder(n, ptrow, indcol, b, R);
+    if (block) *block = b;
+    if (perm)
+        for (int i = 0; i < n; i++) perm[i] = R.perm[i];
+    if (spread_before) *spread_before = R.spread_before;
+    if (spread_after) *spread_after = R.spread_after;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_reorder_info(mi_csr_t A, int* reordered, int* block, double* spread_before, double* spread_after,
+                                   double* us_natural, double* us_reordered)
+{
+    CHECK_ARG(A, "null handle");
+    if (reordered) *reordered = A->inner ? 1 : 0;
+    if (block) *block = A->reorder_block;
+    if (spread_before) *spread_before = A->spread_before;
+    if (spread_after) *spread_after = A->spread_after;
+    if (us_natural) *us_natural = A->us_natural;
+    if (us_reordered) *us_reordered = A->us_reordered;
+    return MI_OK;
 }
 
 extern "C" int mi_csr_create_mapped(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
@@ -519,6 +698,12 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->ring.d_ok);
     dfree(A->ring.d_slots);
     mi_bcsr4_destroy(A->blocked);
+    mi_csr_destroy(A->inner);
+    dfree(A->d_iperm);
+    dfree(A->d_src_start);
+    dfree(A->d_xp);
+    dfree(A->d_vtmp);
+    for (double* p : A->d_pp) dfree(p);
     delete A;
     return MI_OK;
 }
@@ -555,12 +740,28 @@ static int refresh_blocked_values(mi_csr_t A, hipStream_t s)
 // iteration, src/solve_newton.c:1245-1247): only the value array is replaced.  Row-block tables, the
 // ring plan, the 16-bit column stream and the kernel choice depend on the pattern alone and are kept;
 // the blocked copy's values are regenerated on the device.
+// values of a reordered twin from the caller's (original order) values: new row r' copies its segment
+__global__ __launch_bounds__(kWG) void permute_values_kernel(int n, const int* __restrict__ new_ptrow, const int* __restrict__ src_start,
+                                                              const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int r = blockIdx.x * kWG + threadIdx.x;
+    if (r >= n) return;
+    const int b = new_ptrow[r], len = new_ptrow[r + 1] - b, a = src_start[r];
+    for (int k = 0; k < len; k++) dst[b + k] = src[a + k];
+}
+
 extern "C" int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_stream_t s_)
 {
     CHECK_ARG(A, "null handle");
     if (A->nnz == 0) return MI_OK;
     CHECK_ARG(d_coef, "null coef");
     hipStream_t s = (hipStream_t)s_;
+    if (A->inner) {
+        mi_csr_t I = A->inner;
+        hipLaunchKernelGGL(permute_values_kernel, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, A->n, I->d_ptrow, A->d_src_start, d_coef, I->d_coef);
+        HIP_TRY(hipGetLastError());
+        return refresh_blocked_values(I, s);
+    }
     HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
     return refresh_blocked_values(A, s);
 }
@@ -570,6 +771,14 @@ extern "C" int mi_csr_update_values(mi_csr_t A, const double* coef)
     CHECK_ARG(A, "null handle");
     if (A->nnz == 0) return MI_OK;
     CHECK_ARG(coef, "null coef");
+    if (A->inner) {
+        if (!A->d_vtmp) HIP_TRY(hipMalloc(&A->d_vtmp, sizeof(double) * (size_t)A->nnz));
+        HIP_TRY(hipMemcpy(A->d_vtmp, coef, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice));
+        int rc = mi_csr_update_values_dev(A, A->d_vtmp, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return MI_OK;
+    }
     HIP_TRY(hipMemcpy(A->d_coef, coef, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice));
     int rc = refresh_blocked_values(A, nullptr);
     if (rc) return rc;
@@ -597,6 +806,7 @@ static int resolve_kernel(const mi_csr_s* A)
 extern "C" int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream)
 {
     CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
     if (us_ring) *us_ring = A->ring.nt ? A->tune_us_ring_nt : A->tune_us_ring;
     if (us_stream) *us_stream = A->stream_nt ? A->tune_us_stream_nt : A->tune_us_stream;
     return MI_OK;
@@ -605,6 +815,7 @@ extern "C" int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream)
 extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt)
 {
     CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
     if (us) {
         us[0] = A->tune_us_ring;
         us[1] = A->tune_us_ring_nt;
@@ -718,6 +929,7 @@ extern "C" int mi_csr_block4_structure(int n, const int* ptrow, const int* indco
 extern "C" int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt)
 {
     CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
     if (ring_nt >= 0) A->ring.nt = ring_nt != 0 && A->ring.d_slots;
     if (stream_nt >= 0) A->stream_nt = stream_nt != 0;
     return MI_OK;
@@ -726,6 +938,7 @@ extern "C" int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt)
 extern "C" int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable)
 {
     CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
     if (config_id) *config_id = A->ring.cfg.id;
     if (runs) *runs = A->ring.wgs;
     if (runs_not_ringable) *runs_not_ringable = A->ring.bad_runs;
@@ -736,6 +949,7 @@ extern "C" int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs
 extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
 {
     CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
     CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_BCSR4, "unknown kernel id");
     if (kernel_id == MI_KERNEL_BCSR4 && !A->blocked)
         return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_BCSR4: this matrix has no exact 4x4 block structure (or is row-mapped)");
@@ -746,6 +960,7 @@ extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
 extern "C" int mi_csr_get_kernel(mi_csr_t A, int* kernel_id)
 {
     CHECK_ARG(A && kernel_id, "null argument");
+    if (A->inner) A = A->inner;
     *kernel_id = resolve_kernel(A);
     return MI_OK;
 }
@@ -753,6 +968,7 @@ extern "C" int mi_csr_get_kernel(mi_csr_t A, int* kernel_id)
 extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
 {
     if (!A) return "";
+    if (A->inner) A = A->inner;
     switch (resolve_kernel(A)) {
     case MI_KERNEL_STREAM: return A->stream_nt ? "spmv_csr_stream<1024, true>" : "spmv_csr_stream<1024, false>";
     case MI_KERNEL_RING: { // the name rocprofv3 prints for the instantiation launch_ring picks
@@ -792,26 +1008,39 @@ template <int T, int NNZB, int RING, int D>
 static void launch_ring(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
 {
     static_assert(NNZB <= kRingPadNnz && 2 * T + 1 <= kRingPadRows, "device arrays are padded for the kernel's unclamped loads");
-    if (A->d_rowmap) launch_ring1<T, NNZB, RING, D, true>(A, V, d_x, d_y, s);
+    if (V.rowmap) launch_ring1<T, NNZB, RING, D, true>(A, V, d_x, d_y, s);
     else launch_ring1<T, NNZB, RING, D, false>(A, V, d_x, d_y, s);
 }
 
-static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s)
+// dst[idx[i]] = src[i]
+__global__ __launch_bounds__(256) void scatter_kernel(int m, const int* __restrict__ idx, const double* __restrict__ src,
+                                                      double* __restrict__ dst)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) dst[idx[i]] = src[i];
+}
+
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map)
 {
     if (A->n == 0) return MI_OK;
+    if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
+        int rc = mi_gather_dev(A->n, A->d_iperm, d_x, A->d_xp, (mi_stream_t)s);
+        if (rc) return rc;
+        return launch_spmv(A->inner, A->d_xp, d_y, s, true);
+    }
     const int kid = resolve_kernel(A);
-    d_y += A->y_offset;
+    if (use_map) d_y += A->y_offset;
     CsrView V;
     V.n = A->n;
     V.ncols = A->ncols;
     V.ptrow = A->d_ptrow;
     V.indcol = A->d_indcol;
     V.coef = A->d_coef;
-    V.rowmap = A->d_rowmap;
+    V.rowmap = use_map ? A->d_rowmap : nullptr;
     V.blk = nullptr;
     V.blk_span = nullptr;
     V.nblk = 0;
-    if (kid == MI_KERNEL_BCSR4 && (((uintptr_t)d_x) & 15) == 0) return mi_bcsr4_spmv_dev(A->blocked, d_x, d_y, (mi_stream_t)s);
+    if (kid == MI_KERNEL_BCSR4 && (((uintptr_t)d_x) & 15) == 0) return launch_bcsr4(A->blocked, d_x, d_y, (mi_stream_t)s, use_map);
     if (kid == MI_KERNEL_BCSR4) { // x not 16-byte aligned: the blocked kernel's paired loads cannot be used
         BlockTable* T = nullptr;
         int rc = get_table(A, 1024, &T);
@@ -877,6 +1106,28 @@ extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* 
     CHECK_ARG(A->n == A->ncols, "matrix powers need a square matrix");
     CHECK_ARG(!A->mapped, "matrix powers need an unmapped matrix");
     CHECK_ARG(d_y_out, "null output array");
+    if (A->inner && A->n > 0) {
+        // the whole chain in the new numbering (each power feeds the next without leaving it), every power scattered
+        // to the caller's numbering as it completes
+        while ((int)A->d_pp.size() < k) {
+            double* p = nullptr;
+            HIP_TRY(hipMalloc(&p, sizeof(double) * (size_t)A->n));
+            A->d_pp.push_back(p);
+        }
+        int rc = mi_gather_dev(A->n, A->d_iperm, d_x, A->d_xp, s);
+        if (rc) return rc;
+        const double* src = A->d_xp;
+        int grid = (A->n + 255) / 256;
+        if (grid > 2048) grid = 2048;
+        for (int p = 0; p < k; p++) {
+            CHECK_ARG(d_y_out[p], "null output vector");
+            if ((rc = launch_spmv(A->inner, src, A->d_pp[p], (hipStream_t)s, false))) return rc;
+            hipLaunchKernelGGL(scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, A->n, A->d_iperm, A->d_pp[p], d_y_out[p]);
+            src = A->d_pp[p];
+        }
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
     const double* src = d_x;
     for (int p = 0; p < k; p++) {
         CHECK_ARG(A->n == 0 || d_y_out[p], "null output vector");
@@ -1214,6 +1465,7 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     dfree(A->d_ptrow);
     dfree(A->d_indcol);
     dfree(A->d_coef);
+    dfree(A->d_browmap);
     dfree(A->d_x);
     dfree(A->d_y);
     for (double* p : A->d_pow) dfree(p);
@@ -1221,17 +1473,22 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     return MI_OK;
 }
 
-extern "C" int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s)
+static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map)
 {
     CHECK_ARG(A, "null handle");
     if (A->nbrows == 0) return MI_OK;
     CHECK_ARG(d_x && d_y, "null vector");
     CHECK_ARG((((uintptr_t)d_x) & 15) == 0, "x must be 16-byte aligned");
-    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef};
+    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map ? A->d_browmap : nullptr};
     const long long threads = 4LL * A->nbrows;
     hipLaunchKernelGGL(spmv_bcsr4<kBcsrDepth>, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y);
     HIP_TRY(hipGetLastError());
     return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s)
+{
+    return launch_bcsr4(A, d_x, d_y, s, true);
 }
 
 extern "C" int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y)

@@ -195,6 +195,30 @@ inline void build_row_blocks(int n, const int* ptrow, int nnzb, int max_rows, st
 // nonzeros in the same order: n % 4 == 0, the four rows of a block row hold the same columns, and
 // these come in aligned groups {4j, 4j+1, 4j+2, 4j+3}.  Then a BCSR row chain visits exactly the
 // CSR row's terms in CSR order, so the two kernels return the same bits.
+// pattern-only form of the test in csr_to_bcsr4_exact below (no values copied)
+inline bool csr_has_block4_pattern(int n, const int* ptrow, const int* indcol)
+{
+    if (n <= 0 || n % 4 != 0) return false;
+    for (int b = 0; b < n / 4; b++) {
+        const int p0 = ptrow[4 * b], len = ptrow[4 * b + 1] - p0;
+        if (len % 4 != 0) return false;
+        for (int r = 1; r < 4; r++)
+            if (ptrow[4 * b + r + 1] - ptrow[4 * b + r] != len) return false;
+        for (int g = 0; g < len; g += 4) {
+            const int c0 = indcol[p0 + g];
+            if (c0 % 4 != 0) return false;
+            for (int k = 1; k < 4; k++)
+                if (indcol[p0 + g + k] != c0 + k) return false;
+        }
+        for (int r = 1; r < 4; r++) {
+            const int pr = ptrow[4 * b + r];
+            for (int k = 0; k < len; k++)
+                if (indcol[pr + k] != indcol[p0 + k]) return false;
+        }
+    }
+    return true;
+}
+
 inline bool csr_to_bcsr4_exact(int n, const int* ptrow, const int* indcol, const double* coef, std::vector<int>& bptr,
                                std::vector<int>& bcol, std::vector<double>& bval)
 {

@@ -203,6 +203,7 @@ struct Bcsr4View {
     const int* ptrow;
     const int* indcol;
     const double* coef; // 16 per block
+    const int* browmap; // nullptr, or block row bi writes y[4 * browmap[bi] + q] (reordered matrices, reorder.hpp)
 };
 
 // Software pipeline per lane, P blocks deep: while block ia's four fmas run, the values and x
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __r
             }
         }
     }
-    y[4 * (size_t)bi + q] = s;
+    y[4 * (size_t)(A.browmap ? A.browmap[bi] : bi) + q] = s;
 }
 
 } // namespace mi355

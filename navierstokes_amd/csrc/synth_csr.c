@@ -179,3 +179,50 @@ void synth_x_sin(long long jb, long long je, double *x)
 {
     for (long long j = jb; j < je; j++) x[j - jb] = sin(0.001 * (double)j);
 }
+
+/* ---- unstructured node numbering ---------------------------------------------------------------------
+ * The reference's matrices come from gmsh meshes (src/solve_newton.c:91-197 reads them, src/benchmark_spmv.c:
+ * 76-123 assembles): node numbers follow the mesher, not geometry.  synth_node_permutation draws a seeded
+ * random numbering of the nn nodes (Fisher-Yates on splitmix64) and synth_permute_sym_sorted applies it
+ * symmetrically, B = P A P^T, delivering every row with ASCENDING columns — what MatView + COO2CSR
+ * (mpk/utils.cpp:5-43) hand to the kernels for such a mesh.  block = 4 keeps the four dofs of a node
+ * together (new row = 4 * perm[row / 4] + row % 4), so the 4x4 node-block structure survives. */
+void synth_node_permutation(unsigned long long seed, int nn, int *perm)
+{
+    uint64_t s = row_seed(seed, 0x9e3779b9u, nn);
+    for (int i = 0; i < nn; i++) perm[i] = i;
+    for (int i = nn - 1; i > 0; i--) {
+        const int j = (int)(sm64_next(&s) % (uint64_t)(i + 1));
+        const int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+}
+
+/* p2/c2/v2 sized like the input; returns 0, or -1 on bad arguments */
+int synth_permute_sym_sorted(int n, int block, const int *p, const int *c, const double *v, const int *perm_nodes,
+                             int *p2, int *c2, double *v2)
+{
+    if (n < 0 || block < 1 || n % block) return -1;
+    const int nn = n / block;
+    int *inv = (int *)malloc(sizeof(int) * (size_t)(nn > 0 ? nn : 1));
+    if (!inv) return -1;
+    for (int i = 0; i < nn; i++) inv[perm_nodes[i]] = i;
+    p2[0] = 0;
+    for (int rn = 0; rn < n; rn++) {
+        const int ro = inv[rn / block] * block + rn % block;
+        p2[rn + 1] = p2[rn] + (p[ro + 1] - p[ro]);
+    }
+    for (int rn = 0; rn < n; rn++) {
+        const int ro = inv[rn / block] * block + rn % block;
+        const int a = p[ro], len = p[ro + 1] - p[ro], b = p2[rn];
+        for (int k = 0; k < len; k++) { /* insertion sort by new column: rows are short */
+            const int cn = perm_nodes[c[a + k] / block] * block + c[a + k] % block;
+            const double val = v[a + k];
+            int m = k;
+            while (m > 0 && c2[b + m - 1] > cn) { c2[b + m] = c2[b + m - 1]; v2[b + m] = v2[b + m - 1]; m--; }
+            c2[b + m] = cn;
+            v2[b + m] = val;
+        }
+    }
+    free(inv);
+    return 0;
+}

@@ -76,6 +76,8 @@ def lib():
         "mi_orthonormalize_against_basis": [i, i, _vp, _vp, _vp],
         "mi_orthonormalize_against_basis_dev": [i, i, _vp, _vp, _vp, _vp],
         "mi_part_status": [_vp],
+        "mi_csr_reorder_info": [_vp, P(i), P(i), P(d), P(d), P(d), P(d)],
+        "mi_reorder_probe": [i, _vp, _vp, P(i), _vp, P(d), P(d)],
         "mi_csr_dims": [_vp, P(i), P(i), P(ll)],
         "mi_csr_set_kernel": [_vp, i],
         "mi_csr_get_kernel": [_vp, P(i)],
@@ -237,6 +239,14 @@ class csrmatrix:
         check(lib().mi_csr_tune_detail(self.handle, us, _c.byref(rnt), _c.byref(snt)))
         nt = rnt.value if "ring" in self.kernel_name() else snt.value
         return dict(ring=us[0], ring_nt=us[1], stream=us[2], stream_nt=us[3], bcsr4=us[4]), bool(nt)
+
+    def reorder_info(self):
+        """dict(reordered, block, spread_before, spread_after, us_natural, us_reordered) — mi_csr_reorder_info."""
+        r, b = _c.c_int(), _c.c_int()
+        v = [_c.c_double() for _ in range(4)]
+        check(lib().mi_csr_reorder_info(self.handle, _c.byref(r), _c.byref(b), *[_c.byref(t) for t in v]))
+        return dict(reordered=bool(r.value), block=b.value, spread_before=v[0].value, spread_after=v[1].value,
+                    us_natural=v[2].value, us_reordered=v[3].value)
 
     def update_values(self, coef):
         """New coefficients for the same pattern (mi_csr_update_values): numpy array (host) or CUDA tensor."""

@@ -48,6 +48,10 @@ def _lib():
         lib.fe_matrix_assemble.restype = ctypes.c_int
         lib.fe_matrix_assemble.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_ulonglong, i32p, i32p, f64p]
+        lib.synth_node_permutation.restype = None
+        lib.synth_node_permutation.argtypes = [ctypes.c_ulonglong, ctypes.c_int, i32p]
+        lib.synth_permute_sym_sorted.restype = ctypes.c_int
+        lib.synth_permute_sym_sorted.argtypes = [ctypes.c_int, ctypes.c_int, i32p, i32p, f64p, i32p, i32p, i32p, f64p]
         lib.fe_element_blocks.restype = None
         lib.fe_element_blocks.argtypes = [f64p, ctypes.c_double, ctypes.c_double, f64p]
         _LIB = lib
@@ -110,6 +114,32 @@ def fe_matrix(nx, ny=None, nz=None, Re=100.0, delta=0.05, jitter=0.1, seed=DEFAU
     if rc != 0:
         raise ValueError(f"fe_matrix_assemble({nx}, {ny}, {nz}) -> {rc}")
     return ptrow, indcol, coef
+
+
+def node_permutation(nn, seed=DEFAULT_SEED):
+    """Seeded random numbering of nn mesh nodes (perm[old] = new)."""
+    perm = np.empty(nn, np.int32)
+    _lib().synth_node_permutation(seed, nn, perm)
+    return perm
+
+
+def permute_nodes(ptrow, indcol, coef, block=1, seed=DEFAULT_SEED, perm=None):
+    """The same operator under an unstructured (mesher-like) node numbering: B = P A P^T with every row's
+    columns ascending, as MatView + COO2CSR deliver a gmsh mesh's matrix (src/benchmark_spmv.c:184-190,
+    mpk/utils.cpp:5-43).  block = 4 renumbers NODES (4 dofs stay together).  Returns (ptrow, indcol, coef, perm_nodes)."""
+    n = len(ptrow) - 1
+    assert n % block == 0
+    if perm is None:
+        perm = node_permutation(n // block, seed)
+    perm = np.ascontiguousarray(perm, dtype=np.int32)
+    p2 = np.empty(n + 1, np.int32)
+    c2 = np.empty(len(indcol), np.int32)
+    v2 = np.empty(len(coef), np.float64)
+    rc = _lib().synth_permute_sym_sorted(n, block, np.ascontiguousarray(ptrow, dtype=np.int32), np.ascontiguousarray(indcol, dtype=np.int32),
+                                         np.ascontiguousarray(coef, dtype=np.float64), perm, p2, c2, v2)
+    if rc != 0:
+        raise ValueError("synth_permute_sym_sorted rejected its arguments")
+    return p2, c2, v2, perm
 
 
 def fe_element_blocks(a, Re=100.0, delta=0.05):

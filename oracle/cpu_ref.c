@@ -539,3 +539,62 @@ double orc_time_spmv(int n, const int *ptrow, const int *indcol, const double *c
     }
     return best;
 }
+
+/* y = A x for row-major 4x4 blocks with PER-BLOCK partial sums: for every block the four products of a
+ * row are chained from zero (p = B[4r]*x0; p = fma(B[4r+c], xc, p)) and the block's partial is then
+ * ADDED to the running row value.  This is the arithmetic of the fused BCSR kernels SpM2V_BCSR_OPT /
+ * _FMA (mpk/SpM2V.cpp:473-525, :566-618: "sum += B[4*r+c]*xk[c]" per block, then "yj[r] += sum") and of
+ * the s-step multi-vector product MatMatMult_SeqBAIJ_4_AVX2 (src/kernels/spmm_avx2.c:77-88: acc per
+ * block, then sum += acc) — NOT that of SpMV_BCSR_FMA, whose row is one continuous chain. */
+void orc_spmv_bcsr4_blockacc(int nbrows, const int *ptrow, const int *indcol, const double *coef,
+                             const double *x, double *y)
+{
+    for (int bi = 0; bi < nbrows; bi++) {
+        double acc[4] = {0, 0, 0, 0};
+        for (int ia = ptrow[bi]; ia < ptrow[bi + 1]; ia++) {
+            const double *blk = coef + 16 * (size_t)ia;
+            const double *xb = x + 4 * (size_t)indcol[ia];
+            for (int i = 0; i < 4; i++) {
+                double p = 0.0;
+                for (int j = 0; j < 4; j++) p = fma(blk[4 * i + j], xb[j], p);
+                volatile double t = acc[i] + p;
+                acc[i] = t;
+            }
+        }
+        for (int i = 0; i < 4; i++) y[4 * bi + i] = acc[i];
+    }
+}
+
+
+/* Row-parallel form of orc_spmv_csr_fma for the bench's all-cores CPU column (SURVEY.md §8d "CPU baseline
+ * beside it" (2)): rows are independent, each still ONE sequential fma chain, so the bits are those of the
+ * single-thread function.  The reference itself is single-threaded (mpk/Makefile:10 has no -fopenmp);
+ * this is the fair upper bound for its algorithm on the host's cores, not something the reference ships. */
+#include <omp.h>
+void orc_spmv_csr_fma_omp(int n, const int *ptrow, const int *indcol, const double *coef,
+                          const double *x, double *y, int nthreads)
+{
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int i = 0; i < n; i++) {
+        double s = 0.0;
+        for (int ia = ptrow[i]; ia < ptrow[i + 1]; ia++) s = fma(coef[ia], x[indcol[ia]], s);
+        y[i] = s;
+    }
+}
+
+/* best-of-reps seconds, warm (repeated products, as a solver would run them) */
+double orc_time_spmv_omp(int n, const int *ptrow, const int *indcol, const double *coef,
+                         const double *x, double *y, int reps, int nthreads)
+{
+    double best = 1e300;
+    orc_spmv_csr_fma_omp(n, ptrow, indcol, coef, x, y, nthreads); /* first touch / page-in */
+    for (int r = 0; r < reps; r++) {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC_RAW, &t0);
+        orc_spmv_csr_fma_omp(n, ptrow, indcol, coef, x, y, nthreads);
+        clock_gettime(CLOCK_MONOTONIC_RAW, &t1);
+        double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (dt < best) best = dt;
+    }
+    return best;
+}

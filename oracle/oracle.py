@@ -48,6 +48,7 @@ def cpu():
         L.orc_spm2v_fused_x87.argtypes = [_c.c_int, _i32, _i32, _f64, _i32, _f64, _f64, _f64]
         L.orc_spmkv_fused.argtypes = [_c.c_int, _c.c_int, _c.c_int, _i32, _i32, _f64, _f64, _f64]
         L.orc_spmv_bcsr4_fma.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64]
+        L.orc_spmv_bcsr4_blockacc.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64]
         L.orc_norm2.argtypes = [_c.c_int, _f64]
         L.orc_norm2.restype = _c.c_double
         L.orc_rel_error.argtypes = [_c.c_int, _f64, _f64]
@@ -74,6 +75,9 @@ def cpu():
         L.orc_read_mtx.restype = _c.c_int
         L.orc_time_spmv.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64, _c.c_int, _c.c_int]
         L.orc_time_spmv.restype = _c.c_double
+        L.orc_spmv_csr_fma_omp.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64, _c.c_int]
+        L.orc_time_spmv_omp.argtypes = [_c.c_int, _i32, _i32, _f64, _f64, _f64, _c.c_int, _c.c_int]
+        L.orc_time_spmv_omp.restype = _c.c_double
         _CPU = L
     return _CPU
 
@@ -143,6 +147,15 @@ def spmv_bcsr4(ptrow, indcol, coef, x):
     nb = len(ptrow) - 1
     y = np.empty(4 * nb, np.float64)
     cpu().orc_spmv_bcsr4_fma(nb, ptrow, indcol, coef, x, y)
+    return y
+
+
+def spmv_bcsr4_blockacc(ptrow, indcol, coef, x):
+    """y = A x with per-block partial sums (SpM2V_BCSR_OPT / spmm_avx2.c arithmetic, see cpu_ref.c)."""
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    nb = len(ptrow) - 1
+    y = np.empty(4 * nb, np.float64)
+    cpu().orc_spmv_bcsr4_blockacc(nb, ptrow, indcol, coef, x, y)
     return y
 
 
@@ -278,6 +291,14 @@ def time_spmv(ptrow, indcol, coef, x, reps=3, flush=True):
     n = len(ptrow) - 1
     y = np.empty(n, np.float64)
     return cpu().orc_time_spmv(n, ptrow, indcol, coef, x, y, reps, 1 if flush else 0), y
+
+
+def time_spmv_omp(ptrow, indcol, coef, x, nthreads, reps=5):
+    """Best-of-reps seconds of the row-parallel fma SpMV on nthreads host threads (warm), and y."""
+    ptrow, indcol, coef, x = _as_i32(ptrow), _as_i32(indcol), _as_f64(coef), _as_f64(x)
+    n = len(ptrow) - 1
+    y = np.empty(n, np.float64)
+    return cpu().orc_time_spmv_omp(n, ptrow, indcol, coef, x, y, reps, int(nthreads)), y
 
 
 # ------------------------------------------------ the real reference (if built)

@@ -170,3 +170,23 @@ def test_first_touch_tables_of_coo_built_matrices(golden, name):
     assert np.array_equal(O.gen_layer1(g["csr_ptrow"], g["csr_indcol"]), g["end1"])
     if "bcsr_end1" in g:
         assert np.array_equal(O.gen_layer1_bcsr4(g["bcsr_ptrow"], g["bcsr_indcol"]), g["bcsr_end1"])
+
+
+def test_fused_bcsr_variants_pin_two_associations(golden):
+    """SpM2V_BCSR_FMA / _AVX2 = one continuous fma chain per row (= two chained SpMV_BCSR_FMA); SpM2V_BCSR_OPT =
+    per-block partial sums (mpk/SpM2V.cpp:502-507).  Both restated and pinned bitwise (rows the CPU traversal computed)."""
+    g = golden("edge_coo_n40")
+    bp, bc, bv, x = g["bcsr_ptrow"], g["bcsr_indcol"], g["bcsr_coef"], g["x"]
+    seen = np.zeros(len(bp) - 1, bool)
+    seen[bc] = True
+    rows = np.repeat(seen, 4)
+    y = O.spmv_bcsr4(bp, bc, bv, x)
+    z = O.spmv_bcsr4(bp, bc, bv, np.where(rows, y, 0.0))
+    for var in ("fma", "avx2"):
+        assert_bit_equal(y[rows], g["m2b_y_" + var][rows])
+        assert_bit_equal(z, g["m2b_z_" + var])
+    yb = O.spmv_bcsr4_blockacc(bp, bc, bv, x)
+    zb = O.spmv_bcsr4_blockacc(bp, bc, bv, np.where(rows, yb, 0.0))
+    assert_bit_equal(yb[rows], g["m2b_y_opt"][rows], "SpM2V_BCSR_OPT y")
+    assert_bit_equal(zb, g["m2b_z_opt"], "SpM2V_BCSR_OPT z")
+    assert O.rel_error(zb, z) <= 1e-15

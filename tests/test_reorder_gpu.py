@@ -1,0 +1,103 @@
+"""Unstructured (mesher-like) node numberings on the GPU: mi_csr_create relabels the matrix behind the API
+(reorder.hpp) and every bit of y still equals the oracle's fma chain ON THE MATRIX AS DELIVERED — the reordering keeps
+each row's terms in the caller's order.  Reference input being mimicked: gmsh meshes, src/solve_newton.c:91-197."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bit_equal
+from navierstokes_amd import mpk, synth
+from oracle import oracle as O  # checker only
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _check_all_entry_points(p, c, v, n, expect_reordered, expect_block):
+    x = synth.x_sin(0, n)
+    A = mpk.csrmatrix(n, p, c, v)
+    info = A.reorder_info()
+    assert info["reordered"] == expect_reordered, info
+    if expect_reordered:
+        assert info["block"] == expect_block and info["spread_after"] < 0.5 * info["spread_before"], info
+    yo = O.spmv(p, c, v, x)
+    # host entry, device entry
+    y = np.full(n, np.nan)
+    mpk.SpMV_CSR(y, x, A)
+    assert_bit_equal(y, yo, f"host SpMV_CSR ({A.kernel_name()}, {info})")
+    yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(yd, dev(x), A)
+    assert_bit_equal(yd.cpu().numpy(), yo, "device SpMV_CSR")
+    # every kernel of the relabelled twin
+    for kern in ("stream", "ring", "rowpar") + (("bcsr4",) if expect_block == 4 else ()):
+        A.set_kernel(kern)
+        mpk.SpMV_CSR(yd.fill_(float("nan")), dev(x), A)
+        assert_bit_equal(yd.cpu().numpy(), yo, f"kernel {kern} -> {A.kernel_name()}")
+    A.set_kernel("auto")
+    # matrix powers: the chain runs in the new numbering, every power is returned in the caller's
+    Y = O.spmk_chain(4, p, c, v, x)
+    outs = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(4)]
+    mpk.SpMkV(outs, dev(x), A)
+    for k in range(4):
+        assert_bit_equal(outs[k].cpu().numpy(), Y[k], f"power {k + 1}")
+    hy = [np.empty(n) for _ in range(2)]
+    mpk.SpM2V_CSR(hy[1], hy[0], x, A)
+    assert_bit_equal(hy[1], Y[1], "host SpM2V z")
+    # new coefficients for the same pattern
+    v2 = v * np.cos(np.arange(len(v)))
+    A.update_values(v2)
+    mpk.SpMV_CSR(y, x, A)
+    assert_bit_equal(y, O.spmv(p, c, v2, x), "after mi_csr_update_values")
+    A.update_values(dev(v))
+    mpk.SpMV_CSR(yd, dev(x), A)
+    assert_bit_equal(yd.cpu().numpy(), yo, "after mi_csr_update_values_dev")
+    return info
+
+
+def test_permuted_fe_matrix_is_relabelled_and_bit_identical(monkeypatch):
+    """FE matrix, random node numbering, 4x4 blocks intact: reordered by nodes, blocked kernel still eligible."""
+    monkeypatch.setenv("MI355_REORDER", "1")  # small enough for a test: force the attempt the size threshold would skip
+    p0, c0, v0 = synth.fe_matrix(12)
+    n = len(p0) - 1
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=4, seed=11)
+    info = _check_all_entry_points(p, c, v, n, True, 4)
+    assert info["spread_after"] < 0.2 * info["spread_before"]
+
+
+def test_permuted_scalar_matrices_are_relabelled_and_bit_identical(monkeypatch):
+    monkeypatch.setenv("MI355_REORDER", "1")
+    for kind, n, w in (("s15", 30000, 300), ("svar", 20000, 200)):
+        p0, c0, v0 = synth.rows(kind, n, w=w)
+        p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=1, seed=7)
+        _check_all_entry_points(p, c, v, n, True, 1)
+
+
+def test_reordering_can_be_switched_off_and_natural_orders_are_left_alone(monkeypatch):
+    p0, c0, v0 = synth.fe_matrix(12)
+    n = len(p0) - 1
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=4, seed=11)
+    monkeypatch.setenv("MI355_REORDER", "0")
+    _check_all_entry_points(p, c, v, n, False, 0)
+    monkeypatch.delenv("MI355_REORDER")
+    _check_all_entry_points(p0, c0, v0, n, False, 0)  # small + natural: nothing to do
+
+
+def test_auto_decision_on_a_large_scrambled_fe_matrix():
+    """No environment override: a 300k-row FE matrix under a random node numbering is relabelled by mi_csr_create on its
+    own measurement, and runs the blocked kernel close to the natural-order rate."""
+    p0, c0, v0 = synth.fe_matrix(42)   # 4 * 43^3 = 318 028 rows
+    n = len(p0) - 1
+    x = synth.x_sin(0, n)
+    A0 = mpk.csrmatrix(n, p0, c0, v0)
+    assert not A0.reorder_info()["reordered"]
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=4, seed=2)
+    A = mpk.csrmatrix(n, p, c, v)
+    info = A.reorder_info()
+    assert info["reordered"] and info["block"] == 4, info
+    assert info["us_reordered"] < info["us_natural"], info
+    yd = torch.empty(n, dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(yd, dev(x), A)
+    assert_bit_equal(yd.cpu().numpy(), O.spmv(p, c, v, x), f"{A.kernel_name()} {info}")
