@@ -85,19 +85,33 @@ def test_reordering_can_be_switched_off_and_natural_orders_are_left_alone(monkey
     _check_all_entry_points(p0, c0, v0, n, False, 0)  # small + natural: nothing to do
 
 
-def test_auto_decision_on_a_large_scrambled_fe_matrix():
-    """No environment override: a 300k-row FE matrix under a random node numbering is relabelled by mi_csr_create on its
-    own measurement, and runs the blocked kernel close to the natural-order rate."""
+def test_auto_decision_is_measured_and_never_changes_bits():
+    """No environment override.  A scrambled matrix above the size threshold is relabelled on the host, the twin is timed
+    against the natural-order choice on the device, and the faster one is kept — either way the bits are the oracle's.
+    (On this part a scrambled x of a few MB still sits in L2 / Infinity Cache, so for mid-size FE matrices the decision can
+    go either way; the 1.3 M-row bench workload `fe_perm` and the scrambled S15 below are clear wins.)"""
     p0, c0, v0 = synth.fe_matrix(42)   # 4 * 43^3 = 318 028 rows
     n = len(p0) - 1
     x = synth.x_sin(0, n)
     A0 = mpk.csrmatrix(n, p0, c0, v0)
-    assert not A0.reorder_info()["reordered"]
+    assert not A0.reorder_info()["reordered"]  # natural numbering: below the spread threshold, RCM not even computed
+    assert A0.reorder_info()["spread_after"] == 0.0
     p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=4, seed=2)
     A = mpk.csrmatrix(n, p, c, v)
     info = A.reorder_info()
-    assert info["reordered"] and info["block"] == 4, info
-    assert info["us_reordered"] < info["us_natural"], info
+    assert info["block"] == 4 and info["spread_after"] < 0.1 * info["spread_before"], info   # RCM was computed ...
+    assert info["us_natural"] > 0 and info["us_reordered"] > 0, info                          # ... and both were timed
+    assert info["reordered"] == (info["us_reordered"] < 0.97 * info["us_natural"]), info
     yd = torch.empty(n, dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(yd, dev(x), A)
+    assert_bit_equal(yd.cpu().numpy(), O.spmv(p, c, v, x), f"{A.kernel_name()} {info}")
+    # scrambled banded matrix, 400k rows: the natural-order kernels gather x from all over HBM; relabelled it is local again
+    p0, c0, v0 = synth.rows("s15", 400000)
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=1, seed=4)
+    A = mpk.csrmatrix(400000, p, c, v)
+    info = A.reorder_info()
+    assert info["reordered"] and info["block"] == 1 and info["us_reordered"] < 0.8 * info["us_natural"], info
+    x = synth.x_sin(0, 400000)
+    yd = torch.empty(400000, dtype=torch.float64, device="cuda")
     mpk.SpMV_CSR(yd, dev(x), A)
     assert_bit_equal(yd.cpu().numpy(), O.spmv(p, c, v, x), f"{A.kernel_name()} {info}")
