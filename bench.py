@@ -44,6 +44,9 @@ WORKLOADS = {
     # mesh delivers (src/solve_newton.c:91-197): mi_csr_create relabels it behind the API (reorder.hpp), bits unchanged
     "fe_perm": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, perm_block=4, desc="the fe matrix under a random node numbering (unstructured-mesh order), CSR, y=Ax"),
     "c2_perm": dict(kind="s15", n=1_000_000, k=1, perm_block=1, desc="the c2 matrix under a random row/column numbering, CSR, y=Ax"),
+    # multi-vector product, s = 4 columns, matrix read once (MatMatMult_SeqBAIJ_4_AVX2, src/kernels/spmm_avx2.c:7-109)
+    "fe_spmm4": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, bcsr=True, spmm=4, desc="the FE matrix as BCSR 4x4, Y = A X for 4 column vectors in one launch (spmm_avx2.c)"),
+    "fe_spmm8": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, bcsr=True, spmm=8, desc="the FE matrix as BCSR 4x4, Y = A X for 8 column vectors in one launch (spmm_avx2.c)"),
     "fe_bcsr": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, bcsr=True, desc="same FE matrix as BCSR 4x4 (SpMV_BCSR path, mpk/SpMV.cpp:90-219), y=Ax"),
 }
 
@@ -192,9 +195,18 @@ def main():
         ring_cfg, ring_runs, ring_bad, ring_frac = 0, 0, 0, 0.0
         x = torch.from_numpy(x_host).cuda()
         ys = [torch.empty(n, dtype=torch.float64, device="cuda")]
+        nvec = int(W.get("spmm", 0))
+        if nvec:
+            kernel_name = f"spmm_bcsr4<{nvec}, 0, {'true' if nvec <= 4 else 'false'}>"
+            Xh = np.stack([np.sin(0.001 * np.arange(n) + j) for j in range(nvec)])  # v_i[j] = sin(0.001 j + i), mpk/2SpMV.cpp:110-116
+            Xd = torch.from_numpy(Xh).cuda()
+            Yd = torch.empty((nvec, n), dtype=torch.float64, device="cuda")
 
-        def step():
-            mpk.SpMV_BCSR(ys[0], x, A)
+            def step():
+                mpk.MatMatMult_SeqBAIJ_4(A, Xd, Yd, "chain")
+        else:
+            def step():
+                mpk.SpMV_BCSR(ys[0], x, A)
         halo_info = None
     elif world == 1:
         A = mpk.csrmatrix(n, p, c, v)
@@ -268,7 +280,7 @@ def main():
     barrier()
     # ---- the same kernel in two other regimes (N = 1, y = A x workloads only; never `value`) -------------------
     extra = {}
-    if world == 1 and k == 1 and not args.cold and not args.no_extras:
+    if world == 1 and k == 1 and not args.cold and not args.no_extras and not W.get("spmm"):
         # (1) cold single shot: L2s and the 256 MiB Infinity Cache evicted before EVERY launch (the reference's own
         #     protocol: flush_cache() before each timed call, mpk/SpM2V.cpp:895-904)
         ms = 0.0
@@ -320,7 +332,13 @@ def main():
     parity = None
     if not args.no_parity:
         from oracle import oracle as O  # checker only
-        if world == 1 and bcsr:
+        if world == 1 and bcsr and W.get("spmm"):
+            got = Yd.cpu().numpy()
+            refs = [O.spmv_bcsr4(bp, bc, bv, Xh[j]) for j in range(nvec)]
+            parity = dict(rel_error=max(O.rel_error(refs[j], got[j]) for j in range(nvec)),
+                          bitwise=all(np.array_equal(refs[j].view(np.uint64), got[j].view(np.uint64)) for j in range(nvec)),
+                          against="oracle SpMV_BCSR_FMA restatement, every column")
+        elif world == 1 and bcsr:
             Yb = O.spmv_bcsr4(bp, bc, bv, x_host)
             got = ys[0].cpu().numpy()
             parity = dict(rel_error=O.rel_error(Yb, got), bitwise=bool(np.array_equal(Yb.view(np.uint64), got.view(np.uint64))),
@@ -365,7 +383,8 @@ def main():
             del ctypes
 
     # ---- numbers -------------------------------------------------------------------------------
-    flops = 2.0 * nnz_global * k * args.steps
+    nvec = int(W.get("spmm", 0)) or 1
+    flops = 2.0 * nnz_global * k * nvec * args.steps
     value = flops / wall / 1e9
     launches = args.steps * k
     n_loc, nnz_loc = (n, nnz_global) if world == 1 else (hi - lo, len(c))
@@ -373,7 +392,7 @@ def main():
     # bytes of the format the launched kernel actually reads (what `frac` is priced on, so it can never exceed 1):
     # 16 values + 1 block column per block, block-row pointers, x once, y once for the BCSR kernel
     runs_blocked = bcsr or (world == 1 and "bcsr4" in kernel_name)
-    B_exec = (132 * (nnz_loc // 16) + 4 * (n_loc // 4 + 1) + 16 * n_loc) if runs_blocked else B_csr
+    B_exec = (132 * (nnz_loc // 16) + 4 * (n_loc // 4 + 1) + 16 * n_loc * nvec) if runs_blocked else B_csr  # x, y once per column
     launch_s = ev_ms / 1e3 / launches
     achieved = B_exec / launch_s / 1e9
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",

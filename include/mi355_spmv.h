@@ -208,6 +208,29 @@ int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t 
 int mi_bcsr4_spmk(mi_bcsr4_t A, int k, const double* x, double* const* y_out);
 int mi_bcsr4_spmk_dev(mi_bcsr4_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s);
 
+/* ---- multi-vector products and the s-step Krylov basis ----
+ * Y[:, j] = A X[:, j] for j < s with the matrix read ONCE for the s columns: MatMatMult_SeqBAIJ_4_AVX2(A, X, Y, s_step),
+ * src/kernels/spmm_avx2.c:7-109.  X, Y dense column-major, column j at X + j*ldx (the reference's MatDense layout,
+ * lda = 4 * mbs at :23); ldx >= 4*nbcols even, ldy >= 4*nbrows.  arith selects the association of a row's sum:
+ *   MI_ARITH_CHAIN     one continuous fma chain over the row's blocks — every column bit-equal to SpMV_BCSR_FMA
+ *                      (mpk/SpMV.cpp:150-178), i.e. to the CSR fma chain;
+ *   MI_ARITH_BLOCKACC  per block the four products chained from zero, the partial added to the row value — what
+ *                      spmm_avx2.c:77-88 and SpM2V_BCSR_OPT (mpk/SpM2V.cpp:502-507) do.  The reference's final
+ *                      horizontal add (:96-101) sums four identical broadcast lanes and returns 4 A X; not reproduced. */
+enum { MI_ARITH_CHAIN = 0, MI_ARITH_BLOCKACC = 1 };
+int mi_bcsr4_spmm(mi_bcsr4_t A, int s, const double* X, long long ldx, double* Y, long long ldy, int arith);          /* host */
+int mi_bcsr4_spmm_dev(mi_bcsr4_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, int arith,
+                      mi_stream_t st);
+/* the same for a CSR handle (MI_ARITH_CHAIN bits = SpMV_CSR_FMA per column): one launch over the blocked copy when the
+ * matrix has exact 4x4 node-block structure, else s single-vector launches */
+int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, mi_stream_t st);
+/* V[:, 0] = v0, V[:, k+1] = A V[:, k], k < s — BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168 (dense column-major
+ * n x (s+1) V, ldv >= n).  orth != 0: each new column is also passed through orthonormalize_against_basis
+ * (mpk/2SpMV.cpp:13-28) against the columns before it; coefficient of column k+1 against column j at
+ * d_coef[k*(s+1) + j], j <= k.  Nothing is normalised (the reference's helper does not). */
+int mi_krylov_basis_dev(mi_csr_t A, int s, const double* d_v0, double* d_V, long long ldv, int orth, double* d_coef,
+                        mi_stream_t st);
+
 /* ---- row-range partition of one matrix over the GPUs of a node ----------
  * New design (the reference has no distributed code).  Rank r
  * owns global rows [row_starts[r], row_starts[r+1]) and the matching slice of

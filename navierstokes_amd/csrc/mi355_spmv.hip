@@ -1545,6 +1545,131 @@ extern "C" int mi_bcsr4_spmk(mi_bcsr4_t A, int k, const double* x, double* const
     return MI_OK;
 }
 
+// ---------------------------------------------------------------- multi-vector products, Krylov basis
+template <int S>
+static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t s)
+{
+    const long long threads = 4LL * V.nbrows;
+    const dim3 grid((unsigned)((threads + kWG - 1) / kWG)), block(kWG);
+    constexpr bool PF = S <= 4; // beyond four columns the prefetch stage costs more occupancy than it hides latency
+    if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4<S, 1, PF>), grid, block, 0, s, V, X, ldx, Y, ldy);
+    else hipLaunchKernelGGL((spmm_bcsr4<S, 0, PF>), grid, block, 0, s, V, X, ldx, Y, ldy);
+}
+
+static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t st,
+                       bool use_map)
+{
+    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map ? A->d_browmap : nullptr};
+    for (int j0 = 0; j0 < s; j0 += 8) { // more than eight columns: batches of eight (the matrix is read once per batch)
+        const int m = std::min(8, s - j0);
+        const double* Xj = X + (size_t)j0 * ldx;
+        double* Yj = Y + (size_t)j0 * ldy;
+        switch (m) {
+        case 1: launch_spmm_s<1>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 2: launch_spmm_s<2>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 3: launch_spmm_s<3>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 4: launch_spmm_s<4>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 5: launch_spmm_s<5>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 6: launch_spmm_s<6>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 7: launch_spmm_s<7>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        default: launch_spmm_s<8>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmm_dev(mi_bcsr4_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, int arith,
+                                 mi_stream_t st)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(s >= 0, "negative column count");
+    CHECK_ARG(arith == MI_ARITH_CHAIN || arith == MI_ARITH_BLOCKACC, "unknown arithmetic id");
+    if (s == 0 || A->nbrows == 0) return MI_OK;
+    CHECK_ARG(d_X && d_Y, "null matrix");
+    CHECK_ARG(ldx >= 4LL * A->nbcols && ldy >= 4LL * A->nbrows, "leading dimension shorter than a column");
+    CHECK_ARG((((uintptr_t)d_X) & 15) == 0 && (ldx & 1) == 0, "X columns must be 16-byte aligned (even ldx)");
+    return launch_spmm(A, s, arith, d_X, ldx, d_Y, ldy, (hipStream_t)st, true);
+}
+
+extern "C" int mi_bcsr4_spmm(mi_bcsr4_t A, int s, const double* X, long long ldx, double* Y, long long ldy, int arith)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(s >= 0, "negative column count");
+    if (s == 0 || A->nbrows == 0) return MI_OK;
+    CHECK_ARG(X && Y, "null matrix");
+    CHECK_ARG(ldx >= 4LL * A->nbcols && ldy >= 4LL * A->nbrows, "leading dimension shorter than a column");
+    int rc = need_device();
+    if (rc) return rc;
+    Scratch S;
+    double *dX = nullptr, *dY = nullptr;
+    const size_t nx = 4 * (size_t)A->nbcols, ny = 4 * (size_t)A->nbrows;
+    if ((rc = S.up(nullptr, nx * s, &dX)) || (rc = S.up(nullptr, ny * s, &dY))) return rc;
+    for (int j = 0; j < s; j++) HIP_TRY(hipMemcpy(dX + nx * j, X + (size_t)ldx * j, sizeof(double) * nx, hipMemcpyHostToDevice));
+    if ((rc = mi_bcsr4_spmm_dev(A, s, dX, (long long)nx, dY, (long long)ny, arith, nullptr))) return rc;
+    for (int j = 0; j < s; j++) HIP_TRY(hipMemcpy(Y + (size_t)ldy * j, dY + ny * j, sizeof(double) * ny, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// CSR handle: through the blocked copy when the matrix has one (matrix read once for all columns; a BCSR chain visits
+// the CSR row's terms in CSR order, so every column carries the bits of SpMV_CSR_FMA), else column by column.
+extern "C" int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, mi_stream_t st_)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(s >= 0, "negative column count");
+    CHECK_ARG(!A->mapped, "multi-vector products need an unmapped matrix");
+    if (s == 0 || A->n == 0) return MI_OK;
+    CHECK_ARG(d_X && d_Y, "null matrix");
+    CHECK_ARG(ldx >= A->ncols && ldy >= A->n, "leading dimension shorter than a column");
+    hipStream_t st = (hipStream_t)st_;
+    const bool aligned = (((uintptr_t)d_X) & 15) == 0 && (ldx & 1) == 0;
+    if (A->inner && A->inner->blocked && aligned) { // reordered: gather the s columns into the new numbering first
+        const size_t n = (size_t)A->n;
+        double* Xp = nullptr; // the gathered columns as one dense block, stream-ordered allocation
+        HIP_TRY(hipMallocAsync((void**)&Xp, sizeof(double) * n * s, st));
+        int rc = MI_OK;
+        for (int j = 0; j < s && !rc; j++) rc = mi_gather_dev(A->n, A->d_iperm, d_X + (size_t)j * ldx, Xp + n * j, st);
+        if (!rc) rc = launch_spmm(A->inner->blocked, s, MI_ARITH_CHAIN, Xp, (long long)n, d_Y, ldy, st, true);
+        (void)hipFreeAsync(Xp, st);
+        return rc;
+    }
+    if (!A->inner && A->blocked && aligned) return launch_spmm(A->blocked, s, MI_ARITH_CHAIN, d_X, ldx, d_Y, ldy, st, true);
+    for (int j = 0; j < s; j++) {
+        int rc = launch_spmv(A, d_X + (size_t)j * ldx, d_Y + (size_t)j * ldy, st);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
+// V[:, 0] = v0, V[:, k+1] = A V[:, k] for k < s: BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168 (a dense n x (s+1)
+// column-major V, each new column one product).  orth != 0: every new column is additionally passed through
+// orthonormalize_against_basis (mpk/2SpMV.cpp:13-28 — the call the reference's harness has between its products,
+// commented out at :132) against the columns before it; the coefficients go to d_coef[k * (s + 1) + j], j <= k
+// (d_coef: s * (s + 1) doubles).  Like the reference's helper nothing is normalised.
+extern "C" int mi_krylov_basis_dev(mi_csr_t A, int s, const double* d_v0, double* d_V, long long ldv, int orth, double* d_coef,
+                                   mi_stream_t st_)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(s >= 0 && s <= 64, "s must be in 0..64");
+    CHECK_ARG(A->n == A->ncols && !A->mapped, "a Krylov basis needs a square, unmapped matrix");
+    if (A->n == 0) return MI_OK;
+    CHECK_ARG(d_v0 && d_V && ldv >= A->n, "bad argument");
+    CHECK_ARG(!orth || d_coef, "null coefficient array");
+    hipStream_t st = (hipStream_t)st_;
+    if (d_V != d_v0) HIP_TRY(hipMemcpyAsync(d_V, d_v0, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToDevice, st));
+    std::vector<const double*> cols;
+    for (int k = 0; k < s; k++) {
+        double* next = d_V + (size_t)(k + 1) * ldv;
+        int rc = launch_spmv(A, d_V + (size_t)k * ldv, next, st);
+        if (rc) return rc;
+        if (orth) {
+            cols.push_back(d_V + (size_t)k * ldv);
+            if ((rc = mi_orthonormalize_against_basis_dev(A->n, (int)cols.size(), cols.data(), next, d_coef + (size_t)k * (s + 1), st))) return rc;
+        }
+    }
+    return MI_OK;
+}
+
 // ---------------------------------------------------------------- RCCL, resolved at run time (rccl_loader.hpp)
 static Rccl& g_rccl = rccl_state();
 static_assert(MI_COMM_ID_BYTES == kCommIdBytes, "id size");

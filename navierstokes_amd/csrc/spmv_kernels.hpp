@@ -276,3 +276,106 @@ __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __r
 }
 
 } // namespace mi355
+
+namespace mi355 {
+
+// ---------------------------------------------------------------------------
+// Multi-vector product on the blocked matrix: Y[:, j] = A X[:, j] for j < S, the matrix read ONCE for
+// the S vectors — the operation of the reference's s-step kernel MatMatMult_SeqBAIJ_4_AVX2
+// (src/kernels/spmm_avx2.c:7-109; X and Y dense column-major with leading dimension lda = 4 * mbs, :23).
+// Same lane layout as spmv_bcsr4 (four lanes per block row, lane q owns row 4*bi+q, two 16-byte
+// loads of coefficients per block) with S accumulators per lane; the x blocks of the S columns are
+// gathered through L2.  Per block and lane 2 + 2 S loads feed 4 S fmas, so from S = 2 on the loop is
+// no longer latency-bound the way the single-vector kernel is, and the matrix bytes per flop fall
+// with S: bytes = 132 per block + 16 S per row (x read + y written once per column).
+// ARITH 0: every row of every column is ONE continuous fma chain over the row's blocks — bit-equal to
+//          SpMV_BCSR_FMA (mpk/SpMV.cpp:150-178) column by column, hence to the CSR fma chain.
+// ARITH 1: per block the four products are chained from zero and the partial is ADDED to the row's
+//          running value — the association spmm_avx2.c:77-88 (and SpM2V_BCSR_OPT, mpk/SpM2V.cpp:502-507)
+//          use.  (The reference's horizontal sum at :96-101 adds four identical broadcast lanes and so
+//          returns 4 A X; that defect is not reproduced.)
+// PF: the next block's S x blocks are requested one block ahead (register-hungry: on for small S).
+// ---------------------------------------------------------------------------
+template <int S, int ARITH, bool PF>
+__global__ __launch_bounds__(kWG) void spmm_bcsr4(Bcsr4View A, const double* __restrict__ X, long long ldx,
+                                                  double* __restrict__ Y, long long ldy)
+{
+    const int g = blockIdx.x * kWG + threadIdx.x;
+    const int bi = g >> 2, q = g & 3;
+    if (bi >= A.nbrows) return;
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int ia0 = A.ptrow[bi], ia1 = A.ptrow[bi + 1];
+    double acc[S];
+#pragma unroll
+    for (int j = 0; j < S; j++) acc[j] = 0.0;
+    if (ia0 < ia1) {
+        const int last = ia1 - 1;
+        const double* cq = A.coef + 4 * q;
+        // stage: coefficients + column of the block about to be consumed, its x blocks (PF) and the column after it
+        const double2* row = reinterpret_cast<const double2*>(cq + 16 * (size_t)ia0);
+        double2 a01 = row[0], a23 = row[1];
+        unsigned col = ucol[ia0];
+        unsigned coln = ucol[min(ia0 + 1, last)];
+        double2 x01[S], x23[S];
+        if (PF) {
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                const double2* xb = reinterpret_cast<const double2*>(X + (size_t)j * ldx + 4 * (size_t)col);
+                x01[j] = xb[0];
+                x23[j] = xb[1];
+            }
+        }
+        for (int ia = ia0; ia < ia1; ia++) {
+            const double2 c01 = a01, c23 = a23;
+            double2 v01[S], v23[S];
+            if (PF) {
+#pragma unroll
+                for (int j = 0; j < S; j++) { v01[j] = x01[j]; v23[j] = x23[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < S; j++) {
+                    const double2* xb = reinterpret_cast<const double2*>(X + (size_t)j * ldx + 4 * (size_t)col);
+                    v01[j] = xb[0];
+                    v23[j] = xb[1];
+                }
+            }
+            // refill: block ia+1 (clamped, unconditional), the column of ia+2
+            const int nb = min(ia + 1, last);
+            const double2* nrow = reinterpret_cast<const double2*>(cq + 16 * (size_t)nb);
+            a01 = nrow[0];
+            a23 = nrow[1];
+            col = coln;
+            coln = ucol[min(ia + 2, last)];
+            if (PF) {
+#pragma unroll
+                for (int j = 0; j < S; j++) {
+                    const double2* xb = reinterpret_cast<const double2*>(X + (size_t)j * ldx + 4 * (size_t)col);
+                    x01[j] = xb[0];
+                    x23[j] = xb[1];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                if (ARITH == 0) {
+                    double s = acc[j];
+                    s = fma(c01.x, v01[j].x, s);
+                    s = fma(c01.y, v01[j].y, s);
+                    s = fma(c23.x, v23[j].x, s);
+                    s = fma(c23.y, v23[j].y, s);
+                    acc[j] = s;
+                } else {
+                    double p = fma(c01.x, v01[j].x, 0.0);
+                    p = fma(c01.y, v01[j].y, p);
+                    p = fma(c23.x, v23[j].x, p);
+                    p = fma(c23.y, v23[j].y, p);
+                    acc[j] = __dadd_rn(acc[j], p);
+                }
+            }
+        }
+    }
+    const size_t orow = 4 * (size_t)(A.browmap ? A.browmap[bi] : bi) + q;
+#pragma unroll
+    for (int j = 0; j < S; j++) Y[(size_t)j * ldy + orow] = acc[j];
+}
+
+} // namespace mi355

@@ -76,6 +76,10 @@ def lib():
         "mi_orthonormalize_against_basis": [i, i, _vp, _vp, _vp],
         "mi_orthonormalize_against_basis_dev": [i, i, _vp, _vp, _vp, _vp],
         "mi_part_status": [_vp],
+        "mi_bcsr4_spmm": [_vp, i, _vp, ll, _vp, ll, i],
+        "mi_bcsr4_spmm_dev": [_vp, i, _vp, ll, _vp, ll, i, _vp],
+        "mi_spmm_dev": [_vp, i, _vp, ll, _vp, ll, _vp],
+        "mi_krylov_basis_dev": [_vp, i, _vp, _vp, ll, i, _vp, _vp],
         "mi_csr_reorder_info": [_vp, P(i), P(i), P(d), P(d), P(d), P(d)],
         "mi_reorder_probe": [i, _vp, _vp, P(i), _vp, P(d), P(d)],
         "mi_csr_dims": [_vp, P(i), P(i), P(ll)],
@@ -441,6 +445,41 @@ def SpM2V_BCSR(z, y, x, A, ptrowend1=None):
 SpM2V_BCSR_OPT = SpM2V_BCSR
 SpM2V_BCSR_FMA = SpM2V_BCSR
 SpM2V_BCSR_AVX2 = SpM2V_BCSR
+
+
+# ------------------------------------------------- multi-vector products, Krylov basis
+
+ARITH = {"chain": 0, "blockacc": 1}
+
+
+def MatMatMult_SeqBAIJ_4(A, X, Y, arith="chain"):
+    """Y[:, j] = A X[:, j] for the s columns of X with the matrix read once — MatMatMult_SeqBAIJ_4_AVX2(A, X, Y, s_step),
+    src/kernels/spmm_avx2.c:7-109.  A: bcsr4x4_matrix (any arith) or csrmatrix (chain).  X, Y: column-major (n, s): CUDA
+    tensors of shape (s, n) (row j = column j, as MatDense stores it) or numpy arrays of shape (s, n)."""
+    s = int(X.shape[0])
+    if isinstance(A, csrmatrix):
+        assert arith == "chain"
+        check(lib().mi_spmm_dev(A.handle, s, _dev_ptr(X), int(X.stride(0)), _dev_ptr(Y), int(Y.stride(0)), _stream_ptr()))
+        return Y
+    if _is_torch(X):
+        check(lib().mi_bcsr4_spmm_dev(A.handle, s, _dev_ptr(X), int(X.stride(0)), _dev_ptr(Y), int(Y.stride(0)), ARITH[arith], _stream_ptr()))
+    else:
+        XX = np.ascontiguousarray(X, dtype=np.float64)
+        assert isinstance(Y, np.ndarray) and Y.flags.c_contiguous and Y.dtype == np.float64
+        check(lib().mi_bcsr4_spmm(A.handle, s, XX.ctypes.data, XX.shape[1], Y.ctypes.data, Y.shape[1], ARITH[arith]))
+    return Y
+
+
+def BuildKrylovBasis(A, v0, s, orth=False):
+    """V[0] = v0, V[k+1] = A V[k], k < s — BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168.  Returns (V, coef): V a
+    CUDA tensor of shape (s+1, n) (row k = basis vector k), coef (s, s+1) Gram-Schmidt coefficients when orth else None."""
+    import torch
+    n = A.n
+    V = torch.empty((s + 1, n), dtype=torch.float64, device="cuda")
+    coef = torch.zeros((max(s, 1), s + 1), dtype=torch.float64, device="cuda") if orth else None
+    check(lib().mi_krylov_basis_dev(A.handle, s, _dev_ptr(v0, n), _dev_ptr(V), n, 1 if orth else 0,
+                                    _dev_ptr(coef) if orth else None, _stream_ptr()))
+    return V, coef
 
 
 # ------------------------------------------------------------------- BLAS-1

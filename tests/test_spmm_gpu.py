@@ -1,0 +1,115 @@
+"""Multi-vector products and the s-step Krylov basis (src/kernels/spmm_avx2.c:7-168) on the GPU.
+Oracle: per column, orc_spmv_bcsr4_fma (bit-pinned to SpMV_BCSR_FMA) for MI_ARITH_CHAIN and orc_spmv_bcsr4_blockacc
+(bit-pinned to SpM2V_BCSR_OPT, the same association spmm_avx2.c:77-88 uses) for MI_ARITH_BLOCKACC.
+The arithmetic of spmm_avx2.c itself cannot be run here (PETSc is absent: SURVEY F6) — for that file parity is
+UNPINNED; what is pinned is the association it shares with SpM2V_BCSR_OPT, and its x4 defect is documented, not copied."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bit_equal
+from navierstokes_amd import mpk, synth
+from oracle import oracle as O  # checker only
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _vectors(n, s):
+    return np.stack([np.sin(0.001 * np.arange(n) + j) for j in range(s)])  # v_i[j] = sin(0.001 j + i), mpk/2SpMV.cpp:110-116
+
+
+@pytest.mark.parametrize("s", [1, 2, 3, 4, 5, 8, 11])
+def test_bcsr4_spmm_columns_bitwise(s):
+    p, c, v = synth.fe_matrix(9)
+    n = len(p) - 1
+    bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+    A = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
+    X = _vectors(n, s)
+    for arith, orc in (("chain", O.spmv_bcsr4), ("blockacc", O.spmv_bcsr4_blockacc)):
+        Y = torch.full((s, n), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.MatMatMult_SeqBAIJ_4(A, dev(X), Y, arith)
+        Yh = np.full((s, n), np.nan)
+        mpk.MatMatMult_SeqBAIJ_4(A, X, Yh, arith)
+        for j in range(s):
+            ref = orc(bp, bc, bv, X[j])
+            assert_bit_equal(Y[j].cpu().numpy(), ref, f"{arith} column {j} of {s} (device)")
+            assert_bit_equal(Yh[j], ref, f"{arith} column {j} of {s} (host)")
+        if arith == "chain":  # = the CSR fma chain = the single-vector kernels
+            assert_bit_equal(Y[0].cpu().numpy(), O.spmv(p, c, v, X[0]))
+    # the two associations differ in the last bits only
+    assert O.rel_error(O.spmv_bcsr4(bp, bc, bv, X[0]), O.spmv_bcsr4_blockacc(bp, bc, bv, X[0])) <= 1e-15
+
+
+def test_bcsr4_spmm_padded_leading_dimension_and_empty_rows():
+    # block rows 1 and 3 empty; columns strided with ldx > n
+    bp = np.array([0, 2, 2, 3, 3], np.int32)
+    bc = np.array([0, 3, 2], np.int32)
+    rng = np.random.default_rng(3)
+    bv = rng.uniform(-1, 1, 3 * 16)
+    A = mpk.bcsr4x4_matrix(4, bp, bc, bv, nbcols=4)
+    Xbig = torch.zeros((3, 24), dtype=torch.float64, device="cuda")
+    X = rng.uniform(-1, 1, (3, 16))
+    Xbig[:, :16] = dev(X)
+    Ybig = torch.full((3, 20), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.MatMatMult_SeqBAIJ_4(A, Xbig, Ybig, "chain")
+    for j in range(3):
+        assert_bit_equal(Ybig[j, :16].cpu().numpy(), O.spmv_bcsr4(bp, bc, bv, X[j]))
+    assert torch.isnan(Ybig[:, 16:]).all()  # nothing written behind a column
+
+
+def test_csr_spmm_blocked_scrambled_and_unblocked(monkeypatch):
+    """mi_spmm_dev on CSR handles: FE matrix (one launch over the blocked copy), the same matrix under a scrambled node
+    numbering with the relabelling forced (gathered columns, block-row map), and a matrix without block structure."""
+    p, c, v = synth.fe_matrix(10)
+    n = len(p) - 1
+    s = 4
+    X = _vectors(n, s)
+    cases = [("fe", p, c, v)]
+    ps, cs, vs, _ = synth.permute_nodes(p, c, v, block=4, seed=9)
+    cases.append(("fe scrambled", ps, cs, vs))
+    p1, c1, v1 = synth.rows("svar", n, w=200)
+    cases.append(("svar", p1, c1, v1))
+    monkeypatch.setenv("MI355_REORDER", "1")
+    for name, pp, cc, vv in cases:
+        A = mpk.csrmatrix(n, pp, cc, vv)
+        Y = torch.full((s, n), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.MatMatMult_SeqBAIJ_4(A, dev(X), Y)
+        for j in range(s):
+            assert_bit_equal(Y[j].cpu().numpy(), O.spmv(pp, cc, vv, X[j]), f"{name} column {j} ({A.kernel_name()}, {A.reorder_info()['reordered']})")
+
+
+@pytest.mark.parametrize("orth", [False, True])
+def test_krylov_basis(orth):
+    """BuildKrylovBasis_AVX2 (spmm_avx2.c:112-168): V[k+1] = A V[k]; with orth each new vector also goes through
+    orthonormalize_against_basis (mpk/2SpMV.cpp:13-28) against the earlier ones."""
+    p, c, v = synth.fe_matrix(8)
+    n = len(p) - 1
+    s = 5
+    v0 = synth.x_sin(0, n)
+    A = mpk.csrmatrix(n, p, c, v)
+    V, coef = mpk.BuildKrylovBasis(A, dev(v0), s, orth=orth)
+    V = V.cpu().numpy()
+    assert_bit_equal(V[0], v0)
+    if not orth:
+        Y = O.spmk_chain(s, p, c, v, v0)
+        for k in range(s):
+            assert_bit_equal(V[k + 1], Y[k], f"basis vector {k + 1}")
+        return
+    coef = coef.cpu().numpy()
+    W = [v0]
+    for k in range(s):
+        w = O.spmv(p, c, v, W[k])
+        # the device's dots come from a fixed tree, not the CPU's left-to-right sum: replay the recurrence with ITS coefficients
+        # (bit-exact), and bound their distance from the oracle's
+        wo, dots_o = O.mgs(np.stack(W), w)
+        for j in range(k + 1):
+            w = O.ortho_update(coef[k, j], W[j], w)
+        assert_bit_equal(V[k + 1], w, f"basis vector {k + 1} with the device's coefficients")
+        scale = max(1.0, np.abs(dots_o).max())
+        assert np.abs(coef[k, : k + 1] - dots_o).max() <= 1e-9 * scale  # the chain of k products amplifies rounding
+        assert O.rel_error(wo, V[k + 1]) <= 1e-9
+        W.append(V[k + 1])

@@ -4,7 +4,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 -Wno-deprecated-declarations tools/rocsparse_cmp.hip synth_csr.o \
 //         -Inavierstokes_amd/csrc -Iinclude -Lnavierstokes_amd/csrc -lmi355spmv -lrocsparse -o tools/rocsparse_cmp
-//   tools/rocsparse_cmp [kind 0|1|2] [n] [alg mask: 1 rowsplit, 2 adaptive, 4 lrb, 8 nnzsplit; default 13]
+//   tools/rocsparse_cmp [kind 0|1|2] [n] [alg mask: 1 rowsplit, 2 adaptive, 4 lrb, 8 nnzsplit, 16 adaptive via rocsparse_dcsrmv; default 13]
 #include <hip/hip_runtime.h>
 #include <rocsparse/rocsparse.h>
 
@@ -176,6 +176,35 @@ int main(int argc, char** argv)
         report(a.name, us, prep);
         (void)hipFree(buf);
         RSC(rocsparse_destroy_spmat_descr(A));
+    }
+
+    // ---- csr_adaptive through the level-2 API (rocsparse_dcsrmv_analysis + rocsparse_dcsrmv): the same algorithm the generic
+    //      rocsparse_spmv(csr_adaptive) wraps, with the analysis data in a rocsparse_mat_info the caller owns.  The generic
+    //      path faulted on a nil address at 5 M rows in round 1 (mask bit 2); this one is mask bit 16.
+    if (mask & 16) {
+        rocsparse_mat_descr descr;
+        rocsparse_mat_info info;
+        RSC(rocsparse_create_mat_descr(&descr));
+        RSC(rocsparse_create_mat_info(&info));
+        printf("[rocsparse_dcsrmv adaptive] analysis...\n");
+        HIPC(hipEventRecord(e0, st));
+        rocsparse_status s = rocsparse_dcsrmv_analysis(h, rocsparse_operation_none, n, n, (rocsparse_int)nnz, descr, d_coef, d_ptrow, d_indcol, info);
+        HIPC(hipEventRecord(e1, st));
+        HIPC(hipEventSynchronize(e1));
+        float prep = 0;
+        HIPC(hipEventElapsedTime(&prep, e0, e1));
+        if (s != rocsparse_status_success) printf("rocsparse_dcsrmv_analysis failed (status %d)\n", (int)s);
+        else {
+            HIPC(hipMemsetAsync(d_y, 0xff, sizeof(double) * n, st));
+            HIPC(hipStreamSynchronize(st));
+            printf("[rocsparse_dcsrmv adaptive] compute...\n");
+            const double us = time_it([&] {
+                RSC(rocsparse_dcsrmv(h, rocsparse_operation_none, n, n, (rocsparse_int)nnz, &alpha, descr, d_coef, d_ptrow, d_indcol, info, d_x, &beta, d_y));
+            });
+            report("rocsparse_dcsrmv + analysis (adaptive)", us, prep);
+        }
+        RSC(rocsparse_destroy_mat_info(info));
+        RSC(rocsparse_destroy_mat_descr(descr));
     }
 
     // ---- this library, through the C-ABI
