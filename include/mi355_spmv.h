@@ -224,10 +224,12 @@ int mi_bcsr4_spmm_dev(mi_bcsr4_t A, int s, const double* d_X, long long ldx, dou
 /* the same for a CSR handle (MI_ARITH_CHAIN bits = SpMV_CSR_FMA per column): one launch over the blocked copy when the
  * matrix has exact 4x4 node-block structure, else s single-vector launches */
 int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, mi_stream_t st);
-/* V[:, 0] = v0, V[:, k+1] = A V[:, k], k < s — BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168 (dense column-major
- * n x (s+1) V, ldv >= n).  orth != 0: each new column is also passed through orthonormalize_against_basis
- * (mpk/2SpMV.cpp:13-28) against the columns before it; coefficient of column k+1 against column j at
- * d_coef[k*(s+1) + j], j <= k.  Nothing is normalised (the reference's helper does not). */
+/* orth == 0: V[:, 0] = v0, V[:, k+1] = A V[:, k], k < s — BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168 (dense
+ * column-major n x (s+1) V, ldv >= n): the monomial basis, bit-equal to the matrix-powers chain.
+ * orth != 0: the orthonormal (Arnoldi) basis of the same space, from the reference's own pieces: V[:, 0] = v0/||v0||, each
+ * product passed through orthonormalize_against_basis (mpk/2SpMV.cpp:13-28) against the earlier columns, then divided by
+ * its norm2 — the normalisation that helper computes and drops.  d_coef (s*(s+2)+1 doubles): [k*(s+2) + j] = dot of step
+ * k with column j (j <= k), [k*(s+2) + k+1] = the norm, [s*(s+2)] = ||v0||. */
 int mi_krylov_basis_dev(mi_csr_t A, int s, const double* d_v0, double* d_V, long long ldv, int orth, double* d_coef,
                         mi_stream_t st);
 

@@ -1550,10 +1550,17 @@ template <int S>
 static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t s)
 {
     const long long threads = 4LL * V.nbrows;
-    const dim3 grid((unsigned)((threads + kWG - 1) / kWG)), block(kWG);
+    const int nwg = (int)((threads + kWG - 1) / kWG);
+    static const bool xcd = !(getenv("MI355_SPMM_XCD") && !strcmp(getenv("MI355_SPMM_XCD"), "0"));
+    const dim3 grid((unsigned)(xcd ? kNXCD * ((nwg + kNXCD - 1) / kNXCD) : nwg)), block(kWG);
     constexpr bool PF = S <= 4; // beyond four columns the prefetch stage costs more occupancy than it hides latency
-    if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4<S, 1, PF>), grid, block, 0, s, V, X, ldx, Y, ldy);
-    else hipLaunchKernelGGL((spmm_bcsr4<S, 0, PF>), grid, block, 0, s, V, X, ldx, Y, ldy);
+    if (xcd) {
+        if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4<S, 1, PF, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+        else hipLaunchKernelGGL((spmm_bcsr4<S, 0, PF, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+    } else {
+        if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4<S, 1, PF, false>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+        else hipLaunchKernelGGL((spmm_bcsr4<S, 0, PF, false>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+    }
 }
 
 static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t st,
@@ -1641,11 +1648,22 @@ extern "C" int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, 
     return MI_OK;
 }
 
+// y[i] /= *d (IEEE division by a scalar read from device memory)
+__global__ __launch_bounds__(256) void div_by_scalar_kernel(int n, const double* __restrict__ d, double* __restrict__ y)
+{
+    const double q = d[0];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = __ddiv_rn(y[i], q);
+}
+
 // V[:, 0] = v0, V[:, k+1] = A V[:, k] for k < s: BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168 (a dense n x (s+1)
-// column-major V, each new column one product).  orth != 0: every new column is additionally passed through
-// orthonormalize_against_basis (mpk/2SpMV.cpp:13-28 — the call the reference's harness has between its products,
-// commented out at :132) against the columns before it; the coefficients go to d_coef[k * (s + 1) + j], j <= k
-// (d_coef: s * (s + 1) doubles).  Like the reference's helper nothing is normalised.
+// column-major V, each new column one product) — that is orth == 0, the monomial basis, bit-equal to the matrix-powers
+// chain.  orth != 0 builds the ORTHONORMAL (Arnoldi) basis an s-step GMRES needs out of the reference's own pieces:
+// V[:, 0] = v0 / ||v0||; each product is passed through orthonormalize_against_basis (mpk/2SpMV.cpp:13-28) against the
+// columns before it and then divided by its norm2 (mpk/utils.cpp:131-136) — the normalisation that helper computes and
+// drops (:23-26), without which its projections y -= (y.v) v are only meaningful for unit v.  Coefficients (the Hessenberg
+// column of step k) go to d_coef[k * (s + 2) + j]: j <= k the dots in the order taken, j = k + 1 the norm;
+// d_coef[s * (s + 2)] = ||v0||.  d_coef: s * (s + 2) + 1 doubles.
 extern "C" int mi_krylov_basis_dev(mi_csr_t A, int s, const double* d_v0, double* d_V, long long ldv, int orth, double* d_coef,
                                    mi_stream_t st_)
 {
@@ -1656,17 +1674,29 @@ extern "C" int mi_krylov_basis_dev(mi_csr_t A, int s, const double* d_v0, double
     CHECK_ARG(d_v0 && d_V && ldv >= A->n, "bad argument");
     CHECK_ARG(!orth || d_coef, "null coefficient array");
     hipStream_t st = (hipStream_t)st_;
-    if (d_V != d_v0) HIP_TRY(hipMemcpyAsync(d_V, d_v0, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToDevice, st));
+    const int n = A->n;
+    int grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    int rc;
+    if (d_V != d_v0) HIP_TRY(hipMemcpyAsync(d_V, d_v0, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (orth) {
+        double* nrm0 = d_coef + (size_t)s * (s + 2);
+        if ((rc = mi_norm2_dev(n, d_V, nrm0, st))) return rc;
+        hipLaunchKernelGGL(div_by_scalar_kernel, dim3(grid), dim3(256), 0, st, n, nrm0, d_V);
+    }
     std::vector<const double*> cols;
     for (int k = 0; k < s; k++) {
         double* next = d_V + (size_t)(k + 1) * ldv;
-        int rc = launch_spmv(A, d_V + (size_t)k * ldv, next, st);
-        if (rc) return rc;
+        if ((rc = launch_spmv(A, d_V + (size_t)k * ldv, next, st))) return rc;
         if (orth) {
+            double* h = d_coef + (size_t)k * (s + 2);
             cols.push_back(d_V + (size_t)k * ldv);
-            if ((rc = mi_orthonormalize_against_basis_dev(A->n, (int)cols.size(), cols.data(), next, d_coef + (size_t)k * (s + 1), st))) return rc;
+            if ((rc = mi_orthonormalize_against_basis_dev(n, (int)cols.size(), cols.data(), next, h, st))) return rc;
+            if ((rc = mi_norm2_dev(n, next, h + k + 1, st))) return rc;
+            hipLaunchKernelGGL(div_by_scalar_kernel, dim3(grid), dim3(256), 0, st, n, h + k + 1, next);
         }
     }
+    HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 

@@ -296,11 +296,16 @@ namespace mi355 {
 //          returns 4 A X; that defect is not reproduced.)
 // PF: the next block's S x blocks are requested one block ahead (register-hungry: on for small S).
 // ---------------------------------------------------------------------------
-template <int S, int ARITH, bool PF>
+// XCD: workgroup b works on chunk (b & 7) * ceil(nwg / 8) + (b >> 3) of the block rows, so that each XCD (round-robin
+// dispatch) sweeps one contiguous eighth of the matrix and the x blocks its L2 fetched for one workgroup serve the next;
+// in dispatch order all eight L2s walk the same region and each fetches every x block for itself (S columns of them).
+template <int S, int ARITH, bool PF, bool XCD>
 __global__ __launch_bounds__(kWG) void spmm_bcsr4(Bcsr4View A, const double* __restrict__ X, long long ldx,
-                                                  double* __restrict__ Y, long long ldy)
+                                                  double* __restrict__ Y, long long ldy, int nwg)
 {
-    const int g = blockIdx.x * kWG + threadIdx.x;
+    const int wg = XCD ? xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
+    if (wg >= nwg) return;
+    const int g = wg * kWG + threadIdx.x;
     const int bi = g >> 2, q = g & 3;
     if (bi >= A.nbrows) return;
     const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);

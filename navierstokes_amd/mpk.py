@@ -471,15 +471,19 @@ def MatMatMult_SeqBAIJ_4(A, X, Y, arith="chain"):
 
 
 def BuildKrylovBasis(A, v0, s, orth=False):
-    """V[0] = v0, V[k+1] = A V[k], k < s — BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168.  Returns (V, coef): V a
-    CUDA tensor of shape (s+1, n) (row k = basis vector k), coef (s, s+1) Gram-Schmidt coefficients when orth else None."""
+    """orth=False: V[0] = v0, V[k+1] = A V[k], k < s — BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168.
+    orth=True: the orthonormal (Arnoldi) basis of the same space (mi_krylov_basis_dev explains).  Returns (V, H, nrm0):
+    V a CUDA tensor of shape (s+1, n) (row k = basis vector k); H (s, s+2) with H[k, :k+1] the dots of step k and
+    H[k, k+1] the norm, nrm0 = ||v0|| (both None when orth is False)."""
     import torch
     n = A.n
     V = torch.empty((s + 1, n), dtype=torch.float64, device="cuda")
-    coef = torch.zeros((max(s, 1), s + 1), dtype=torch.float64, device="cuda") if orth else None
+    coef = torch.zeros(s * (s + 2) + 1, dtype=torch.float64, device="cuda") if orth else None
     check(lib().mi_krylov_basis_dev(A.handle, s, _dev_ptr(v0, n), _dev_ptr(V), n, 1 if orth else 0,
                                     _dev_ptr(coef) if orth else None, _stream_ptr()))
-    return V, coef
+    if not orth:
+        return V, None, None
+    return V, coef[: s * (s + 2)].reshape(s, s + 2), coef[s * (s + 2)]
 
 
 # ------------------------------------------------------------------- BLAS-1

@@ -82,34 +82,47 @@ def test_csr_spmm_blocked_scrambled_and_unblocked(monkeypatch):
             assert_bit_equal(Y[j].cpu().numpy(), O.spmv(pp, cc, vv, X[j]), f"{name} column {j} ({A.kernel_name()}, {A.reorder_info()['reordered']})")
 
 
-@pytest.mark.parametrize("orth", [False, True])
-def test_krylov_basis(orth):
-    """BuildKrylovBasis_AVX2 (spmm_avx2.c:112-168): V[k+1] = A V[k]; with orth each new vector also goes through
-    orthonormalize_against_basis (mpk/2SpMV.cpp:13-28) against the earlier ones."""
+def test_krylov_basis_monomial():
+    """BuildKrylovBasis_AVX2 (spmm_avx2.c:112-168): V[k+1] = A V[k] — bit-equal to the matrix-powers chain."""
     p, c, v = synth.fe_matrix(8)
     n = len(p) - 1
     s = 5
     v0 = synth.x_sin(0, n)
     A = mpk.csrmatrix(n, p, c, v)
-    V, coef = mpk.BuildKrylovBasis(A, dev(v0), s, orth=orth)
+    V, H, _ = mpk.BuildKrylovBasis(A, dev(v0), s)
     V = V.cpu().numpy()
+    assert H is None
     assert_bit_equal(V[0], v0)
-    if not orth:
-        Y = O.spmk_chain(s, p, c, v, v0)
-        for k in range(s):
-            assert_bit_equal(V[k + 1], Y[k], f"basis vector {k + 1}")
-        return
-    coef = coef.cpu().numpy()
-    W = [v0]
+    Y = O.spmk_chain(s, p, c, v, v0)
     for k in range(s):
-        w = O.spmv(p, c, v, W[k])
-        # the device's dots come from a fixed tree, not the CPU's left-to-right sum: replay the recurrence with ITS coefficients
-        # (bit-exact), and bound their distance from the oracle's
-        wo, dots_o = O.mgs(np.stack(W), w)
+        assert_bit_equal(V[k + 1], Y[k], f"basis vector {k + 1}")
+
+
+def test_krylov_basis_orthonormal():
+    """orth: product -> orthonormalize_against_basis (mpk/2SpMV.cpp:13-28) -> / norm2 (mpk/utils.cpp:131-136).
+    The device's dots and norms come from fixed trees, not the CPU's left-to-right sums, so (a) the recurrence is replayed
+    with ITS coefficients and must then match bit for bit, (b) the coefficients are held against the oracle's with a
+    rounding-level bound, (c) the result is what it claims to be: orthonormal, spanning the Krylov space (A V_k = V_{k+1} H_k)."""
+    p, c, v = synth.rows("s15", 40000, w=300)   # ||A|| < 2: a well-scaled Krylov sequence
+    n = len(p) - 1
+    s = 6
+    v0 = synth.x_sin(0, n) + 0.25
+    A = mpk.csrmatrix(n, p, c, v)
+    V, H, nrm0 = mpk.BuildKrylovBasis(A, dev(v0), s, orth=True)
+    V, H, nrm0 = V.cpu().numpy(), H.cpu().numpy(), float(nrm0)
+    assert abs(nrm0 - O.norm2(v0)) <= 1e-13 * nrm0
+    assert_bit_equal(V[0], v0 / nrm0, "v0 / ||v0|| (IEEE division)")
+    for k in range(s):
+        w = O.spmv(p, c, v, V[k])
+        wo, dots_o = O.mgs(V[: k + 1], w)
         for j in range(k + 1):
-            w = O.ortho_update(coef[k, j], W[j], w)
-        assert_bit_equal(V[k + 1], w, f"basis vector {k + 1} with the device's coefficients")
-        scale = max(1.0, np.abs(dots_o).max())
-        assert np.abs(coef[k, : k + 1] - dots_o).max() <= 1e-9 * scale  # the chain of k products amplifies rounding
-        assert O.rel_error(wo, V[k + 1]) <= 1e-9
-        W.append(V[k + 1])
+            w = O.ortho_update(H[k, j], V[j], w)
+        assert_bit_equal(V[k + 1], w / H[k, k + 1], f"basis vector {k + 1} from the device's own coefficients")
+        assert np.abs(H[k, : k + 1] - dots_o).max() <= 1e-12 * max(1.0, np.abs(dots_o).max())
+        assert abs(H[k, k + 1] - O.norm2(wo)) <= 1e-11 * O.norm2(wo)
+    G = V @ V.T
+    assert np.abs(G - np.eye(s + 1)).max() <= 1e-10, np.abs(G - np.eye(s + 1)).max()
+    for k in range(s):  # Arnoldi relation
+        lhs = O.spmv(p, c, v, V[k])
+        rhs = H[k, : k + 1] @ V[: k + 1] + H[k, k + 1] * V[k + 1]
+        assert O.rel_error(lhs, rhs) <= 1e-12
