@@ -1551,7 +1551,11 @@ static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long l
 {
     const long long threads = 4LL * V.nbrows;
     const int nwg = (int)((threads + kWG - 1) / kWG);
-    static const bool xcd = !(getenv("MI355_SPMM_XCD") && !strcmp(getenv("MI355_SPMM_XCD"), "0"));
+    // measured on the FE matrix (bench.py --workload fe_spmm4 / fe_spmm8, MI355_SPMM_XCD=0|1): 8 columns 284 us in XCD order
+    // against 343 in dispatch order (x traffic is 8x a single product's and every L2 fetched all of it); 4 columns 179
+    // against 173 (not bound by x traffic yet) — so XCD order from five columns on.  MI355_SPMM_XCD=0|1 forces.
+    static const int xcd_env = getenv("MI355_SPMM_XCD") ? atoi(getenv("MI355_SPMM_XCD")) : -1;
+    const bool xcd = xcd_env >= 0 ? xcd_env != 0 : S > 4;
     const dim3 grid((unsigned)(xcd ? kNXCD * ((nwg + kNXCD - 1) / kNXCD) : nwg)), block(kWG);
     constexpr bool PF = S <= 4; // beyond four columns the prefetch stage costs more occupancy than it hides latency
     if (xcd) {
