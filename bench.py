@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--exchange", default=None, choices=["native", "push", "torch"], help="N > 1: which halo exchange drives the step")
     ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold single-shot and in-pipeline measurements")
     args = ap.parse_args()
@@ -225,7 +226,7 @@ def main():
                 mpk.SpMkV(ys, x, A)
         halo_info = None
     else:
-        dc = D.DistCSR(rs, p, c, v, kernel=None if args.kernel == "auto" else args.kernel)
+        dc = D.DistCSR(rs, p, c, v, kernel=None if args.kernel == "auto" else args.kernel, exchange=args.exchange)
         x_ext = dc.new_x_ext()
         x_ext[: dc.n_local] = torch.from_numpy(x_host).cuda()
         kernel_name = "interior+boundary pieces, kernel=" + args.kernel
@@ -243,6 +244,7 @@ def main():
                 dc.spmk(x_ext, pbufs, sp)
         halo_info = dict(n_halo=dc.n_halo, n_send=dc.n_send, interior_rows=dc.n_interior, boundary_rows=dc.n_boundary,
                          exchange="native RCCL send/recv (mi_part_spmv_dev)" if dc.native
+                         else "peer push over HIP IPC windows, no RCCL (mi_part_spmv_push_dev)" if dc.push
                          else ("torch.distributed all_to_all_single" if dc._nccl else "host-staged (non-NCCL backend, development)"))
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
@@ -278,6 +280,8 @@ def main():
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
     barrier()
+    if world > 1:
+        dc.status()  # a hand-off / halo wait that gave up during the timed region fails the run here, loudly
     # ---- the same kernel in two other regimes (N = 1, y = A x workloads only; never `value`) -------------------
     extra = {}
     if world == 1 and k == 1 and not args.cold and not args.no_extras and not W.get("spmm"):

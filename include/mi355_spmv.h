@@ -283,6 +283,21 @@ int mi_part_comm_init(mi_part_t P, const void* id128);
 int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s);
 /* MI_OK, or MI_ERR_HIP once a hand-off wait has given up (call after synchronising; no GPU work, no copy) */
 int mi_part_status(mi_part_t P);
+/* ---- halo exchange by peer push (no RCCL, one stream) -------------------------
+ * Each rank's kernel writes the x entries a neighbour needs straight into a receive window in the NEIGHBOUR's memory
+ * (HIP IPC mapping; xGMI between GPUs) and raises a flag there; the receiver's kernel waits for its neighbours' flags and
+ * moves the window behind x_local (navierstokes_amd/csrc/push_exchange.hpp has the protocol).  The step is four launches
+ * on the caller's stream — push, interior rows, wait + copy, boundary rows — with no RCCL call, no second stream and no
+ * cross-stream hand-off.  Set-up (collective, once): every rank calls mi_part_push_export, the 64-byte handles and the
+ * (2*nranks+1)-entry layouts are all-gathered by any side channel, every rank calls mi_part_push_connect with all of
+ * them.  Ranks of one process (threads) are connected directly, ranks of other processes through hipIpcOpenMemHandle.
+ * All ranks must then call mi_part_spmv_push_dev the same number of times (the flags carry the step number).
+ * A wait on a stalled neighbour gives up after minutes; that is sticky and reported like a hand-off time-out. */
+#define MI_IPC_HANDLE_BYTES 64
+int mi_part_push_export(mi_part_t P, void* handle64, long long* layout /* [2*nranks + 1] */);
+int mi_part_push_connect(mi_part_t P, const void* handles /* nranks x 64 B */, const long long* layouts /* nranks x (2*nranks+1) */);
+int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s);
+
 /* development check of the RCCL plumbing on ONE GPU: a communicator of size 1 sends
  * `count` doubles to itself through the same send/recv/stream/event code path
  * (the per-step cost measurements of this path live in tools/comm_timing.hip) */

@@ -22,6 +22,7 @@
 #include "blas1_kernels.hpp"
 #include "handoff_kernels.hpp"
 #include "partition.hpp"
+#include "push_exchange.hpp"
 #include "rccl_loader.hpp"
 #include "reorder.hpp"
 #include "ring_plan.hpp"
@@ -157,7 +158,24 @@ struct mi_part_s {
     // step cheaper in the one-GPU harness but have not run against real multi-GPU RCCL yet: opt in with
     // MI355_PART_HANDOFF=flags.
     bool flag_handoff = false;
+    // peer-push exchange (push_exchange.hpp): my receive window, the peers' windows I write to
+    void* win = nullptr;          // [flags: nranks x 64 B][pad][data: 2 x n_halo doubles]
+    bool win_uncached = false, win_registered = false;
+    std::string win_key;          // the IPC handle bytes (key of the in-process registry)
+    unsigned* win_flags = nullptr;
+    double* win_data = nullptr;
+    std::vector<void*> ipc_opened; // mappings to close
+    PushLink* d_links = nullptr;
+    int n_links = 0;
+    int* d_nb = nullptr;           // ranks whose flags I wait for
+    int n_nb = 0;
+    unsigned push_step = 0;
+    bool push_ready = false;
 };
+
+// windows of ranks living in THIS process (rank threads; hipIpcOpenMemHandle refuses a handle of the opening process)
+static std::map<std::string, void*> g_win_registry;
+static size_t win_data_offset(int nranks) { return ((size_t)nranks * kWinFlagStride * sizeof(unsigned) + 255) / 256 * 256; }
 
 static void part_comm_release(mi_part_s* P);
 
@@ -1726,6 +1744,20 @@ static void part_comm_release(mi_part_s* P)
     if (P->d_sendbuf) dfree(P->d_sendbuf);
     if (P->d_flags) dfree(P->d_flags);
     if (P->h_timeouts) (void)hipHostFree(P->h_timeouts);
+    for (void* m : P->ipc_opened) (void)hipIpcCloseMemHandle(m);
+    P->ipc_opened.clear();
+    if (P->win_registered) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        g_win_registry.erase(P->win_key);
+        P->win_registered = false;
+    }
+    dfree(P->win);
+    dfree(P->d_links);
+    dfree(P->d_nb);
+    P->win = nullptr;
+    P->d_links = nullptr;
+    P->d_nb = nullptr;
+    P->push_ready = false;
     P->d_sendbuf = nullptr;
     P->d_flags = nullptr;
     P->h_timeouts = P->d_timeouts = nullptr;
@@ -1851,8 +1883,9 @@ extern "C" int mi_part_destroy(mi_part_t P)
 {
     if (!P) return MI_OK;
     int status = MI_OK;
-    if (P->comm_stream) { // let queued steps finish, then report a hand-off that gave up during them
-        (void)hipStreamSynchronize(P->comm_stream);
+    if (P->comm_stream || P->push_ready) { // let queued steps finish, then report a wait that gave up during them
+        if (P->comm_stream) (void)hipStreamSynchronize(P->comm_stream);
+        else (void)hipDeviceSynchronize();
         status = part_handoff_status(P);
     }
     mi_csr_destroy(P->piece[0]);
@@ -2017,6 +2050,142 @@ extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local,
     if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;
     if (P->flag_handoff) hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s, P->d_flags + 1, step, P->d_timeouts);
     else HIP_TRY(hipStreamWaitEvent(s, P->ev_comm, 0));
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// ---- peer-push exchange (push_exchange.hpp) ----------------------------------------------------------------------
+static int part_need_timeouts(mi_part_s* P)
+{
+    if (P->h_timeouts) return MI_OK;
+    HIP_TRY(hipHostMalloc((void**)&P->h_timeouts, sizeof(unsigned), hipHostMallocMapped));
+    *P->h_timeouts = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&P->d_timeouts, P->h_timeouts, 0));
+    return MI_OK;
+}
+
+extern "C" int mi_part_push_export(mi_part_t P, void* handle64, long long* layout)
+{
+    CHECK_ARG(P && handle64 && layout, "null argument");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    static_assert(sizeof(hipIpcMemHandle_t) == MI_IPC_HANDLE_BYTES, "IPC handle size");
+    const PartPlan& pl = P->plan;
+    if (!P->win) {
+        const size_t bytes = win_data_offset(pl.nranks) + sizeof(double) * 2 * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1);
+        // uncached: neither the writer's nor the reader's L2 may keep a line of the window
+        hipError_t e = hipExtMallocWithFlags(&P->win, bytes, hipDeviceMallocUncached);
+        P->win_uncached = e == hipSuccess;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipMalloc(&P->win, bytes));
+        }
+        HIP_TRY(hipMemset(P->win, 0, bytes));
+        HIP_TRY(hipDeviceSynchronize());
+        P->win_flags = (unsigned*)P->win;
+        P->win_data = (double*)((char*)P->win + win_data_offset(pl.nranks));
+    }
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, P->win));
+    memcpy(handle64, &h, sizeof h);
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        P->win_key.assign((const char*)&h, sizeof h);
+        g_win_registry[P->win_key] = P->win;
+        P->win_registered = true;
+    }
+    layout[0] = pl.n_halo;
+    for (int p = 0; p < pl.nranks; p++) {
+        layout[1 + p] = pl.recv_offsets[p];
+        layout[1 + pl.nranks + p] = pl.recv_counts[p];
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long long* layouts)
+{
+    CHECK_ARG(P && handles && layouts, "null argument");
+    if (!P->win) return fail(MI_ERR_STATE, "mi_part_push_export was not called");
+    if (P->push_ready) return MI_OK;
+    const PartPlan& pl = P->plan;
+    const int R = pl.nranks, me = pl.rank, LW = 2 * R + 1;
+    int rc = part_need_timeouts(P);
+    if (rc) return rc;
+    std::vector<PushLink> links;
+    std::vector<int> nb;
+    for (int p = 0; p < R; p++) {
+        if (p == me) continue;
+        const long long* Lp = layouts + (size_t)p * LW;
+        const long long peer_nhalo = Lp[0], peer_off = Lp[1 + me], peer_cnt = Lp[1 + R + me];
+        if (peer_cnt != pl.send_counts[p]) return fail(MI_ERR_STATE, "peer expects a different number of entries than this rank sends");
+        if (pl.send_counts[p] == 0 && pl.recv_counts[p] == 0) continue; // not a neighbour
+        nb.push_back(p);
+        void* base = nullptr;
+        const std::string key((const char*)handles + (size_t)p * MI_IPC_HANDLE_BYTES, MI_IPC_HANDLE_BYTES);
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            auto it = g_win_registry.find(key);
+            if (it != g_win_registry.end()) base = it->second; // a rank of this very process
+        }
+        if (!base) {
+            hipIpcMemHandle_t h;
+            memcpy(&h, key.data(), sizeof h);
+            HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+            P->ipc_opened.push_back(base);
+        }
+        double* pdata = (double*)((char*)base + win_data_offset(R));
+        PushLink L;
+        L.dst[0] = pdata + peer_off;
+        L.dst[1] = pdata + (peer_nhalo > 0 ? peer_nhalo : 1) + peer_off;
+        L.flag = (unsigned*)base + (size_t)me * kWinFlagStride;
+        L.send_off = pl.send_offsets[p];
+        L.count = pl.send_counts[p];
+        L.first = -1;
+        if (L.count > 0) {
+            bool contiguous = true;
+            for (int i = 1; i < L.count && contiguous; i++) contiguous = pl.send_lists[p][i] == pl.send_lists[p][0] + i;
+            if (contiguous) L.first = pl.send_lists[p][0];
+        }
+        links.push_back(L);
+    }
+    P->n_links = (int)links.size();
+    P->n_nb = (int)nb.size();
+    if (P->n_links) {
+        HIP_TRY(hipMalloc(&P->d_links, sizeof(PushLink) * links.size()));
+        HIP_TRY(hipMemcpy(P->d_links, links.data(), sizeof(PushLink) * links.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&P->d_nb, sizeof(int) * nb.size()));
+        HIP_TRY(hipMemcpy(P->d_nb, nb.data(), sizeof(int) * nb.size(), hipMemcpyHostToDevice));
+    }
+    P->push_step = 0;
+    P->push_ready = true;
+    return MI_OK;
+}
+
+extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s_)
+{
+    CHECK_ARG(P, "null handle");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    hipStream_t s = (hipStream_t)s_;
+    const PartPlan& pl = P->plan;
+    int rc;
+    if (pl.nranks == 1) {
+        if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;
+        return mi_spmv_dev(P->piece[1], d_x_ext, d_y_local, s);
+    }
+    if (!P->push_ready) return fail(MI_ERR_STATE, "mi_part_push_connect was not called");
+    if ((rc = part_handoff_status(P))) return rc;
+    const unsigned step = ++P->push_step;
+    // one stream, four launches: my entries to the neighbours' windows, interior rows (need owned x only), wait for the
+    // neighbours' entries and move them behind x_local, boundary rows
+    if (P->n_links) hipLaunchKernelGGL(halo_push_kernel, dim3(P->n_links), dim3(256), 0, s, P->d_links, P->d_send_idx, d_x_ext, step);
+    if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;
+    if (P->n_nb) {
+        int grid = (pl.n_halo + 4095) / 4096;
+        grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
+        hipLaunchKernelGGL(halo_wait_copy_kernel, dim3(grid), dim3(256), 0, s, P->win_flags, P->d_nb, P->n_nb, step,
+                           P->win_data + (size_t)(step & 1u) * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1), d_x_ext + pl.n_local, pl.n_halo,
+                           P->d_timeouts);
+    }
+    if ((rc = mi_spmv_dev(P->piece[1], d_x_ext, d_y_local, s))) return rc;
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }

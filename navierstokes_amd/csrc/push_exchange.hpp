@@ -1,0 +1,72 @@
+// push_exchange.hpp — halo exchange by PEER PUSH: each rank's kernel writes the x entries its neighbours
+// need straight into a receive window in THEIR memory (mapped through HIP IPC; over xGMI between GPUs)
+// and raises a flag there; the receiver's kernel waits for its neighbours' flags and moves the window
+// into the halo part of x.  No RCCL call, no second stream, no event or flag-kernel hand-off: the step
+// is four launches on the caller's stream (push, interior rows, wait+copy, boundary rows).
+//
+// New design (the reference has no distributed code).  Protocol, per partition handle:
+//   * window = nranks flag slots (64 B apart, slot p written only by rank p) + 2 x n_halo doubles
+//     (two parities), allocated uncached so that neither side's L2 can hold a stale line;
+//   * step t (both sides count calls): the sender stores its entries into parity t & 1 of the peer's
+//     window, every storing thread drains its stores (system-scope fence), the workgroup meets at a
+//     barrier, ONE lane then stores t into its flag slot with system-scope release;
+//   * the receiver spins (bounded; a give-up is counted in host-visible memory and is sticky) until
+//     every NEIGHBOUR's slot shows >= t, fences (system acquire), and copies parity t & 1 into x;
+//   * neighbours are made symmetric (a rank also flags peers it only receives from): a sender can then
+//     only reach step t + 2 — and overwrite parity t & 1 — after it saw the receiver's flag of step
+//     t + 1, which the receiver raises after its copy of step t in stream order.  Two parities suffice.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mi355 {
+
+constexpr int kWinFlagStride = 16; // unsigneds: one 64-byte line per sender
+
+struct PushLink {
+    double* dst[2];  // where my entries go in the peer's window, per parity
+    unsigned* flag;  // my slot in the peer's window
+    int send_off;    // offset of this peer's list in send_idx
+    int count;       // entries to push (0: flag only)
+    int first;       // >= 0: the list is the contiguous slice x[first .. first+count)
+};
+
+__global__ __launch_bounds__(256) void halo_push_kernel(const PushLink* __restrict__ links, const int* __restrict__ send_idx,
+                                                        const double* __restrict__ x, unsigned step)
+{
+    const PushLink L = links[blockIdx.x];
+    double* dst = L.dst[step & 1u];
+    if (L.first >= 0) {
+        for (int i = threadIdx.x; i < L.count; i += 256) dst[i] = x[L.first + i];
+    } else {
+        for (int i = threadIdx.x; i < L.count; i += 256) dst[i] = x[send_idx[L.send_off + i]];
+    }
+    __threadfence_system(); // every storing thread: its stores have left for the peer
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(L.flag, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void halo_wait_copy_kernel(const unsigned* flags, const int* __restrict__ nb, int n_nb, unsigned step,
+                                                             const double* src, double* __restrict__ dst, int n_halo,
+                                                             unsigned* timeouts /* host-visible */)
+{
+    for (int j = threadIdx.x; j < n_nb; j += 256) {
+        const unsigned* f = flags + (size_t)nb[j] * kWinFlagStride;
+        unsigned spins = 0;
+        // flags are monotone step numbers; "behind" is computed modulo 2^32 so that a wrap after 4e9 steps is harmless
+        while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
+            if (spins < 4096) __builtin_amdgcn_s_sleep(2);
+            else __builtin_amdgcn_s_sleep(127);
+            if (++spins > (1u << 26)) {
+                __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // system scope: the data the flags announce
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_halo; i += stride)
+        dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+} // namespace mi355

@@ -10,9 +10,12 @@ GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on the GPU box,
     3. interior  rows without ghost columns                     (overlaps 2.)
     4. boundary  rows with ghost columns, after the halos land
 
-Two drivers of the same step: ``mi_part_spmv_dev`` (C++, grouped ncclSend/ncclRecv
+Three drivers of the same step: ``mi_part_spmv_dev`` (C++, grouped ncclSend/ncclRecv
 on the partition's own stream, no per-step Python) when librccl resolves on every
-rank, else steps 1-4 from here with one ``all_to_all_single``.
+rank; ``mi_part_spmv_push_dev`` (C++, peer-push windows over HIP IPC, no RCCL and no
+second stream; ``exchange="push"`` / ``MI355_DIST_EXCHANGE=push``); else steps 1-4 from
+here with one ``all_to_all_single``.  Whichever is chosen is first checked bit for
+bit against the ``torch.distributed`` exchange, collectively.
 
 The planner (column relabelling, interior/boundary split, send lists) is the
 C++ code behind ``mi_part_*`` in the C-ABI; this module only moves the ids and
@@ -48,7 +51,7 @@ def balanced_row_starts(n, nranks, nnz_per_row=None):
 class DistCSR:
     """This rank's share of a row-partitioned csrmatrix."""
 
-    def __init__(self, row_starts, ptrow, indcol_global, coef, group=None, device=None, compute=None, kernel=None):
+    def __init__(self, row_starts, ptrow, indcol_global, coef, group=None, device=None, compute=None, kernel=None, exchange=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.nranks = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -105,15 +108,25 @@ class DistCSR:
             if kernel is not None:
                 mpk.check(L.mi_part_set_kernel(h, mpk.KERNELS[kernel] if isinstance(kernel, str) else int(kernel)))
             self._send_idx = None
-            self.native = self._try_native_exchange()
+            import os
+            # which exchange drives the step (collective choice; every candidate is self-checked against the
+            # torch.distributed exchange before it is trusted): "native" = C++ step over RCCL send/recv (default where
+            # librccl resolves), "push" = peer-push windows over HIP IPC, no RCCL (mi_part_spmv_push_dev), "torch"
+            self.exchange = exchange or os.environ.get("MI355_DIST_EXCHANGE", "native")
+            assert self.exchange in ("native", "push", "torch"), self.exchange
+            self.push = self.exchange == "push" and self._try_push_exchange()
+            self.native = self.exchange == "native" and self._try_native_exchange()
         else:
             self.native = False
+            self.push = False
             tot, ptr = _c.c_int(), _vp()
             mpk.check(L.mi_part_send_index(h, _c.byref(tot), _c.byref(ptr)))
             self._send_idx = (np.ctypeslib.as_array(_c.cast(ptr, _c.POINTER(_c.c_int)), shape=(tot.value,)).copy()
                               if tot.value else np.zeros(0, np.int32))
         self.sendbuf = torch.empty(max(self.n_send, 1), dtype=torch.float64, device=self.device)
         import os
+        if self.push and not self._native_selfcheck():
+            self.push = False
         if self.native and not self._native_selfcheck():
             self.native = False  # collective decision: every rank falls back to the torch.distributed exchange
         elif not self.native and compute is None and self.nranks > 1 and os.environ.get("MI355_DIST_FORCE_SELFCHECK") == "1":
@@ -148,6 +161,32 @@ class DistCSR:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag) == 1
 
+    def _try_push_exchange(self):
+        """Set up the peer-push exchange (include/mi355_spmv.h: mi_part_push_*): every rank exports its receive window,
+        the IPC handles and layouts are all-gathered, every rank maps its neighbours' windows.  Collective."""
+        if self.nranks == 1:
+            return False
+        L = mpk.lib()
+        handle = _c.create_string_buffer(64)
+        layout = np.zeros(2 * self.nranks + 1, np.int64)
+        rc = L.mi_part_push_export(self._h, handle, layout.ctypes.data)
+        mine = (rc, bytes(handle.raw), layout.tolist())
+        everyone = [None] * self.nranks
+        dist.all_gather_object(everyone, mine, group=self.group)
+        ok = all(e[0] == 0 for e in everyone)
+        if ok:
+            handles = b"".join(e[1] for e in everyone)
+            layouts = np.ascontiguousarray([e[2] for e in everyone], dtype=np.int64)
+            ok = L.mi_part_push_connect(self._h, _c.create_string_buffer(handles, len(handles)), layouts.ctypes.data) == 0
+        flags = [None] * self.nranks
+        dist.all_gather_object(flags, bool(ok), group=self.group)
+        return all(flags)
+
+    def status(self):
+        """Raises if a hand-off / halo wait of the native or push step ever gave up (call after synchronising)."""
+        if self.compute is None:
+            mpk.check(mpk.lib().mi_part_status(self._h))
+
     def _native_selfcheck(self):
         """One product through the native C++ step and one through the torch.distributed exchange on the same
         (seeded) vector: the two must agree bit for bit on every rank, or nobody uses the native step."""
@@ -161,11 +200,11 @@ class DistCSR:
             torch.cuda.synchronize()
             halo_native = x_ext[self.n_local:].clone()
             x_ext[self.n_local:] = float("nan")
-            was_native, self.native = self.native, False
+            was_native, was_push, self.native, self.push = self.native, self.push, False, False
             y_torch = self.new_y()
             self.spmv(x_ext, y_torch)
             torch.cuda.synchronize()
-            self.native = was_native
+            self.native, self.push = was_native, was_push
             if not (torch.equal(y_native, y_torch) and torch.equal(halo_native, x_ext[self.n_local:])):
                 ok = 0
         except Exception:  # noqa: BLE001 - any failure means: do not use it
@@ -216,6 +255,9 @@ class DistCSR:
             px, py = _vp(x_ext.data_ptr()), _vp(y_local.data_ptr())
             if self.native:  # the whole step inside the library: pack, RCCL exchange, interior, boundary
                 mpk.check(L.mi_part_spmv_dev(self._h, px, py, sp))
+                return y_local
+            if self.push:    # the whole step inside the library, no RCCL: push, interior, wait + copy, boundary
+                mpk.check(L.mi_part_spmv_push_dev(self._h, px, py, sp))
                 return y_local
         if self.nranks > 1:
             if dev:

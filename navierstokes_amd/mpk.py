@@ -76,6 +76,9 @@ def lib():
         "mi_orthonormalize_against_basis": [i, i, _vp, _vp, _vp],
         "mi_orthonormalize_against_basis_dev": [i, i, _vp, _vp, _vp, _vp],
         "mi_part_status": [_vp],
+        "mi_part_push_export": [_vp, _vp, _vp],
+        "mi_part_push_connect": [_vp, _vp, _vp],
+        "mi_part_spmv_push_dev": [_vp, _vp, _vp, _vp],
         "mi_bcsr4_spmm": [_vp, i, _vp, ll, _vp, ll, i],
         "mi_bcsr4_spmm_dev": [_vp, i, _vp, ll, _vp, ll, i, _vp],
         "mi_spmm_dev": [_vp, i, _vp, ll, _vp, ll, _vp],

@@ -26,15 +26,24 @@ def main():
     lo, hi = int(rs[rank]), int(rs[rank + 1])
     p, c, v = synth.rows(kind, n, lo, hi, w=w)
     ok = True
+    exchange = os.environ.get("MI355_TEST_EXCHANGE", "torch")
     for kernel in (None, "ring", "stream"):
-        dc = D.DistCSR(rs, p, c, v, kernel=kernel)
-        assert not dc.native  # gloo: host-staged exchange
+        dc = D.DistCSR(rs, p, c, v, kernel=kernel, exchange=exchange)
+        assert not dc.native  # gloo: no RCCL
+        assert dc.push == (exchange == "push"), "peer-push exchange was requested but did not come up (or vice versa)"
         x_ext = dc.new_x_ext()
         x_ext[: dc.n_local] = torch.from_numpy(synth.x_sin(lo, hi)).cuda()
         ys = dc.spmk(x_ext, dc.new_power_buffers(3))
         torch.cuda.synchronize()
         Y = O.spmk_chain(3, Pg, Cg, Vg, synth.x_sin(0, n))
         ok = ok and all(np.array_equal(ys[k].cpu().numpy().view(np.uint64), Y[k][lo:hi].view(np.uint64)) for k in range(3))
+        if dc.push:  # many unsynchronised repetitions of one step into the same buffers: the windows' two parities at work
+            y = dc.new_y()
+            for _ in range(50):
+                dc.spmv(x_ext, y)
+            torch.cuda.synchronize()
+            dc.status()
+            ok = ok and np.array_equal(y.cpu().numpy().view(np.uint64), Y[0][lo:hi].view(np.uint64))
         g = float(dc.dot(ys[0], ys[0]))
         ref = float(np.dot(Y[0], Y[0]))
         ok = ok and abs(g - ref) <= 1e-12 * ref

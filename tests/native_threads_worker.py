@@ -24,10 +24,12 @@ vp = ctypes.c_void_p
 
 def main():
     kind, n, w, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    assert os.environ.get("MI355_RCCL_LIBRARY", "").endswith("libfake_rccl.so")
+    push = os.environ.get("MI355_TEST_EXCHANGE") == "push"  # peer-push windows instead of the (stand-in) RCCL exchange
+    assert push or os.environ.get("MI355_RCCL_LIBRARY", "").endswith("libfake_rccl.so")
     torch.cuda.set_device(0)
     L = mpk.lib()
-    mpk.check(L.mi_comm_available())
+    if not push:
+        mpk.check(L.mi_comm_available())
     Pg, Cg, Vg = synth.rows(kind, n, w=w)
     rs = D.balanced_row_starts(n, N, np.diff(Pg))
     # ---- setup on the main thread: plans, id exchange (all ranks live here), finalize
@@ -53,7 +55,20 @@ def main():
         mpk.check(L.mi_part_set_send_ids(parts[r], r, 0, np.empty(1, np.int64).ctypes.data))
         mpk.check(L.mi_part_finalize(parts[r]))
     idbuf = ctypes.create_string_buffer(128)
-    mpk.check(L.mi_comm_unique_id(idbuf))
+    if push:  # windows of ranks living in one process are connected through the library's registry, not hipIpcOpenMemHandle
+        handles, layouts = b"", []
+        for r in range(N):
+            hb, lay = ctypes.create_string_buffer(64), np.zeros(2 * N + 1, np.int64)
+            mpk.check(L.mi_part_push_export(parts[r], hb, lay.ctypes.data))
+            handles += hb.raw
+            layouts.append(lay)
+        layouts = np.ascontiguousarray(layouts)
+        for r in range(N):
+            mpk.check(L.mi_part_push_connect(parts[r], ctypes.create_string_buffer(handles, len(handles)), layouts.ctypes.data))
+        step_fn = L.mi_part_spmv_push_dev
+    else:
+        mpk.check(L.mi_comm_unique_id(idbuf))
+        step_fn = L.mi_part_spmv_dev
     Y = O.spmk_chain(4, Pg, Cg, Vg, synth.x_sin(0, n))
     results = [None] * N
 
@@ -64,21 +79,23 @@ def main():
             nl, nh = ctypes.c_int(), ctypes.c_int()
             mpk.check(L.mi_part_sizes(h, ctypes.byref(nl), ctypes.byref(nh), None, None))
             nl, nh = nl.value, nh.value
-            mpk.check(L.mi_part_comm_init(h, ctypes.create_string_buffer(idbuf.raw, 128)))  # collective over the threads
+            if not push:
+                mpk.check(L.mi_part_comm_init(h, ctypes.create_string_buffer(idbuf.raw, 128)))  # collective over the threads
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 bufs = [torch.zeros(nl + nh, dtype=torch.float64, device="cuda") for _ in range(5)]
                 bufs[0][:nl] = torch.from_numpy(synth.x_sin(lo, hi)).cuda()
                 sp = vp(st.cuda_stream)
                 for k in range(4):  # powers: output of step k is the owned part of step k+1's input
-                    mpk.check(L.mi_part_spmv_dev(h, vp(bufs[k].data_ptr()), vp(bufs[k + 1].data_ptr()), sp))
+                    mpk.check(step_fn(h, vp(bufs[k].data_ptr()), vp(bufs[k + 1].data_ptr()), sp))
                 st.synchronize()
                 ok = all(np.array_equal(bufs[k + 1][:nl].cpu().numpy().view(np.uint64), Y[k][lo:hi].view(np.uint64))
                          for k in range(4))
                 y = torch.full((nl,), float("nan"), dtype=torch.float64, device="cuda")
                 for _ in range(40):  # same buffers again and again, never synchronising in between
-                    mpk.check(L.mi_part_spmv_dev(h, vp(bufs[0].data_ptr()), vp(y.data_ptr()), sp))
+                    mpk.check(step_fn(h, vp(bufs[0].data_ptr()), vp(y.data_ptr()), sp))
                 st.synchronize()
+                mpk.check(L.mi_part_status(h))
                 ok = ok and np.array_equal(y.cpu().numpy().view(np.uint64), Y[0][lo:hi].view(np.uint64))
             results[r] = ok
         except Exception as e:  # noqa: BLE001

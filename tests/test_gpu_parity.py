@@ -341,15 +341,19 @@ def test_native_step_single_rank():
     assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v, x), "native step, 1 rank")
 
 
-@pytest.mark.parametrize("world,kind,n,w,port", [(3, "svar", 120_000, 2000, 29611), (2, "sfe", 60_000, 1500, 29612)])
-def test_ranks_sharing_one_card(world, kind, n, w, port):
-    """The N>1 pipeline on real HIP kernels: `world` ranks on cuda:0, halos over gloo (host-staged; RCCL
-    rejects duplicate devices), A x, A^2 x, A^3 x and a global dot, every rank's slice bitwise."""
+@pytest.mark.parametrize("world,kind,n,w,port,exchange", [(3, "svar", 120_000, 2000, 29611, "torch"), (2, "sfe", 60_000, 1500, 29612, "torch"),
+                                                           (2, "s15", 200_000, 2000, 29613, "push"), (4, "svar", 160_000, 2000, 29614, "push"),
+                                                           (3, "sfe", 60_000, 1500, 29615, "push")])
+def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
+    """The N>1 pipeline on real HIP kernels: `world` ranks (processes) on cuda:0, A x, A^2 x, A^3 x and a global dot, every
+    rank's slice bitwise.  exchange "torch": halos over gloo, host-staged (RCCL rejects duplicate devices).  exchange "push":
+    the library's peer-push step (mi_part_spmv_push_dev) — receive windows mapped into the other PROCESSES with HIP IPC,
+    kernels of one process writing into the window of another and raising its flags; gloo only carries the set-up."""
     import os
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MI355_DIST_FORCE_SELFCHECK="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MI355_DIST_FORCE_SELFCHECK="1", MI355_TEST_EXCHANGE=exchange)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_gpu_worker.py"), kind, str(n), str(w)]
@@ -397,10 +401,12 @@ def test_fe_matrix_takes_the_blocked_kernel_with_identical_bits():
         B.set_kernel("bcsr4")
 
 
-@pytest.mark.parametrize("kind,n,w,ranks,dense", [("s15", 240_000, 2000, 4, "1"), ("svar", 90_000, 2000, 3, "1"),
-                                                    ("sfe", 64_000, 1500, 2, "1"), ("s15", 150_000, 2000, 3, "0"),
-                                                    ("s15", 480_000, 2000, 8, "1")])
-def test_native_step_multirank_threads(kind, n, w, ranks, dense):
+@pytest.mark.parametrize("kind,n,w,ranks,dense,mode", [("s15", 240_000, 2000, 4, "1", "events"), ("svar", 90_000, 2000, 3, "1", "events"),
+                                                         ("sfe", 64_000, 1500, 2, "1", "flags"), ("s15", 150_000, 2000, 3, "0", "flags"),
+                                                         ("s15", 480_000, 2000, 8, "1", "events"),
+                                                         ("s15", 240_000, 2000, 4, "1", "push"), ("s15", 150_000, 2000, 3, "0", "push"),
+                                                         ("s15", 480_000, 2000, 8, "1", "push")])
+def test_native_step_multirank_threads(kind, n, w, ranks, dense, mode):
     """The library's native multi-rank step (C++: pack + exchange on a comm stream, interior beside, boundary
     behind) with `ranks` ranks as threads on this one GPU and tests/fake_rccl in place of librccl, which refuses
     two ranks per device.  Bitwise for 4 chained powers and for 40 unsynchronised repetitions of one step."""
@@ -411,7 +417,13 @@ def test_native_step_multirank_threads(kind, n, w, ranks, dense):
     fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
     assert os.path.exists(fake), "run __graft_entry__.build() first (it builds tests/fake_rccl)"
     # dense = "1": ghost ranges, contiguous slices of x sent in place; "0": exact ghost sets, pack kernel + send buffer
+    # mode: "events" / "flags" = cross-stream hand-offs of the RCCL step (mi_part_spmv_dev); "push" = the peer-push step
+    # (mi_part_spmv_push_dev: no RCCL at all, windows connected through the in-process registry)
     env = dict(os.environ, MI355_RCCL_LIBRARY=fake, OMP_NUM_THREADS="1", MI355_PART_DENSE_HALO=dense)
+    if mode == "push":
+        env["MI355_TEST_EXCHANGE"] = "push"
+    else:
+        env["MI355_PART_HANDOFF"] = mode
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native_threads_worker.py"), kind, str(n), str(w), str(ranks)],
                        env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
