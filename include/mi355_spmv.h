@@ -290,7 +290,7 @@ int mi_part_status(mi_part_t P);
  * on the caller's stream — push, interior rows, wait + copy, boundary rows — with no RCCL call, no second stream and no
  * cross-stream hand-off.  Set-up (collective, once): every rank calls mi_part_push_export, the 64-byte handles and the
  * (2*nranks+1)-entry layouts are all-gathered by any side channel, every rank calls mi_part_push_connect with all of
- * them.  Ranks of one process (threads) are connected directly, ranks of other processes through hipIpcOpenMemHandle.
+ * them.  One PROCESS per rank (ranks as threads of one process share hardware queues and can deadlock in the wait).
  * All ranks must then call mi_part_spmv_push_dev the same number of times (the flags carry the step number).
  * A wait on a stalled neighbour gives up after minutes; that is sticky and reported like a hand-off time-out. */
 #define MI_IPC_HANDLE_BYTES 64

@@ -29,7 +29,7 @@ __global__ void flag_wait_kernel(const unsigned* flag, unsigned value, unsigned*
             // minutes (a peer may be busy setting up its RCCL channels on the first steps) — never hang for good
             if (spins < 4096) __builtin_amdgcn_s_sleep(2);
             else __builtin_amdgcn_s_sleep(127);
-            if (++spins > (1u << 26)) {
+            if (++spins > (1u << 24)) { // ~1 min
                 __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }

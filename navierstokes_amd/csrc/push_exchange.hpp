@@ -10,6 +10,9 @@
 //   * step t (both sides count calls): the sender stores its entries into parity t & 1 of the peer's
 //     window, every storing thread drains its stores (system-scope fence), the workgroup meets at a
 //     barrier, ONE lane then stores t into its flag slot with system-scope release;
+//   * ONE PROCESS PER RANK: the receiver's wait kernel spins until another rank's push kernel has run; ranks that are
+//     threads of one process share that process's few hardware queues, where a waiting kernel can be queued in front
+//     of the very kernel it waits for (observed: 4 rank threads hang).  Separate processes have separate queues.
 //   * the receiver spins (bounded; a give-up is counted in host-visible memory and is sticky) until
 //     every NEIGHBOUR's slot shows >= t, fences (system acquire), and copies parity t & 1 into x;
 //   * neighbours are made symmetric (a rank also flags peers it only receives from): a sender can then
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void halo_wait_copy_kernel(const unsigned* fla
         while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
             if (spins < 4096) __builtin_amdgcn_s_sleep(2);
             else __builtin_amdgcn_s_sleep(127);
-            if (++spins > (1u << 26)) {
+            if (++spins > (1u << 23)) { // ~30 s
                 __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }

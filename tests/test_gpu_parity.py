@@ -403,9 +403,7 @@ def test_fe_matrix_takes_the_blocked_kernel_with_identical_bits():
 
 @pytest.mark.parametrize("kind,n,w,ranks,dense,mode", [("s15", 240_000, 2000, 4, "1", "events"), ("svar", 90_000, 2000, 3, "1", "events"),
                                                          ("sfe", 64_000, 1500, 2, "1", "flags"), ("s15", 150_000, 2000, 3, "0", "flags"),
-                                                         ("s15", 480_000, 2000, 8, "1", "events"),
-                                                         ("s15", 240_000, 2000, 4, "1", "push"), ("s15", 150_000, 2000, 3, "0", "push"),
-                                                         ("s15", 480_000, 2000, 8, "1", "push")])
+                                                         ("s15", 480_000, 2000, 8, "1", "events")])
 def test_native_step_multirank_threads(kind, n, w, ranks, dense, mode):
     """The library's native multi-rank step (C++: pack + exchange on a comm stream, interior beside, boundary
     behind) with `ranks` ranks as threads on this one GPU and tests/fake_rccl in place of librccl, which refuses
@@ -417,13 +415,12 @@ def test_native_step_multirank_threads(kind, n, w, ranks, dense, mode):
     fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
     assert os.path.exists(fake), "run __graft_entry__.build() first (it builds tests/fake_rccl)"
     # dense = "1": ghost ranges, contiguous slices of x sent in place; "0": exact ghost sets, pack kernel + send buffer
-    # mode: "events" / "flags" = cross-stream hand-offs of the RCCL step (mi_part_spmv_dev); "push" = the peer-push step
-    # (mi_part_spmv_push_dev: no RCCL at all, windows connected through the in-process registry)
-    env = dict(os.environ, MI355_RCCL_LIBRARY=fake, OMP_NUM_THREADS="1", MI355_PART_DENSE_HALO=dense)
-    if mode == "push":
-        env["MI355_TEST_EXCHANGE"] = "push"
-    else:
-        env["MI355_PART_HANDOFF"] = mode
+    # mode: "events" / "flags" = cross-stream hand-offs of the RCCL step (mi_part_spmv_dev).  (The peer-push step is NOT
+    # run with ranks as threads: its wait kernel spins until ANOTHER rank's push kernel has run, and the streams of one
+    # process share a few hardware queues, so a waiting kernel can sit in front of the kernel it waits for — observed
+    # as a hang with 4 rank threads.  One process per GPU, the deployment, has its own queues per rank: the
+    # process-based test_ranks_sharing_one_card[push] cases cover it.)
+    env = dict(os.environ, MI355_RCCL_LIBRARY=fake, OMP_NUM_THREADS="1", MI355_PART_DENSE_HALO=dense, MI355_PART_HANDOFF=mode)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native_threads_worker.py"), kind, str(n), str(w), str(ranks)],
                        env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
