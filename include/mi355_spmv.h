@@ -297,6 +297,8 @@ int mi_part_status(mi_part_t P);
 int mi_part_push_export(mi_part_t P, void* handle64, long long* layout /* [2*nranks + 1] */);
 int mi_part_push_connect(mi_part_t P, const void* handles /* nranks x 64 B */, const long long* layouts /* nranks x (2*nranks+1) */);
 int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s);
+/* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
+int mi_part_push_debug_preset(mi_part_t P, unsigned value);
 
 /* development check of the RCCL plumbing on ONE GPU: a communicator of size 1 sends
  * `count` doubles to itself through the same send/recv/stream/event code path

@@ -2160,6 +2160,16 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
     return MI_OK;
 }
 
+// development aid (tools/sim_rank.py): set every flag slot of MY window to `value`, so that one rank's step can be timed on
+// one GPU with its pushes looped back into its own window and its waits satisfied in advance
+extern "C" int mi_part_push_debug_preset(mi_part_t P, unsigned value)
+{
+    CHECK_ARG(P && P->win, "no window");
+    std::vector<unsigned> f((size_t)P->plan.nranks * kWinFlagStride, value);
+    HIP_TRY(hipMemcpy(P->win_flags, f.data(), sizeof(unsigned) * f.size(), hipMemcpyHostToDevice));
+    return MI_OK;
+}
+
 extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s_)
 {
     CHECK_ARG(P, "null handle");
