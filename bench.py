@@ -244,7 +244,7 @@ def main():
                 dc.spmk(x_ext, pbufs, sp)
         halo_info = dict(n_halo=dc.n_halo, n_send=dc.n_send, interior_rows=dc.n_interior, boundary_rows=dc.n_boundary,
                          exchange="native RCCL send/recv (mi_part_spmv_dev)" if dc.native
-                         else "peer push over HIP IPC windows, no RCCL (mi_part_spmv_push_dev)" if dc.push
+                         else ("peer push over HIP IPC windows, no RCCL (mi_part_spmv_push_dev), " + ("ONE launch per step" if dc.push_fused else "four launches per step")) if dc.push
                          else ("torch.distributed all_to_all_single" if dc._nccl else "host-staged (non-NCCL backend, development)"))
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
@@ -376,6 +376,10 @@ def main():
                 how = "oracle fma chain on each rank's rows, halos from the generator"
             else:  # power 1 as above (checks the exchange); power i+1 from power i's exchanged buffer
                 same = np.array_equal(O.spmv(p, cl, v, xe).view(np.uint64), pbufs[0][: dc.n_local].cpu().numpy().view(np.uint64))
+                if dc.push_fused:  # that step reads ghosts from its window and leaves the halo parts alone: fetch them for the check
+                    for i in range(k - 1):
+                        dc.refresh_halo(pbufs[i])
+                    torch.cuda.synchronize()
                 for i in range(1, k):
                     yo = O.spmv(p, cl, v, pbufs[i - 1].cpu().numpy())
                     same = same and np.array_equal(yo.view(np.uint64), pbufs[i][: dc.n_local].cpu().numpy().view(np.uint64))

@@ -297,6 +297,11 @@ int mi_part_status(mi_part_t P);
 int mi_part_push_export(mi_part_t P, void* handle64, long long* layout /* [2*nranks + 1] */);
 int mi_part_push_connect(mi_part_t P, const void* handles /* nranks x 64 B */, const long long* layouts /* nranks x (2*nranks+1) */);
 int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s);
+/* *fused = 1: the step is ONE launch — when all local rows form a piece the ring kernel serves, the push duty (first
+ * workgroups of the grid) and the ghost reads (straight from the window, behind an in-kernel wait in the runs that
+ * touch ghosts, which are ordered last) live inside that kernel (spmv_ring.hpp, FUSED; MI355_PUSH_FUSED=0 disables).
+ * In the fused form the halo part of d_x_ext is neither read nor written. */
+int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
 /* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
 int mi_part_push_debug_preset(mi_part_t P, unsigned value);
 

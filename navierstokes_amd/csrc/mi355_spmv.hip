@@ -171,6 +171,10 @@ struct mi_part_s {
     int n_nb = 0;
     unsigned push_step = 0;
     bool push_ready = false;
+    // the one-launch form of the push step (spmv_ring.hpp, FUSED): all local rows in one ring-served, row-mapped piece
+    mi_csr_t piece_all = nullptr;
+    int* d_run_halo = nullptr;
+    bool fused = false;
 };
 
 // windows of ranks living in THIS process (rank threads; hipIpcOpenMemHandle refuses a handle of the opening process)
@@ -282,7 +286,7 @@ static int get_table(mi_csr_t A, int nnzb, BlockTable** out)
     return MI_OK;
 }
 
-static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true);
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr);
 static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);
 static int resolve_kernel(const mi_csr_s* A);
 
@@ -1004,30 +1008,35 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
 
 // ---------------------------------------------------------------- SpMV launch
 template <int T, int NNZB, int RING, int D, bool MAPPED, bool NT, bool SKEW>
-static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
+static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm)
 {
-    hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW>), dim3(A->ring.wgs), dim3(T), 0, s, V,
-                       reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, A->ring.bpw);
+    if (MAPPED && comm) { // the fused multi-GPU step: push workgroups in front of the grid (spmv_ring.hpp)
+        hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, true>), dim3(A->ring.wgs + comm->push_wgs), dim3(T), 0, s,
+                           V, reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, A->ring.bpw, *comm);
+        return;
+    }
+    hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, false>), dim3(A->ring.wgs), dim3(T), 0, s, V,
+                       reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, A->ring.bpw, RingComm{});
 }
 
 template <int T, int NNZB, int RING, int D, bool MAPPED>
-static void launch_ring1(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
+static void launch_ring1(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm)
 {
     if (A->ring.nt) {
-        if (A->ring.skew) launch_ring2<T, NNZB, RING, D, MAPPED, true, true>(A, V, d_x, d_y, s);
-        else launch_ring2<T, NNZB, RING, D, MAPPED, true, false>(A, V, d_x, d_y, s);
+        if (A->ring.skew) launch_ring2<T, NNZB, RING, D, MAPPED, true, true>(A, V, d_x, d_y, s, comm);
+        else launch_ring2<T, NNZB, RING, D, MAPPED, true, false>(A, V, d_x, d_y, s, comm);
     } else {
-        if (A->ring.skew) launch_ring2<T, NNZB, RING, D, MAPPED, false, true>(A, V, d_x, d_y, s);
-        else launch_ring2<T, NNZB, RING, D, MAPPED, false, false>(A, V, d_x, d_y, s);
+        if (A->ring.skew) launch_ring2<T, NNZB, RING, D, MAPPED, false, true>(A, V, d_x, d_y, s, comm);
+        else launch_ring2<T, NNZB, RING, D, MAPPED, false, false>(A, V, d_x, d_y, s, comm);
     }
 }
 
 template <int T, int NNZB, int RING, int D>
-static void launch_ring(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s)
+static void launch_ring(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm)
 {
     static_assert(NNZB <= kRingPadNnz && 2 * T + 1 <= kRingPadRows, "device arrays are padded for the kernel's unclamped loads");
-    if (V.rowmap) launch_ring1<T, NNZB, RING, D, true>(A, V, d_x, d_y, s);
-    else launch_ring1<T, NNZB, RING, D, false>(A, V, d_x, d_y, s);
+    if (V.rowmap) launch_ring1<T, NNZB, RING, D, true>(A, V, d_x, d_y, s, comm);
+    else launch_ring1<T, NNZB, RING, D, false>(A, V, d_x, d_y, s, comm);
 }
 
 // dst[idx[i]] = src[i]
@@ -1038,7 +1047,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(int m, const int* __restri
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) dst[idx[i]] = src[i];
 }
 
-static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map)
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm)
 {
     if (A->n == 0) return MI_OK;
     if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
@@ -1075,10 +1084,10 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
     } else if (kid == MI_KERNEL_RING) {
         V.nblk = A->ring.nblk;
         switch (A->ring.cfg.id) {
-        case 1: launch_ring<512, 2048, 5120, 2>(A, V, d_x, d_y, s); break;
-        case 2: launch_ring<512, 4096, 5120, 2>(A, V, d_x, d_y, s); break;
-        case 3: launch_ring<512, 4096, 11264, 2>(A, V, d_x, d_y, s); break;
-        default: launch_ring<256, 2048, 5120, 2>(A, V, d_x, d_y, s); break;
+        case 1: launch_ring<512, 2048, 5120, 2>(A, V, d_x, d_y, s, comm); break;
+        case 2: launch_ring<512, 4096, 5120, 2>(A, V, d_x, d_y, s, comm); break;
+        case 3: launch_ring<512, 4096, 11264, 2>(A, V, d_x, d_y, s, comm); break;
+        default: launch_ring<256, 2048, 5120, 2>(A, V, d_x, d_y, s, comm); break;
         }
     } else {
         BlockTable* T = nullptr;
@@ -1754,6 +1763,11 @@ static void part_comm_release(mi_part_s* P)
     dfree(P->win);
     dfree(P->d_links);
     dfree(P->d_nb);
+    dfree(P->d_run_halo);
+    mi_csr_destroy(P->piece_all);
+    P->piece_all = nullptr;
+    P->d_run_halo = nullptr;
+    P->fused = false;
     P->win = nullptr;
     P->d_links = nullptr;
     P->d_nb = nullptr;
@@ -2157,6 +2171,46 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
     }
     P->push_step = 0;
     P->push_ready = true;
+    // The one-launch step needs all local rows as ONE piece that the ring kernel serves (the push duty and the ghost
+    // reads live in that kernel).  MI355_PUSH_FUSED=0 keeps the four-launch form.
+    const char* fe = getenv("MI355_PUSH_FUSED");
+    if (!(fe && !strcmp(fe, "0")) && pl.n_local > 0) {
+        P->plan.build_combined();
+        const LocalPiece& L = P->plan.all;
+        rc = mi_csr_create_mapped((int)L.rowmap.size(), pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), L.rowmap.data(),
+                                  &P->piece_all);
+        if (rc) return rc;
+        mi_csr_t A = P->piece_all;
+        if (P->kernel != MI_KERNEL_AUTO && P->kernel != MI_KERNEL_RING) A->kernel = P->kernel;
+        if (resolve_kernel(A) == MI_KERNEL_RING && A->d_rowmap) {
+            // which runs touch a ghost column (replay the plan's row blocks: the same deterministic cut)
+            std::vector<int> rows, ptrs;
+            build_row_blocks(A->n, L.ptrow.data(), A->ring.cfg.nnzb, 2 * A->ring.cfg.threads, rows, ptrs);
+            std::vector<int> run_halo((size_t)A->ring.wgs, 0);
+            if ((int)rows.size() - 1 == A->ring.nblk) {
+                for (int g = 0; g < A->ring.wgs; g++) {
+                    const int b0 = std::min(A->ring.nblk, g * A->ring.bpw), b1 = std::min(A->ring.nblk, (g + 1) * A->ring.bpw);
+                    for (int k = ptrs[b0]; k < ptrs[b1] && !run_halo[g]; k++) run_halo[g] = L.indcol[k] >= pl.n_local;
+                }
+                HIP_TRY(hipMalloc(&P->d_run_halo, sizeof(int) * run_halo.size()));
+                HIP_TRY(hipMemcpy(P->d_run_halo, run_halo.data(), sizeof(int) * run_halo.size(), hipMemcpyHostToDevice));
+                P->fused = true;
+            }
+        }
+        if (!P->fused) {
+            mi_csr_destroy(P->piece_all);
+            P->piece_all = nullptr;
+        }
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours)
+{
+    CHECK_ARG(P, "null handle");
+    if (ready) *ready = P->push_ready ? 1 : 0;
+    if (fused) *fused = P->fused ? 1 : 0;
+    if (neighbours) *neighbours = P->n_nb;
     return MI_OK;
 }
 
@@ -2184,6 +2238,23 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
     if (!P->push_ready) return fail(MI_ERR_STATE, "mi_part_push_connect was not called");
     if ((rc = part_handoff_status(P))) return rc;
     const unsigned step = ++P->push_step;
+    if (P->fused) { // ONE launch: push workgroups first, then the ring kernel over all rows, ghost readers waiting in-kernel
+        RingComm C;
+        C.links = P->d_links;
+        C.send_idx = P->d_send_idx;
+        C.flags = P->win_flags;
+        C.nb = P->d_nb;
+        C.halo = P->win_data + (size_t)(step & 1u) * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1);
+        C.run_halo = P->d_run_halo;
+        C.timeouts = P->d_timeouts;
+        C.n_links = P->n_links;
+        C.n_nb = P->n_nb;
+        C.n_local = pl.n_local;
+        C.push_wgs = kNXCD; // a multiple of the XCD count keeps the run-to-XCD mapping of the ring workgroups
+        C.step = step;
+        if ((rc = launch_spmv(P->piece_all, d_x_ext, d_y_local, s, true, &C))) return rc;
+        return MI_OK;
+    }
     // one stream, four launches: my entries to the neighbours' windows, interior rows (need owned x only), wait for the
     // neighbours' entries and move them behind x_local, boundary rows
     if (P->n_links) hipLaunchKernelGGL(halo_push_kernel, dim3(P->n_links), dim3(256), 0, s, P->d_links, P->d_send_idx, d_x_ext, step);

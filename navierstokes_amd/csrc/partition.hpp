@@ -34,6 +34,7 @@ struct PartPlan {
     std::vector<std::vector<int>> send_lists;   // local ids per peer
     std::vector<int> send_idx;                  // concatenated by peer
     LocalPiece piece[2];               // 0 interior, 1 boundary
+    LocalPiece all;                    // interior rows then boundary rows in ONE piece (the fused step); built on demand
     bool sends_set = false;
     bool sends_contiguous = false;     // every non-empty send list is a run of consecutive local ids: no pack needed
 
@@ -132,6 +133,22 @@ struct PartPlan {
         send_idx.clear();
         sends_set = (nranks == 1);
         return "";
+    }
+
+    // the one-launch step works on all local rows at once: interior rows first, boundary rows (the only ones that read
+    // ghosts) last, so that the workgroups which must wait for the neighbours start last
+    void build_combined()
+    {
+        if (!all.ptrow.empty()) return;
+        all.ptrow.push_back(0);
+        for (int w = 0; w < 2; w++) {
+            const LocalPiece& L = piece[w];
+            const int base = (int)all.indcol.size();
+            all.indcol.insert(all.indcol.end(), L.indcol.begin(), L.indcol.end());
+            all.coef.insert(all.coef.end(), L.coef.begin(), L.coef.end());
+            for (size_t r = 0; r < L.rowmap.size(); r++) all.ptrow.push_back(base + L.ptrow[r + 1]);
+            all.rowmap.insert(all.rowmap.end(), L.rowmap.begin(), L.rowmap.end());
+        }
     }
 
     std::string set_send(int peer, int count, const long long* ids)

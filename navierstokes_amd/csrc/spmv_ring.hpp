@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "push_exchange.hpp"
 #include "spmv_kernels.hpp"
 
 namespace mi355 {
@@ -49,12 +50,40 @@ __device__ __forceinline__ int ring_slot(int c, int base)
     return p >= RING ? p - RING : p;
 }
 
+// The fused multi-GPU step (FUSED = true; mi_part_spmv_push_dev): ONE launch does a rank's whole product.
+//   * the first push_wgs workgroups do the peer push of push_exchange.hpp (this rank's entries into the neighbours'
+//     windows, then the flags) and exit; being first in the grid they are dispatched first and wait for nothing;
+//   * the others are the ring kernel over ALL local rows, interior rows first, boundary rows last.  Column ids
+//     >= n_local are ghosts: they are read from this rank's receive window (`halo`, uncached memory the neighbours'
+//     kernels write) instead of from x.  A run that touches a ghost (run_halo) first waits — bounded, loud — until every
+//     neighbour's flag shows this step; those runs are the last of the grid, by which time the flags are long up.
+// Against the four-launch form (push, interior, wait + copy, boundary) this removes three launches of ~4 us each from
+// a step whose whole interior kernel is 23 us at 8 ranks.
+struct RingComm {
+    const PushLink* links;
+    const int* send_idx;
+    const unsigned* flags; // my window's flag slots
+    const int* nb;         // neighbours to wait for
+    const double* halo;    // my window's data, this step's parity
+    const int* run_halo;   // per run: touches a ghost column
+    unsigned* timeouts;    // host-visible
+    int n_links, n_nb, n_local, push_wgs;
+    unsigned step;
+};
+
+template <bool FUSED>
+__device__ __forceinline__ double ring_ldx(const double* __restrict__ x, const RingComm& C, int c)
+{
+    if (FUSED) return *(c < C.n_local ? x + c : C.halo + (c - C.n_local));
+    return x[c];
+}
+
 // Plain per-block SpMV (global gather, any row length): the path of runs the ring
 // cannot serve.  Same arithmetic, no pipelining.
-template <int T, int NNZB, bool MAPPED>
+template <int T, int NNZB, bool MAPPED, bool FUSED>
 __device__ __forceinline__ void ring_simple_block(const CsrView& A, const double* __restrict__ x,
                                                   double* __restrict__ y, int r0, int p0, int nrows, int nn,
-                                                  double* s_c, double* s_x)
+                                                  double* s_c, double* s_x, const RingComm& C)
 {
     const int tid = threadIdx.x;
     __syncthreads();
@@ -65,7 +94,7 @@ __device__ __forceinline__ void ring_simple_block(const CsrView& A, const double
             __syncthreads();
             for (int k = tid; k < m; k += T) {
                 s_c[sk(k)] = A.coef[bs + k];
-                s_x[sk(k)] = x[A.indcol[bs + k]];
+                s_x[sk(k)] = ring_ldx<FUSED>(x, C, A.indcol[bs + k]);
             }
             __syncthreads();
             if (tid == 0)
@@ -76,7 +105,7 @@ __device__ __forceinline__ void ring_simple_block(const CsrView& A, const double
     }
     for (int k = tid; k < nn; k += T) {
         s_c[sk(k)] = A.coef[p0 + k];
-        s_x[sk(k)] = x[A.indcol[p0 + k]];
+        s_x[sk(k)] = ring_ldx<FUSED>(x, C, A.indcol[p0 + k]);
     }
     __syncthreads();
     for (int r = r0 + tid; r < r0 + nrows; r += T) {
@@ -138,12 +167,12 @@ __device__ __forceinline__ double ring_row_chain(const double* s_c, const double
 // displacing x, the plan and the y lines being written (C4: 190 -> 169 us).  A matrix that fits
 // the cache is better served by it across repeated products (C2: 38 us temporal, 44 us NT), so
 // mi_csr_create times both and keeps the faster.
-template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool NT, bool SKEW>
+template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool NT, bool SKEW, bool FUSED = false>
 __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __restrict__ plan,
                                                    const int* __restrict__ run_ok,
                                                    const unsigned short* __restrict__ slots,
                                                    const double* __restrict__ x, double* __restrict__ y,
-                                                   int bpw)
+                                                   int bpw, RingComm C)
 {
     constexpr int PER = NNZB / T;
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
@@ -154,10 +183,27 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     __shared__ double s_ring[RING];
     __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
     const int tid = threadIdx.x;
+    if (FUSED && (int)blockIdx.x < C.push_wgs) { // push duty (push_exchange.hpp: halo_push_kernel's body, T threads)
+        for (int l = blockIdx.x; l < C.n_links; l += C.push_wgs) {
+            const PushLink L = C.links[l];
+            double* dst = L.dst[C.step & 1u];
+            if (L.first >= 0) {
+                for (int i = tid; i < L.count; i += T) dst[i] = x[L.first + i];
+            } else {
+                for (int i = tid; i < L.count; i += T) dst[i] = x[C.send_idx[L.send_off + i]];
+            }
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(L.flag, C.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     // XCD-aware run order: workgroups with equal (blockIdx & 7) share an XCD (observed
     // round-robin dispatch, a speed assumption only) and get neighbouring runs, so
     // the x columns one run loads are L2 hits for the next.
-    const int gw = (blockIdx.x & (kNXCD - 1)) * (gridDim.x / kNXCD) + (blockIdx.x >> 3);
+    const int bid = FUSED ? (int)blockIdx.x - C.push_wgs : (int)blockIdx.x;
+    const int nwg = FUSED ? (int)gridDim.x - C.push_wgs : (int)gridDim.x;
+    const int gw = (bid & (kNXCD - 1)) * (nwg / kNXCD) + (bid >> 3);
     const int b_begin = gw * bpw;
     const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
     if (nb <= 0) return;
@@ -179,10 +225,26 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
         }
     }
     __syncthreads();
+    if (FUSED && C.run_halo[gw]) { // this run reads ghosts: every neighbour's entries of this step must have landed
+        for (int j = tid; j < C.n_nb; j += T) {
+            const unsigned* f = C.flags + (size_t)C.nb[j] * kWinFlagStride;
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - C.step) < 0) {
+                if (spins < 4096) __builtin_amdgcn_s_sleep(2);
+                else __builtin_amdgcn_s_sleep(127);
+                if (++spins > (1u << 23)) {
+                    __hip_atomic_fetch_add(C.timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
     if (!run_ok[gw]) {
         for (int lb = 0; lb < nb; lb++) {
             const int4 m0 = s_plan[2 * lb];
-            ring_simple_block<T, NNZB, MAPPED>(A, x, y, m0.x, m0.y, m0.z, m0.w, s_c, s_x);
+            ring_simple_block<T, NNZB, MAPPED, FUSED>(A, x, y, m0.x, m0.y, m0.z, m0.w, s_c, s_x, C);
         }
         return;
     }
@@ -212,7 +274,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
         const int* rp = A.ptrow + uni(m0.x) + tid;
         pr[s] = make_int2(rp[0], rp[1]);
         if (MAPPED) rm[s] = (A.rowmap + uni(m0.x))[tid];
-        xr[s] = x[min(uni(m1.x) + tid, clast)];
+        xr[s] = ring_ldx<FUSED>(x, C, min(uni(m1.x) + tid, clast));
     };
 
 #pragma unroll
@@ -225,7 +287,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
         const int c0 = uni(q.x) + tid, cend = uni(q.x) + uni(q.y), qz = uni(q.z);
         double v[FILL];
 #pragma unroll
-        for (int u = 0; u < FILL; u++) v[u] = x[min(c0 + u * T, clast)];
+        for (int u = 0; u < FILL; u++) v[u] = ring_ldx<FUSED>(x, C, min(c0 + u * T, clast));
 #pragma unroll
         for (int u = 0; u < FILL; u++)
             if (c0 + u * T < cend) s_ring[ring_slot<RING>(c0 + u * T, qz)] = v[u];
@@ -264,7 +326,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
                 if (qy <= T) {
                     if (tid < qy) s_ring[ring_slot<RING>(qx + tid, qz)] = xn;
                 } else { // the window restarts inside the run (a jump in the column range)
-                    for (int cc = qx + tid; cc < qx + qy; cc += T) s_ring[ring_slot<RING>(cc, qz)] = x[cc];
+                    for (int cc = qx + tid; cc < qx + qy; cc += T) s_ring[ring_slot<RING>(cc, qz)] = ring_ldx<FUSED>(x, C, cc);
                 }
             }
             // ---- row chains

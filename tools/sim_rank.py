@@ -66,15 +66,11 @@ lays = []
 for q in range(N):
     lq = np.zeros(2 * N + 1, np.int64)
     if q != rank and rc[q]:           # q receives from me what I receive from it (symmetric band)
-        left = int(rc[q]) if q - 1 >= 0 and q - 1 != rank else 0   # entries q gets from ITS left neighbour come first
-        if rank < q:                  # I am q's left neighbour: my entries start at 0
-            lq[0] = int(rc[q]) + (int(rc[q]) if q + 1 < N else 0); lq[1 + rank] = 0
-        else:                         # I am q's right neighbour: after its left neighbour's
-            lq[0] = left + int(rc[q]); lq[1 + rank] = left
+        lq[0] = lay[0]                # looped back: its window is mine
+        lq[1 + rank] = 0 if rank < q else int(lay[0]) - int(rc[q])   # left neighbour's entries first, right neighbour's last
         lq[1 + N + rank] = int(rc[q])
     lays.append(lq)
 lays = np.ascontiguousarray(lays)
-assert all(lays[q][0] <= lay[0] for q in range(N)), "looped-back pushes must fit this rank's own window"
 handles = hb.raw * N
 mpk.check(L.mi_part_push_connect(h, ctypes.create_string_buffer(handles, len(handles)), lays.ctypes.data))
 mpk.check(L.mi_part_push_debug_preset(h, 0x3fffffff))
@@ -88,10 +84,11 @@ for _ in range(500): pstep()
 e1.record(); torch.cuda.synchronize()
 pwall = (time.perf_counter() - t0) / 500 * 1e6
 mpk.check(L.mi_part_status(h))
-print(f"    push step (push, interior, wait+copy, boundary; flags preset, pushes looped back): GPU {e0.elapsed_time(e1) / 500 * 1e3:.1f} us/step, "
+fz = ctypes.c_int(); mpk.check(L.mi_part_push_info(h, None, ctypes.byref(fz), None))
+print(f"    push step ({'ONE launch (fused)' if fz.value else 'push, interior, wait+copy, boundary'}; flags preset, pushes looped back): GPU {e0.elapsed_time(e1) / 500 * 1e3:.1f} us/step, "
       f"host {pwall:.1f} us/step to enqueue")
 x_ext[nl.value:] = halo_keep   # the looped-back window content is not this rank's true halo: restore it for the check below
-step(); torch.cuda.synchronize()
+y.fill_(float("nan")); step(); torch.cuda.synchronize()
 cl = np.where((c >= lo) & (c < hi), c - lo, nl.value + np.searchsorted(halo_ids, c)).astype(np.int32)
 ok = np.array_equal(O.spmv(p, cl, v, xe).view(np.uint64), y.cpu().numpy().view(np.uint64))
 print(f"N={N} rank={rank} rows={nl.value} halo={nh.value} interior={ni.value} boundary={nb.value}: "
