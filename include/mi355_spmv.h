@@ -252,9 +252,12 @@ int mi_part_recv_counts(mi_part_t P, int* counts /* [nranks] */);
 int mi_part_recv_ids(mi_part_t P, int peer, long long* ids /* [recv_counts[peer]] global, ascending */);
 int mi_part_set_send_ids(mi_part_t P, int peer, int count, const long long* ids /* global ids peer needs from me */);
 int mi_part_send_counts(mi_part_t P, int* counts /* [nranks] */);
-/* local pieces on the host, for CPU checks: which = 0 interior, 1 boundary */
+/* local pieces on the host, for CPU checks: which = 0 interior, 1 boundary, 2 = the one-launch step's piece: ALL local rows
+ * in natural order (rowmap NULL), columns numbered [ghosts of lower ranks | owned | ghosts of higher ranks];
+ * mi_part_combined_info gives the number of ghosts in front */
 int mi_part_local_csr(mi_part_t P, int which, int* nrows, const int** ptrow, const int** indcol_local,
                       const double** coef, const int** rowmap);
+int mi_part_combined_info(mi_part_t P, int* n_left);
 int mi_part_send_index(mi_part_t P, int* total, const int** local_idx /* packed by peer, ascending */);
 /* upload the two pieces and the send index to the current device */
 int mi_part_finalize(mi_part_t P);

@@ -1010,7 +1010,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
 template <int T, int NNZB, int RING, int D, bool MAPPED, bool NT, bool SKEW>
 static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm)
 {
-    if (MAPPED && comm) { // the fused multi-GPU step: push workgroups in front of the grid (spmv_ring.hpp)
+    if (!MAPPED && comm) { // the fused multi-GPU step: push workgroups in front of the grid (spmv_ring.hpp)
         hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, true>), dim3(A->ring.wgs + comm->push_wgs), dim3(T), 0, s,
                            V, reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, A->ring.bpw, *comm);
         return;
@@ -1955,13 +1955,22 @@ extern "C" int mi_part_send_counts(mi_part_t P, int* counts)
 extern "C" int mi_part_local_csr(mi_part_t P, int which, int* nrows, const int** ptrow, const int** indcol_local,
                                  const double** coef, const int** rowmap)
 {
-    CHECK_ARG(P && (which == 0 || which == 1), "bad argument");
-    const LocalPiece& L = P->plan.piece[which];
-    if (nrows) *nrows = (int)L.rowmap.size();
+    CHECK_ARG(P && (which == 0 || which == 1 || which == 2), "bad argument");
+    if (which == 2) P->plan.build_combined(); // all rows, natural order, columns [ghosts in front | owned | ghosts behind]
+    const LocalPiece& L = which == 2 ? P->plan.all : P->plan.piece[which];
+    if (nrows) *nrows = which == 2 ? P->plan.n_local : (int)L.rowmap.size();
     if (ptrow) *ptrow = L.ptrow.data();
     if (indcol_local) *indcol_local = L.indcol.data();
     if (coef) *coef = L.coef.data();
-    if (rowmap) *rowmap = L.rowmap.data();
+    if (rowmap) *rowmap = which == 2 ? nullptr : L.rowmap.data();
+    return MI_OK;
+}
+
+extern "C" int mi_part_combined_info(mi_part_t P, int* n_left)
+{
+    CHECK_ARG(P && n_left, "null argument");
+    P->plan.build_combined();
+    *n_left = P->plan.n_left;
     return MI_OK;
 }
 
@@ -2177,20 +2186,20 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
     if (!(fe && !strcmp(fe, "0")) && pl.n_local > 0) {
         P->plan.build_combined();
         const LocalPiece& L = P->plan.all;
-        rc = mi_csr_create_mapped((int)L.rowmap.size(), pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), L.rowmap.data(),
-                                  &P->piece_all);
+        rc = csr_create_impl(pl.n_local, pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), nullptr, &P->piece_all);
         if (rc) return rc;
         mi_csr_t A = P->piece_all;
         if (P->kernel != MI_KERNEL_AUTO && P->kernel != MI_KERNEL_RING) A->kernel = P->kernel;
-        if (resolve_kernel(A) == MI_KERNEL_RING && A->d_rowmap) {
+        if (resolve_kernel(A) == MI_KERNEL_RING) {
             // which runs touch a ghost column (replay the plan's row blocks: the same deterministic cut)
             std::vector<int> rows, ptrs;
             build_row_blocks(A->n, L.ptrow.data(), A->ring.cfg.nnzb, 2 * A->ring.cfg.threads, rows, ptrs);
             std::vector<int> run_halo((size_t)A->ring.wgs, 0);
             if ((int)rows.size() - 1 == A->ring.nblk) {
+                const int nl0 = P->plan.n_left, nl1 = P->plan.n_left + pl.n_local;
                 for (int g = 0; g < A->ring.wgs; g++) {
                     const int b0 = std::min(A->ring.nblk, g * A->ring.bpw), b1 = std::min(A->ring.nblk, (g + 1) * A->ring.bpw);
-                    for (int k = ptrs[b0]; k < ptrs[b1] && !run_halo[g]; k++) run_halo[g] = L.indcol[k] >= pl.n_local;
+                    for (int k = ptrs[b0]; k < ptrs[b1] && !run_halo[g]; k++) run_halo[g] = L.indcol[k] < nl0 || L.indcol[k] >= nl1;
                 }
                 HIP_TRY(hipMalloc(&P->d_run_halo, sizeof(int) * run_halo.size()));
                 HIP_TRY(hipMemcpy(P->d_run_halo, run_halo.data(), sizeof(int) * run_halo.size(), hipMemcpyHostToDevice));
@@ -2250,6 +2259,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.n_links = P->n_links;
         C.n_nb = P->n_nb;
         C.n_local = pl.n_local;
+        C.n_left = pl.n_left;
         C.push_wgs = kNXCD; // a multiple of the XCD count keeps the run-to-XCD mapping of the ring workgroups
         C.step = step;
         if ((rc = launch_spmv(P->piece_all, d_x_ext, d_y_local, s, true, &C))) return rc;

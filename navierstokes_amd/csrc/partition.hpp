@@ -135,19 +135,32 @@ struct PartPlan {
         return "";
     }
 
-    // the one-launch step works on all local rows at once: interior rows first, boundary rows (the only ones that read
-    // ghosts) last, so that the workgroups which must wait for the neighbours start last
+    // The one-launch step works on ALL local rows at once, in their natural order (no row map), with the columns in a
+    // numbering of its own: [ghosts owned by lower ranks | owned | ghosts owned by higher ranks] — ascending global id
+    // throughout, so a banded matrix stays banded across the partition boundary and the ring kernel serves the boundary
+    // rows like any others.  n_left = number of ghosts in front.  Ghost g of the halo (x_ext order) is column g if
+    // g < n_left, else g + n_local; owned entry i is column n_left + i.
+    int n_left = 0;
     void build_combined()
     {
         if (!all.ptrow.empty()) return;
+        n_left = recv_offsets[rank];
+        std::vector<int> where((size_t)n_local), which((size_t)n_local);
+        for (int w = 0; w < 2; w++)
+            for (size_t r = 0; r < piece[w].rowmap.size(); r++) {
+                where[piece[w].rowmap[r]] = (int)r;
+                which[piece[w].rowmap[r]] = w;
+            }
         all.ptrow.push_back(0);
-        for (int w = 0; w < 2; w++) {
-            const LocalPiece& L = piece[w];
-            const int base = (int)all.indcol.size();
-            all.indcol.insert(all.indcol.end(), L.indcol.begin(), L.indcol.end());
-            all.coef.insert(all.coef.end(), L.coef.begin(), L.coef.end());
-            for (size_t r = 0; r < L.rowmap.size(); r++) all.ptrow.push_back(base + L.ptrow[r + 1]);
-            all.rowmap.insert(all.rowmap.end(), L.rowmap.begin(), L.rowmap.end());
+        for (int r = 0; r < n_local; r++) {
+            const LocalPiece& L = piece[which[r]];
+            for (int k = L.ptrow[where[r]]; k < L.ptrow[where[r] + 1]; k++) {
+                const int c = L.indcol[k];
+                const int g = c - n_local;
+                all.indcol.push_back(c < n_local ? n_left + c : (g < n_left ? g : g + n_local));
+                all.coef.push_back(L.coef[k]);
+            }
+            all.ptrow.push_back((int)all.indcol.size());
         }
     }
 

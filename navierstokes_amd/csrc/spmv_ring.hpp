@@ -53,10 +53,12 @@ __device__ __forceinline__ int ring_slot(int c, int base)
 // The fused multi-GPU step (FUSED = true; mi_part_spmv_push_dev): ONE launch does a rank's whole product.
 //   * the first push_wgs workgroups do the peer push of push_exchange.hpp (this rank's entries into the neighbours'
 //     windows, then the flags) and exit; being first in the grid they are dispatched first and wait for nothing;
-//   * the others are the ring kernel over ALL local rows, interior rows first, boundary rows last.  Column ids
-//     >= n_local are ghosts: they are read from this rank's receive window (`halo`, uncached memory the neighbours'
-//     kernels write) instead of from x.  A run that touches a ghost (run_halo) first waits — bounded, loud — until every
-//     neighbour's flag shows this step; those runs are the last of the grid, by which time the flags are long up.
+//   * the others are the ring kernel over ALL local rows in their natural order, columns numbered [ghosts of lower
+//     ranks | owned | ghosts of higher ranks] (partition.hpp: build_combined) so that a band stays a band across the
+//     partition boundary and boundary rows are ring-served like the rest.  Ghost columns are read from this rank's
+//     receive window (`halo`, uncached memory the neighbours' kernels write), owned ones from x.  A run that touches a
+//     ghost (run_halo: the first and last few runs of a banded partition) first waits — bounded, loud — until every
+//     neighbour's flag shows this step.
 // Against the four-launch form (push, interior, wait + copy, boundary) this removes three launches of ~4 us each from
 // a step whose whole interior kernel is 23 us at 8 ranks.
 struct RingComm {
@@ -67,14 +69,17 @@ struct RingComm {
     const double* halo;    // my window's data, this step's parity
     const int* run_halo;   // per run: touches a ghost column
     unsigned* timeouts;    // host-visible
-    int n_links, n_nb, n_local, push_wgs;
+    int n_links, n_nb, n_local, n_left, push_wgs;
     unsigned step;
 };
 
 template <bool FUSED>
 __device__ __forceinline__ double ring_ldx(const double* __restrict__ x, const RingComm& C, int c)
 {
-    if (FUSED) return *(c < C.n_local ? x + c : C.halo + (c - C.n_local));
+    if (FUSED) { // [0, n_left) ghosts in front | owned | ghosts behind (halo order: front ghosts first)
+        const int o = c - C.n_left;
+        return *(o < 0 ? C.halo + c : (o < C.n_local ? x + o : C.halo + (c - C.n_local)));
+    }
     return x[c];
 }
 

@@ -184,3 +184,41 @@ def test_planner_rejects_bad_input():
     assert L.mi_part_set_send_ids(h, 1, 1, bad.ctypes.data) == 1
     assert L.mi_part_finalize(h) in (2, 6)  # no GPU here / sends never set
     L.mi_part_destroy(h)
+
+
+@pytest.mark.parametrize("kind,n,w,nranks", [("s15", 6000, 150, 4), ("svar", 5000, 400, 3), ("sfe", 2000, 120, 5), ("s15", 3000, 2900, 2)])
+def test_combined_piece_of_the_one_launch_step(kind, n, w, nranks):
+    """The fused multi-GPU step computes on ONE piece per rank: all local rows in natural order, columns numbered
+    [ghosts of lower ranks | owned | ghosts of higher ranks] (partition.hpp: build_combined).  With x laid out the same way
+    the oracle on that piece reproduces the global product bit for bit, the numbering is monotone in the global column id
+    (a band stays a band), and the ring planner serves boundary rows too."""
+    import ctypes
+    from navierstokes_amd import mpk
+    (P, C, V), rs, plans = build_plans(kind, n, w, nranks)
+    x = synth.x_sin(0, n)
+    yg = O.spmv(P, C, V, x)
+    L = mpk.lib()
+    for pl in plans:
+        lo, hi = int(rs[pl.rank]), int(rs[pl.rank + 1])
+        nr, pp, pc, pv, pm = ctypes.c_int(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        mpk.check(L.mi_part_local_csr(pl._h, 2, ctypes.byref(nr), ctypes.byref(pp), ctypes.byref(pc), ctypes.byref(pv), ctypes.byref(pm)))
+        assert nr.value == pl.n_local and not pm.value
+        nleft = ctypes.c_int()
+        mpk.check(L.mi_part_combined_info(pl._h, ctypes.byref(nleft)))
+        nleft = nleft.value
+        ptrow = np.ctypeslib.as_array(ctypes.cast(pp, ctypes.POINTER(ctypes.c_int)), shape=(nr.value + 1,)).copy()
+        nnz = int(ptrow[-1])
+        col = np.ctypeslib.as_array(ctypes.cast(pc, ctypes.POINTER(ctypes.c_int)), shape=(max(nnz, 1),))[:nnz].copy()
+        val = np.ctypeslib.as_array(ctypes.cast(pv, ctypes.POINTER(ctypes.c_double)), shape=(max(nnz, 1),))[:nnz].copy()
+        halo = np.concatenate([pl.recv_ids[q] for q in range(nranks)]) if pl.n_halo else np.zeros(0, np.int64)
+        assert nleft == int((halo < lo).sum())
+        gid = np.concatenate([halo[:nleft], np.arange(lo, hi), halo[nleft:]])  # global id of every combined column
+        assert np.all(np.diff(gid) > 0)                                        # monotone: local bands are global bands
+        assert np.array_equal(gid[col], C[P[lo]:P[hi]])                        # same terms, same order, per row
+        xv = x[gid]
+        assert_bit_equal(O.spmv(ptrow, col, val, xv), yg[lo:hi], f"rank {pl.rank}")
+        if kind == "s15" and w < 1000 and pl.n_local > 600:  # banded: every row block of the piece fits the ring, boundary rows included
+            nb_, runs, bad, frac, ms = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double(), ctypes.c_int())
+            mpk.check(L.mi_ring_plan_probe(nr.value, ptrow.ctypes.data, col.ctypes.data, 4, ctypes.byref(nb_), ctypes.byref(runs),
+                                           ctypes.byref(bad), ctypes.byref(frac), ctypes.byref(ms)))
+            assert bad.value == 0 and frac.value == 1.0
