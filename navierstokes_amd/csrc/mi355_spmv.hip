@@ -84,6 +84,8 @@ struct RingTable {
     double ok_fraction = 0.0; // share of the nonzeros in ring-served runs
     int* d_plan = nullptr; // 8 ints per block, read as two int4
     int* d_ok = nullptr;
+    int* d_rng = nullptr;      // {first block, end block} per run
+    int* d_run_halo = nullptr; // per run: touches a ghost column (fused multi-GPU step)
     unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block
     bool nt = false;                   // non-temporal loads of the values (chosen by measurement)
     bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
@@ -291,7 +293,7 @@ static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_
 static int resolve_kernel(const mi_csr_s* A);
 
 static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
-                           const int* rowmap, mi_csr_t* out)
+                           const int* rowmap, mi_csr_t* out, int ghost_lo = 0, int ghost_hi = 0)
 {
     CHECK_ARG(out, "out is null");
     *out = nullptr;
@@ -369,7 +371,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         for (int t = 0; t < kNumRingConfigs && !have; t++) {
             const int id = forced >= 1 && forced <= kNumRingConfigs ? forced : order[t];
             RingPlanHost P;
-            build_ring_plan(kRingConfigs[id - 1], n, ptrow, row_min.data(), row_max.data(), P);
+            build_ring_plan(kRingConfigs[id - 1], n, ptrow, row_min.data(), row_max.data(), P, ghost_lo, ghost_hi);
             const double okf = 1.0 - (double)P.bad_nnz / (double)nnz;
             if (forced || okf >= 0.90) {
                 best = std::move(P);
@@ -390,6 +392,12 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
             TRY_OR_CLEAN(hipMalloc(&A->ring.d_ok, sizeof(int) * best.run_ok.size()));
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
+            TRY_OR_CLEAN(hipMalloc(&A->ring.d_rng, sizeof(int) * best.run_rng.size()));
+            TRY_OR_CLEAN(hipMemcpy(A->ring.d_rng, best.run_rng.data(), sizeof(int) * best.run_rng.size(), hipMemcpyHostToDevice));
+            if (ghost_lo < ghost_hi) {
+                TRY_OR_CLEAN(hipMalloc(&A->ring.d_run_halo, sizeof(int) * best.run_halo.size()));
+                TRY_OR_CLEAN(hipMemcpy(A->ring.d_run_halo, best.run_halo.data(), sizeof(int) * best.run_halo.size(), hipMemcpyHostToDevice));
+            }
             {
                 std::vector<unsigned short> slots;
                 build_ring_slots(best, indcol, slots);
@@ -584,6 +592,8 @@ static void release_natural_arrays(mi_csr_t A)
     A->tables.clear();
     dfree(A->ring.d_plan);
     dfree(A->ring.d_ok);
+    dfree(A->ring.d_rng);
+    dfree(A->ring.d_run_halo);
     dfree(A->ring.d_slots);
     A->ring = RingTable();
     mi_bcsr4_destroy(A->blocked);
@@ -718,6 +728,8 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     }
     dfree(A->ring.d_plan);
     dfree(A->ring.d_ok);
+    dfree(A->ring.d_rng);
+    dfree(A->ring.d_run_halo);
     dfree(A->ring.d_slots);
     mi_bcsr4_destroy(A->blocked);
     mi_csr_destroy(A->inner);
@@ -906,7 +918,7 @@ extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, in
         next_row += Q[2];
         next_nz += Q[3];
         if (Q[3] != ptrow[Q[0] + Q[2]] - ptrow[Q[0]]) return fail(MI_ERR_STATE, "block nonzero count disagrees with ptrow");
-        const int run = b / (P.bpw > 0 ? P.bpw : 1);
+        const int run = b / (P.bpw > 0 ? P.bpw : 1); // the probe plans without ghosts: uniform runs
         if (!P.run_ok[run] || Q[3] == 0) continue;
         if (!Q[7] || Q[3] > c.nnzb || Q[2] > 2 * T) return fail(MI_ERR_STATE, "a served run holds a block the kernel cannot take");
         int cmin = 0x7fffffff, cmax = -1;
@@ -1012,11 +1024,11 @@ static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x,
 {
     if (!MAPPED && comm) { // the fused multi-GPU step: push workgroups in front of the grid (spmv_ring.hpp)
         hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, true>), dim3(A->ring.wgs + comm->push_wgs), dim3(T), 0, s,
-                           V, reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, A->ring.bpw, *comm);
+                           V, reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, reinterpret_cast<const int2*>(A->ring.d_rng), *comm);
         return;
     }
     hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, false>), dim3(A->ring.wgs), dim3(T), 0, s, V,
-                       reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, A->ring.bpw, RingComm{});
+                       reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, reinterpret_cast<const int2*>(A->ring.d_rng), RingComm{});
 }
 
 template <int T, int NNZB, int RING, int D, bool MAPPED>
@@ -2186,26 +2198,12 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
     if (!(fe && !strcmp(fe, "0")) && pl.n_local > 0) {
         P->plan.build_combined();
         const LocalPiece& L = P->plan.all;
-        rc = csr_create_impl(pl.n_local, pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), nullptr, &P->piece_all);
+        rc = csr_create_impl(pl.n_local, pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), nullptr, &P->piece_all,
+                             P->plan.n_left, P->plan.n_left + pl.n_local); // ghosts: columns outside [n_left, n_left + n_local)
         if (rc) return rc;
         mi_csr_t A = P->piece_all;
         if (P->kernel != MI_KERNEL_AUTO && P->kernel != MI_KERNEL_RING) A->kernel = P->kernel;
-        if (resolve_kernel(A) == MI_KERNEL_RING) {
-            // which runs touch a ghost column (replay the plan's row blocks: the same deterministic cut)
-            std::vector<int> rows, ptrs;
-            build_row_blocks(A->n, L.ptrow.data(), A->ring.cfg.nnzb, 2 * A->ring.cfg.threads, rows, ptrs);
-            std::vector<int> run_halo((size_t)A->ring.wgs, 0);
-            if ((int)rows.size() - 1 == A->ring.nblk) {
-                const int nl0 = P->plan.n_left, nl1 = P->plan.n_left + pl.n_local;
-                for (int g = 0; g < A->ring.wgs; g++) {
-                    const int b0 = std::min(A->ring.nblk, g * A->ring.bpw), b1 = std::min(A->ring.nblk, (g + 1) * A->ring.bpw);
-                    for (int k = ptrs[b0]; k < ptrs[b1] && !run_halo[g]; k++) run_halo[g] = L.indcol[k] < nl0 || L.indcol[k] >= nl1;
-                }
-                HIP_TRY(hipMalloc(&P->d_run_halo, sizeof(int) * run_halo.size()));
-                HIP_TRY(hipMemcpy(P->d_run_halo, run_halo.data(), sizeof(int) * run_halo.size(), hipMemcpyHostToDevice));
-                P->fused = true;
-            }
-        }
+        P->fused = resolve_kernel(A) == MI_KERNEL_RING && A->ring.d_run_halo;
         if (!P->fused) {
             mi_csr_destroy(P->piece_all);
             P->piece_all = nullptr;
@@ -2254,7 +2252,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.flags = P->win_flags;
         C.nb = P->d_nb;
         C.halo = P->win_data + (size_t)(step & 1u) * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1);
-        C.run_halo = P->d_run_halo;
+        C.run_halo = P->piece_all->ring.d_run_halo;
         C.timeouts = P->d_timeouts;
         C.n_links = P->n_links;
         C.n_nb = P->n_nb;

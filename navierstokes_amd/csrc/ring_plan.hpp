@@ -47,11 +47,21 @@ struct RingPlanHost {
     long long bad_nnz = 0;     // nonzeros living in runs that take the plain path
     std::vector<int> plan;     // 8 ints per block: {r0, p0, rows, nnz, new_lo, new_cnt, base, flags}
     std::vector<int> run_ok;   // per run
+    std::vector<int> run_rng;  // per run: {first block, end block} — a run is a contiguous block range, runs need not be in order
+    std::vector<int> run_halo; // per run: touches a ghost column (fused multi-GPU step only)
 };
 
+// The fused multi-GPU step (spmv_ring.hpp, FUSED): columns outside [ghost_lo, ghost_hi) are ghosts that arrive from the
+// neighbours a few microseconds into the kernel, and a run that touches one waits for them first.  All runs start together
+// (persistent grid), so a waiting run must be SHORTER than the others by the length of that wait or it becomes the tail of
+// the launch: the blocks touching ghosts — a prefix and a suffix of the rows for a banded partition — are dealt out in runs
+// of bpw - kGhostRunSlack blocks, the rest in runs of bpw as usual.
+constexpr int kGhostRunSlack = 2; // blocks (~2.5 us each at 2048 nonzeros) — the push of push_exchange.hpp lands within ~5 us
+
 // row_min/row_max: smallest / largest column of each row (row_min > row_max for an empty row)
+// ghost_lo < ghost_hi: shape the runs for the fused step as described above (and fill run_halo)
 inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, const int* row_min, const int* row_max,
-                            RingPlanHost& out)
+                            RingPlanHost& out, int ghost_lo = 0, int ghost_hi = 0)
 {
     out = RingPlanHost();
     out.cfg = cfg;
@@ -67,13 +77,43 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     out.bpw = bpw;
     out.plan.assign((size_t)8 * nblk, 0);
     out.run_ok.assign(wgs, 1);
+    out.run_rng.assign((size_t)2 * wgs, 0);
+    out.run_halo.assign(wgs, 0);
+    for (int g = 0; g < wgs; g++) { // default: consecutive runs of bpw blocks
+        out.run_rng[2 * g] = std::min(nblk, g * bpw);
+        out.run_rng[2 * g + 1] = std::min(nblk, (g + 1) * bpw);
+    }
+    if (ghost_lo < ghost_hi) {
+        std::vector<char> gh((size_t)nblk, 0);
+        for (int b = 0; b < nblk; b++)
+            for (int r = rows[b]; r < rows[b + 1] && !gh[b]; r++)
+                gh[b] = row_min[r] <= row_max[r] && (row_min[r] < ghost_lo || row_max[r] >= ghost_hi);
+        int F = 0, T = 0;
+        while (F < nblk && gh[F]) F++;
+        while (T < nblk - F && gh[nblk - 1 - T]) T++;
+        bool middle_clean = true;
+        for (int b = F; b < nblk - T; b++) middle_clean = middle_clean && !gh[b];
+        const int m = std::max(1, bpw - kGhostRunSlack);
+        const int rf = (F + m - 1) / m, rt = (T + m - 1) / m, rmid = wgs - rf - rt;
+        const long long M = (long long)nblk - F - T;
+        if (middle_clean && (F || T) && rmid > 0 && M <= (long long)rmid * bpw) {
+            int g = 0;
+            for (int b = F; b < nblk - T; b += bpw, g++) { out.run_rng[2 * g] = b; out.run_rng[2 * g + 1] = std::min(nblk - T, b + bpw); }
+            for (; g < rmid; g++) out.run_rng[2 * g] = out.run_rng[2 * g + 1] = 0; // idle runs
+            for (int b = 0; b < F; b += m, g++) { out.run_rng[2 * g] = b; out.run_rng[2 * g + 1] = std::min(F, b + m); }
+            for (int b = nblk - T; b < nblk; b += m, g++) { out.run_rng[2 * g] = b; out.run_rng[2 * g + 1] = std::min(nblk, b + m); }
+            for (; g < wgs; g++) out.run_rng[2 * g] = out.run_rng[2 * g + 1] = 0;
+        }
+        for (int g = 0; g < wgs; g++)
+            for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1] && !out.run_halo[g]; b++) out.run_halo[g] = gh[b];
+    }
     const int ring = cfg.ring;
     for (int g = 0; g < wgs; g++) {
         int wlo = 0, whi = 0, base = 0;
         bool live = false;
         long long run_nnz = 0;
         bool ok = true;
-        for (int b = g * bpw; b < std::min(nblk, (g + 1) * bpw); b++) {
+        for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1]; b++) {
             const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b];
             int* P = &out.plan[(size_t)8 * b];
             P[0] = rows[b]; P[1] = ptrs[b]; P[2] = nrows; P[3] = nn;

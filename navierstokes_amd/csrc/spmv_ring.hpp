@@ -177,7 +177,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
                                                    const int* __restrict__ run_ok,
                                                    const unsigned short* __restrict__ slots,
                                                    const double* __restrict__ x, double* __restrict__ y,
-                                                   int bpw, RingComm C)
+                                                   const int2* __restrict__ run_rng, RingComm C)
 {
     constexpr int PER = NNZB / T;
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
@@ -209,8 +209,9 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     const int bid = FUSED ? (int)blockIdx.x - C.push_wgs : (int)blockIdx.x;
     const int nwg = FUSED ? (int)gridDim.x - C.push_wgs : (int)gridDim.x;
     const int gw = (bid & (kNXCD - 1)) * (nwg / kNXCD) + (bid >> 3);
-    const int b_begin = gw * bpw;
-    const int nb = min(A.nblk, b_begin + bpw) - b_begin; // <= MAXB by construction of the launch
+    const int2 rng = run_rng[gw]; // this workgroup's run: blocks [rng.x, rng.y)
+    const int b_begin = rng.x;
+    const int nb = rng.y - rng.x; // <= MAXB by construction of the plan
     if (nb <= 0) return;
     const int clast = A.ncols - 1;
     // the plan is read back from LDS at a uniform address: tell the compiler so (SGPRs, scalar
