@@ -2245,6 +2245,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
     if (!P->push_ready) return fail(MI_ERR_STATE, "mi_part_push_connect was not called");
     if ((rc = part_handoff_status(P))) return rc;
     const unsigned step = ++P->push_step;
+    static const unsigned spin_max = 1u << (getenv("MI355_PUSH_SPIN_LOG2") ? std::max(8, std::min(30, atoi(getenv("MI355_PUSH_SPIN_LOG2")))) : 23);
     if (P->fused) { // ONE launch: push workgroups first, then the ring kernel over all rows, ghost readers waiting in-kernel
         RingComm C;
         C.links = P->d_links;
@@ -2260,6 +2261,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.n_left = pl.n_left;
         C.push_wgs = kNXCD; // a multiple of the XCD count keeps the run-to-XCD mapping of the ring workgroups
         C.step = step;
+        C.spin_max = spin_max;
         if ((rc = launch_spmv(P->piece_all, d_x_ext, d_y_local, s, true, &C))) return rc;
         return MI_OK;
     }
@@ -2272,7 +2274,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
         hipLaunchKernelGGL(halo_wait_copy_kernel, dim3(grid), dim3(256), 0, s, P->win_flags, P->d_nb, P->n_nb, step,
                            P->win_data + (size_t)(step & 1u) * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1), d_x_ext + pl.n_local, pl.n_halo,
-                           P->d_timeouts);
+                           P->d_timeouts, spin_max);
     }
     if ((rc = mi_spmv_dev(P->piece[1], d_x_ext, d_y_local, s))) return rc;
     HIP_TRY(hipGetLastError());

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void halo_push_kernel(const PushLink* __restri
 
 __global__ __launch_bounds__(256) void halo_wait_copy_kernel(const unsigned* flags, const int* __restrict__ nb, int n_nb, unsigned step,
                                                              const double* src, double* __restrict__ dst, int n_halo,
-                                                             unsigned* timeouts /* host-visible */)
+                                                             unsigned* timeouts /* host-visible */, unsigned spin_max)
 {
     for (int j = threadIdx.x; j < n_nb; j += 256) {
         const unsigned* f = flags + (size_t)nb[j] * kWinFlagStride;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void halo_wait_copy_kernel(const unsigned* fla
         while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
             if (spins < 4096) __builtin_amdgcn_s_sleep(2);
             else __builtin_amdgcn_s_sleep(127);
-            if (++spins > (1u << 23)) { // ~30 s
+            if (++spins > spin_max) { // default 2^23: ~30 s
                 __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }

@@ -71,6 +71,7 @@ struct RingComm {
     unsigned* timeouts;    // host-visible
     int n_links, n_nb, n_local, n_left, push_wgs;
     unsigned step;
+    unsigned spin_max; // polls before a wait gives up (MI355_PUSH_SPIN_LOG2, default 23: ~30 s)
 };
 
 template <bool FUSED>
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
             while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - C.step) < 0) {
                 if (spins < 4096) __builtin_amdgcn_s_sleep(2);
                 else __builtin_amdgcn_s_sleep(127);
-                if (++spins > (1u << 23)) {
+                if (++spins > C.spin_max) {
                     __hip_atomic_fetch_add(C.timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
