@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--exchange", default=None, choices=["native", "push", "torch"], help="N > 1: which halo exchange drives the step")
+    ap.add_argument("--exchange", default=None, choices=["auto", "native", "push", "torch"], help="N > 1: which halo exchange drives the step")
     ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold single-shot and in-pipeline measurements")
     args = ap.parse_args()

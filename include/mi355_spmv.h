@@ -305,6 +305,8 @@ int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_st
  * touch ghosts, which are ordered last) live inside that kernel (spmv_ring.hpp, FUSED; MI355_PUSH_FUSED=0 disables).
  * In the fused form the halo part of d_x_ext is neither read nor written. */
 int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
+/* give the push exchange up again (e.g. after a failed collective self-check): windows released, sticky give-ups cleared */
+int mi_part_push_disable(mi_part_t P);
 /* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
 int mi_part_push_debug_preset(mi_part_t P, unsigned value);
 

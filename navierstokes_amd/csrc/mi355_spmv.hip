@@ -2212,6 +2212,33 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
     return MI_OK;
 }
 
+// give the peer-push exchange up again (a failed collective self-check): windows and mappings released, a give-up counted
+// during the check forgotten, so that the handle can go on with another exchange
+extern "C" int mi_part_push_disable(mi_part_t P)
+{
+    CHECK_ARG(P, "null handle");
+    HIP_TRY(hipDeviceSynchronize());
+    for (void* m : P->ipc_opened) (void)hipIpcCloseMemHandle(m);
+    P->ipc_opened.clear();
+    if (P->win_registered) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        g_win_registry.erase(P->win_key);
+        P->win_registered = false;
+    }
+    dfree(P->win);
+    dfree(P->d_links);
+    dfree(P->d_nb);
+    mi_csr_destroy(P->piece_all);
+    P->win = nullptr;
+    P->d_links = nullptr;
+    P->d_nb = nullptr;
+    P->piece_all = nullptr;
+    P->fused = P->push_ready = false;
+    P->n_links = P->n_nb = 0;
+    if (P->h_timeouts) *P->h_timeouts = 0;
+    return MI_OK;
+}
+
 extern "C" int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours)
 {
     CHECK_ARG(P, "null handle");
@@ -2245,7 +2272,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
     if (!P->push_ready) return fail(MI_ERR_STATE, "mi_part_push_connect was not called");
     if ((rc = part_handoff_status(P))) return rc;
     const unsigned step = ++P->push_step;
-    static const unsigned spin_max = 1u << (getenv("MI355_PUSH_SPIN_LOG2") ? std::max(8, std::min(30, atoi(getenv("MI355_PUSH_SPIN_LOG2")))) : 23);
+    static const unsigned spin_max = 1u << (getenv("MI355_PUSH_SPIN_LOG2") ? std::max(8, std::min(30, atoi(getenv("MI355_PUSH_SPIN_LOG2")))) : 20); // 2^20 polls: ~4 s
     if (P->fused) { // ONE launch: push workgroups first, then the ring kernel over all rows, ghost readers waiting in-kernel
         RingComm C;
         C.links = P->d_links;

@@ -113,10 +113,11 @@ class DistCSR:
             # torch.distributed exchange before it is trusted): "native" = C++ step over RCCL send/recv (default where
             # librccl resolves), "push" = peer-push windows over HIP IPC, no RCCL (mi_part_spmv_push_dev), "torch"
             self.push_fused = False
-            self.exchange = exchange or os.environ.get("MI355_DIST_EXCHANGE", "native")
-            assert self.exchange in ("native", "push", "torch"), self.exchange
-            self.push = self.exchange == "push" and self._try_push_exchange()
-            self.native = self.exchange == "native" and self._try_native_exchange()
+            # "auto" (default): push, else native, else torch — each step down only after the collective self-check below
+            self.exchange = exchange or os.environ.get("MI355_DIST_EXCHANGE", "auto")
+            assert self.exchange in ("auto", "native", "push", "torch"), self.exchange
+            self.push = self.exchange in ("auto", "push") and self._try_push_exchange()
+            self.native = False
         else:
             self.native = False
             self.push = False
@@ -128,7 +129,10 @@ class DistCSR:
         self.sendbuf = torch.empty(max(self.n_send, 1), dtype=torch.float64, device=self.device)
         import os
         if self.push and not self._native_selfcheck():
-            self.push = False
+            self.push = self.push_fused = False
+            mpk.lib().mi_part_push_disable(self._h)
+        if compute is None and not self.push and self.exchange in ("auto", "native"):
+            self.native = self._try_native_exchange()
         if self.native and not self._native_selfcheck():
             self.native = False  # collective decision: every rank falls back to the torch.distributed exchange
         elif not self.native and compute is None and self.nranks > 1 and os.environ.get("MI355_DIST_FORCE_SELFCHECK") == "1":
@@ -176,12 +180,17 @@ class DistCSR:
         everyone = [None] * self.nranks
         dist.all_gather_object(everyone, mine, group=self.group)
         ok = all(e[0] == 0 for e in everyone)
+        if not ok:  # nothing was connected anywhere: the windows some ranks did allocate go away
+            L.mi_part_push_disable(self._h)
+            return False
         if ok:
             handles = b"".join(e[1] for e in everyone)
             layouts = np.ascontiguousarray([e[2] for e in everyone], dtype=np.int64)
             ok = L.mi_part_push_connect(self._h, _c.create_string_buffer(handles, len(handles)), layouts.ctypes.data) == 0
         flags = [None] * self.nranks
         dist.all_gather_object(flags, bool(ok), group=self.group)
+        if not all(flags):
+            L.mi_part_push_disable(self._h)
         if all(flags):
             fused = _c.c_int()
             mpk.check(L.mi_part_push_info(self._h, None, _c.byref(fused), None))

@@ -30,7 +30,7 @@ def main():
     for kernel in (None, "ring", "stream"):
         dc = D.DistCSR(rs, p, c, v, kernel=kernel, exchange=exchange)
         assert not dc.native  # gloo: no RCCL
-        assert dc.push == (exchange == "push"), "peer-push exchange was requested but did not come up (or vice versa)"
+        assert dc.push == (exchange in ("push", "auto")), "peer-push exchange was requested but did not come up (or vice versa)"
         x_ext = dc.new_x_ext()
         x_ext[: dc.n_local] = torch.from_numpy(synth.x_sin(lo, hi)).cuda()
         ys = dc.spmk(x_ext, dc.new_power_buffers(3))
