@@ -46,6 +46,12 @@ for s in "$@"; do
     bench_fe_bcsr) step bench_fe_bcsr 300 python bench.py --workload fe_bcsr --no-cpu-baseline ;;
     bench_cold) step bench_cold 400 python bench.py --cold --steps 30 --warmup 3 --no-cpu-baseline ;;
     bench_gloo3) MI355_FORCE_DEVICE=0 MI355_BENCH_BACKEND=gloo step bench_gloo3 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 3 --workload c3 --steps 3 --warmup 1 --no-cpu-baseline ;;
+    # ---- round 2 profile set: the SAME kernel as the unprofiled bench by construction (ring, non-temporal values forced:
+    #      under a counter pass every launch takes ~2x as long and the create-time measurement would compare candidates in that regime)
+    r2prof)   rm -rf gpurun_out/r2prof; step r2prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2prof -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity --no-extras ;;
+    r2prof_cold) rm -rf gpurun_out/r2prof_cold; step r2prof_cold 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2prof_cold -- python bench.py --cold --steps 30 --warmup 3 --no-cpu-baseline --no-parity ;;
+    r2pmc)    for c in FETCH_SIZE WRITE_SIZE; do rm -rf gpurun_out/r2pmc_$c; MI355_SPMV_KERNEL=ring MI355_RING_NT=1 step r2pmc_$c 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/r2pmc_$c -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-extras || exit 1; done ;;
+    r2pmc_cold) for c in FETCH_SIZE WRITE_SIZE; do rm -rf gpurun_out/r2pmc_cold_$c; MI355_SPMV_KERNEL=ring MI355_RING_NT=1 step r2pmc_cold_$c 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/r2pmc_cold_$c -- python bench.py --cold --steps 10 --warmup 2 --no-cpu-baseline --no-parity || exit 1; done ;;
     prof)     rm -rf gpurun_out/prof; step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity ;;
     pmc_fetch) rm -rf gpurun_out/pmc_fetch; MI355_SPMV_AUTOTUNE=0 step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
     pmc_write) rm -rf gpurun_out/pmc_write; MI355_SPMV_AUTOTUNE=0 step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-parity ;;
