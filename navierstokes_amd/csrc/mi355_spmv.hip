@@ -86,6 +86,7 @@ struct RingTable {
     int* d_ok = nullptr;
     int* d_rng = nullptr;      // {first block, end block} per run
     int* d_run_halo = nullptr; // per run: touches a ghost column (fused multi-GPU step)
+    std::vector<int> h_run_halo;
     unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block
     bool nt = false;                   // non-temporal loads of the values (chosen by measurement)
     bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
@@ -176,6 +177,8 @@ struct mi_part_s {
     // the one-launch form of the push step (spmv_ring.hpp, FUSED): all local rows in one ring-served, row-mapped piece
     mi_csr_t piece_all = nullptr;
     int* d_run_halo = nullptr;
+    int* d_run_link = nullptr; // per run of piece_all: first push link it serves, or -1
+    int npush_runs = 0;
     bool fused = false;
 };
 
@@ -395,6 +398,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             TRY_OR_CLEAN(hipMalloc(&A->ring.d_rng, sizeof(int) * best.run_rng.size()));
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_rng, best.run_rng.data(), sizeof(int) * best.run_rng.size(), hipMemcpyHostToDevice));
             if (ghost_lo < ghost_hi) {
+                A->ring.h_run_halo = best.run_halo;
                 TRY_OR_CLEAN(hipMalloc(&A->ring.d_run_halo, sizeof(int) * best.run_halo.size()));
                 TRY_OR_CLEAN(hipMemcpy(A->ring.d_run_halo, best.run_halo.data(), sizeof(int) * best.run_halo.size(), hipMemcpyHostToDevice));
             }
@@ -1776,9 +1780,11 @@ static void part_comm_release(mi_part_s* P)
     dfree(P->d_links);
     dfree(P->d_nb);
     dfree(P->d_run_halo);
+    dfree(P->d_run_link);
     mi_csr_destroy(P->piece_all);
     P->piece_all = nullptr;
     P->d_run_halo = nullptr;
+    P->d_run_link = nullptr;
     P->fused = false;
     P->win = nullptr;
     P->d_links = nullptr;
@@ -2204,6 +2210,15 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
         mi_csr_t A = P->piece_all;
         if (P->kernel != MI_KERNEL_AUTO && P->kernel != MI_KERNEL_RING) A->kernel = P->kernel;
         P->fused = resolve_kernel(A) == MI_KERNEL_RING && A->ring.d_run_halo;
+        if (P->fused) { // push duty goes to the ghost-touching runs (short by construction): link l to the (l mod k)-th of them
+            std::vector<int> link((size_t)A->ring.wgs, -1);
+            int k = 0;
+            for (int g = 0; g < A->ring.wgs && k < P->n_links; g++)
+                if (A->ring.h_run_halo[g]) link[g] = k++;
+            P->npush_runs = k; // 0: no ghost runs in the plan -> dedicated push workgroups in front of the grid
+            HIP_TRY(hipMalloc(&P->d_run_link, sizeof(int) * link.size()));
+            HIP_TRY(hipMemcpy(P->d_run_link, link.data(), sizeof(int) * link.size(), hipMemcpyHostToDevice));
+        }
         if (!P->fused) {
             mi_csr_destroy(P->piece_all);
             P->piece_all = nullptr;
@@ -2228,6 +2243,8 @@ extern "C" int mi_part_push_disable(mi_part_t P)
     dfree(P->win);
     dfree(P->d_links);
     dfree(P->d_nb);
+    dfree(P->d_run_link);
+    P->d_run_link = nullptr;
     mi_csr_destroy(P->piece_all);
     P->win = nullptr;
     P->d_links = nullptr;
@@ -2286,7 +2303,9 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.n_nb = P->n_nb;
         C.n_local = pl.n_local;
         C.n_left = pl.n_left;
-        C.push_wgs = kNXCD; // a multiple of the XCD count keeps the run-to-XCD mapping of the ring workgroups
+        C.run_link = P->d_run_link;
+        C.npush_runs = P->npush_runs;
+        C.push_wgs = (P->npush_runs == 0 && P->n_links > 0) ? kNXCD : 0; // fallback only; a multiple of the XCD count keeps the run-to-XCD mapping
         C.step = step;
         C.spin_max = spin_max;
         if ((rc = launch_spmv(P->piece_all, d_x_ext, d_y_local, s, true, &C))) return rc;

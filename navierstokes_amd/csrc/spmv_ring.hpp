@@ -51,8 +51,12 @@ __device__ __forceinline__ int ring_slot(int c, int base)
 }
 
 // The fused multi-GPU step (FUSED = true; mi_part_spmv_push_dev): ONE launch does a rank's whole product.
-//   * the first push_wgs workgroups do the peer push of push_exchange.hpp (this rank's entries into the neighbours'
-//     windows, then the flags) and exit; being first in the grid they are dispatched first and wait for nothing;
+//   * the peer push of push_exchange.hpp (this rank's entries into the neighbours' windows, then the flags) is done by the
+//     ghost-touching runs themselves, FIRST thing, before they wait: those runs are short by construction (ring_plan.hpp,
+//     kGhostRunSlack), so the ~3 us of a push (stores, system-scope fence, flag) fit into their slack and no workgroup is
+//     added to the grid (with 8 extra push workgroups in front of 512 resident ones, eight ring workgroups started 3 us
+//     late: 26.8 instead of 23 us per step at N = 8).  A push depends on nothing, so pushing before waiting cannot
+//     deadlock.  push_wgs > 0 (extra workgroups in front) remains as the fallback for a plan without ghost runs;
 //   * the others are the ring kernel over ALL local rows in their natural order, columns numbered [ghosts of lower
 //     ranks | owned | ghosts of higher ranks] (partition.hpp: build_combined) so that a band stays a band across the
 //     partition boundary and boundary rows are ring-served like the rest.  Ghost columns are read from this rank's
@@ -68,11 +72,29 @@ struct RingComm {
     const int* nb;         // neighbours to wait for
     const double* halo;    // my window's data, this step's parity
     const int* run_halo;   // per run: touches a ghost column
+    const int* run_link;   // per run: first push link this run serves (then every npush_runs-th), or -1
     unsigned* timeouts;    // host-visible
-    int n_links, n_nb, n_local, n_left, push_wgs;
+    int n_links, n_nb, n_local, n_left, push_wgs, npush_runs;
     unsigned step;
     unsigned spin_max; // polls before a wait gives up (MI355_PUSH_SPIN_LOG2, default 23: ~30 s)
 };
+
+// one push link by the T threads of a workgroup (push_exchange.hpp: halo_push_kernel's body)
+template <int T>
+__device__ __forceinline__ void ring_push_link(const RingComm& C, const double* __restrict__ x, int l)
+{
+    const int tid = threadIdx.x;
+    const PushLink L = C.links[l];
+    double* dst = L.dst[C.step & 1u];
+    if (L.first >= 0) {
+        for (int i = tid; i < L.count; i += T) dst[i] = x[L.first + i];
+    } else {
+        for (int i = tid; i < L.count; i += T) dst[i] = x[C.send_idx[L.send_off + i]];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(L.flag, C.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 template <bool FUSED>
 __device__ __forceinline__ double ring_ldx(const double* __restrict__ x, const RingComm& C, int c)
@@ -189,19 +211,8 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     __shared__ double s_ring[RING];
     __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
     const int tid = threadIdx.x;
-    if (FUSED && (int)blockIdx.x < C.push_wgs) { // push duty (push_exchange.hpp: halo_push_kernel's body, T threads)
-        for (int l = blockIdx.x; l < C.n_links; l += C.push_wgs) {
-            const PushLink L = C.links[l];
-            double* dst = L.dst[C.step & 1u];
-            if (L.first >= 0) {
-                for (int i = tid; i < L.count; i += T) dst[i] = x[L.first + i];
-            } else {
-                for (int i = tid; i < L.count; i += T) dst[i] = x[C.send_idx[L.send_off + i]];
-            }
-            __threadfence_system();
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(L.flag, C.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    if (FUSED && (int)blockIdx.x < C.push_wgs) { // fallback: dedicated push workgroups in front of the grid
+        for (int l = blockIdx.x; l < C.n_links; l += C.push_wgs) ring_push_link<T>(C, x, l);
         return;
     }
     // XCD-aware run order: workgroups with equal (blockIdx & 7) share an XCD (observed
@@ -213,6 +224,11 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     const int2 rng = run_rng[gw]; // this workgroup's run: blocks [rng.x, rng.y)
     const int b_begin = rng.x;
     const int nb = rng.y - rng.x; // <= MAXB by construction of the plan
+    if (FUSED && C.npush_runs > 0) { // push duty of this run, before anything that could wait
+        const int l0 = C.run_link[gw];
+        if (l0 >= 0)
+            for (int l = l0; l < C.n_links; l += C.npush_runs) ring_push_link<T>(C, x, l);
+    }
     if (nb <= 0) return;
     const int clast = A.ncols - 1;
     // the plan is read back from LDS at a uniform address: tell the compiler so (SGPRs, scalar
