@@ -8,8 +8,11 @@
 //   * window = nranks flag slots (64 B apart, slot p written only by rank p) + 2 x n_halo doubles
 //     (two parities), allocated uncached so that neither side's L2 can hold a stale line;
 //   * step t (both sides count calls): the sender stores its entries into parity t & 1 of the peer's
-//     window, every storing thread drains its stores (system-scope fence), the workgroup meets at a
-//     barrier, ONE lane then stores t into its flag slot with system-scope release;
+//     window with WRITE-THROUGH stores (system-scope relaxed atomic stores = `global_store … sc0 sc1`: they never
+//     sit dirty in the sender's L2, so no L2 write-back is needed — a release fence there costs microseconds once
+//     the product's own y stores have dirtied the L2), every storing wave drains them (`s_waitcnt vmcnt(0)`), the
+//     workgroup meets at a barrier, ONE lane then stores t into its flag slot (system-scope atomic store) — the
+//     "write-through payload, drained, then flag" form of MI355X_MICROARCH.md § visibility;
 //   * ONE PROCESS PER RANK: the receiver's wait kernel spins until another rank's push kernel has run; ranks that are
 //     threads of one process share that process's few hardware queues, where a waiting kernel can be queued in front
 //     of the very kernel it waits for (observed: 4 rank threads hang).  Separate processes have separate queues.
@@ -25,6 +28,14 @@ namespace mi355 {
 
 constexpr int kWinFlagStride = 16; // unsigneds: one 64-byte line per sender
 
+// payload store that leaves for the peer at once (sc0 sc1), and the drain behind a batch of them
+__device__ __forceinline__ void push_store(double* p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void push_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 struct PushLink {
     double* dst[2];  // where my entries go in the peer's window, per parity
     unsigned* flag;  // my slot in the peer's window
@@ -39,13 +50,13 @@ __global__ __launch_bounds__(256) void halo_push_kernel(const PushLink* __restri
     const PushLink L = links[blockIdx.x];
     double* dst = L.dst[step & 1u];
     if (L.first >= 0) {
-        for (int i = threadIdx.x; i < L.count; i += 256) dst[i] = x[L.first + i];
+        for (int i = threadIdx.x; i < L.count; i += 256) push_store(dst + i, x[L.first + i]);
     } else {
-        for (int i = threadIdx.x; i < L.count; i += 256) dst[i] = x[send_idx[L.send_off + i]];
+        for (int i = threadIdx.x; i < L.count; i += 256) push_store(dst + i, x[send_idx[L.send_off + i]]);
     }
-    __threadfence_system(); // every storing thread: its stores have left for the peer
+    push_drain(); // every storing wave: its stores have left for the peer
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(L.flag, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(L.flag, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void halo_wait_copy_kernel(const unsigned* flags, const int* __restrict__ nb, int n_nb, unsigned step,

@@ -87,13 +87,13 @@ __device__ __forceinline__ void ring_push_link(const RingComm& C, const double* 
     const PushLink L = C.links[l];
     double* dst = L.dst[C.step & 1u];
     if (L.first >= 0) {
-        for (int i = tid; i < L.count; i += T) dst[i] = x[L.first + i];
+        for (int i = tid; i < L.count; i += T) push_store(dst + i, x[L.first + i]);
     } else {
-        for (int i = tid; i < L.count; i += T) dst[i] = x[C.send_idx[L.send_off + i]];
+        for (int i = tid; i < L.count; i += T) push_store(dst + i, x[C.send_idx[L.send_off + i]]);
     }
-    __threadfence_system();
+    push_drain();
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(L.flag, C.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(L.flag, C.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <bool FUSED>
