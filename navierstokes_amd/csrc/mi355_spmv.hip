@@ -87,6 +87,7 @@ struct RingTable {
     int* d_rng = nullptr;      // {first block, end block} per run
     int* d_run_halo = nullptr; // per run: touches a ghost column (fused multi-GPU step)
     std::vector<int> h_run_halo;
+    bool uniform = true;       // runs are consecutive ranges of bpw blocks (the kernel then computes them)
     unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block
     bool nt = false;                   // non-temporal loads of the values (chosen by measurement)
     bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
@@ -395,6 +396,9 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
             TRY_OR_CLEAN(hipMalloc(&A->ring.d_ok, sizeof(int) * best.run_ok.size()));
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
+            for (int g = 0; g < best.wgs; g++)
+                A->ring.uniform = A->ring.uniform && best.run_rng[2 * g] == std::min(best.nblk, g * best.bpw) &&
+                                  best.run_rng[2 * g + 1] == std::min(best.nblk, (g + 1) * best.bpw);
             TRY_OR_CLEAN(hipMalloc(&A->ring.d_rng, sizeof(int) * best.run_rng.size()));
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_rng, best.run_rng.data(), sizeof(int) * best.run_rng.size(), hipMemcpyHostToDevice));
             if (ghost_lo < ghost_hi) {
@@ -1028,11 +1032,11 @@ static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x,
 {
     if (!MAPPED && comm) { // the fused multi-GPU step: push workgroups in front of the grid (spmv_ring.hpp)
         hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, true>), dim3(A->ring.wgs + comm->push_wgs), dim3(T), 0, s,
-                           V, reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, reinterpret_cast<const int2*>(A->ring.d_rng), *comm);
+                           V, reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, reinterpret_cast<const int2*>(A->ring.d_rng), A->ring.uniform ? A->ring.bpw : 0, *comm);
         return;
     }
     hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, false>), dim3(A->ring.wgs), dim3(T), 0, s, V,
-                       reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, reinterpret_cast<const int2*>(A->ring.d_rng), RingComm{});
+                       reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, reinterpret_cast<const int2*>(A->ring.d_rng), A->ring.uniform ? A->ring.bpw : 0, RingComm{});
 }
 
 template <int T, int NNZB, int RING, int D, bool MAPPED>

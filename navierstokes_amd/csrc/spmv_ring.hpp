@@ -200,7 +200,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
                                                    const int* __restrict__ run_ok,
                                                    const unsigned short* __restrict__ slots,
                                                    const double* __restrict__ x, double* __restrict__ y,
-                                                   const int2* __restrict__ run_rng, RingComm C)
+                                                   const int2* __restrict__ run_rng, int bpw, RingComm C)
 {
     constexpr int PER = NNZB / T;
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
@@ -221,7 +221,9 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     const int bid = FUSED ? (int)blockIdx.x - C.push_wgs : (int)blockIdx.x;
     const int nwg = FUSED ? (int)gridDim.x - C.push_wgs : (int)gridDim.x;
     const int gw = (bid & (kNXCD - 1)) * (nwg / kNXCD) + (bid >> 3);
-    const int2 rng = run_rng[gw]; // this workgroup's run: blocks [rng.x, rng.y)
+    // this workgroup's run: blocks [rng.x, rng.y).  Plans with consecutive runs of bpw blocks (everything but the fused
+    // multi-GPU piece) say so with bpw > 0 and spare the kernel a dependent global load in front of its plan loads.
+    const int2 rng = bpw > 0 ? make_int2(min(A.nblk, gw * bpw), min(A.nblk, (gw + 1) * bpw)) : run_rng[gw];
     const int b_begin = rng.x;
     const int nb = rng.y - rng.x; // <= MAXB by construction of the plan
     if (FUSED && C.npush_runs > 0) { // push duty of this run, before anything that could wait
