@@ -1605,6 +1605,18 @@ static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long l
     const bool xcd = xcd_env >= 0 ? xcd_env != 0 : S > 4;
     const dim3 grid((unsigned)(xcd ? kNXCD * ((nwg + kNXCD - 1) / kNXCD) : nwg)), block(kWG);
     constexpr bool PF = S <= 4; // beyond four columns the prefetch stage costs more occupancy than it hides latency
+    static const bool quad = !(getenv("MI355_SPMM_QUAD") && !strcmp(getenv("MI355_SPMM_QUAD"), "0"));
+    if (S % 4 == 0 && quad) { // the quad of a block row shares its x blocks through DPP (spmv_kernels.hpp: spmm_bcsr4_quad)
+        constexpr int SQ = S % 4 == 0 ? S : 4;
+        if (xcd) {
+            if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 1, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+            else hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 0, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+        } else {
+            if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 1, false>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+            else hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 0, false>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+        }
+        return;
+    }
     if (xcd) {
         if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4<S, 1, PF, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
         else hipLaunchKernelGGL((spmm_bcsr4<S, 0, PF, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);

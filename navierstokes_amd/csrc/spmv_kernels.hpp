@@ -299,6 +299,103 @@ namespace mi355 {
 // XCD: workgroup b works on chunk (b & 7) * ceil(nwg / 8) + (b >> 3) of the block rows, so that each XCD (round-robin
 // dispatch) sweeps one contiguous eighth of the matrix and the x blocks its L2 fetched for one workgroup serve the next;
 // in dispatch order all eight L2s walk the same region and each fetches every x block for itself (S columns of them).
+// The four lanes of a block row need the same x block; loaded by each of them it costs four times the L1 bandwidth of the
+// one copy (a 16-byte-per-lane load occupies the CU's L1 path for 16 cycles whatever the addresses), and from four columns
+// on that path, not HBM, bounds the kernel.  quad_bcast hands lane K's value to all four lanes of its quad through DPP
+// (`v_mov_b32 … quad_perm:[K,K,K,K]`): two full-rate VALU moves per double instead of a memory instruction.
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v)
+{
+    constexpr int ctrl = K * 0x55; // quad_perm:[K,K,K,K]
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// one block's update of accumulator j from coefficients (c01, c23) and x block (v01, v23)
+template <int ARITH>
+__device__ __forceinline__ double spmm_block_update(double acc, double2 c01, double2 c23, double x0, double x1, double x2, double x3)
+{
+    if (ARITH == 0) {
+        acc = fma(c01.x, x0, acc);
+        acc = fma(c01.y, x1, acc);
+        acc = fma(c23.x, x2, acc);
+        return fma(c23.y, x3, acc);
+    }
+    double p = fma(c01.x, x0, 0.0);
+    p = fma(c01.y, x1, p);
+    p = fma(c23.x, x2, p);
+    p = fma(c23.y, x3, p);
+    return __dadd_rn(acc, p);
+}
+
+// S a multiple of 4: lane q of a block row loads the x blocks of columns q, q + 4, ... only (S/4 x blocks instead of S) and
+// the quad shares them through DPP.  Same arithmetic, same order per (row, column) as spmm_bcsr4: bit-identical.
+template <int S, int ARITH, bool XCD>
+__global__ __launch_bounds__(kWG) void spmm_bcsr4_quad(Bcsr4View A, const double* __restrict__ X, long long ldx,
+                                                       double* __restrict__ Y, long long ldy, int nwg)
+{
+    static_assert(S % 4 == 0, "quad sharing needs a multiple of four columns");
+    constexpr int G = S / 4;
+    const int wg = XCD ? xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
+    if (wg >= nwg) return;
+    const int g = wg * kWG + threadIdx.x;
+    // no early exit per lane: DPP reads the quad's other lanes, which must be live; the last block row is clamped instead
+    const int bi_raw = g >> 2, q = g & 3;
+    const int bi = min(bi_raw, A.nbrows - 1);
+    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+    const int ia0 = A.ptrow[bi], ia1 = A.ptrow[bi + 1];
+    double acc[S];
+#pragma unroll
+    for (int j = 0; j < S; j++) acc[j] = 0.0;
+    if (ia0 < ia1) { // uniform within a quad (the four lanes share bi)
+        const int last = ia1 - 1;
+        const double* cq = A.coef + 4 * q;
+        const double* Xq = X + (size_t)q * ldx; // this lane's first column; its others are 4 * ldx apart
+        const double2* row = reinterpret_cast<const double2*>(cq + 16 * (size_t)ia0);
+        double2 a01 = row[0], a23 = row[1];
+        unsigned col = ucol[ia0];
+        unsigned coln = ucol[min(ia0 + 1, last)];
+        double2 x01[G], x23[G];
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const double2* xb = reinterpret_cast<const double2*>(Xq + (size_t)(4 * t) * ldx + 4 * (size_t)col);
+            x01[t] = xb[0];
+            x23[t] = xb[1];
+        }
+        for (int ia = ia0; ia < ia1; ia++) {
+            const double2 c01 = a01, c23 = a23;
+            double2 v01[G], v23[G];
+#pragma unroll
+            for (int t = 0; t < G; t++) { v01[t] = x01[t]; v23[t] = x23[t]; }
+            const int nb = min(ia + 1, last);
+            const double2* nrow = reinterpret_cast<const double2*>(cq + 16 * (size_t)nb);
+            a01 = nrow[0];
+            a23 = nrow[1];
+            col = coln;
+            coln = ucol[min(ia + 2, last)];
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                const double2* xb = reinterpret_cast<const double2*>(Xq + (size_t)(4 * t) * ldx + 4 * (size_t)col);
+                x01[t] = xb[0];
+                x23[t] = xb[1];
+            }
+#pragma unroll
+            for (int t = 0; t < G; t++) { // columns 4t + K come from lane K of the quad
+                acc[4 * t + 0] = spmm_block_update<ARITH>(acc[4 * t + 0], c01, c23, quad_bcast<0>(v01[t].x), quad_bcast<0>(v01[t].y), quad_bcast<0>(v23[t].x), quad_bcast<0>(v23[t].y));
+                acc[4 * t + 1] = spmm_block_update<ARITH>(acc[4 * t + 1], c01, c23, quad_bcast<1>(v01[t].x), quad_bcast<1>(v01[t].y), quad_bcast<1>(v23[t].x), quad_bcast<1>(v23[t].y));
+                acc[4 * t + 2] = spmm_block_update<ARITH>(acc[4 * t + 2], c01, c23, quad_bcast<2>(v01[t].x), quad_bcast<2>(v01[t].y), quad_bcast<2>(v23[t].x), quad_bcast<2>(v23[t].y));
+                acc[4 * t + 3] = spmm_block_update<ARITH>(acc[4 * t + 3], c01, c23, quad_bcast<3>(v01[t].x), quad_bcast<3>(v01[t].y), quad_bcast<3>(v23[t].x), quad_bcast<3>(v23[t].y));
+            }
+        }
+    }
+    if (bi_raw < A.nbrows) {
+        const size_t orow = 4 * (size_t)(A.browmap ? A.browmap[bi] : bi) + q;
+#pragma unroll
+        for (int j = 0; j < S; j++) Y[(size_t)j * ldy + orow] = acc[j];
+    }
+}
+
 template <int S, int ARITH, bool PF, bool XCD>
 __global__ __launch_bounds__(kWG) void spmm_bcsr4(Bcsr4View A, const double* __restrict__ X, long long ldx,
                                                   double* __restrict__ Y, long long ldy, int nwg)
