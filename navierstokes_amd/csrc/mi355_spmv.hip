@@ -1608,13 +1608,23 @@ static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long l
     static const bool quad = !(getenv("MI355_SPMM_QUAD") && !strcmp(getenv("MI355_SPMM_QUAD"), "0"));
     if (S % 4 == 0 && quad) { // the quad of a block row shares its x blocks through DPP (spmv_kernels.hpp: spmm_bcsr4_quad)
         constexpr int SQ = S % 4 == 0 ? S : 4;
-        if (xcd) {
-            if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 1, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
-            else hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 0, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
-        } else {
-            if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 1, false>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
-            else hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 0, false>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
-        }
+        static const int depth_env = getenv("MI355_SPMM_DEPTH") ? atoi(getenv("MI355_SPMM_DEPTH")) : 0;
+        const int depth = depth_env >= 1 && depth_env <= 4 ? depth_env : (S == 4 ? 3 : 2);
+#define MI_SPMM_QUAD(PD)                                                                                                               \
+    do {                                                                                                                               \
+        if (xcd) {                                                                                                                     \
+            if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 1, true, PD>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg); \
+            else hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 0, true, PD>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);                    \
+        } else {                                                                                                                       \
+            if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 1, false, PD>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg); \
+            else hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 0, false, PD>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);                   \
+        }                                                                                                                              \
+    } while (0)
+        if (depth == 1) MI_SPMM_QUAD(1);
+        else if (depth == 2) MI_SPMM_QUAD(2);
+        else if (depth == 3) MI_SPMM_QUAD(3);
+        else MI_SPMM_QUAD(4);
+#undef MI_SPMM_QUAD
         return;
     }
     if (xcd) {

@@ -331,7 +331,13 @@ __device__ __forceinline__ double spmm_block_update(double acc, double2 c01, dou
 
 // S a multiple of 4: lane q of a block row loads the x blocks of columns q, q + 4, ... only (S/4 x blocks instead of S) and
 // the quad shares them through DPP.  Same arithmetic, same order per (row, column) as spmm_bcsr4: bit-identical.
-template <int S, int ARITH, bool XCD>
+// What bounds these kernels is not L1 bandwidth but memory-level parallelism — a lane's chain over its ~15 blocks is
+// sequential, so its speed is (loads in flight) / latency: with one block of look-ahead the quad form, which issues FEWER
+// loads per block, was SLOWER at four columns (254 vs 176 us) and faster at eight only because the plain form there has
+// no look-ahead at all.  The registers the shared x blocks free are therefore spent on a P-deep software pipeline like
+// spmv_bcsr4's: stage t holds coefficients and x blocks of block ia + t, refilled with block ia + t + P as soon as it is
+// consumed; block columns run another P ahead (an x address needs its column first).
+template <int S, int ARITH, bool XCD, int P>
 __global__ __launch_bounds__(kWG) void spmm_bcsr4_quad(Bcsr4View A, const double* __restrict__ X, long long ldx,
                                                        double* __restrict__ Y, long long ldy, int nwg)
 {
@@ -352,40 +358,54 @@ __global__ __launch_bounds__(kWG) void spmm_bcsr4_quad(Bcsr4View A, const double
         const int last = ia1 - 1;
         const double* cq = A.coef + 4 * q;
         const double* Xq = X + (size_t)q * ldx; // this lane's first column; its others are 4 * ldx apart
-        const double2* row = reinterpret_cast<const double2*>(cq + 16 * (size_t)ia0);
-        double2 a01 = row[0], a23 = row[1];
-        unsigned col = ucol[ia0];
-        unsigned coln = ucol[min(ia0 + 1, last)];
-        double2 x01[G], x23[G];
+        double2 a01[P], a23[P], x01[P][G], x23[P][G];
+        unsigned cn[P];
 #pragma unroll
-        for (int t = 0; t < G; t++) {
-            const double2* xb = reinterpret_cast<const double2*>(Xq + (size_t)(4 * t) * ldx + 4 * (size_t)col);
-            x01[t] = xb[0];
-            x23[t] = xb[1];
+        for (int t = 0; t < P; t++) {
+            const int blk = min(ia0 + t, last);
+            const double2* row = reinterpret_cast<const double2*>(cq + 16 * (size_t)blk);
+            a01[t] = row[0];
+            a23[t] = row[1];
+            cn[t] = ucol[blk];
         }
-        for (int ia = ia0; ia < ia1; ia++) {
-            const double2 c01 = a01, c23 = a23;
-            double2 v01[G], v23[G];
 #pragma unroll
-            for (int t = 0; t < G; t++) { v01[t] = x01[t]; v23[t] = x23[t]; }
-            const int nb = min(ia + 1, last);
-            const double2* nrow = reinterpret_cast<const double2*>(cq + 16 * (size_t)nb);
-            a01 = nrow[0];
-            a23 = nrow[1];
-            col = coln;
-            coln = ucol[min(ia + 2, last)];
+        for (int t = 0; t < P; t++)
 #pragma unroll
-            for (int t = 0; t < G; t++) {
-                const double2* xb = reinterpret_cast<const double2*>(Xq + (size_t)(4 * t) * ldx + 4 * (size_t)col);
-                x01[t] = xb[0];
-                x23[t] = xb[1];
+            for (int u = 0; u < G; u++) {
+                const double2* xb = reinterpret_cast<const double2*>(Xq + (size_t)(4 * u) * ldx + 4 * (size_t)cn[t]);
+                x01[t][u] = xb[0];
+                x23[t][u] = xb[1];
             }
 #pragma unroll
-            for (int t = 0; t < G; t++) { // columns 4t + K come from lane K of the quad
-                acc[4 * t + 0] = spmm_block_update<ARITH>(acc[4 * t + 0], c01, c23, quad_bcast<0>(v01[t].x), quad_bcast<0>(v01[t].y), quad_bcast<0>(v23[t].x), quad_bcast<0>(v23[t].y));
-                acc[4 * t + 1] = spmm_block_update<ARITH>(acc[4 * t + 1], c01, c23, quad_bcast<1>(v01[t].x), quad_bcast<1>(v01[t].y), quad_bcast<1>(v23[t].x), quad_bcast<1>(v23[t].y));
-                acc[4 * t + 2] = spmm_block_update<ARITH>(acc[4 * t + 2], c01, c23, quad_bcast<2>(v01[t].x), quad_bcast<2>(v01[t].y), quad_bcast<2>(v23[t].x), quad_bcast<2>(v23[t].y));
-                acc[4 * t + 3] = spmm_block_update<ARITH>(acc[4 * t + 3], c01, c23, quad_bcast<3>(v01[t].x), quad_bcast<3>(v01[t].y), quad_bcast<3>(v23[t].x), quad_bcast<3>(v23[t].y));
+        for (int t = 0; t < P; t++) cn[t] = ucol[min(ia0 + P + t, last)];
+        for (int ia = ia0; ia < ia1; ia += P) {
+#pragma unroll
+            for (int t = 0; t < P; t++) {
+                const double2 c01 = a01[t], c23 = a23[t];
+                double2 v01[G], v23[G];
+#pragma unroll
+                for (int u = 0; u < G; u++) { v01[u] = x01[t][u]; v23[u] = x23[t][u]; }
+                // refill stage t with block ia + t + P (its column arrived a round ago), then ask for the column of ia + t + 2P
+                const int nb = min(ia + t + P, last);
+                const double2* nrow = reinterpret_cast<const double2*>(cq + 16 * (size_t)nb);
+                a01[t] = nrow[0];
+                a23[t] = nrow[1];
+#pragma unroll
+                for (int u = 0; u < G; u++) {
+                    const double2* xb = reinterpret_cast<const double2*>(Xq + (size_t)(4 * u) * ldx + 4 * (size_t)cn[t]);
+                    x01[t][u] = xb[0];
+                    x23[t][u] = xb[1];
+                }
+                cn[t] = ucol[min(ia + t + 2 * P, last)];
+                if (ia + t < ia1) { // uniform within the quad
+#pragma unroll
+                    for (int u = 0; u < G; u++) { // columns 4u + K come from lane K of the quad
+                        acc[4 * u + 0] = spmm_block_update<ARITH>(acc[4 * u + 0], c01, c23, quad_bcast<0>(v01[u].x), quad_bcast<0>(v01[u].y), quad_bcast<0>(v23[u].x), quad_bcast<0>(v23[u].y));
+                        acc[4 * u + 1] = spmm_block_update<ARITH>(acc[4 * u + 1], c01, c23, quad_bcast<1>(v01[u].x), quad_bcast<1>(v01[u].y), quad_bcast<1>(v23[u].x), quad_bcast<1>(v23[u].y));
+                        acc[4 * u + 2] = spmm_block_update<ARITH>(acc[4 * u + 2], c01, c23, quad_bcast<2>(v01[u].x), quad_bcast<2>(v01[u].y), quad_bcast<2>(v23[u].x), quad_bcast<2>(v23[u].y));
+                        acc[4 * u + 3] = spmm_block_update<ARITH>(acc[4 * u + 3], c01, c23, quad_bcast<3>(v01[u].x), quad_bcast<3>(v01[u].y), quad_bcast<3>(v23[u].x), quad_bcast<3>(v23[u].y));
+                    }
+                }
             }
         }
     }
