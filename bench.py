@@ -198,7 +198,7 @@ def main():
         ys = [torch.empty(n, dtype=torch.float64, device="cuda")]
         nvec = int(W.get("spmm", 0))
         if nvec:
-            kernel_name = (f"spmm_bcsr4_quad<{nvec}, 0, {'true' if os.environ.get('MI355_SPMM_XCD', '1' if nvec > 4 else '0') != '0' else 'false'}, {os.environ.get('MI355_SPMM_DEPTH') or (3 if nvec == 4 else 2)}>"
+            kernel_name = (f"spmm_bcsr4_quad<{nvec}, 0, {'true' if os.environ.get('MI355_SPMM_XCD', '1' if nvec > 4 else '0') != '0' else 'false'}, {os.environ.get('MI355_SPMM_DEPTH') or (2 if nvec == 4 else 1)}>"
                            if nvec % 4 == 0 and os.environ.get("MI355_SPMM_QUAD") != "0" else None) or f"spmm_bcsr4<{nvec}, 0, {'true' if nvec <= 4 else 'false'}, {'true' if os.environ.get('MI355_SPMM_XCD', '1' if nvec > 4 else '0') != '0' else 'false'}>"
             Xh = np.stack([np.sin(0.001 * np.arange(n) + j) for j in range(nvec)])  # v_i[j] = sin(0.001 j + i), mpk/2SpMV.cpp:110-116
             Xd = torch.from_numpy(Xh).cuda()

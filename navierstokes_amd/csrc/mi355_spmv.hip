@@ -1609,7 +1609,9 @@ static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long l
     if (S % 4 == 0 && quad) { // the quad of a block row shares its x blocks through DPP (spmv_kernels.hpp: spmm_bcsr4_quad)
         constexpr int SQ = S % 4 == 0 ? S : 4;
         static const int depth_env = getenv("MI355_SPMM_DEPTH") ? atoi(getenv("MI355_SPMM_DEPTH")) : 0;
-        const int depth = depth_env >= 1 && depth_env <= 4 ? depth_env : (S == 4 ? 3 : 2);
+        // measured on the FE matrix (bench.py fe_spmm4 / fe_spmm8, MI355_SPMM_DEPTH): 4 columns 254 / 168 / 168 / 173 us at depth 1 / 2 / 3 / 4
+        // (registers cost occupancy: 7 / 5 / 4 / 3 waves per SIMD), 8 columns 223 / 232 / 237 us at depth 1 / 2 / 3
+        const int depth = depth_env >= 1 && depth_env <= 4 ? depth_env : (S == 4 ? 2 : 1);
 #define MI_SPMM_QUAD(PD)                                                                                                               \
     do {                                                                                                                               \
         if (xcd) {                                                                                                                     \
