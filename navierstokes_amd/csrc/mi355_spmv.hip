@@ -1067,11 +1067,25 @@ __global__ __launch_bounds__(256) void scatter_kernel(int m, const int* __restri
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) dst[idx[i]] = src[i];
 }
 
+// x into a reordered handle's numbering (whole nodes at a time when nodes were moved and x allows 16-byte accesses)
+static int gather_perm(mi_csr_t A, const double* d_x, double* d_xp, hipStream_t s)
+{
+    if (A->reorder_block == 4 && (((uintptr_t)d_x | (uintptr_t)d_xp) & 15) == 0) {
+        const int nn = A->n / 4;
+        int grid = (nn + 255) / 256;
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(gather_nodes_kernel, dim3(grid), dim3(256), 0, s, nn, A->d_iperm, d_x, d_xp);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
+    return mi_gather_dev(A->n, A->d_iperm, d_x, d_xp, (mi_stream_t)s);
+}
+
 static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm)
 {
     if (A->n == 0) return MI_OK;
     if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
-        int rc = mi_gather_dev(A->n, A->d_iperm, d_x, A->d_xp, (mi_stream_t)s);
+        int rc = gather_perm(A, d_x, A->d_xp, s);
         if (rc) return rc;
         return launch_spmv(A->inner, A->d_xp, d_y, s, true);
     }
@@ -1161,7 +1175,7 @@ extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* 
             HIP_TRY(hipMalloc(&p, sizeof(double) * (size_t)A->n));
             A->d_pp.push_back(p);
         }
-        int rc = mi_gather_dev(A->n, A->d_iperm, d_x, A->d_xp, s);
+        int rc = gather_perm(A, d_x, A->d_xp, (hipStream_t)s);
         if (rc) return rc;
         const double* src = A->d_xp;
         int grid = (A->n + 255) / 256;
@@ -1710,7 +1724,7 @@ extern "C" int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, 
         double* Xp = nullptr; // the gathered columns as one dense block, stream-ordered allocation
         HIP_TRY(hipMallocAsync((void**)&Xp, sizeof(double) * n * s, st));
         int rc = MI_OK;
-        for (int j = 0; j < s && !rc; j++) rc = mi_gather_dev(A->n, A->d_iperm, d_X + (size_t)j * ldx, Xp + n * j, st);
+        for (int j = 0; j < s && !rc; j++) rc = gather_perm(A, d_X + (size_t)j * ldx, Xp + n * j, st);
         if (!rc) rc = launch_spmm(A->inner->blocked, s, MI_ARITH_CHAIN, Xp, (long long)n, d_Y, ldy, st, true);
         (void)hipFreeAsync(Xp, st);
         return rc;

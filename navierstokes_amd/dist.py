@@ -69,6 +69,12 @@ class DistCSR:
         mpk.check(L.mi_part_sizes(h, _c.byref(nl), _c.byref(nh), _c.byref(ni), _c.byref(nb)))
         self.n_local, self.n_halo, self.n_interior, self.n_boundary = nl.value, nh.value, ni.value, nb.value
         self.nnz_local = int(ptrow[-1])
+        # `compute=` is a TEST seam (the CPU tests inject the oracle as local compute to exercise planner + exchange without a
+        # GPU).  It must never carry a product run: where a GPU is present it is refused unless the test harness says so.
+        if compute is not None and torch.cuda.is_available():
+            import os
+            if os.environ.get("MI355_TEST_COMPUTE_HOOK") != "1":
+                raise RuntimeError("DistCSR(compute=...) is a test-only hook and is refused on a machine with a GPU")
         self.compute = compute
         self.device = torch.device(device) if device is not None else torch.device("cuda" if compute is None else "cpu")
 

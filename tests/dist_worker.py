@@ -3,6 +3,7 @@ Runs the product's DistCSR (planner + torch.distributed exchange) with the local
 SpMV injected from the test oracle, and checks every rank's slice bitwise against
 the global oracle SpMV."""
 import os
+os.environ["MI355_TEST_COMPUTE_HOOK"] = "1"  # this worker injects the oracle as local compute (CPU test seam)
 import sys
 
 import numpy as np
