@@ -1542,7 +1542,11 @@ static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_
     CHECK_ARG((((uintptr_t)d_x) & 15) == 0, "x must be 16-byte aligned");
     Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map ? A->d_browmap : nullptr};
     const long long threads = 4LL * A->nbrows;
-    hipLaunchKernelGGL(spmv_bcsr4<kBcsrDepth>, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y);
+    const int nwg = (int)((threads + kWG - 1) / kWG);
+    static const int chunk = getenv("MI355_BCSR_XCD_CHUNK") ? atoi(getenv("MI355_BCSR_XCD_CHUNK")) : 0;
+    // padded grid for the chunked order: whole rounds of 8 chunks
+    const int grid = chunk > 0 ? ((nwg + kNXCD * chunk - 1) / (kNXCD * chunk)) * kNXCD * chunk : nwg;
+    hipLaunchKernelGGL(spmv_bcsr4<kBcsrDepth>, dim3((unsigned)grid), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y, chunk, nwg);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }

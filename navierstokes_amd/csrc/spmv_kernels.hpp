@@ -58,6 +58,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk)
     return (bid & (kNXCD - 1)) * per + (bid >> 3);
 }
 
+// Chunked form: the work is cut into chunks of `chunk` consecutive workgroups, dealt to the XCDs round-robin.  Each XCD
+// (blockIdx & 7) then walks chunks c = xcd, xcd + 8, ... — contiguous work inside a chunk (its L2 reuses the x neighbourhood)
+// while all eight XCDs stay in the same region of the matrix at any time (one moving front through memory, as in dispatch
+// order) instead of eight distant streams.  chunk >= ceil(n / 8) degenerates to xcd_remap.  Returns >= n for padding ids.
+__device__ __forceinline__ int xcd_remap_chunked(int bid, int n, int chunk)
+{
+    const int xcd = bid & (kNXCD - 1), slot = bid >> 3;
+    const int round = slot / chunk, within = slot - round * chunk;
+    return (round * kNXCD + xcd) * chunk + within;
+}
+
 // ---------------------------------------------------------------------------
 // stream kernel.  NNZB: nonzeros per row block (LDS = 2 * 8 B * sk(NNZB)).
 // ---------------------------------------------------------------------------
@@ -218,11 +229,14 @@ struct Bcsr4View {
 // 2-3 % SLOWER at every depth, so the kernel is not traffic-bound; non-temporal loads of the block
 // values lose badly (870 GFLOP/s: a lane's two 16-byte loads touch the same 128-byte line twice).
 constexpr int kBcsrDepth = 2;
+// xcd_chunk > 0: workgroups take their block rows in XCD-chunked order (xcd_remap_chunked); the grid is then padded
 template <int P>
 __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __restrict__ x,
-                                                  double* __restrict__ y)
+                                                  double* __restrict__ y, int xcd_chunk, int nwg)
 {
-    const int g = blockIdx.x * kWG + threadIdx.x;
+    const int wg = xcd_chunk > 0 ? xcd_remap_chunked(blockIdx.x, nwg, xcd_chunk) : (int)blockIdx.x;
+    if (wg >= nwg) return;
+    const int g = wg * kWG + threadIdx.x;
     const int bi = g >> 2, q = g & 3;
     if (bi >= A.nbrows) return;
     const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
