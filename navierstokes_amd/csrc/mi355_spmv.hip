@@ -1544,8 +1544,7 @@ static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_
     const long long threads = 4LL * A->nbrows;
     const int nwg = (int)((threads + kWG - 1) / kWG);
     static const int chunk = getenv("MI355_BCSR_XCD_CHUNK") ? atoi(getenv("MI355_BCSR_XCD_CHUNK")) : 0;
-    // padded grid for the chunked order: whole rounds of 8 chunks
-    const int grid = chunk > 0 ? ((nwg + kNXCD * chunk - 1) / (kNXCD * chunk)) * kNXCD * chunk : nwg;
+    const int grid = nwg;
     hipLaunchKernelGGL(spmv_bcsr4<kBcsrDepth>, dim3((unsigned)grid), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y, chunk, nwg);
     HIP_TRY(hipGetLastError());
     return MI_OK;

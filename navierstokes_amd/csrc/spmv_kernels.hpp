@@ -61,9 +61,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk)
 // Chunked form: the work is cut into chunks of `chunk` consecutive workgroups, dealt to the XCDs round-robin.  Each XCD
 // (blockIdx & 7) then walks chunks c = xcd, xcd + 8, ... — contiguous work inside a chunk (its L2 reuses the x neighbourhood)
 // while all eight XCDs stay in the same region of the matrix at any time (one moving front through memory, as in dispatch
-// order) instead of eight distant streams.  chunk >= ceil(n / 8) degenerates to xcd_remap.  Returns >= n for padding ids.
+// order) instead of eight distant streams.  Only whole rounds of 8 chunks are remapped; the tail keeps its dispatch order, so
+// the grid needs no padding.
 __device__ __forceinline__ int xcd_remap_chunked(int bid, int n, int chunk)
 {
+    const int span = kNXCD * chunk;
+    if (bid >= (n / span) * span) return bid;
     const int xcd = bid & (kNXCD - 1), slot = bid >> 3;
     const int round = slot / chunk, within = slot - round * chunk;
     return (round * kNXCD + xcd) * chunk + within;
