@@ -262,6 +262,9 @@ int mi_part_send_index(mi_part_t P, int* total, const int** local_idx /* packed 
 /* upload the two pieces and the send index to the current device */
 int mi_part_finalize(mi_part_t P);
 int mi_part_set_kernel(mi_part_t P, int kernel_id);
+/* new coefficients for an unchanged pattern: this rank's values in the order of the arrays given to mi_part_create
+ * (host pointer; after mi_part_finalize).  Every piece of the handle is refreshed, plans and exchange set-up are kept. */
+int mi_part_update_values(mi_part_t P, const double* coef);
 /* per step, on device: x_ext = [x_local | halo], sendbuf packed by peer */
 int mi_part_pack_dev(mi_part_t P, const double* d_x_ext, double* d_sendbuf, mi_stream_t s);
 int mi_part_spmv_interior_dev(mi_part_t P, const double* d_x_ext, double* d_y_local, mi_stream_t s);

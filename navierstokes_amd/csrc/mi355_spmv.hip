@@ -2372,6 +2372,30 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
     return MI_OK;
 }
 
+// New coefficients for an unchanged pattern (see mi_csr_update_values): coef = this rank's values in the order of the arrays
+// given to mi_part_create.  The interior / boundary pieces take theirs through the nonzero positions recorded at plan time;
+// the fused step's piece holds all rows in the caller's order, so it takes the array as it is.
+extern "C" int mi_part_update_values(mi_part_t P, const double* coef)
+{
+    CHECK_ARG(P, "null handle");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    for (int w = 0; w < 2; w++) {
+        LocalPiece& L = P->plan.piece[w];
+        if (L.src.empty()) continue;
+        CHECK_ARG(coef, "null coef");
+        for (size_t k = 0; k < L.src.size(); k++) L.coef[k] = coef[L.src[k]];
+        int rc = mi_csr_update_values(P->piece[w], L.coef.data());
+        if (rc) return rc;
+    }
+    if (P->piece_all) {
+        LocalPiece& L = P->plan.all;
+        for (size_t k = 0; k < L.coef.size(); k++) L.coef[k] = coef[k];
+        int rc = mi_csr_update_values(P->piece_all, coef);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
 extern "C" int mi_part_set_kernel(mi_part_t P, int kernel_id)
 {
     CHECK_ARG(P, "null handle");

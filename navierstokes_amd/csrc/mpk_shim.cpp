@@ -50,7 +50,7 @@ uint64_t hash_chunk(const unsigned char* p, size_t bytes)
         for (int i = 0; i < 8; i++) lane[i] = (lane[i] ^ w[i]) * K[i] + (lane[i] >> 29);
     }
     uint64_t tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    std::memcpy(tail, p + k, bytes - k);
+    if (bytes > k) std::memcpy(tail, p + k, bytes - k);
     uint64_t h = 0xcbf29ce484222325ull;
     for (int i = 0; i < 8; i++) {
         lane[i] = (lane[i] ^ tail[i]) * K[i] + (lane[i] >> 29);
@@ -117,7 +117,8 @@ H device_copy(std::map<Key, Slot<H>>& cache, const Key& k, int n, const int* ptr
     typename std::map<Key, Slot<H>>::iterator it = cache.find(k);
     const bool cached = it != cache.end() && it->second.n == n && it->second.stored == stored;
     if (cached && g_assume_unchanged) return it->second.handle;
-    const uint64_t pfp = hash_bytes(ptrow, sizeof(int) * ((size_t)n + 1)) ^ (hash_bytes(indcol, sizeof(int) * (size_t)stored) * 3);
+    // (an empty matrix may come with empty vectors: nothing to read then)
+    const uint64_t pfp = hash_bytes(ptrow, n > 0 ? sizeof(int) * ((size_t)n + 1) : 0) ^ (hash_bytes(indcol, sizeof(int) * (size_t)stored) * 3);
     const uint64_t vfp = hash_bytes(coef, sizeof(double) * per_entry * (size_t)stored);
     if (cached && it->second.pattern_fp == pfp) {
         if (it->second.values_fp != vfp) { // same pattern, new coefficients: refresh the values only

@@ -22,6 +22,7 @@ struct LocalPiece {           // interior or boundary rows of one rank
     std::vector<int> indcol;  // local column ids
     std::vector<double> coef;
     std::vector<int> rowmap;  // local row index of each piece row
+    std::vector<int> src;     // position of each nonzero in the caller's (rank-local) CSR arrays: refreshes coef in place
 };
 
 struct PartPlan {
@@ -123,6 +124,7 @@ struct PartPlan {
                 else lc = n_local + (int)(std::lower_bound(halo_ids.begin(), halo_ids.end(), c) - halo_ids.begin());
                 P.indcol.push_back(lc);
                 P.coef.push_back(coef[k]);
+                P.src.push_back(k);
             }
             P.ptrow.push_back((int)P.indcol.size());
             P.rowmap.push_back(r);

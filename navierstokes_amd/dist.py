@@ -203,6 +203,12 @@ class DistCSR:
             self.push_fused = bool(fused.value)
         return all(flags)
 
+    def update_values(self, coef):
+        """New coefficients (this rank's rows, same order as at construction) for the same pattern."""
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        assert len(coef) == self.nnz_local
+        mpk.check(mpk.lib().mi_part_update_values(self._h, coef.ctypes.data))
+
     def status(self):
         """Raises if a hand-off / halo wait of the native or push step ever gave up (call after synchronising)."""
         if self.compute is None:

@@ -131,6 +131,7 @@ def lib():
         "mi_part_send_index": [_vp, P(i), P(_vp)],
         "mi_part_finalize": [_vp],
         "mi_part_set_kernel": [_vp, i],
+        "mi_part_update_values": [_vp, _vp],
         "mi_part_pack_dev": [_vp, _vp, _vp, _vp],
         "mi_part_spmv_interior_dev": [_vp, _vp, _vp, _vp],
         "mi_part_spmv_boundary_dev": [_vp, _vp, _vp, _vp],

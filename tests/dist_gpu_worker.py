@@ -44,6 +44,16 @@ def main():
             torch.cuda.synchronize()
             dc.status()
             ok = ok and np.array_equal(y.cpu().numpy().view(np.uint64), Y[0][lo:hi].view(np.uint64))
+        # coefficients replaced in place (a Newton loop's Jacobian): same plan, same exchange, new bits
+        v2 = v * np.cos(np.arange(len(v)) + lo)
+        dc.update_values(v2)
+        y2 = dc.new_y()
+        dc.spmv(x_ext, y2)
+        torch.cuda.synchronize()
+        full_v2 = Vg.copy()
+        full_v2[Pg[lo]:Pg[hi]] = v2
+        ok = ok and np.array_equal(y2.cpu().numpy().view(np.uint64), O.spmv(Pg, Cg, full_v2, synth.x_sin(0, n))[lo:hi].view(np.uint64))
+        dc.update_values(v)
         g = float(dc.dot(ys[0], ys[0]))
         ref = float(np.dot(Y[0], Y[0]))
         ok = ok and abs(g - ref) <= 1e-12 * ref
