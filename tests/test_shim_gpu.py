@@ -266,3 +266,16 @@ def test_reference_SpMVmulti0_driver_routed_to_the_gpu(tmp_path):
     assert cpu.returncode == 0
     R = table(cpu.stderr)
     assert np.allclose(T, R, rtol=2e-6, atol=1e-300), np.abs(T - R).max()  # six printed digits
+
+
+def test_shim_degenerate_shapes():
+    """Empty matrix, empty rows, one row: the shim (full-content hash, device copy) must not trip over empty arrays."""
+    assert len(shim.spmv_csr("SpMV_CSR", np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0), np.zeros(0))) == 0
+    p = np.array([0, 0, 2, 2, 3], np.int32)   # rows 0 and 2 empty
+    c = np.array([1, 3, 0], np.int32)
+    v = np.array([2.0, -1.0, 0.5])
+    x = np.array([1.0, 2.0, 3.0, 4.0])
+    assert np.array_equal(shim.spmv_csr("SpMV_CSR_FMA", p, c, v, x), [0.0, 0.0, 0.0, 0.5])
+    y, z = shim.spm2v_csr("SpM2V_CSR", p, c, v, x)
+    assert np.array_equal(y, [0.0, 0.0, 0.0, 0.5]) and np.array_equal(z, O.spmv(p, c, v, y))
+    assert np.array_equal(shim.spmv_csr("SpMV_CSR", np.array([0, 1], np.int32), np.array([0], np.int32), np.array([3.0]), np.array([2.0])), [6.0])
