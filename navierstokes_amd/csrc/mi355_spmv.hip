@@ -101,7 +101,6 @@ struct mi_csr_s {
     int* d_indcol = nullptr;
     double* d_coef = nullptr;
     int* d_rowmap = nullptr;
-    int* d_rowmap2 = nullptr; // relabelled twin with rows sorted by smallest column: position of row r'' in the column numbering
     bool mapped = false;  // created with a rowmap (device-only entry points, no powers)
     int y_offset = 0;     // a rowmap that is just "row r -> y[r + offset]" is applied as a pointer offset, not as a gather
     std::vector<int> h_ptrow; // kept to (re)build row-block tables
@@ -139,7 +138,6 @@ struct mi_bcsr4_s {
     int* d_indcol = nullptr;
     double* d_coef = nullptr;
     int* d_browmap = nullptr; // block-row map of a reordered matrix's blocked copy, else null
-    int* d_browmap2 = nullptr; // ... and its second map (see mi_csr_s::d_rowmap2)
     double* d_x = nullptr;
     double* d_y = nullptr;
     std::vector<double*> d_pow;
@@ -294,8 +292,8 @@ static int get_table(mi_csr_t A, int nnzb, BlockTable** out)
     return MI_OK;
 }
 
-static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, int use_map = 1, const RingComm* comm = nullptr);
-static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, int use_map);
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr);
+static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);
 static int resolve_kernel(const mi_csr_s* A);
 
 static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
@@ -636,37 +634,16 @@ static int maybe_reorder(mi_csr_t A, const int* ptrow, const int* indcol, const 
     if (!force && R.spread_after > 0.5 * spread) return MI_OK; // nothing gained
     std::vector<int> p2, c2, src_start;
     std::vector<double> v2;
-    if (const char* e2 = getenv("MI355_REORDER_SORT_ROWS"))
-        if (!strcmp(e2, "0")) { // development A/B: rows in the column numbering's own order
-            R.row_of = R.iperm;
-            R.rows_sorted = false;
-        }
     permute_csr(n, ptrow, indcol, coef, R, p2, c2, v2, src_start);
     mi_csr_t inner = nullptr;
-    int rc = csr_create_impl(n, n, p2.data(), c2.data(), v2.data(), R.row_of.data(), &inner); // row map 1: stored row -> the caller's row
+    int rc = csr_create_impl(n, n, p2.data(), c2.data(), v2.data(), R.iperm.data(), &inner);
     if (rc) return rc;
     A->inner = inner; // from here on launch_spmv(A) goes through the twin; destroy releases it
-    if (R.rows_sorted) { // row map 2: stored row -> its position in the COLUMN numbering (chained products stay in that numbering)
-        std::vector<int> map2((size_t)n);
-        for (int k = 0; k < n; k++) map2[k] = R.perm[R.row_of[k]];
-        hipError_t e2;
-        if ((e2 = hipMalloc(&inner->d_rowmap2, sizeof(int) * (size_t)(n + kRingPadRows))) != hipSuccess ||
-            (e2 = hipMemset(inner->d_rowmap2 + n, 0, sizeof(int) * kRingPadRows)) != hipSuccess ||
-            (e2 = hipMemcpy(inner->d_rowmap2, map2.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess)
-            return fail(MI_ERR_HIP, std::string("reorder row map: ") + hipGetErrorString(e2));
-        if (inner->blocked) {
-            std::vector<int> bmap2((size_t)n / 4);
-            for (int b = 0; b < n / 4; b++) bmap2[b] = map2[4 * b] / 4;
-            if ((e2 = hipMalloc(&inner->blocked->d_browmap2, sizeof(int) * bmap2.size())) != hipSuccess ||
-                (e2 = hipMemcpy(inner->blocked->d_browmap2, bmap2.data(), sizeof(int) * bmap2.size(), hipMemcpyHostToDevice)) != hipSuccess)
-                return fail(MI_ERR_HIP, std::string("reorder block-row map: ") + hipGetErrorString(e2));
-        }
-    }
     hipError_t e;
     if ((e = hipMalloc(&A->d_iperm, sizeof(int) * (size_t)n)) != hipSuccess ||
         (e = hipMalloc(&A->d_src_start, sizeof(int) * (size_t)n)) != hipSuccess ||
         (e = hipMalloc(&A->d_xp, sizeof(double) * (size_t)n)) != hipSuccess ||
-        (e = hipMemcpy(A->d_iperm, R.iperm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess || // x gather: column numbering
+        (e = hipMemcpy(A->d_iperm, R.iperm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(A->d_src_start, src_start.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("reorder upload: ") + hipGetErrorString(e));
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
@@ -751,7 +728,6 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->d_indcol);
     dfree(A->d_coef);
     dfree(A->d_rowmap);
-    dfree(A->d_rowmap2);
     dfree(A->d_x);
     dfree(A->d_y);
     for (double* p : A->d_pow) dfree(p);
@@ -1105,25 +1081,23 @@ static int gather_perm(mi_csr_t A, const double* d_x, double* d_xp, hipStream_t 
     return mi_gather_dev(A->n, A->d_iperm, d_x, d_xp, (mi_stream_t)s);
 }
 
-// use_map: 0 rows write y[r]; 1 through the handle's row map (the caller's numbering); 2 through its second map (a
-// relabelled twin whose rows are sorted by smallest column: row r'' belongs at position rowmap2[r''] of the COLUMN numbering)
-static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, int use_map, const RingComm* comm)
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm)
 {
     if (A->n == 0) return MI_OK;
     if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
         int rc = gather_perm(A, d_x, A->d_xp, s);
         if (rc) return rc;
-        return launch_spmv(A->inner, A->d_xp, d_y, s, 1);
+        return launch_spmv(A->inner, A->d_xp, d_y, s, true);
     }
     const int kid = resolve_kernel(A);
-    if (use_map == 1) d_y += A->y_offset;
+    if (use_map) d_y += A->y_offset;
     CsrView V;
     V.n = A->n;
     V.ncols = A->ncols;
     V.ptrow = A->d_ptrow;
     V.indcol = A->d_indcol;
     V.coef = A->d_coef;
-    V.rowmap = use_map == 1 ? A->d_rowmap : (use_map == 2 ? A->d_rowmap2 : nullptr);
+    V.rowmap = use_map ? A->d_rowmap : nullptr;
     V.blk = nullptr;
     V.blk_span = nullptr;
     V.nblk = 0;
@@ -1208,7 +1182,7 @@ extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* 
         if (grid > 2048) grid = 2048;
         for (int p = 0; p < k; p++) {
             CHECK_ARG(d_y_out[p], "null output vector");
-            if ((rc = launch_spmv(A->inner, src, A->d_pp[p], (hipStream_t)s, A->inner->d_rowmap2 ? 2 : 0))) return rc;
+            if ((rc = launch_spmv(A->inner, src, A->d_pp[p], (hipStream_t)s, false))) return rc;
             hipLaunchKernelGGL(scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, A->n, A->d_iperm, A->d_pp[p], d_y_out[p]);
             src = A->d_pp[p];
         }
@@ -1553,7 +1527,6 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     dfree(A->d_indcol);
     dfree(A->d_coef);
     dfree(A->d_browmap);
-    dfree(A->d_browmap2);
     dfree(A->d_x);
     dfree(A->d_y);
     for (double* p : A->d_pow) dfree(p);
@@ -1561,13 +1534,13 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     return MI_OK;
 }
 
-static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, int use_map)
+static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map)
 {
     CHECK_ARG(A, "null handle");
     if (A->nbrows == 0) return MI_OK;
     CHECK_ARG(d_x && d_y, "null vector");
     CHECK_ARG((((uintptr_t)d_x) & 15) == 0, "x must be 16-byte aligned");
-    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map == 1 ? A->d_browmap : (use_map == 2 ? A->d_browmap2 : nullptr)};
+    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map ? A->d_browmap : nullptr};
     const long long threads = 4LL * A->nbrows;
     const int nwg = (int)((threads + kWG - 1) / kWG);
     static const int chunk = getenv("MI355_BCSR_XCD_CHUNK") ? atoi(getenv("MI355_BCSR_XCD_CHUNK")) : 0;
@@ -1579,7 +1552,7 @@ static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_
 
 extern "C" int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s)
 {
-    return launch_bcsr4(A, d_x, d_y, s, 1);
+    return launch_bcsr4(A, d_x, d_y, s, true);
 }
 
 extern "C" int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y)
@@ -1683,9 +1656,9 @@ static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long l
 }
 
 static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t st,
-                       int use_map)
+                       bool use_map)
 {
-    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map == 1 ? A->d_browmap : (use_map == 2 ? A->d_browmap2 : nullptr)};
+    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map ? A->d_browmap : nullptr};
     for (int j0 = 0; j0 < s; j0 += 8) { // more than eight columns: batches of eight (the matrix is read once per batch)
         const int m = std::min(8, s - j0);
         const double* Xj = X + (size_t)j0 * ldx;
@@ -1715,7 +1688,7 @@ extern "C" int mi_bcsr4_spmm_dev(mi_bcsr4_t A, int s, const double* d_X, long lo
     CHECK_ARG(d_X && d_Y, "null matrix");
     CHECK_ARG(ldx >= 4LL * A->nbcols && ldy >= 4LL * A->nbrows, "leading dimension shorter than a column");
     CHECK_ARG((((uintptr_t)d_X) & 15) == 0 && (ldx & 1) == 0, "X columns must be 16-byte aligned (even ldx)");
-    return launch_spmm(A, s, arith, d_X, ldx, d_Y, ldy, (hipStream_t)st, 1);
+    return launch_spmm(A, s, arith, d_X, ldx, d_Y, ldy, (hipStream_t)st, true);
 }
 
 extern "C" int mi_bcsr4_spmm(mi_bcsr4_t A, int s, const double* X, long long ldx, double* Y, long long ldy, int arith)
@@ -1755,11 +1728,11 @@ extern "C" int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, 
         HIP_TRY(hipMallocAsync((void**)&Xp, sizeof(double) * n * s, st));
         int rc = MI_OK;
         for (int j = 0; j < s && !rc; j++) rc = gather_perm(A, d_X + (size_t)j * ldx, Xp + n * j, st);
-        if (!rc) rc = launch_spmm(A->inner->blocked, s, MI_ARITH_CHAIN, Xp, (long long)n, d_Y, ldy, st, 1);
+        if (!rc) rc = launch_spmm(A->inner->blocked, s, MI_ARITH_CHAIN, Xp, (long long)n, d_Y, ldy, st, true);
         (void)hipFreeAsync(Xp, st);
         return rc;
     }
-    if (!A->inner && A->blocked && aligned) return launch_spmm(A->blocked, s, MI_ARITH_CHAIN, d_X, ldx, d_Y, ldy, st, 1);
+    if (!A->inner && A->blocked && aligned) return launch_spmm(A->blocked, s, MI_ARITH_CHAIN, d_X, ldx, d_Y, ldy, st, true);
     for (int j = 0; j < s; j++) {
         int rc = launch_spmv(A, d_X + (size_t)j * ldx, d_Y + (size_t)j * ldy, st);
         if (rc) return rc;
@@ -2380,7 +2353,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.push_wgs = (P->npush_runs == 0 && P->n_links > 0) ? kNXCD : 0; // fallback only; a multiple of the XCD count keeps the run-to-XCD mapping
         C.step = step;
         C.spin_max = spin_max;
-        if ((rc = launch_spmv(P->piece_all, d_x_ext, d_y_local, s, 1, &C))) return rc;
+        if ((rc = launch_spmv(P->piece_all, d_x_ext, d_y_local, s, true, &C))) return rc;
         return MI_OK;
     }
     // one stream, four launches: my entries to the neighbours' windows, interior rows (need owned x only), wait for the

@@ -32,12 +32,6 @@ struct Reorder {
     int block = 1;          // 1: rows are the graph's nodes; 4: node = four consecutive rows
     std::vector<int> perm;  // [n] new index of old row/column
     std::vector<int> iperm; // [n] old index of new row/column
-    // Row ORDER of the relabelled matrix (a row permutation is free: y goes through a row map anyway).  Rows are stored by
-    // increasing smallest new column, nodes kept whole: the ring kernel's x window then only ever slides forward, which is
-    // what it needs to serve a run without restarts — under plain RCM a row's LARGEST column is monotone (reverse
-    // Cuthill-McKee) but its smallest is not.  row_of[k] = the caller's row stored at position k.
-    std::vector<int> row_of;
-    bool rows_sorted = false; // row_of differs from iperm
     double spread_before = 0.0, spread_after = 0.0; // mean |column - row| over the nonzeros, in nodes
 };
 
@@ -183,36 +177,17 @@ inline void rcm_reorder(int n, const int* ptrow, const int* indcol, int block, R
     for (int i = 0; i < n; i++) out.iperm[out.perm[i]] = i;
     out.spread_before = mean_column_distance(n, ptrow, indcol, block);
     out.spread_after = mean_column_distance(n, ptrow, indcol, block, pnode.data());
-    // row order: nodes by (smallest new column of the node's rows, new index)
-    std::vector<int> cmin((size_t)nn), nodes((size_t)nn);
-    for (int b = 0; b < nn; b++) {
-        int lo = 0x7fffffff;
-        for (int q = 0; q < block; q++) {
-            const int r0 = b * block + q;
-            for (int k = ptrow[r0]; k < ptrow[r0 + 1]; k++) lo = std::min(lo, out.perm[indcol[k]] / block);
-        }
-        cmin[b] = lo == 0x7fffffff ? pnode[b] : lo; // a node without entries sorts by its own position
-    }
-    for (int k = 0; k < nn; k++) nodes[k] = order[nn - 1 - k]; // nodes in new-index order
-    std::stable_sort(nodes.begin(), nodes.end(), [&](int a, int b) { return cmin[a] < cmin[b]; });
-    out.row_of.resize((size_t)n);
-    for (int k = 0; k < nn; k++)
-        for (int q = 0; q < block; q++) out.row_of[(size_t)k * block + q] = nodes[k] * block + q;
-    for (int i = nn * block; i < n; i++) out.row_of[i] = i;
-    out.rows_sorted = false;
-    for (int i = 0; i < n && !out.rows_sorted; i++) out.rows_sorted = out.row_of[i] != out.iperm[i];
 }
 
-// The relabelled matrix: columns renamed by R.perm, rows stored in the order R.row_of, every row's nonzeros in their
-// ORIGINAL order.  src_start[k] = offset of stored row k in the caller's arrays (for refreshing the values later without
-// redoing any of this).
+// A' = P A P^T with every row's nonzeros in their ORIGINAL order.  src_start[r'] = offset of new row r' in the
+// caller's arrays (for refreshing the values later without redoing any of this).
 inline void permute_csr(int n, const int* ptrow, const int* indcol, const double* coef, const Reorder& R,
                         std::vector<int>& p2, std::vector<int>& c2, std::vector<double>& v2, std::vector<int>& src_start)
 {
     p2.assign((size_t)n + 1, 0);
     src_start.assign((size_t)n, 0);
     for (int rn = 0; rn < n; rn++) {
-        const int ro = R.row_of[rn];
+        const int ro = R.iperm[rn];
         p2[rn + 1] = p2[rn] + (ptrow[ro + 1] - ptrow[ro]);
         src_start[rn] = ptrow[ro];
     }
