@@ -350,8 +350,16 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
                 const double xn = xr[(s + 1) % D];
                 if (qy <= T) {
                     if (tid < qy) s_ring[ring_slot<RING>(qx + tid, qz)] = xn;
-                } else { // the window restarts inside the run (a jump in the column range)
-                    for (int cc = qx + tid; cc < qx + qy; cc += T) s_ring[ring_slot<RING>(cc, qz)] = ring_ldx<FUSED>(x, C, cc);
+                } else { // more than T new columns at once: a window restart, or the ragged edge of a relabelled band.  Four
+                         // loads in flight per thread and round trip (one per round trip made this path 4x as long)
+                    for (int c0 = qx + tid; c0 < qx + qy; c0 += 4 * T) {
+                        double v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) v[u] = ring_ldx<FUSED>(x, C, min(c0 + u * T, clast));
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (c0 + u * T < qx + qy) s_ring[ring_slot<RING>(c0 + u * T, qz)] = v[u];
+                    }
                 }
             }
             // ---- row chains
