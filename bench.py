@@ -172,16 +172,24 @@ def main():
     W = WORKLOADS[args.workload]
     n, k, kind = W["n"], W["k"], W["kind"]
     is_fe = kind == "fe"
-    if is_fe and world > 1:
-        sys.exit("the fe workloads are 1-GPU configurations")
+    if is_fe and world > 1 and (W.get("bcsr") or W.get("spmm")):
+        sys.exit("the BCSR-API and multi-vector FE workloads are 1-GPU configurations")
     nnz_global = (int(synth._lib().fe_matrix_count(W["cells"], W["cells"], W["cells"])) if is_fe else
                   int(synth._lib().synth_count(synth.KINDS[kind], synth.DEFAULT_SEED, n, synth.DEFAULT_W, 0, n)))
 
     # ---- build this rank's share -------------------------------------------------------
     t_setup = time.perf_counter()
-    rs = D.balanced_row_starts(n, world)  # S15 rows all hold 15 nnz: equal rows == equal nnz
-    lo, hi = int(rs[rank]), int(rs[rank + 1])
-    p, c, v = synth.fe_matrix(W["cells"]) if is_fe else synth.rows(kind, n, lo, hi)
+    if is_fe and world > 1:
+        # every rank assembles the whole FE matrix (1 GB on the host) and keeps its rows; cuts at node boundaries, nnz-balanced
+        P_, C_, V_ = synth.fe_matrix(W["cells"])
+        rs = D.balanced_row_starts(n, world, np.diff(P_), align=4)
+        lo, hi = int(rs[rank]), int(rs[rank + 1])
+        p, c, v = (P_[lo:hi + 1] - P_[lo]).astype(np.int32), C_[P_[lo]:P_[hi]].copy(), V_[P_[lo]:P_[hi]].copy()
+        del P_, C_, V_
+    else:
+        rs = D.balanced_row_starts(n, world)  # S15 rows all hold 15 nnz: equal rows == equal nnz
+        lo, hi = int(rs[rank]), int(rs[rank + 1])
+        p, c, v = synth.fe_matrix(W["cells"]) if is_fe else synth.rows(kind, n, lo, hi)
     if W.get("perm_block"):
         if world > 1:
             sys.exit("the permuted workloads are 1-GPU configurations")

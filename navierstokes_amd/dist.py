@@ -37,14 +37,19 @@ _c = ctypes
 _vp = ctypes.c_void_p
 
 
-def balanced_row_starts(n, nranks, nnz_per_row=None):
+def balanced_row_starts(n, nranks, nnz_per_row=None, align=1):
     """Contiguous row ranges with (nearly) equal nonzero counts.
-    nnz_per_row: None (equal row counts) or an int64 array of row lengths."""
+    nnz_per_row: None (equal row counts) or an int64 array of row lengths.
+    align: cut only at multiples of `align` rows (4 for FE matrices: a node's four dofs stay on one rank, so every rank's
+    rows keep their 4x4 node-block structure)."""
     if nnz_per_row is None:
-        return np.array([(n * r) // nranks for r in range(nranks + 1)], dtype=np.int64)
-    cum = np.concatenate([[0], np.cumsum(np.asarray(nnz_per_row, dtype=np.int64))])
-    targets = cum[-1] * np.arange(1, nranks) / nranks
-    cuts = np.searchsorted(cum, targets, side="left")
+        cuts = np.array([(n * r) // nranks for r in range(1, nranks)], dtype=np.int64)
+    else:
+        cum = np.concatenate([[0], np.cumsum(np.asarray(nnz_per_row, dtype=np.int64))])
+        targets = cum[-1] * np.arange(1, nranks) / nranks
+        cuts = np.searchsorted(cum, targets, side="left").astype(np.int64)
+    if align > 1:
+        cuts = np.minimum((cuts + align // 2) // align * align, n // align * align)
     return np.concatenate([[0], cuts, [n]]).astype(np.int64)
 
 
