@@ -441,7 +441,7 @@ def main():
         if "cold_us" in extra:
             roofline["cold_single_shot"] = dict(launch_us=round(extra["cold_us"], 2),
                                                 frac=round(B_exec / (extra["cold_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                protocol="mi_flush_cache() (512 MiB device fill) before every launch, 12 launches, HIP events")
+                                                protocol="mi_flush_cache() (512 MiB device fill + 512 MiB read sweep: caches left full of clean lines) before every launch, 12 launches, HIP events")
         if "pipeline_spmv_us" in extra:
             roofline["in_pipeline"] = dict(spmv_us=round(extra["pipeline_spmv_us"], 2),
                                            frac=round(B_exec / (extra["pipeline_spmv_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),

@@ -72,9 +72,11 @@ const char* mi_last_error(void);
 int mi_device_count(int* count);
 int mi_set_device(int device);
 int mi_device_synchronize(void);
-/* Evict the GPU's L2s and 256 MiB Infinity Cache (a 512 MiB device fill, then
- * a synchronise): the device analogue of flush_cache(), mpk/utils.cpp:146-154,
- * which the reference calls before every timed kernel. */
+/* Evict the GPU's L2s and 256 MiB Infinity Cache: the device analogue of flush_cache(), mpk/utils.cpp:146-154, which the
+ * reference calls before every timed kernel.  A 512 MiB device fill (the reference writes its buffer too) followed by a
+ * 512 MiB READ sweep of a second buffer and a synchronise: the fill alone leaves the Infinity Cache full of dirty lines
+ * whose write-back the next kernel pays for (≈11 us on a 1 GB product); behind the read sweep the caches hold clean lines
+ * of a buffer nobody uses.  MI355_FLUSH_FILL_ONLY=1 restores the fill-only form. */
 int mi_flush_cache(void);
 
 /* ---- CSR matrix handles ------------------------------------------------ */

@@ -255,6 +255,18 @@ extern "C" int mi_device_synchronize(void)
 
 static std::map<int, void*> g_flush;
 
+// read sweep: leaves the caches full of CLEAN lines of a buffer nobody uses
+__global__ __launch_bounds__(256) void flush_read_kernel(const double2* __restrict__ p, size_t n16, double* __restrict__ sink)
+{
+    double s = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const double2 v = p[i];
+        s += v.x + v.y;
+    }
+    if (s == 123.456) sink[0] = s; // never true: keeps the loads alive
+}
+
 extern "C" int mi_flush_cache(void)
 {
     int rc = need_device();
@@ -266,10 +278,19 @@ extern "C" int mi_flush_cache(void)
     {
         std::lock_guard<std::mutex> lock(g_mu);
         void*& slot = g_flush[dev];
-        if (!slot) HIP_TRY(hipMalloc(&slot, bytes));
+        if (!slot) HIP_TRY(hipMalloc(&slot, 2 * bytes + 256));
         buf = slot;
     }
+    // Write 512 MiB (as the reference's flush_cache writes its buffer, mpk/utils.cpp:146-154), then READ another 512 MiB:
+    // the fill alone would leave the 256 MiB Infinity Cache full of DIRTY lines whose write-back the next kernel then pays
+    // for (measured: a cold C4 product 210 us behind the fill alone); behind the read sweep the caches hold clean lines of
+    // a buffer nobody uses, i.e. "nothing of the caller's data is cached" and nothing else.
     HIP_TRY(hipMemsetAsync(buf, 1, bytes, nullptr));
+    const char* only_fill = getenv("MI355_FLUSH_FILL_ONLY");
+    if (!(only_fill && !strcmp(only_fill, "1")))
+        hipLaunchKernelGGL(flush_read_kernel, dim3(4096), dim3(256), 0, nullptr, reinterpret_cast<const double2*>((char*)buf + bytes), bytes / 16,
+                           reinterpret_cast<double*>((char*)buf + 2 * bytes));
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return MI_OK;
 }
