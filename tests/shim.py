@@ -37,6 +37,8 @@ def lib():
         L.shim_spmv_bcsr.argtypes = [i, i, i, _i32, _i32, _f64, _f64, _f64]
         L.shim_spmv_csr_inplace_edit.argtypes = [i, i, _i32, _i32, _f64, _f64, i, _i32, _f64, _f64, _f64]
         L.shim_spmv_bcsr_inplace_edit.argtypes = [i, i, _i32, _i32, _f64, _f64, i, _i32, _f64, _f64, _f64]
+        L.shim_time_spmv_csr.argtypes = [i, i, _i32, _i32, _f64, _f64, _f64, i, i]
+        L.shim_time_spmv_csr.restype = _c.c_double
         L.shim_spm2v_csr.argtypes = [i, i, i, _i32, _i32, _f64, _f64, _f64, _f64]
         L.shim_spm2v_bcsr.argtypes = [i, i, i, _i32, _i32, _f64, _f64, _f64, _f64]
         L.shim_powers.argtypes = [i, i, i, _i32, _i32, _f64, _f64, _f64]
@@ -180,3 +182,11 @@ def orthonormalize_against_basis(basis, y):
     y = _f(y).copy()
     lib().shim_orthonormalize_against_basis(n, m, basis.reshape(-1), y)
     return y
+
+
+def time_spmv_csr(p, c, v, x, reps=3, trust=False):
+    """(seconds per SpMV_CSR call through the shim on a live csrmatrix, y)"""
+    p, c, v, x = _i(p), _i(c), _f(v), _f(x)
+    y = np.full(len(p) - 1, np.nan)
+    t = lib().shim_time_spmv_csr(len(p) - 1, len(c), p, c, v, x, y, reps, 1 if trust else 0)
+    return t, y

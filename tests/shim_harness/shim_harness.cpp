@@ -142,6 +142,24 @@ int shim_spmv_csr(int variant, int n, int nnz, const int* ptrow, const int* indc
     return 0;
 }
 
+// Seconds per SpMV_CSR call on one csrmatrix object kept alive across `reps` calls (first call excluded): what the reference's
+// calling convention costs through the shim — full-content hash of the caller's arrays, x in and y out over PCIe, the kernel.
+// trust != 0: with mi355_assume_unchanged(true), i.e. without the hash.
+double shim_time_spmv_csr(int n, int nnz, const int* ptrow, const int* indcol, const double* coef, const double* x, double* y,
+                          int reps, int trust)
+{
+    csrmatrix a = make_csr(n, nnz, ptrow, indcol, coef);
+    double* xx = const_cast<double*>(x);
+    SpMV_CSR(y, xx, a);
+    mi355_assume_unchanged(trust != 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; r++) SpMV_CSR(y, xx, a);
+    const auto t1 = std::chrono::steady_clock::now();
+    mi355_assume_unchanged(false);
+    mi355_invalidate(a);
+    return std::chrono::duration<double>(t1 - t0).count() / reps;
+}
+
 // The stale-copy scenario: product, then `nedit` coefficients rewritten IN PLACE in the same storage
 // (same addresses, same pattern), product again.  y0 / y1 = results before / after the edit.
 int shim_spmv_csr_inplace_edit(int n, int nnz, const int* ptrow, const int* indcol, const double* coef, const double* x,
