@@ -181,6 +181,8 @@ struct mi_part_s {
     int* d_run_link = nullptr; // per run of piece_all: first push link it serves, or -1
     int npush_runs = 0;
     bool fused = false;
+    bool fused_bcsr = false;   // piece_all is served by the BCSR kernel: spmv_bcsr4_fused
+    int* d_wg_halo = nullptr;  // per workgroup of that launch: its block rows touch a ghost node
 };
 
 // windows of ranks living in THIS process (rank threads; hipIpcOpenMemHandle refuses a handle of the opening process)
@@ -1847,11 +1849,13 @@ static void part_comm_release(mi_part_s* P)
     dfree(P->d_nb);
     dfree(P->d_run_halo);
     dfree(P->d_run_link);
+    dfree(P->d_wg_halo);
     mi_csr_destroy(P->piece_all);
     P->piece_all = nullptr;
     P->d_run_halo = nullptr;
     P->d_run_link = nullptr;
-    P->fused = false;
+    P->d_wg_halo = nullptr;
+    P->fused = P->fused_bcsr = false;
     P->win = nullptr;
     P->d_links = nullptr;
     P->d_nb = nullptr;
@@ -2285,6 +2289,21 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
             HIP_TRY(hipMalloc(&P->d_run_link, sizeof(int) * link.size()));
             HIP_TRY(hipMemcpy(P->d_run_link, link.data(), sizeof(int) * link.size(), hipMemcpyHostToDevice));
         }
+        if (!P->fused && resolve_kernel(A) == MI_KERNEL_BCSR4 && A->blocked && P->plan.n_left % 4 == 0 && pl.n_local % 4 == 0 &&
+            pl.n_halo % 4 == 0) {
+            // FE matrices: the blocked copy of the combined piece, one launch of spmv_bcsr4_fused per step.  Which workgroups
+            // (kWG / 4 block rows each) touch a ghost node:
+            const int nbr = pl.n_local / 4, per = kWG / 4, nwg = (nbr + per - 1) / per;
+            const int nl0 = P->plan.n_left, nl1 = P->plan.n_left + pl.n_local;
+            std::vector<int> wg_halo((size_t)nwg, 0);
+            for (int w = 0; w < nwg; w++) {
+                const int r0 = 4 * w * per, r1 = std::min(pl.n_local, 4 * (w + 1) * per);
+                for (int k = L.ptrow[r0]; k < L.ptrow[r1] && !wg_halo[w]; k++) wg_halo[w] = L.indcol[k] < nl0 || L.indcol[k] >= nl1;
+            }
+            HIP_TRY(hipMalloc(&P->d_wg_halo, sizeof(int) * wg_halo.size()));
+            HIP_TRY(hipMemcpy(P->d_wg_halo, wg_halo.data(), sizeof(int) * wg_halo.size(), hipMemcpyHostToDevice));
+            P->fused = P->fused_bcsr = true;
+        }
         if (!P->fused) {
             mi_csr_destroy(P->piece_all);
             P->piece_all = nullptr;
@@ -2310,7 +2329,10 @@ extern "C" int mi_part_push_disable(mi_part_t P)
     dfree(P->d_links);
     dfree(P->d_nb);
     dfree(P->d_run_link);
+    dfree(P->d_wg_halo);
     P->d_run_link = nullptr;
+    P->d_wg_halo = nullptr;
+    P->fused_bcsr = false;
     mi_csr_destroy(P->piece_all);
     P->win = nullptr;
     P->d_links = nullptr;
@@ -2374,6 +2396,17 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.push_wgs = (P->npush_runs == 0 && P->n_links > 0) ? kNXCD : 0; // fallback only; a multiple of the XCD count keeps the run-to-XCD mapping
         C.step = step;
         C.spin_max = spin_max;
+        if (P->fused_bcsr) {
+            if ((((uintptr_t)d_x_ext) & 15) != 0) return fail(MI_ERR_ARG, "the fused blocked step needs a 16-byte aligned x");
+            mi_bcsr4_t B = P->piece_all->blocked;
+            Bcsr4View V{B->nbrows, B->nbcols, B->d_ptrow, B->d_indcol, B->d_coef, nullptr};
+            C.push_wgs = kNXCD; // dedicated push workgroups in front: the grid is many times the resident capacity
+            C.npush_runs = 0;
+            const int nwg = (4 * B->nbrows + kWG - 1) / kWG;
+            hipLaunchKernelGGL((spmv_bcsr4_fused<kBcsrDepth, kWG>), dim3(nwg + C.push_wgs), dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_wg_halo);
+            HIP_TRY(hipGetLastError());
+            return MI_OK;
+        }
         if ((rc = launch_spmv(P->piece_all, d_x_ext, d_y_local, s, true, &C))) return rc;
         return MI_OK;
     }

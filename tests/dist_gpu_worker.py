@@ -22,7 +22,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     Pg, Cg, Vg = synth.rows(kind, n, w=w)
-    rs = D.balanced_row_starts(n, world, np.diff(Pg))
+    rs = D.balanced_row_starts(n, world, np.diff(Pg), align=4 if kind == "sfe" else 1)  # FE-like: cut at node boundaries
     lo, hi = int(rs[rank]), int(rs[rank + 1])
     p, c, v = synth.rows(kind, n, lo, hi, w=w)
     ok = True
