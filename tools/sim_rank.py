@@ -7,10 +7,19 @@ from navierstokes_amd import mpk, synth, dist as D
 from oracle import oracle as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-n = 5_000_000
-rs = D.balanced_row_starts(n, N)
-lo, hi = int(rs[rank]), int(rs[rank + 1])
-p, c, v = synth.rows("s15", n, lo, hi)
+what = sys.argv[3] if len(sys.argv) > 3 else "c4"   # "c4": S15 5 M rows; "fe": the 68^3-cell FE matrix, cuts at node boundaries
+if what == "fe":
+    P_, C_, V_ = synth.fe_matrix(68)
+    n = len(P_) - 1
+    rs = D.balanced_row_starts(n, N, np.diff(P_), align=4)
+    lo, hi = int(rs[rank]), int(rs[rank + 1])
+    p, c, v = (P_[lo:hi + 1] - P_[lo]).astype(np.int32), C_[P_[lo]:P_[hi]].copy(), V_[P_[lo]:P_[hi]].copy()
+    del P_, C_, V_
+else:
+    n = 5_000_000
+    rs = D.balanced_row_starts(n, N)
+    lo, hi = int(rs[rank]), int(rs[rank + 1])
+    p, c, v = synth.rows("s15", n, lo, hi)
 L = mpk.lib()
 h = ctypes.c_void_p()
 mpk.check(L.mi_part_create(N, rank, rs.ctypes.data, p.ctypes.data, c.ctypes.data, v.ctypes.data, ctypes.byref(h)))
