@@ -171,6 +171,10 @@ struct mi_part_s {
     std::vector<void*> ipc_opened; // mappings to close
     PushLink* d_links = nullptr;
     int n_links = 0;
+    int2* d_push_work = nullptr;   // stand-alone push kernel: {link, chunk} per workgroup
+    int* d_link_chunks = nullptr;  // chunks per link
+    unsigned* d_tickets = nullptr; // per link: chunks out so far
+    int n_push_work = 0;
     int* d_nb = nullptr;           // ranks whose flags I wait for
     int n_nb = 0;
     unsigned push_step = 0;
@@ -1846,6 +1850,12 @@ static void part_comm_release(mi_part_s* P)
     }
     dfree(P->win);
     dfree(P->d_links);
+    dfree(P->d_push_work);
+    dfree(P->d_link_chunks);
+    dfree(P->d_tickets);
+    P->d_push_work = nullptr;
+    P->d_link_chunks = nullptr;
+    P->d_tickets = nullptr;
     dfree(P->d_nb);
     dfree(P->d_run_halo);
     dfree(P->d_run_link);
@@ -2261,6 +2271,19 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
     P->n_links = (int)links.size();
     P->n_nb = (int)nb.size();
     if (P->n_links) {
+        std::vector<int2> work;
+        std::vector<int> chunks(links.size());
+        for (size_t l = 0; l < links.size(); l++) {
+            chunks[l] = std::max(1, (links[l].count + kPushChunk - 1) / kPushChunk);
+            for (int ch = 0; ch < chunks[l]; ch++) work.push_back(make_int2((int)l, ch));
+        }
+        P->n_push_work = (int)work.size();
+        HIP_TRY(hipMalloc(&P->d_push_work, sizeof(int2) * work.size()));
+        HIP_TRY(hipMemcpy(P->d_push_work, work.data(), sizeof(int2) * work.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&P->d_link_chunks, sizeof(int) * chunks.size()));
+        HIP_TRY(hipMemcpy(P->d_link_chunks, chunks.data(), sizeof(int) * chunks.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&P->d_tickets, sizeof(unsigned) * links.size()));
+        HIP_TRY(hipMemset(P->d_tickets, 0, sizeof(unsigned) * links.size()));
         HIP_TRY(hipMalloc(&P->d_links, sizeof(PushLink) * links.size()));
         HIP_TRY(hipMemcpy(P->d_links, links.data(), sizeof(PushLink) * links.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(&P->d_nb, sizeof(int) * nb.size()));
@@ -2289,8 +2312,11 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
             HIP_TRY(hipMalloc(&P->d_run_link, sizeof(int) * link.size()));
             HIP_TRY(hipMemcpy(P->d_run_link, link.data(), sizeof(int) * link.size(), hipMemcpyHostToDevice));
         }
+        // (only while the halo is small: the fused kernel reads ghosts straight from the UNCACHED window, every use of them, and
+        // pushes through two workgroups — with an FE slab's boundary planes, 39 k ghosts for 163 k rows at N = 8, that made the
+        // step 39 us where push + interior + wait-and-copy + boundary as separate launches cost less; sim_rank.py N 1 fe)
         if (!P->fused && resolve_kernel(A) == MI_KERNEL_BCSR4 && A->blocked && P->plan.n_left % 4 == 0 && pl.n_local % 4 == 0 &&
-            pl.n_halo % 4 == 0) {
+            pl.n_halo % 4 == 0 && pl.n_halo <= 16384) {
             // FE matrices: the blocked copy of the combined piece, one launch of spmv_bcsr4_fused per step.  Which workgroups
             // (kWG / 4 block rows each) touch a ghost node:
             const int nbr = pl.n_local / 4, per = kWG / 4, nwg = (nbr + per - 1) / per;
@@ -2327,6 +2353,12 @@ extern "C" int mi_part_push_disable(mi_part_t P)
     }
     dfree(P->win);
     dfree(P->d_links);
+    dfree(P->d_push_work);
+    dfree(P->d_link_chunks);
+    dfree(P->d_tickets);
+    P->d_push_work = nullptr;
+    P->d_link_chunks = nullptr;
+    P->d_tickets = nullptr;
     dfree(P->d_nb);
     dfree(P->d_run_link);
     dfree(P->d_wg_halo);
@@ -2412,7 +2444,9 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
     }
     // one stream, four launches: my entries to the neighbours' windows, interior rows (need owned x only), wait for the
     // neighbours' entries and move them behind x_local, boundary rows
-    if (P->n_links) hipLaunchKernelGGL(halo_push_kernel, dim3(P->n_links), dim3(256), 0, s, P->d_links, P->d_send_idx, d_x_ext, step);
+    if (P->n_links)
+        hipLaunchKernelGGL(halo_push_kernel, dim3(P->n_push_work), dim3(256), 0, s, P->d_links, P->d_push_work, P->d_link_chunks, P->d_tickets,
+                           P->d_send_idx, d_x_ext, step);
     if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;
     if (P->n_nb) {
         int grid = (pl.n_halo + 4095) / 4096;
