@@ -2449,8 +2449,8 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
                            P->d_send_idx, d_x_ext, step);
     if ((rc = mi_spmv_dev(P->piece[0], d_x_ext, d_y_local, s))) return rc;
     if (P->n_nb) {
-        int grid = (pl.n_halo + 4095) / 4096;
-        grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
+        int grid = (pl.n_halo + 511) / 512; // one 16-byte load per thread: the window is uncached, so spread it wide
+        grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
         hipLaunchKernelGGL(halo_wait_copy_kernel, dim3(grid), dim3(256), 0, s, P->win_flags, P->d_nb, P->n_nb, step,
                            P->win_data + (size_t)(step & 1u) * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1), d_x_ext + pl.n_local, pl.n_halo,
                            P->d_timeouts, spin_max);

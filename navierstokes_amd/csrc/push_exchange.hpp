@@ -51,7 +51,7 @@ struct PushLink {
 // (an L2 write-back: microseconds, but amortised over 32 KB, where the write-through form — one fabric write per 8 bytes —
 // costs more).  The flag goes up when the link's last chunk is out: a ticket counter per link, bumped by every chunk's
 // workgroup after its drain / fence; the last arriver resets it and stores the flag.
-constexpr int kPushChunk = 4096;
+constexpr int kPushChunk = 1024; // 8 KB per workgroup: an FE slab's 150 KB plane goes out from ~19 CUs at once
 constexpr int kPushBigLink = 8192;
 
 __global__ __launch_bounds__(256) void halo_push_kernel(const PushLink* __restrict__ links, const int2* __restrict__ work,
@@ -107,8 +107,14 @@ __global__ __launch_bounds__(256) void halo_wait_copy_kernel(const unsigned* fla
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // system scope: the data the flags announce
     const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_halo; i += stride)
-        dst[i] = __builtin_nontemporal_load(src + i);
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) { // 16 bytes per access: the window is uncached, every load is a trip to memory
+        const long long n2 = n_halo >> 1;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride)
+            reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(src)[i];
+        if ((n_halo & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n_halo - 1] = src[n_halo - 1];
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_halo; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+    }
 }
 
 } // namespace mi355
