@@ -181,7 +181,6 @@ struct mi_part_s {
     bool push_ready = false;
     // the one-launch form of the push step (spmv_ring.hpp, FUSED): all local rows in one ring-served, row-mapped piece
     mi_csr_t piece_all = nullptr;
-    int* d_run_halo = nullptr;
     int* d_run_link = nullptr; // per run of piece_all: first push link it serves, or -1
     int npush_runs = 0;
     bool fused = false;
@@ -1857,12 +1856,10 @@ static void part_comm_release(mi_part_s* P)
     P->d_link_chunks = nullptr;
     P->d_tickets = nullptr;
     dfree(P->d_nb);
-    dfree(P->d_run_halo);
     dfree(P->d_run_link);
     dfree(P->d_wg_halo);
     mi_csr_destroy(P->piece_all);
     P->piece_all = nullptr;
-    P->d_run_halo = nullptr;
     P->d_run_link = nullptr;
     P->d_wg_halo = nullptr;
     P->fused = P->fused_bcsr = false;
