@@ -2191,11 +2191,15 @@ extern "C" int mi_part_push_export(mi_part_t P, void* handle64, long long* layou
     if (!P->win) {
         const size_t bytes = win_data_offset(pl.nranks) + sizeof(double) * 2 * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1);
         // uncached: neither the writer's nor the reader's L2 may keep a line of the window
+        // (no fallback to cached memory: the receiver reads the window with plain loads and relies on no cache holding a line
+        // of it — a neighbour's writes over xGMI would not update this GPU's L2.  Without uncached memory the push exchange is
+        // refused and DistCSR falls back to the RCCL or torch.distributed exchange.)
         hipError_t e = hipExtMallocWithFlags(&P->win, bytes, hipDeviceMallocUncached);
         P->win_uncached = e == hipSuccess;
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            HIP_TRY(hipMalloc(&P->win, bytes));
+            P->win = nullptr;
+            return fail(MI_ERR_UNSUPPORTED, std::string("peer push needs uncached device memory (hipExtMallocWithFlags): ") + hipGetErrorString(e));
         }
         HIP_TRY(hipMemset(P->win, 0, bytes));
         HIP_TRY(hipDeviceSynchronize());
