@@ -44,6 +44,26 @@ def main():
             torch.cuda.synchronize()
             dc.status()
             ok = ok and np.array_equal(y.cpu().numpy().view(np.uint64), Y[0][lo:hi].view(np.uint64))
+            # the step protocol under skew: 36 steps that alternate between THREE different x vectors (so a ghost taken from the
+            # wrong step or parity gives a wrong y), ranks stalling at different moments, no synchronisation until the end
+            import random
+            import time
+            rnd = random.Random(1000 + rank)
+            xg = [synth.x_sin(0, n), np.cos(0.002 * np.arange(n)), synth.x_sin(0, n) * 0.5 - 0.25]
+            xs = []
+            for g_ in xg:
+                t_ = dc.new_x_ext()
+                t_[: dc.n_local] = torch.from_numpy(g_[lo:hi]).cuda()
+                xs.append(t_)
+            outs = [dc.new_y() for _ in range(36)]
+            for t in range(36):
+                if rnd.random() < 0.3:
+                    time.sleep(rnd.random() * 0.004)
+                dc.spmv(xs[t % 3], outs[t])
+            torch.cuda.synchronize()
+            dc.status()
+            refs = [O.spmv(Pg, Cg, Vg, g_)[lo:hi] for g_ in xg]
+            ok = ok and all(np.array_equal(outs[t].cpu().numpy().view(np.uint64), refs[t % 3].view(np.uint64)) for t in range(36))
         # coefficients replaced in place (a Newton loop's Jacobian): same plan, same exchange, new bits
         v2 = v * np.cos(np.arange(len(v)) + lo)
         dc.update_values(v2)
