@@ -43,6 +43,13 @@ WORKLOADS = {
     # the same FE matrix under a seeded RANDOM node numbering (4 dofs of a node kept together) — what an unstructured gmsh
     # mesh delivers (src/solve_newton.c:91-197): mi_csr_create relabels it behind the API (reorder.hpp), bits unchanged
     "fe_perm": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, perm_block=4, desc="the fe matrix under a random node numbering (unstructured-mesh order), CSR, y=Ax"),
+    # the reference's SCALAR operator shape (pressure Poisson): the pressure-pressure part of the FE matrix, a P1 Laplacian
+    # on the jittered Kuhn mesh, 15 nonzeros per row like S15 but with a mesh's column sharing and a column span of two
+    # mesh planes (58 k columns here) — no contiguous LDS window holds that: the tile kernel's case (spmv_tile.hpp)
+    "mesh": dict(kind="mesh", n=171 ** 3, k=1, cells=170, desc="P1 pressure operator (stabilisation block of src/integration.c) on a 170^3-cell Kuhn mesh: 5,000,211 rows, 72.9 M nnz, natural node order, CSR, y=Ax"),
+    "mesh_perm": dict(kind="mesh", n=171 ** 3, k=1, cells=170, perm_block=1, desc="the mesh matrix under a random node numbering (unstructured-mesh order), CSR, y=Ax"),
+    "mesh_small": dict(kind="mesh", n=101 ** 3, k=1, cells=100, desc="P1 pressure operator on a 100^3-cell Kuhn mesh: 1,030,301 rows, natural node order, CSR, y=Ax"),
+    "mesh_small_perm": dict(kind="mesh", n=101 ** 3, k=1, cells=100, perm_block=1, desc="the 100^3-cell mesh matrix under a random node numbering, CSR, y=Ax"),
     "c2_perm": dict(kind="s15", n=1_000_000, k=1, perm_block=1, desc="the c2 matrix under a random row/column numbering, CSR, y=Ax"),
     # multi-vector product, s = 4 columns, matrix read once (MatMatMult_SeqBAIJ_4_AVX2, src/kernels/spmm_avx2.c:7-109)
     "fe_spmm4": dict(kind="fe", n=4 * 69 ** 3, k=1, cells=68, bcsr=True, spmm=4, desc="the FE matrix as BCSR 4x4, Y = A X for 4 column vectors in one launch (spmm_avx2.c)"),
@@ -135,7 +142,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4", "tile"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--exchange", default=None, choices=["auto", "native", "push", "torch"], help="N > 1: which halo exchange drives the step")
@@ -172,9 +179,12 @@ def main():
     W = WORKLOADS[args.workload]
     n, k, kind = W["n"], W["k"], W["kind"]
     is_fe = kind == "fe"
+    is_mesh = kind == "mesh"
+    if is_mesh and world > 1:
+        sys.exit("the mesh workloads are 1-GPU configurations")
     if is_fe and world > 1 and (W.get("bcsr") or W.get("spmm")):
         sys.exit("the BCSR-API and multi-vector FE workloads are 1-GPU configurations")
-    nnz_global = (int(synth._lib().fe_matrix_count(W["cells"], W["cells"], W["cells"])) if is_fe else
+    nnz_global = (int(synth._lib().fe_matrix_count(W["cells"], W["cells"], W["cells"])) // (16 if is_mesh else 1) if is_fe or is_mesh else
                   int(synth._lib().synth_count(synth.KINDS[kind], synth.DEFAULT_SEED, n, synth.DEFAULT_W, 0, n)))
 
     # ---- build this rank's share -------------------------------------------------------
@@ -189,7 +199,8 @@ def main():
     else:
         rs = D.balanced_row_starts(n, world)  # S15 rows all hold 15 nnz: equal rows == equal nnz
         lo, hi = int(rs[rank]), int(rs[rank + 1])
-        p, c, v = synth.fe_matrix(W["cells"]) if is_fe else synth.rows(kind, n, lo, hi)
+        p, c, v = (synth.fe_matrix(W["cells"]) if is_fe else synth.pressure_matrix(W["cells"]) if is_mesh
+                   else synth.rows(kind, n, lo, hi))
     if W.get("perm_block"):
         if world > 1:
             sys.exit("the permuted workloads are 1-GPU configurations")
@@ -458,8 +469,12 @@ def main():
         tune, nt = A.tune_detail()
         out["kernel_info"] = dict(kernel=kernel_name, ring_config=ring_cfg, runs=ring_runs, runs_on_plain_path=ring_bad,
                                   nnz_fraction_ring=round(ring_frac, 4), nontemporal_values=nt,
-                                  matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else (8.25 if "bcsr4" in kernel_name else 12),
+                                  matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else (8.25 if "bcsr4" in kernel_name else
+                                                              round(10 + 4 * A.tile_info()["unique_per_nnz"], 2) if "tile" in kernel_name else 12),
                                   autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
+        ti = A.tile_info()
+        if ti["built"]:
+            out["kernel_info"]["tile_plan"] = dict(row_blocks=ti["nblk"], distinct_columns_per_nnz=round(ti["unique_per_nnz"], 4))
         ri = A.reorder_info()
         if ri["reordered"] or ri["block"]:
             out["reorder"] = {k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in ri.items()}

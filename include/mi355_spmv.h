@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 200 /* 0.2.0 */
+#define MI355_SPMV_VERSION 201 /* 0.2.1 */
 
 enum {
     MI_OK = 0,
@@ -60,9 +60,12 @@ enum {
     MI_KERNEL_STREAM = 1,  /* row-block CSR-stream, x gathered through L1/L2 (any matrix) */
     MI_KERNEL_RING = 2,    /* persistent workgroups, sliding x window in LDS, pipelined matrix stream */
     MI_KERNEL_ROWPAR = 3,  /* one thread per row straight from global memory (reference shape; slow) */
-    MI_KERNEL_BCSR4 = 4    /* the BCSR 4x4 kernel on a blocked copy made at mi_csr_create; available only when the
+    MI_KERNEL_BCSR4 = 4,   /* the BCSR 4x4 kernel on a blocked copy made at mi_csr_create; available only when the
                             * CSR matrix has exact 4x4 node-block structure (FE matrices), where it returns the
                             * same bits from 8.25 instead of 12 matrix bytes per nonzero */
+    MI_KERNEL_TILE = 5     /* per row block the DISTINCT columns are gathered once into an LDS tile, nonzeros address it
+                            * through a 16-bit stream: wide-band matrices whose neighbouring rows share columns (P1
+                            * operators on unstructured 3-D meshes), which the ring's contiguous window cannot hold */
 };
 
 /* ---- library / device ------------------------------------------------- */
@@ -123,11 +126,11 @@ int mi_reorder_probe(int n, const int* ptrow, const int* indcol, int* block, int
 int mi_csr_set_kernel(mi_csr_t A, int kernel_id);
 int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable);
 /* MI_KERNEL_AUTO is decided by measurement: mi_csr_create times the candidate kernels (ring if
- * >= 90 % of the nonzeros are ring-served, stream, BCSR 4x4 if a blocked copy exists) on the new
+ * >= 90 % of the nonzeros are ring-served, stream, tile if a plan was kept, BCSR 4x4 if a blocked copy exists) on the new
  * handle, two interleaved rounds of a few launches each, and keeps the fastest.  All kernels produce
  * the same bits, so the choice never changes a result.  Reports the measured microseconds per launch
  * of the chosen temporal / non-temporal form (0 = candidate not eligible / not timed).
- * MI355_SPMV_KERNEL=ring|stream|rowpar|bcsr4 or MI355_SPMV_AUTOTUNE=0 skip the measurement (then: ring
+ * MI355_SPMV_KERNEL=ring|stream|rowpar|bcsr4|tile or MI355_SPMV_AUTOTUNE=0 skip the measurement (then: ring
  * if eligible else stream, BCSR 4x4 if blocked; non-temporal loads for matrices beyond the Infinity Cache). */
 int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
 /* Each candidate is timed twice, with temporal and with non-temporal loads of the matrix (a matrix
@@ -142,6 +145,17 @@ int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt);
  * violation) and report what the ring would serve.  Lets the planner be tested without a GPU. */
 int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, int config_id, int* nblk, int* runs,
                        int* runs_not_ringable, double* nnz_fraction_ringable, int* max_slot);
+/* Tile kernel (MI_KERNEL_TILE): mi_csr_create builds its plan for matrices the ring does not serve and keeps it when the
+ * row blocks average at most 0.6 distinct columns per nonzero (MI355_TILE=0 never, =1 always); mi_csr_set_kernel(A,
+ * MI_KERNEL_TILE) builds it on request.  *built = 1 if the handle holds a plan; unique_per_nnz = distinct columns per
+ * nonzero over all row blocks; us[0..1] = measured microseconds per launch with temporal / non-temporal value loads
+ * (0 = not timed); *nt = 1 if the handle's tile kernel uses non-temporal loads (MI355_TILE_NT=0|1 forces). */
+int mi_csr_tile_info(mi_csr_t A, int* built, int* nblk, double* unique_per_nnz, double us[2], int* nt);
+/* host-only: build the tile kernel's plan (tile_plan.hpp) exactly as mi_csr_create would, verify its invariants
+ * (MI_ERR_STATE names the first violation: every slot names its nonzero's column, lists strictly ascending, 16-byte
+ * aligned slot segments, over-long rows unlisted) and report its size.  threads = 0: as many as the library would use. */
+int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, int* nblk, long long* distinct_total,
+                       int* max_distinct, long long* nnz_listed);
 /* host-only: does this CSR pattern have the exact 4x4 node-block structure mi_csr_create looks for (n % 4 == 0,
  * the four rows of a block row hold the same columns, in aligned groups {4j..4j+3}) — i.e. will a blocked copy be
  * built and the BCSR kernel become an AUTO candidate?  *nblocks = number of 4x4 blocks if so. */

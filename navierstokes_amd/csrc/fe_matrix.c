@@ -149,13 +149,14 @@ long long fe_matrix_count(int nx, int ny, int nz)
  * dof = 4*node + component.  Output CSR with ascending columns; ptrow has rows+1 entries.
  * Returns 0, -1 on bad arguments, -2 on allocation failure.
  */
-int fe_matrix_assemble(int nx, int ny, int nz, double Re, double delta, double jitter, unsigned long long seed,
-                       int* ptrow, int* indcol, double* coef)
+static int fe_assemble_impl(int nx, int ny, int nz, double Re, double delta, double jitter, unsigned long long seed,
+                            int* ptrow, int* indcol, double* coef, int scalar)
 {
     if (nx < 1 || ny < 1 || nz < 1 || Re <= 0.0 || jitter < 0.0 || jitter > 0.4) return -1;
     const long long nn = (long long)(nx + 1) * (ny + 1) * (nz + 1);
-    if (nn * 4 > 0x7fffffffll) return -1;
-    double* acc = (double*)calloc((size_t)nn * 15 * 16, sizeof(double)); /* [node][slot][16] */
+    if (nn * (scalar ? 1 : 4) > 0x7fffffffll) return -1;
+    const int W = scalar ? 1 : 16; /* scalar: only the pressure-pressure entry [3][3] of every node block */
+    double* acc = (double*)calloc((size_t)nn * 15 * W, sizeof(double)); /* [node][slot][W] */
     if (!acc) return -2;
     /* Kuhn split of the unit cube along the (1,1,1) diagonal: one tet per permutation of the axes */
     static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
@@ -187,8 +188,10 @@ int fe_matrix_assemble(int nx, int ny, int nz, double Re, double delta, double j
                         for (int j = 0; j < 4; j++) {
                             const int s = nbr_slot(v[j][0] - v[i][0], v[j][1] - v[i][1], v[j][2] - v[i][2]);
                             if (s < 0) { free(acc); return -1; }
-                            double* d = acc + ((size_t)ni * 15 + s) * 16;
-                            for (int q = 0; q < 16; q++) d[q] += blk[i][j][q];
+                            double* d = acc + ((size_t)ni * 15 + s) * W;
+                            if (scalar) d[0] += blk[i][j][15];
+                            else
+                                for (int q = 0; q < 16; q++) d[q] += blk[i][j][q];
                         }
                     }
                 }
@@ -209,6 +212,18 @@ int fe_matrix_assemble(int nx, int ny, int nz, double Re, double delta, double j
         for (int iy = 0; iy <= ny; iy++)
             for (int ix = 0; ix <= nx; ix++) {
                 const long long ni = ix + (long long)(nx + 1) * (iy + (long long)(ny + 1) * iz);
+                if (scalar) {
+                    for (int k = 0; k < 15; k++) {
+                        const int s = order[k];
+                        const int jx = ix + kNbr[s][0], jy = iy + kNbr[s][1], jz = iz + kNbr[s][2];
+                        if (jx < 0 || jx > nx || jy < 0 || jy > ny || jz < 0 || jz > nz) continue;
+                        indcol[pos] = (int)(ni + delta_id[s]);
+                        coef[pos] = acc[(size_t)ni * 15 + s];
+                        pos++;
+                    }
+                    ptrow[ni + 1] = (int)pos;
+                    continue;
+                }
                 for (int r = 0; r < 4; r++) {
                     for (int k = 0; k < 15; k++) {
                         const int s = order[k];
@@ -227,4 +242,22 @@ int fe_matrix_assemble(int nx, int ny, int nz, double Re, double delta, double j
             }
     free(acc);
     return 0;
+}
+
+int fe_matrix_assemble(int nx, int ny, int nz, double Re, double delta, double jitter, unsigned long long seed,
+                       int* ptrow, int* indcol, double* coef)
+{
+    return fe_assemble_impl(nx, ny, nz, Re, delta, jitter, seed, ptrow, indcol, coef, 0);
+}
+
+/*
+ * The pressure-pressure part of the same matrix: one row per node, entry (i, j) = block (i, j)[3][3] — the stabilisation
+ * term delta h^2 (grad phi_i, grad phi_j) of src/integration.c, i.e. a P1 Laplacian on the jittered Kuhn mesh, the shape of
+ * the reference's pressure Poisson operator: 15 nonzeros per interior row (7-15 on the boundary), ascending columns.
+ * rows = fe_matrix_rows / 4, nonzeros = fe_matrix_count / 16.
+ */
+int fe_pressure_matrix_assemble(int nx, int ny, int nz, double Re, double delta, double jitter, unsigned long long seed,
+                                int* ptrow, int* indcol, double* coef)
+{
+    return fe_assemble_impl(nx, ny, nz, Re, delta, jitter, seed, ptrow, indcol, coef, 1);
 }

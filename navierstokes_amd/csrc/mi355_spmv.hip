@@ -28,6 +28,7 @@
 #include "ring_plan.hpp"
 #include "spmv_kernels.hpp"
 #include "spmv_ring.hpp"
+#include "spmv_tile.hpp"
 
 using namespace mi355;
 
@@ -93,6 +94,17 @@ struct RingTable {
     bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
 };
 
+// plan of the tile kernel (tile_plan.hpp); valid iff d_desc != nullptr
+struct TileTable {
+    int nblk = 0;
+    int* d_desc = nullptr;             // 4 ints per block, read as int4
+    unsigned* d_ulist = nullptr;       // distinct columns per block
+    unsigned short* d_slots = nullptr; // 16-bit column stream: position in the block's list
+    double unique_per_nnz = 0.0;       // distinct columns per nonzero, averaged over the matrix
+    bool nt = false;                   // non-temporal loads of the values
+    bool skew = false;                 // padded staging layout (see RingTable::skew)
+};
+
 struct mi_csr_s {
     int device = 0;
     int n = 0, ncols = 0;
@@ -106,6 +118,8 @@ struct mi_csr_s {
     std::vector<int> h_ptrow; // kept to (re)build row-block tables
     std::map<int, BlockTable> tables;
     RingTable ring;           // valid iff ring.d_plan != nullptr
+    TileTable tile;           // valid iff tile.d_desc != nullptr
+    double tune_us_tile = 0.0, tune_us_tile_nt = 0.0;
     int kernel = MI_KERNEL_AUTO;
     int auto_kernel = MI_KERNEL_STREAM;
     double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0, tune_us_stream_nt = 0.0;
@@ -318,6 +332,51 @@ static int get_table(mi_csr_t A, int nnzb, BlockTable** out)
     return MI_OK;
 }
 
+static void free_tile(mi_csr_t A)
+{
+    dfree(A->tile.d_desc);
+    dfree(A->tile.d_ulist);
+    dfree(A->tile.d_slots);
+    A->tile = TileTable();
+}
+
+// Plan of the tile kernel for this handle's pattern (host arrays of the caller, or nullptr: the handle's own device
+// copy is read back — explicit MI_KERNEL_TILE requests on a handle created without it).
+static int build_tile(mi_csr_t A, const int* indcol)
+{
+    if (A->tile.d_desc || A->n == 0 || A->nnz == 0) return MI_OK;
+    std::vector<int> back;
+    if (!indcol) {
+        if (!A->d_indcol) return fail(MI_ERR_STATE, "tile plan: the handle no longer holds its column indices");
+        back.resize((size_t)A->nnz);
+        HIP_TRY(hipMemcpy(back.data(), A->d_indcol, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+        indcol = back.data();
+    }
+    TilePlanHost P;
+    build_tile_plan(A->n, A->h_ptrow.data(), indcol, P);
+    TileTable& T = A->tile;
+    hipError_t e;
+    if ((e = hipMalloc(&T.d_desc, sizeof(int) * P.desc.size())) != hipSuccess ||
+        (e = hipMalloc(&T.d_ulist, sizeof(unsigned) * P.ulist.size())) != hipSuccess ||
+        (e = hipMalloc(&T.d_slots, sizeof(unsigned short) * P.slots.size())) != hipSuccess ||
+        (e = hipMemcpy(T.d_desc, P.desc.data(), sizeof(int) * P.desc.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_ulist, P.ulist.data(), sizeof(unsigned) * P.ulist.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_slots, P.slots.data(), sizeof(unsigned short) * P.slots.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        free_tile(A);
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("tile plan upload: ") + hipGetErrorString(e));
+    }
+    T.nblk = P.nblk;
+    T.unique_per_nnz = (double)(P.ulist.size() - kTileThreads) / (double)A->nnz;
+    long long mult8 = 0;
+    for (int i = 0; i < A->n; i++) {
+        const int len = A->h_ptrow[i + 1] - A->h_ptrow[i];
+        mult8 += len > 0 && len % 8 == 0;
+    }
+    T.skew = 10 * mult8 > A->n;
+    T.nt = 10.0 * (double)A->nnz + 16.0 * (double)A->n > 0.75 * 256e6;
+    return MI_OK;
+}
+
 static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr);
 static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);
 static int resolve_kernel(const mi_csr_s* A);
@@ -450,6 +509,21 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         }
         A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     }
+    // wide-band matrices (the ring does not serve them): the tile kernel's plan, kept if neighbouring rows share
+    // enough columns for it to pay (tile_plan.hpp); MI355_TILE=0 never, =1 always
+    {
+        const char* te = getenv("MI355_TILE");
+        const char* ke = getenv("MI355_SPMV_KERNEL");
+        const bool asked = (te && !strcmp(te, "1")) || (ke && !strcmp(ke, "tile"));
+        if (n > 0 && nnz > 0 && !(te && !strcmp(te, "0")) && (asked || (A->auto_kernel != MI_KERNEL_RING && nnz >= 200000))) {
+            const int rct = build_tile(A, indcol);
+            if (rct != MI_OK) {
+                mi_csr_destroy(A);
+                return rct;
+            }
+            if (!asked && A->tile.unique_per_nnz > 0.6) free_tile(A); // little sharing: nothing to gain over the stream kernel
+        }
+    }
     // FE matrices: a blocked copy for the BCSR 4x4 kernel (same bits, 8.25 instead of 12 B per nonzero)
     // (a row map that moves whole nodes — rowmap[4b + q] = rowmap[4b] + q, 4-aligned — becomes a block-row map)
     bool node_map = rowmap != nullptr && !offset_only && n % 4 == 0;
@@ -479,6 +553,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
     if (const char* e = getenv("MI355_RING_NT")) A->ring.nt = A->ring.d_slots && atoi(e) != 0;
     A->stream_nt = 12.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
     if (const char* e = getenv("MI355_STREAM_NT")) A->stream_nt = atoi(e) != 0;
+    if (const char* e = getenv("MI355_TILE_NT")) A->tile.nt = atoi(e) != 0;
     if (A->blocked) A->auto_kernel = MI_KERNEL_BCSR4; // unless measured otherwise below
     A->n_out = n;
     if (rowmap)
@@ -490,6 +565,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         else if (!strcmp(e, "ring") && A->ring.d_plan) A->auto_kernel = MI_KERNEL_RING;
         else if (!strcmp(e, "rowpar")) A->auto_kernel = MI_KERNEL_ROWPAR;
         else if (!strcmp(e, "bcsr4") && A->blocked) A->auto_kernel = MI_KERNEL_BCSR4;
+        else if (!strcmp(e, "tile") && A->tile.d_desc) A->auto_kernel = MI_KERNEL_TILE;
         else forced_kernel = false;
     }
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
@@ -517,13 +593,19 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         const bool ring_ok = A->auto_kernel == MI_KERNEL_RING;
         const bool ring_nt_forced = getenv("MI355_RING_NT") != nullptr, stream_nt_forced = getenv("MI355_STREAM_NT") != nullptr;
         const bool ring_nt0 = A->ring.nt, stream_nt0 = A->stream_nt;
-        double us[4] = {0, 0, 0, 0}; // ring, ring nt, stream, stream nt
+        const bool tile_nt_forced = getenv("MI355_TILE_NT") != nullptr;
+        const bool tile_nt0 = A->tile.nt;
+        double us[6] = {0, 0, 0, 0, 0, 0}; // ring, ring nt, stream, stream nt, tile, tile nt
         // two interleaved rounds, the faster of the two counts: one round is not enough to tell two
         // candidates 5 % apart from each other (clock ramps, what the previous candidate left in the caches)
         for (int round = 0; round < 2; round++)
-            for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < 6; c++) {
                 const bool nt = c & 1;
-                if (c < 2) {
+                if (c >= 4) {
+                    if (!A->tile.d_desc || (tile_nt_forced && nt != tile_nt0)) continue;
+                    A->tile.nt = nt;
+                    A->kernel = MI_KERNEL_TILE;
+                } else if (c < 2) {
                     if (!ring_ok || (nt && !A->ring.d_slots) || (ring_nt_forced && nt != ring_nt0)) continue;
                     A->ring.nt = nt;
                     A->kernel = MI_KERNEL_RING;
@@ -557,8 +639,13 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         auto better = [](double a, double b) { return a > 0 && (b <= 0 || a < b); }; // a measured and faster than b
         A->ring.nt = ring_ok ? better(us[1], us[0]) : ring_nt0;
         A->stream_nt = better(us[3], us[2]);
+        A->tune_us_tile = us[4];
+        A->tune_us_tile_nt = us[5];
+        A->tile.nt = A->tile.d_desc ? better(us[5], us[4]) : tile_nt0;
         const double best_ring = A->ring.nt ? us[1] : us[0], best_stream = A->stream_nt ? us[3] : us[2];
+        const double best_tile = A->tile.nt ? us[5] : us[4];
         if (ring_ok && better(best_stream, best_ring)) A->auto_kernel = MI_KERNEL_STREAM;
+        if (better(best_tile, A->auto_kernel == MI_KERNEL_RING ? best_ring : best_stream)) A->auto_kernel = MI_KERNEL_TILE;
         if (A->blocked) { // the blocked copy against the best CSR kernel
             A->kernel = MI_KERNEL_BCSR4;
             for (int w = 0; w < 3; w++)
@@ -572,7 +659,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
             A->tune_us_bcsr = ms * 1e3 / 6;
             A->kernel = MI_KERNEL_AUTO;
-            const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : best_stream;
+            const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : best_stream);
             if (better(A->tune_us_bcsr, best_csr)) A->auto_kernel = MI_KERNEL_BCSR4;
         }
     }
@@ -630,6 +717,7 @@ static void release_natural_arrays(mi_csr_t A)
     dfree(A->ring.d_run_halo);
     dfree(A->ring.d_slots);
     A->ring = RingTable();
+    free_tile(A);
     mi_bcsr4_destroy(A->blocked);
     A->blocked = nullptr;
 }
@@ -765,6 +853,7 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->ring.d_rng);
     dfree(A->ring.d_run_halo);
     dfree(A->ring.d_slots);
+    free_tile(A);
     mi_bcsr4_destroy(A->blocked);
     mi_csr_destroy(A->inner);
     dfree(A->d_iperm);
@@ -868,6 +957,7 @@ static int resolve_kernel(const mi_csr_s* A)
     int k = A->kernel != MI_KERNEL_AUTO ? A->kernel : A->auto_kernel;
     if (k == MI_KERNEL_RING && !A->ring.d_plan) k = MI_KERNEL_STREAM; // empty matrix: nothing to plan
     if (k == MI_KERNEL_BCSR4 && !A->blocked) k = MI_KERNEL_STREAM;
+    if (k == MI_KERNEL_TILE && !A->tile.d_desc) k = MI_KERNEL_STREAM;
     return k;
 }
 
@@ -946,15 +1036,44 @@ extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, in
     const int T = c.threads, per = c.nnzb / T;
     int next_row = 0, mslot = -1;
     long long next_nz = 0;
+    // replay of the window as the kernel keeps it: content[s] = the column whose x value slot s holds
+    std::vector<int> content((size_t)c.ring, -1);
+    int cur_run = -1;
+    // the runs: every block in exactly one, none longer than the kernel's LDS plan, dealt out by weight (ring_plan.hpp)
+    std::vector<int> run_of((size_t)P.nblk, -1);
+    long long wmax = 0, wsum = 0;
+    for (int g = 0; g < P.wgs; g++) {
+        const int b0 = P.run_rng[2 * g], b1 = P.run_rng[2 * g + 1];
+        if (b0 < 0 || b1 < b0 || b1 > P.nblk || b1 - b0 > kRingMaxB) return fail(MI_ERR_STATE, "run range out of bounds or longer than the kernel's plan");
+        long long w = 0;
+        for (int b = b0; b < b1; b++) {
+            if (run_of[b] >= 0) return fail(MI_ERR_STATE, "a block belongs to two runs");
+            run_of[b] = g;
+            w += !P.run_ok[g] || P.plan[(size_t)8 * b + 7] == 2 ? kRingPlainWeight : 1;
+        }
+        wmax = std::max(wmax, w);
+        wsum += w;
+    }
+    for (int b = 0; b < P.nblk; b++)
+        if (run_of[b] < 0) return fail(MI_ERR_STATE, "a block belongs to no run");
+    if (P.wgs > 0 && wmax > 2 * (wsum / P.wgs) + 4 * kRingPlainWeight) return fail(MI_ERR_STATE, "one run carries more than twice the mean weight");
     for (int b = 0; b < P.nblk; b++) {
         const int* Q = &P.plan[(size_t)8 * b];
         if (Q[0] != next_row || Q[1] != next_nz) return fail(MI_ERR_STATE, "plan does not cover rows / nonzeros in order");
-        next_row += Q[2];
+        const int brows = Q[7] == 2 ? Q[4] : Q[2]; // a PLAIN block keeps its row count out of the loop's sight
+        next_row += brows;
         next_nz += Q[3];
-        if (Q[3] != ptrow[Q[0] + Q[2]] - ptrow[Q[0]]) return fail(MI_ERR_STATE, "block nonzero count disagrees with ptrow");
-        const int run = b / (P.bpw > 0 ? P.bpw : 1); // the probe plans without ghosts: uniform runs
-        if (!P.run_ok[run] || Q[3] == 0) continue;
-        if (!Q[7] || Q[3] > c.nnzb || Q[2] > 2 * T) return fail(MI_ERR_STATE, "a served run holds a block the kernel cannot take");
+        if (Q[3] != ptrow[Q[0] + brows] - ptrow[Q[0]]) return fail(MI_ERR_STATE, "block nonzero count disagrees with ptrow");
+        const int run = run_of[b];
+        if (!P.run_ok[run] || Q[3] == 0) {
+            if (Q[7] == 2 || (Q[7] && Q[3] == 0)) return fail(MI_ERR_STATE, "flags of a block outside the ring loop");
+            continue;
+        }
+        if (Q[7] == 2) { // computed behind the loop: the loop must see an empty block
+            if (Q[2] != 0 || Q[5] != 0) return fail(MI_ERR_STATE, "a PLAIN block is visible to the ring loop");
+            continue;
+        }
+        if (Q[7] != 1 || Q[3] > c.nnzb || Q[2] > 2 * T) return fail(MI_ERR_STATE, "a served run holds a block the kernel cannot take");
         int cmin = 0x7fffffff, cmax = -1;
         for (long long k = Q[1]; k < (long long)Q[1] + Q[3]; k++) {
             cmin = std::min(cmin, indcol[k]);
@@ -963,6 +1082,19 @@ extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, in
         if (cmax - cmin + 1 > c.ring) return fail(MI_ERR_STATE, "block window wider than the ring");
         if (cmin - Q[6] < 0 || cmax - Q[6] >= 2 * c.ring) return fail(MI_ERR_STATE, "ring base out of range for the block's columns");
         if (Q[4] + Q[5] < cmax + 1) return fail(MI_ERR_STATE, "window does not reach the block's last column");
+        if (run != cur_run) { // a new workgroup: nothing in its ring yet
+            std::fill(content.begin(), content.end(), -1);
+            cur_run = run;
+        }
+        for (int col = Q[4]; col < Q[4] + Q[5]; col++) { // the columns this block brings in
+            int sl = col - Q[6];
+            if (sl >= c.ring) sl -= c.ring;
+            if (sl < 0 || sl >= c.ring) return fail(MI_ERR_STATE, "a new column falls outside the ring");
+            content[sl] = col;
+        }
+        for (int k = 0; k < Q[3]; k++)
+            if (content[(indcol[Q[1] + k] - Q[6]) >= c.ring ? indcol[Q[1] + k] - Q[6] - c.ring : indcol[Q[1] + k] - Q[6]] != indcol[Q[1] + k])
+                return fail(MI_ERR_STATE, "a nonzero's column is not in the window when its block runs");
         for (int k = 0; k < Q[3]; k++) { // slot of nonzero k as the kernel's thread (k % T), element k / T reads it
             const int slot = slots[(size_t)b * c.nnzb + (size_t)(k % T) * per + k / T];
             int want = indcol[Q[1] + k] - Q[6];
@@ -1014,13 +1146,48 @@ extern "C" int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs
     return MI_OK;
 }
 
+extern "C" int mi_csr_tile_info(mi_csr_t A, int* built, int* nblk, double* unique_per_nnz, double us[2], int* nt)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (built) *built = A->tile.d_desc != nullptr;
+    if (nblk) *nblk = A->tile.nblk;
+    if (unique_per_nnz) *unique_per_nnz = A->tile.unique_per_nnz;
+    if (us) {
+        us[0] = A->tune_us_tile;
+        us[1] = A->tune_us_tile_nt;
+    }
+    if (nt) *nt = A->tile.nt;
+    return MI_OK;
+}
+
+extern "C" int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, int* nblk, long long* distinct_total,
+                                  int* max_distinct, long long* nnz_listed)
+{
+    CHECK_ARG(n >= 0 && ptrow && ptrow[0] == 0, "bad matrix");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    TilePlanHost P;
+    build_tile_plan(n, ptrow, indcol, P, kTileNnzb, threads);
+    if (const char* bad = check_tile_plan(P, n, ptrow, indcol)) return fail(MI_ERR_STATE, std::string("tile plan: ") + bad);
+    if (nblk) *nblk = P.nblk;
+    if (distinct_total) *distinct_total = P.nblk > 0 ? (long long)P.ulist.size() - kTileThreads : 0;
+    if (max_distinct) *max_distinct = P.max_unique;
+    if (nnz_listed) *nnz_listed = P.listed;
+    return MI_OK;
+}
+
 extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
 {
     CHECK_ARG(A, "null handle");
     if (A->inner) A = A->inner;
-    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_BCSR4, "unknown kernel id");
+    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_TILE, "unknown kernel id");
     if (kernel_id == MI_KERNEL_BCSR4 && !A->blocked)
         return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_BCSR4: this matrix has no exact 4x4 block structure (or is row-mapped)");
+    if (kernel_id == MI_KERNEL_TILE) { // the plan is built on first request if mi_csr_create did not keep one
+        int rc = need_device();
+        if (rc) return rc;
+        if ((rc = build_tile(A, nullptr))) return rc;
+    }
     A->kernel = kernel_id;
     return MI_OK;
 }
@@ -1048,6 +1215,11 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
     case MI_KERNEL_BCSR4: return "spmv_bcsr4<2>";
+    case MI_KERNEL_TILE: {
+        static thread_local char nm[64];
+        snprintf(nm, sizeof nm, "spmv_csr_tile<%d, %s, %s>", kTileNnzb, A->tile.nt ? "true" : "false", A->tile.skew ? "true" : "false");
+        return nm;
+    }
     default: return "";
     }
 }
@@ -1139,7 +1311,15 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
         HIP_TRY(hipGetLastError());
         return MI_OK;
     }
-    if (kid == MI_KERNEL_ROWPAR) {
+    if (kid == MI_KERNEL_TILE) {
+        const TileTable& T = A->tile;
+        const int grid = kNXCD * ((T.nblk + kNXCD - 1) / kNXCD);
+        const int4* desc = reinterpret_cast<const int4*>(T.d_desc);
+#define TILE_LAUNCH(NT_, SK_) hipLaunchKernelGGL((spmv_csr_tile<kTileNnzb, NT_, SK_>), dim3(grid), dim3(kTileThreads), 0, s, V, desc, T.nblk, T.d_ulist, T.d_slots, d_x, d_y)
+        if (T.nt) { if (T.skew) TILE_LAUNCH(true, true); else TILE_LAUNCH(true, false); }
+        else { if (T.skew) TILE_LAUNCH(false, true); else TILE_LAUNCH(false, false); }
+#undef TILE_LAUNCH
+    } else if (kid == MI_KERNEL_ROWPAR) {
         hipLaunchKernelGGL(spmv_csr_rowpar, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y);
     } else if (kid == MI_KERNEL_RING) {
         V.nblk = A->ring.nblk;

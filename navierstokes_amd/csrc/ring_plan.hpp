@@ -19,6 +19,14 @@ struct RingConfig {
 };
 
 constexpr int kRingMaxB = 160; // blocks per run (LDS plan capacity)
+// A block the window cannot serve (one row reaching over more columns than the ring holds, or longer than a block) does not
+// disqualify its run: up to this many per run are flagged PLAIN — the pipelined loop passes over them as over an empty block
+// and the workgroup computes them after its loop with direct gathers (spmv_ring.hpp).  More than that and the whole run takes
+// the plain path, as before.
+constexpr int kRingMaxPlain = 3;
+// All runs of the persistent grid start together, so the launch lasts as long as its slowest run: blocks the window cannot
+// serve count this many served blocks when the rows are dealt out to the runs (measured cost of the plain path per block)
+constexpr int kRingPlainWeight = 4;
 // The ring kernel addresses the value stream, ptrow and rowmap with plain tid-strided indices: lanes
 // past a block's last nonzero / last row read what lies behind (never used) instead of clamping
 // every index.  The device copies therefore carry this much initialised padding at the end:
@@ -45,7 +53,8 @@ struct RingPlanHost {
     RingConfig cfg{};
     int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0;
     long long bad_nnz = 0;     // nonzeros living in runs that take the plain path
-    std::vector<int> plan;     // 8 ints per block: {r0, p0, rows, nnz, new_lo, new_cnt, base, flags}
+    std::vector<int> plan;     // 8 ints per block: {r0, p0, rows, nnz, new_lo, new_cnt, base, flags}; flags 1 = window-served,
+                               // 2 = PLAIN: {r0, p0, 0, nnz, rows, 0, base, 2} (rows moved out of the loop's sight), 0 = empty
     std::vector<int> run_ok;   // per run
     std::vector<int> run_rng;  // per run: {first block, end block} — a run is a contiguous block range, runs need not be in order
     std::vector<int> run_halo; // per run: touches a ghost column (fused multi-GPU step only)
@@ -58,6 +67,40 @@ struct RingPlanHost {
 // of bpw - kGhostRunSlack blocks, the rest in runs of bpw as usual.
 constexpr int kGhostRunSlack = 2; // blocks (~2.5 us each at 2048 nonzeros) — the push of push_exchange.hpp lands within ~5 us
 
+// Row blocks for the ring: as build_row_blocks (whole rows, <= nnzb nonzeros, <= max_rows rows), and a block also ends
+// where one more row would stretch its column span beyond the ring.  A relabelled band (reorder.hpp) has a few places
+// where consecutive rows reach far apart; cut there, the two halves each fit a window, where the uncut block would not
+// and would send its whole run down the plain path — with all runs of the persistent grid starting together that one run
+// is then the tail of the launch (measured on the relabelled 1 M-row S15 matrix: 39 such blocks of 7353, 81-88 us against
+// 34 us for the natural order).
+inline void build_ring_blocks(int n, const int* ptrow, const int* row_min, const int* row_max, int nnzb, int max_rows, int ring,
+                              std::vector<int>& out_rows, std::vector<int>& out_ptr)
+{
+    out_rows.clear();
+    out_ptr.clear();
+    int r = 0;
+    while (r < n) {
+        const int start = r, p0 = ptrow[r];
+        int cmin = 0x7fffffff, cmax = -1;
+        if (row_min[r] <= row_max[r]) { cmin = row_min[r]; cmax = row_max[r]; }
+        int e = r + 1; // a block always takes at least one row
+        while (e < n && (e - start) < max_rows && (long long)ptrow[e + 1] - p0 <= nnzb) {
+            if (row_min[e] <= row_max[e]) {
+                const int nmin = std::min(cmin, row_min[e]), nmax = std::max(cmax, row_max[e]);
+                if (cmax >= 0 && nmax - nmin + 1 > ring) break;
+                cmin = nmin;
+                cmax = nmax;
+            }
+            e++;
+        }
+        out_rows.push_back(start);
+        out_ptr.push_back(p0);
+        r = e;
+    }
+    out_rows.push_back(n);
+    out_ptr.push_back(n > 0 ? ptrow[n] : 0);
+}
+
 // row_min/row_max: smallest / largest column of each row (row_min > row_max for an empty row)
 // ghost_lo < ghost_hi: shape the runs for the fused step as described above (and fill run_halo)
 inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, const int* row_min, const int* row_max,
@@ -67,10 +110,35 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     out.cfg = cfg;
     std::vector<int> rows, ptrs;
     build_row_blocks(n, ptrow, cfg.nnzb, 2 * cfg.threads, rows, ptrs);
+    {   // span-limited blocks where that takes only a few cuts; a matrix whose rows themselves outspan the ring would
+        // fall apart into one-row blocks — it is not the ring's to serve, keep the plain blocks (its runs go plain)
+        std::vector<int> rows2, ptrs2;
+        build_ring_blocks(n, ptrow, row_min, row_max, cfg.nnzb, 2 * cfg.threads, cfg.ring, rows2, ptrs2);
+        if (rows2.size() <= rows.size() + rows.size() / 8 + 16) {
+            rows.swap(rows2);
+            ptrs.swap(ptrs2);
+        }
+    }
     const int nblk = (int)rows.size() - 1;
     out.nblk = nblk;
     if (nblk <= 0) return;
-    int wgs = cfg.wg_unit * ((nblk + kRingMaxB * cfg.wg_unit - 1) / (kRingMaxB * cfg.wg_unit));
+    // column range of every block; WIDE blocks (a row longer than a block, or columns further apart than the ring holds)
+    // cannot be window-served whatever the window did before — everything else can (the window restarts where it must)
+    std::vector<int> bmin((size_t)nblk, 0x7fffffff), bmax((size_t)nblk, -1);
+    std::vector<char> wide((size_t)nblk, 0);
+    long long weight = 0;
+    int nwide = 0;
+    for (int b = 0; b < nblk; b++) {
+        for (int r = rows[b]; r < rows[b + 1]; r++)
+            if (row_min[r] <= row_max[r]) { bmin[b] = std::min(bmin[b], row_min[r]); bmax[b] = std::max(bmax[b], row_max[r]); }
+        const int nn = ptrs[b + 1] - ptrs[b];
+        wide[b] = nn > 0 && (nn > cfg.nnzb || bmax[b] - bmin[b] + 1 > cfg.ring);
+        nwide += wide[b];
+        weight += wide[b] ? kRingPlainWeight : 1;
+    }
+    const bool weighted = nwide > 0 && !(ghost_lo < ghost_hi);
+    const long long per_unit = (long long)(weighted ? kRingMaxB - kRingPlainWeight : kRingMaxB) * cfg.wg_unit;
+    int wgs = cfg.wg_unit * (int)(((weighted ? weight : (long long)nblk) + per_unit - 1) / per_unit);
     if (wgs < cfg.wg_unit) wgs = cfg.wg_unit;
     const int bpw = (nblk + wgs - 1) / wgs;
     out.wgs = wgs;
@@ -82,6 +150,22 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     for (int g = 0; g < wgs; g++) { // default: consecutive runs of bpw blocks
         out.run_rng[2 * g] = std::min(nblk, g * bpw);
         out.run_rng[2 * g + 1] = std::min(nblk, (g + 1) * bpw);
+    }
+    if (weighted) { // runs of equal WEIGHT: run g ends with the block that carries the cumulated weight past (g + 1) / wgs of the total
+        long long cum = 0;
+        int g = 0, start = 0;
+        for (int b = 0; b < nblk; b++) {
+            cum += wide[b] ? kRingPlainWeight : 1;
+            while (g < wgs - 1 && cum * wgs >= (long long)(g + 1) * weight) {
+                out.run_rng[2 * g] = start;
+                out.run_rng[2 * g + 1] = b + 1;
+                start = b + 1;
+                g++;
+            }
+        }
+        out.run_rng[2 * g] = start;
+        out.run_rng[2 * g + 1] = nblk;
+        for (g++; g < wgs; g++) out.run_rng[2 * g] = out.run_rng[2 * g + 1] = nblk;
     }
     if (ghost_lo < ghost_hi) {
         std::vector<char> gh((size_t)nblk, 0);
@@ -111,7 +195,8 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     for (int g = 0; g < wgs; g++) {
         int wlo = 0, whi = 0, base = 0;
         bool live = false;
-        long long run_nnz = 0;
+        long long run_nnz = 0, plain_nnz = 0;
+        int nplain = 0;
         bool ok = true;
         for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1]; b++) {
             const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b];
@@ -120,10 +205,8 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
             P[4] = 0; P[5] = 0; P[6] = base; P[7] = 0;
             run_nnz += nn;
             if (nn == 0) continue;
-            int cmin = 0x7fffffff, cmax = -1;
-            for (int r = rows[b]; r < rows[b + 1]; r++)
-                if (row_min[r] <= row_max[r]) { cmin = std::min(cmin, row_min[r]); cmax = std::max(cmax, row_max[r]); }
-            bool use = nn <= cfg.nnzb && (cmax - cmin + 1 <= ring);
+            const int cmin = bmin[b], cmax = bmax[b];
+            bool use = !wide[b];
             if (use) {
                 int lo = live ? wlo : cmin, hi = live ? whi : cmin;
                 bool restart = !live;
@@ -134,7 +217,15 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
                     lo = std::max(0, std::min(cmin, cmax + 1 - ring));
                     hi = lo;
                 }
-                const int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
+                int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
+                if (cmin < nlo) { // the window cannot keep its upper end AND reach down to cmin: give the upper end up —
+                                  // restart on this block's own span (which fits), later blocks reload what they need
+                    restart = true;
+                    lo = std::max(0, std::min(cmin, cmax + 1 - ring));
+                    hi = lo;
+                    nhi = cmax + 1;
+                    nlo = std::max(lo, nhi - ring);
+                }
                 if (cmin < nlo) use = false; // cannot hold [cmin, cmax] at once
                 else {
                     if (restart) base = (lo / ring) * ring;
@@ -143,12 +234,24 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
                     wlo = nlo; whi = nhi; live = true;
                 }
             }
-            if (!use) ok = false;
+            if (!use) { // PLAIN: computed behind the loop; the window starts afresh on the next block
+                P[2] = 0; P[4] = nrows; P[5] = 0; P[6] = base; P[7] = 2;
+                live = false;
+                nplain++;
+                plain_nnz += nn;
+            }
         }
+        if (nplain > kRingMaxPlain) ok = false;
         if (!ok) {
             out.run_ok[g] = 0;
             out.bad_runs++;
             out.bad_nnz += run_nnz;
+            for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1]; b++) { // the plain path reads plain records
+                int* P = &out.plan[(size_t)8 * b];
+                if (P[7] == 2) { P[2] = P[4]; P[4] = 0; P[7] = 0; }
+            }
+        } else {
+            out.bad_nnz += plain_nnz;
         }
     }
 }
@@ -164,7 +267,7 @@ inline void build_ring_slots(const RingPlanHost& P, const int* indcol, std::vect
     for (int b = 0; b < P.nblk; b++) {
         const int* Q = &P.plan[(size_t)8 * b];
         const int p0 = Q[1], nn = Q[3], base = Q[6];
-        if (!Q[7] || nn <= 0 || nn > P.cfg.nnzb) continue;
+        if (Q[7] != 1 || nn <= 0 || nn > P.cfg.nnzb) continue;
         unsigned short* o = &out[(size_t)b * P.cfg.nnzb];
         for (int t = 0; t < T; t++)
             for (int i = 0; i < per; i++) {

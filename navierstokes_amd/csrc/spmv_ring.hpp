@@ -289,7 +289,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
         // kRingPadNnz / kRingPadRows) and their values are never used
         // (a sentinel block behind the run — flags 0 — collapses to one address per load instead of
         // streaming 16 KB of the next run's values nobody uses: 2 % of the kernel's HBM traffic)
-        const double* cb = A.coef + uni(m0.y) + (tid & (uni(m1.w) ? -1 : 0));
+        const double* cb = A.coef + uni(m0.y) + (tid & ((uni(m1.w) & 1) ? -1 : 0));
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             if (NT) c[s][i] = __builtin_nontemporal_load(&cb[i * T]);
@@ -369,6 +369,14 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
                 y[MAPPED ? A.rowmap[r] : r] = ring_row_chain<8, SKEW>(s_c, s_x, a, e);
             }
         }
+    }
+    // PLAIN blocks of this run (ring_plan.hpp: a row the window cannot hold, at most kRingMaxPlain per run): the loop above
+    // passed over them as over empty blocks; here, outside the counted pipeline, with direct gathers
+    for (int lb = 0; lb < nb; lb++) {
+        const int4 m1 = s_plan[2 * lb + 1];
+        if (uni(m1.w) != 2) continue;
+        const int4 m0 = s_plan[2 * lb];
+        ring_simple_block<T, NNZB, MAPPED, FUSED>(A, x, y, uni(m0.x), uni(m0.y), uni(m1.x), uni(m0.w), s_c, s_x, C);
     }
 }
 

@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("MI355_SPMV_LIBRARY") or os.path.join(_HERE, "csrc", "
 
 MI_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_RING, KERNEL_ROWPAR = 0, 1, 2, 3
-KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3, "bcsr4": 4}
+KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3, "bcsr4": 4, "tile": 5}
 
 _c = ctypes
 _vp = ctypes.c_void_p
@@ -98,6 +98,8 @@ def lib():
         "mi_csr_set_nontemporal": [_vp, i, i],
         "mi_csr_block4_structure": [i, _vp, _vp, P(i), P(_c.c_longlong)],
         "mi_ring_plan_probe": [i, _vp, _vp, i, P(i), P(i), P(i), P(d), P(i)],
+        "mi_csr_tile_info": [_vp, P(i), P(i), P(d), P(d), P(i)],
+        "mi_tile_plan_probe": [i, _vp, _vp, i, P(i), P(ll), P(i), P(ll)],
         "mi_debug_xcc_map": [i, _vp],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
@@ -250,7 +252,21 @@ class csrmatrix:
         rnt, snt = _c.c_int(), _c.c_int()
         check(lib().mi_csr_tune_detail(self.handle, us, _c.byref(rnt), _c.byref(snt)))
         nt = rnt.value if "ring" in self.kernel_name() else snt.value
-        return dict(ring=us[0], ring_nt=us[1], stream=us[2], stream_nt=us[3], bcsr4=us[4]), bool(nt)
+        out = dict(ring=us[0], ring_nt=us[1], stream=us[2], stream_nt=us[3], bcsr4=us[4])
+        t = self.tile_info()
+        if t["built"]:
+            out.update(tile=t["us"], tile_nt=t["us_nt"])
+            if "tile" in self.kernel_name():
+                nt = t["nt"]
+        return out, bool(nt)
+
+    def tile_info(self):
+        """dict(built, nblk, unique_per_nnz, us, us_nt, nt) — mi_csr_tile_info (the tile kernel's plan on this handle)."""
+        b, nb, nt = _c.c_int(), _c.c_int(), _c.c_int()
+        u = _c.c_double()
+        us = (_c.c_double * 2)()
+        check(lib().mi_csr_tile_info(self.handle, _c.byref(b), _c.byref(nb), _c.byref(u), us, _c.byref(nt)))
+        return dict(built=bool(b.value), nblk=nb.value, unique_per_nnz=u.value, us=us[0], us_nt=us[1], nt=bool(nt.value))
 
     def reorder_info(self):
         """dict(reordered, block, spread_before, spread_after, us_natural, us_reordered) — mi_csr_reorder_info."""

@@ -48,6 +48,8 @@ def _lib():
         lib.fe_matrix_assemble.restype = ctypes.c_int
         lib.fe_matrix_assemble.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_ulonglong, i32p, i32p, f64p]
+        lib.fe_pressure_matrix_assemble.restype = ctypes.c_int
+        lib.fe_pressure_matrix_assemble.argtypes = lib.fe_matrix_assemble.argtypes
         lib.synth_node_permutation.restype = None
         lib.synth_node_permutation.argtypes = [ctypes.c_ulonglong, ctypes.c_int, i32p]
         lib.synth_permute_sym_sorted.restype = ctypes.c_int
@@ -113,6 +115,27 @@ def fe_matrix(nx, ny=None, nz=None, Re=100.0, delta=0.05, jitter=0.1, seed=DEFAU
     rc = lib.fe_matrix_assemble(nx, ny, nz, Re, delta, jitter, seed, ptrow, indcol, coef)
     if rc != 0:
         raise ValueError(f"fe_matrix_assemble({nx}, {ny}, {nz}) -> {rc}")
+    return ptrow, indcol, coef
+
+
+def pressure_matrix(nx, ny=None, nz=None, Re=100.0, delta=0.05, jitter=0.1, seed=DEFAULT_SEED):
+    """The pressure-pressure part of fe_matrix: one row per mesh node, entry (i, j) = node block (i, j)[3][3] — the
+    stabilisation term delta h^2 (grad phi_i, grad phi_j) of src/integration.c, a P1 Laplacian on the jittered Kuhn mesh,
+    i.e. the shape of the reference's scalar (pressure Poisson) operator: 15 nonzeros per interior row, natural
+    (lexicographic) node order, columns ascending.  Returns (ptrow, indcol, coef); n = (nx+1)(ny+1)(nz+1)."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    lib = _lib()
+    n = lib.fe_matrix_rows(nx, ny, nz) // 4
+    nnz = lib.fe_matrix_count(nx, ny, nz) // 16
+    if n >= 2**31 or nnz >= 2**31:
+        raise ValueError("mesh too large for int32 indices")
+    ptrow = np.empty(n + 1, np.int32)
+    indcol = np.empty(nnz, np.int32)
+    coef = np.empty(nnz, np.float64)
+    rc = lib.fe_pressure_matrix_assemble(nx, ny, nz, Re, delta, jitter, seed, ptrow, indcol, coef)
+    if rc != 0:
+        raise ValueError(f"fe_pressure_matrix_assemble({nx}, {ny}, {nz}) -> {rc}")
     return ptrow, indcol, coef
 
 
