@@ -99,12 +99,8 @@ struct TileTable {
     int nblk = 0;
     int* d_desc = nullptr;             // 4 ints per block, read as int4
     unsigned* d_ulist = nullptr;       // distinct columns per block
-    unsigned* d_ulist_x = nullptr;     // the same lists in the CALLER's numbering (twin of a reordered handle, tile_attach_xmap)
-    size_t ulist_len = 0;
-    bool all_listed = false;           // no row longer than a block (such rows read x through indcol, not through the lists)
     unsigned short* d_slots = nullptr; // 16-bit column stream: position in the block's list
     double unique_per_nnz = 0.0;       // distinct columns per nonzero, averaged over the matrix
-    int nnzb = kTileNnzb;              // nonzeros per row block: 2048, or 1024 (MI355_TILE_NNZB; twice the workgroups per CU)
     bool nt = false;                   // non-temporal loads of the values
     bool skew = false;                 // padded staging layout (see RingTable::skew)
 };
@@ -340,7 +336,6 @@ static void free_tile(mi_csr_t A)
 {
     dfree(A->tile.d_desc);
     dfree(A->tile.d_ulist);
-    dfree(A->tile.d_ulist_x);
     dfree(A->tile.d_slots);
     A->tile = TileTable();
 }
@@ -358,11 +353,8 @@ static int build_tile(mi_csr_t A, const int* indcol)
         indcol = back.data();
     }
     TilePlanHost P;
-    int nnzb = kTileNnzb;
-    if (const char* e = getenv("MI355_TILE_NNZB")) nnzb = atoi(e) == 1024 ? 1024 : kTileNnzb;
-    build_tile_plan(A->n, A->h_ptrow.data(), indcol, P, nnzb);
+    build_tile_plan(A->n, A->h_ptrow.data(), indcol, P);
     TileTable& T = A->tile;
-    T.nnzb = nnzb;
     hipError_t e;
     if ((e = hipMalloc(&T.d_desc, sizeof(int) * P.desc.size())) != hipSuccess ||
         (e = hipMalloc(&T.d_ulist, sizeof(unsigned) * P.ulist.size())) != hipSuccess ||
@@ -374,8 +366,6 @@ static int build_tile(mi_csr_t A, const int* indcol)
         return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("tile plan upload: ") + hipGetErrorString(e));
     }
     T.nblk = P.nblk;
-    T.ulist_len = P.ulist.size();
-    T.all_listed = P.listed == A->nnz;
     T.unique_per_nnz = (double)(P.ulist.size() - kTileThreads) / (double)A->nnz;
     long long mult8 = 0;
     for (int i = 0; i < A->n; i++) {
@@ -387,25 +377,7 @@ static int build_tile(mi_csr_t A, const int* indcol)
     return MI_OK;
 }
 
-// The twin of a reordered handle computes in the new numbering, and the front gathers x into it before every product
-// (random 8-byte reads: 14 us at 1 M rows, 80 us at 5 M).  The tile kernel reads x only through its per-block lists of
-// distinct columns — an indirection already — so the relabelling can be folded into the lists: the same lists naming the
-// CALLER's columns let the twin read the caller's x directly, and the gather disappears.
-static int tile_attach_xmap(mi_csr_t A, const int* iperm /* host: caller's index of new column */)
-{
-    TileTable& T = A->tile;
-    if (!T.d_desc || !T.all_listed || T.d_ulist_x || T.ulist_len == 0) return MI_OK;
-    std::vector<unsigned> u(T.ulist_len);
-    HIP_TRY(hipMemcpy(u.data(), T.d_ulist, sizeof(unsigned) * u.size(), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i + kTileThreads < u.size(); i++) u[i] = (unsigned)iperm[u[i]];
-    for (size_t i = u.size() - kTileThreads; i < u.size(); i++) u[i] = 0; // padding
-    HIP_TRY(hipMalloc(&T.d_ulist_x, sizeof(unsigned) * u.size()));
-    HIP_TRY(hipMemcpy(T.d_ulist_x, u.data(), sizeof(unsigned) * u.size(), hipMemcpyHostToDevice));
-    return MI_OK;
-}
-
-static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr,
-                       bool caller_x = false);
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr);
 static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);
 static int resolve_kernel(const mi_csr_s* A);
 
@@ -789,27 +761,8 @@ static int maybe_reorder(mi_csr_t A, const int* ptrow, const int* indcol, const 
         (e = hipMemcpy(A->d_src_start, src_start.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("reorder upload: ") + hipGetErrorString(e));
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
-    const bool tune = !(at && !strcmp(at, "0"));
-    {   // the twin's tile kernel can read the caller's x through its lists (tile_attach_xmap): no gather.  The twin's own
-        // measurement at create compared its kernels WITHOUT the gather the others need; settle that here.
-        const char* xe = getenv("MI355_TILE_XMAP");
-        if (!(xe && !strcmp(xe, "0")) && inner->tile.d_desc && inner->tile.all_listed) {
-            if ((rc = tile_attach_xmap(inner, R.iperm.data()))) return rc;
-            if (inner->tile.d_ulist_x && resolve_kernel(inner) != MI_KERNEL_TILE && inner->kernel == MI_KERNEL_AUTO) {
-                if (tune && !getenv("MI355_SPMV_KERNEL")) {
-                    const int timed = A->nnz < 40000000 ? 12 : 6;
-                    double us_auto = 0.0, us_tile = 0.0;
-                    if ((rc = time_handle(A, 3, timed, &us_auto))) return rc;
-                    const int was = inner->auto_kernel;
-                    inner->auto_kernel = MI_KERNEL_TILE;
-                    if ((rc = time_handle(A, 3, timed, &us_tile))) return rc;
-                    if (!(us_tile < us_auto)) inner->auto_kernel = was;
-                }
-            }
-        }
-    }
     bool keep = true;
-    if (!force && tune) { // measure: natural choice against the twin (gather included)
+    if (!force && !(at && !strcmp(at, "0"))) { // measure: natural choice against the twin (gather included)
         const int timed = A->nnz < 40000000 ? 12 : 6;
         A->inner = nullptr;
         rc = time_handle(A, 3, timed, &A->us_natural);
@@ -1264,7 +1217,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     case MI_KERNEL_BCSR4: return "spmv_bcsr4<2>";
     case MI_KERNEL_TILE: {
         static thread_local char nm[64];
-        snprintf(nm, sizeof nm, "spmv_csr_tile<%d, %s, %s>", A->tile.nnzb, A->tile.nt ? "true" : "false", A->tile.skew ? "true" : "false");
+        snprintf(nm, sizeof nm, "spmv_csr_tile<%d, %s, %s>", kTileNnzb, A->tile.nt ? "true" : "false", A->tile.skew ? "true" : "false");
         return nm;
     }
     default: return "";
@@ -1326,12 +1279,10 @@ static int gather_perm(mi_csr_t A, const double* d_x, double* d_xp, hipStream_t 
     return mi_gather_dev(A->n, A->d_iperm, d_x, d_xp, (mi_stream_t)s);
 }
 
-static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm, bool caller_x)
+static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm)
 {
     if (A->n == 0) return MI_OK;
     if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
-        if (A->inner->tile.d_ulist_x && resolve_kernel(A->inner) == MI_KERNEL_TILE) // ... unless its lists name the caller's columns
-            return launch_spmv(A->inner, d_x, d_y, s, true, nullptr, true);
         int rc = gather_perm(A, d_x, A->d_xp, s);
         if (rc) return rc;
         return launch_spmv(A->inner, A->d_xp, d_y, s, true);
@@ -1364,13 +1315,9 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
         const TileTable& T = A->tile;
         const int grid = kNXCD * ((T.nblk + kNXCD - 1) / kNXCD);
         const int4* desc = reinterpret_cast<const int4*>(T.d_desc);
-        const unsigned* ul = caller_x ? T.d_ulist_x : T.d_ulist;
-#define TILE_LAUNCH(NB_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_tile<NB_, NT_, SK_>), dim3(grid), dim3(kTileThreads), 0, s, V, desc, T.nblk, ul, T.d_slots, d_x, d_y)
-#define TILE_LAUNCH2(NB_) do { if (T.nt) { if (T.skew) TILE_LAUNCH(NB_, true, true); else TILE_LAUNCH(NB_, true, false); } \
-                               else { if (T.skew) TILE_LAUNCH(NB_, false, true); else TILE_LAUNCH(NB_, false, false); } } while (0)
-        if (T.nnzb == 1024) TILE_LAUNCH2(1024);
-        else TILE_LAUNCH2(kTileNnzb);
-#undef TILE_LAUNCH2
+#define TILE_LAUNCH(NT_, SK_) hipLaunchKernelGGL((spmv_csr_tile<kTileNnzb, NT_, SK_>), dim3(grid), dim3(kTileThreads), 0, s, V, desc, T.nblk, T.d_ulist, T.d_slots, d_x, d_y)
+        if (T.nt) { if (T.skew) TILE_LAUNCH(true, true); else TILE_LAUNCH(true, false); }
+        else { if (T.skew) TILE_LAUNCH(false, true); else TILE_LAUNCH(false, false); }
 #undef TILE_LAUNCH
     } else if (kid == MI_KERNEL_ROWPAR) {
         hipLaunchKernelGGL(spmv_csr_rowpar, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y);

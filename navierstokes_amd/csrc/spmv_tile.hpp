@@ -66,8 +66,7 @@ __device__ __forceinline__ void tile_block(const CsrView& A, const int4 d0, cons
 #pragma unroll
     for (int i = 0; i < R; i++) uid[i] = ul[min(tid + i * T, ulast)];
     // ... then slots, row extents and values
-    typedef unsigned short SlotVec __attribute__((ext_vector_type(PER))); // a thread's PER slots: one 8- or 16-byte load
-    const SlotVec sv = *reinterpret_cast<const SlotVec*>(slots + (size_t)s0 + PER * tid);
+    const uint4 sv = *reinterpret_cast<const uint4*>(slots + (size_t)s0 + 8 * tid);
     const int rowc = min(r0 + tid, r1 - 1);
     const int pa = A.ptrow[rowc], pe = A.ptrow[rowc + 1];
     double c[PER];
@@ -91,7 +90,7 @@ __device__ __forceinline__ void tile_block(const CsrView& A, const int4 d0, cons
         const int k = tid + i * T;
         s_c[SKEW ? sk(k) : k] = c[i];
     }
-    *reinterpret_cast<SlotVec*>(s_j + PER * tid) = sv;
+    *reinterpret_cast<uint4*>(s_j + 8 * tid) = sv;
     __syncthreads();
     // ---- C: row chains
     if (r0 + tid < r1) y[A.rowmap ? A.rowmap[r0 + tid] : r0 + tid] = tile_row_chain<8, SKEW>(s_c, s_j, s_xs, pa - p0, pe - p0);
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(kTileThreads) void spmv_csr_tile(CsrView A, const i
                                                              const double* __restrict__ x, double* __restrict__ y)
 {
     constexpr int T = kTileThreads;
-    static_assert(NNZB / T == 8 || NNZB / T == 4, "a thread's slots are one 16- or 8-byte load");
+    static_assert(NNZB / T == 8, "a thread's slots are one 16-byte load");
     constexpr int LDSN = SKEW ? NNZB + NNZB / 32 + 1 : NNZB;
     __shared__ double s_c[LDSN];
     __shared__ double s_xs[NNZB];
@@ -141,16 +140,15 @@ __global__ __launch_bounds__(kTileThreads) void spmv_csr_tile(CsrView A, const i
         if (tid == 0) y[A.rowmap ? A.rowmap[r0] : r0] = s;
         return;
     }
-    constexpr int RMAX = NNZB / T;
     switch ((U + T - 1) / T) {
     case 1: tile_block<NNZB, NT, SKEW, 1>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
     case 2: tile_block<NNZB, NT, SKEW, 2>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
     case 3: tile_block<NNZB, NT, SKEW, 3>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
     case 4: tile_block<NNZB, NT, SKEW, 4>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
-    case 5: tile_block<NNZB, NT, SKEW, RMAX >= 5 ? 5 : RMAX>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
-    case 6: tile_block<NNZB, NT, SKEW, RMAX >= 6 ? 6 : RMAX>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
-    case 7: tile_block<NNZB, NT, SKEW, RMAX >= 7 ? 7 : RMAX>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
-    default: tile_block<NNZB, NT, SKEW, RMAX>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
+    case 5: tile_block<NNZB, NT, SKEW, 5>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
+    case 6: tile_block<NNZB, NT, SKEW, 6>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
+    case 7: tile_block<NNZB, NT, SKEW, 7>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
+    default: tile_block<NNZB, NT, SKEW, 8>(A, d0, d1, ulist, slots, x, y, s_c, s_xs, s_j); break;
     }
 }
 
