@@ -131,6 +131,27 @@ def test_structure_and_row_lengths():
     assert_bit_equal(O.spmv_bcsr4(bp, bc, bv, x), O.spmv(p, c, v, x), "BCSR4 view of the FE matrix = CSR result")
 
 
+def test_pressure_matrix_is_the_pressure_part_of_the_fe_matrix():
+    """synth.pressure_matrix (the scalar, pressure-Poisson-shaped operator of the mesh workloads) = entry [3][3] of every
+    node block of the FE matrix, bit for bit: one row per node, same neighbours, ascending columns; a P1 Laplacian (zero row
+    sums, positive diagonal) with 15 nonzeros per interior row."""
+    dims = (7, 5, 6)
+    P, C, V = synth.fe_matrix(*dims)
+    p, c, v = synth.pressure_matrix(*dims)
+    n = len(p) - 1
+    assert n == 8 * 6 * 7 and len(P) - 1 == 4 * n and p[-1] * 16 == P[-1]
+    rows = np.repeat(np.arange(4 * n), np.diff(P))
+    pp = (rows % 4 == 3) & (C % 4 == 3)
+    assert np.array_equal(rows[pp] // 4, np.repeat(np.arange(n), np.diff(p)))
+    assert np.array_equal(C[pp] // 4, c)
+    assert_bit_equal(V[pp], v, "pressure-pressure entries")
+    lens = np.diff(p)
+    assert lens.max() == 15 and lens.min() == 5
+    assert np.abs(np.add.reduceat(v, p[:-1])).max() <= 1e-12 * np.abs(v).max()
+    diag = v[[p[i] + int(np.searchsorted(c[p[i]:p[i + 1]], i)) for i in range(n)]]
+    assert (diag > 0).all()
+
+
 @pytest.mark.gpu
 def test_fe_matrix_gpu_parity():
     import torch

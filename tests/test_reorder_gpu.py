@@ -32,7 +32,7 @@ def _check_all_entry_points(p, c, v, n, expect_reordered, expect_block):
     mpk.SpMV_CSR(yd, dev(x), A)
     assert_bit_equal(yd.cpu().numpy(), yo, "device SpMV_CSR")
     # every kernel of the relabelled twin
-    for kern in ("stream", "ring", "rowpar") + (("bcsr4",) if expect_block == 4 else ()):
+    for kern in ("stream", "ring", "rowpar", "tile") + (("bcsr4",) if expect_block == 4 else ()):
         A.set_kernel(kern)
         mpk.SpMV_CSR(yd.fill_(float("nan")), dev(x), A)
         assert_bit_equal(yd.cpu().numpy(), yo, f"kernel {kern} -> {A.kernel_name()}")
@@ -73,6 +73,26 @@ def test_permuted_scalar_matrices_are_relabelled_and_bit_identical(monkeypatch):
         p0, c0, v0 = synth.rows(kind, n, w=w)
         p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=1, seed=7)
         _check_all_entry_points(p, c, v, n, True, 1)
+
+
+def test_scrambled_mesh_operator_is_relabelled_and_served_by_the_tile_kernel(monkeypatch):
+    """The scalar pressure operator of a 3-D mesh under a random node numbering: relabelled behind the API; with the tile
+    kernel forced and with the measured choice, every entry point is bit-equal to the oracle on the matrix as delivered."""
+    monkeypatch.setenv("MI355_REORDER", "1")
+    monkeypatch.setenv("MI355_TILE", "1")
+    p0, c0, v0 = synth.pressure_matrix(30, 28, 26)
+    n = len(p0) - 1
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=1, seed=5)
+    for forced in ("tile", None):
+        if forced:
+            monkeypatch.setenv("MI355_SPMV_KERNEL", forced)
+        else:
+            monkeypatch.delenv("MI355_SPMV_KERNEL")
+        info = _check_all_entry_points(p, c, v, n, True, 1)
+        assert info["spread_after"] < 0.2 * info["spread_before"]
+    monkeypatch.setenv("MI355_SPMV_KERNEL", "tile")
+    A = mpk.csrmatrix(n, p, c, v)
+    assert "tile" in A.kernel_name() and A.tile_info()["built"] and A.tile_info()["unique_per_nnz"] < 0.6
 
 
 def test_reordering_can_be_switched_off_and_natural_orders_are_left_alone(monkeypatch):
