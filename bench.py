@@ -284,7 +284,7 @@ def main():
     if args.cold:
         ev_ms = 0.0
         for _ in range(args.steps):
-            mpk.flush_cache()
+            mpk.flush_cache(sync=False)  # eviction enqueued in front of the launch: cold caches, GPU not idle
             ev0.record()
             step()
             ev1.record()
@@ -307,16 +307,25 @@ def main():
     if world == 1 and k == 1 and not args.cold and not args.no_extras and not W.get("spmm"):
         # (1) cold single shot: L2s and the 256 MiB Infinity Cache evicted before EVERY launch (the reference's own
         #     protocol: flush_cache() before each timed call, mpk/SpM2V.cpp:895-904)
-        ms = 0.0
+        #     Two forms: the eviction ENQUEUED in front of the launch (cold caches, GPU never idle: what "cold cache" means on
+        #     the CPU, where there is no idle state to wake from) and the synchronous form (the device idles while the host
+        #     returns and launches: a kernel started on an idle MI355X runs 8-26 us longer whatever the caches hold,
+        #     tools/cold_probe.py); plus a single warm launch from idle, which separates the two effects.
         ncold = 12
-        for _ in range(ncold):
-            mpk.flush_cache()
-            ev0.record()
-            step()
-            ev1.record()
-            torch.cuda.synchronize()
-            ms += ev0.elapsed_time(ev1)
-        extra["cold_us"] = ms * 1e3 / ncold
+
+        def single_shots(prepare):
+            ms = 0.0
+            for _ in range(ncold):
+                prepare()
+                ev0.record()
+                step()
+                ev1.record()
+                torch.cuda.synchronize()
+                ms += ev0.elapsed_time(ev1)
+            return ms * 1e3 / ncold
+        extra["cold_us"] = single_shots(lambda: mpk.flush_cache(sync=False))
+        extra["cold_idle_us"] = single_shots(lambda: mpk.flush_cache())
+        extra["warm_idle_us"] = single_shots(lambda: None)
         # (2) inside the Krylov-step pipeline SpMV -> dot + AXPY (orthogonalize) -> SpMV of mpk/SpMVmulti.cpp:559-574:
         #     the vector kernels between two products compete with the matrix stream for the caches
         if not bcsr:
@@ -452,7 +461,13 @@ def main():
         if "cold_us" in extra:
             roofline["cold_single_shot"] = dict(launch_us=round(extra["cold_us"], 2),
                                                 frac=round(B_exec / (extra["cold_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                protocol="mi_flush_cache() (512 MiB device fill + 512 MiB read sweep: caches left full of clean lines) before every launch, 12 launches, HIP events")
+                                                protocol="mi_flush_cache_async() (512 MiB device fill + 512 MiB read sweep: L2s and Infinity Cache left full of clean "
+                                                         "lines of an unused buffer) enqueued in front of EVERY launch, 12 launches, one HIP event pair each",
+                                                from_idle_us=round(extra["cold_idle_us"], 2),
+                                                from_idle_frac=round(B_exec / (extra["cold_idle_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                from_idle_note="same with the synchronous mi_flush_cache(): the device idles before the launch",
+                                                warm_from_idle_us=round(extra["warm_idle_us"], 2),
+                                                warm_from_idle_note="no eviction at all, one launch per synchronise: what starting on an idle GPU costs by itself")
         if "pipeline_spmv_us" in extra:
             roofline["in_pipeline"] = dict(spmv_us=round(extra["pipeline_spmv_us"], 2),
                                            frac=round(B_exec / (extra["pipeline_spmv_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),

@@ -81,6 +81,11 @@ int mi_device_synchronize(void);
  * whose write-back the next kernel pays for (≈11 us on a 1 GB product); behind the read sweep the caches hold clean lines
  * of a buffer nobody uses.  MI355_FLUSH_FILL_ONLY=1 restores the fill-only form. */
 int mi_flush_cache(void);
+/* The same eviction enqueued on stream s WITHOUT the closing synchronise: a product enqueued right behind it starts on cold
+ * caches but on a GPU that never went idle.  (Behind the synchronous form the device idles until the host has returned and
+ * launched; a kernel started on an idle MI355X measures 8-26 us longer than the same kernel behind another one, whatever
+ * the caches hold — tools/cold_probe.py.  The reference's CPU protocol has no such effect to separate.) */
+int mi_flush_cache_async(mi_stream_t s);
 
 /* ---- CSR matrix handles ------------------------------------------------ */
 /* Upload a csrmatrix (mpk/SpMV.h:18-24: n, ptrow[n+1], indcol, coef; nnz taken
@@ -164,6 +169,10 @@ int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_
 int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt);
 /* diagnostic: host_out[b] = XCD (HW_REG_XCC_ID) that workgroup b of a `wgs`-workgroup launch ran on */
 int mi_debug_xcc_map(int wgs, int* host_out);
+/* diagnostic: one 4-byte read every stride_bytes of each device array the handle's kernels stream (and of up to two caller
+ * buffers, e.g. x and y), then a synchronise.  Behind mi_flush_cache() this brings the address translations back without
+ * bringing the data back (one line per stride): it separates "cold caches" from "cold TLB" in a cold-start measurement. */
+int mi_debug_touch_pages(mi_csr_t A, int stride_bytes, const void* d_extra0, long long bytes0, const void* d_extra1, long long bytes1);
 int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
 /* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
 const char* mi_csr_kernel_name(mi_csr_t A);

@@ -286,7 +286,13 @@ __global__ __launch_bounds__(256) void flush_read_kernel(const double2* __restri
     if (s == 123.456) sink[0] = s; // never true: keeps the loads alive
 }
 
-extern "C" int mi_flush_cache(void)
+static int flush_cache_on(hipStream_t st, bool sync);
+
+extern "C" int mi_flush_cache(void) { return flush_cache_on(nullptr, true); }
+
+extern "C" int mi_flush_cache_async(mi_stream_t s) { return flush_cache_on((hipStream_t)s, false); }
+
+static int flush_cache_on(hipStream_t st, bool sync)
 {
     int rc = need_device();
     if (rc) return rc;
@@ -304,13 +310,13 @@ extern "C" int mi_flush_cache(void)
     // the fill alone would leave the 256 MiB Infinity Cache full of DIRTY lines whose write-back the next kernel then pays
     // for (measured: a cold C4 product 210 us behind the fill alone); behind the read sweep the caches hold clean lines of
     // a buffer nobody uses, i.e. "nothing of the caller's data is cached" and nothing else.
-    HIP_TRY(hipMemsetAsync(buf, 1, bytes, nullptr));
+    HIP_TRY(hipMemsetAsync(buf, 1, bytes, st));
     const char* only_fill = getenv("MI355_FLUSH_FILL_ONLY");
     if (!(only_fill && !strcmp(only_fill, "1")))
-        hipLaunchKernelGGL(flush_read_kernel, dim3(4096), dim3(256), 0, nullptr, reinterpret_cast<const double2*>((char*)buf + bytes), bytes / 16,
+        hipLaunchKernelGGL(flush_read_kernel, dim3(4096), dim3(256), 0, st, reinterpret_cast<const double2*>((char*)buf + bytes), bytes / 16,
                            reinterpret_cast<double*>((char*)buf + 2 * bytes));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    if (sync) HIP_TRY(hipDeviceSynchronize());
     return MI_OK;
 }
 
@@ -471,6 +477,15 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             if (forced) break;
         }
         A->ring.cfg = best.cfg;
+        // Blocks of prefetch: with long runs (C4: 72 blocks per workgroup) four blocks in flight instead of two hide more of
+        // the HBM latency — same handle, same box, back to back 172.8 / 168.8 / 167.5 us at depth 2 / 3 / 4, cold caches
+        // 198.2 / 194.2 / 191.9 us; with short runs (1 M rows: 14 blocks) the longer pipeline fill costs more than it hides:
+        // 34.7 / 35.1 / 37.3 us (tools/depth_ab.py, profiles/r02_ring_depth_ab.txt).  Configuration 4 only.
+        if (best.cfg.id == 4 && best.bpw >= 40) A->ring.cfg.depth = 4;
+        if (const char* e = getenv("MI355_RING_DEPTH")) {
+            const int d = atoi(e);
+            if (best.cfg.id == 4 && d >= 2 && d <= 4) A->ring.cfg.depth = d;
+        }
         A->ring.nblk = best.nblk;
         A->ring.wgs = best.wgs;
         A->ring.bpw = best.bpw;
@@ -1008,6 +1023,54 @@ extern "C" int mi_debug_xcc_map(int wgs, int* host_out)
     return MI_OK;
 }
 
+// one 4-byte read every `stride` bytes of an array: brings its address translations (and 1 line per stride) back after
+// mi_flush_cache() without bringing the data back — separates "cold caches" from "cold TLB" in a cold-start measurement
+__global__ __launch_bounds__(256) void touch_pages_kernel(const char* __restrict__ p, size_t bytes, size_t stride, int* __restrict__ sink)
+{
+    int acc = 0;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i * stride < bytes; i += step)
+        acc += *reinterpret_cast<const int*>(p + i * stride);
+    if (acc == 0x7fffffff) sink[0] = acc;
+}
+
+extern "C" int mi_debug_touch_pages(mi_csr_t A, int stride_bytes, const void* d_extra0, long long bytes0, const void* d_extra1, long long bytes1)
+{
+    CHECK_ARG(A && stride_bytes >= 64 && stride_bytes % 4 == 0, "bad argument");
+    if (A->inner) A = A->inner;
+    int* sink = nullptr;
+    HIP_TRY(hipMalloc(&sink, 64));
+    auto touch = [&](const void* p, size_t bytes) {
+        if (!p || bytes < 4) return;
+        hipLaunchKernelGGL(touch_pages_kernel, dim3(256), dim3(256), 0, nullptr, (const char*)p, bytes - 3, (size_t)stride_bytes, sink);
+    };
+    const size_t nnz = (size_t)A->nnz, n = (size_t)A->n;
+    touch(A->d_coef, 8 * nnz);
+    touch(A->d_indcol, 4 * nnz);
+    touch(A->d_ptrow, 4 * (n + 1));
+    touch(A->d_rowmap, 4 * n);
+    if (A->ring.d_plan) {
+        touch(A->ring.d_plan, 32 * (size_t)A->ring.nblk);
+        touch(A->ring.d_slots, 2 * (size_t)A->ring.nblk * A->ring.cfg.nnzb);
+    }
+    if (A->tile.d_desc) {
+        touch(A->tile.d_desc, 16 * (size_t)A->tile.nblk);
+        touch(A->tile.d_ulist, (size_t)(A->tile.unique_per_nnz * 4.0 * (double)nnz));
+        touch(A->tile.d_slots, 2 * nnz);
+    }
+    if (A->blocked) {
+        touch(A->blocked->d_coef, 128 * (size_t)A->blocked->nblocks);
+        touch(A->blocked->d_indcol, 4 * (size_t)A->blocked->nblocks);
+        touch(A->blocked->d_ptrow, 4 * ((size_t)A->blocked->nbrows + 1));
+    }
+    touch(d_extra0, (size_t)bytes0);
+    touch(d_extra1, (size_t)bytes1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    dfree(sink);
+    return MI_OK;
+}
+
 // host-only: build the ring plan and the 16-bit column stream for one configuration exactly as
 // mi_csr_create would, and check their invariants (every block of a served run keeps its columns
 // inside one window of at most RING entries, distinct columns of a block get distinct slots, slots
@@ -1327,7 +1390,14 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
         case 1: launch_ring<512, 2048, 5120, 2>(A, V, d_x, d_y, s, comm); break;
         case 2: launch_ring<512, 4096, 5120, 2>(A, V, d_x, d_y, s, comm); break;
         case 3: launch_ring<512, 4096, 11264, 2>(A, V, d_x, d_y, s, comm); break;
-        default: launch_ring<256, 2048, 5120, 2>(A, V, d_x, d_y, s, comm); break;
+        default: {
+            int depth = A->ring.cfg.depth; // chosen at create (long runs: 4 blocks of prefetch); MI355_RING_DEPTH is read per
+                                           // launch so that tools/depth_ab.py can compare the depths on one handle
+            if (const char* e = getenv("MI355_RING_DEPTH")) depth = atoi(e);
+            if (depth == 3) launch_ring<256, 2048, 5120, 3>(A, V, d_x, d_y, s, comm);
+            else if (depth == 4) launch_ring<256, 2048, 5120, 4>(A, V, d_x, d_y, s, comm);
+            else launch_ring<256, 2048, 5120, 2>(A, V, d_x, d_y, s, comm);
+        } break;
         }
     } else {
         BlockTable* T = nullptr;

@@ -66,6 +66,7 @@ def lib():
         "mi_set_device": [i],
         "mi_device_synchronize": [],
         "mi_flush_cache": [],
+        "mi_flush_cache_async": [_vp],
         "mi_csr_create": [i, i, _vp, _vp, _vp, P(_vp)],
         "mi_csr_create_mapped": [i, i, _vp, _vp, _vp, _vp, P(_vp)],
         "mi_csr_destroy": [_vp],
@@ -101,6 +102,7 @@ def lib():
         "mi_csr_tile_info": [_vp, P(i), P(i), P(d), P(d), P(i)],
         "mi_tile_plan_probe": [i, _vp, _vp, i, P(i), P(ll), P(i), P(ll)],
         "mi_debug_xcc_map": [i, _vp],
+        "mi_debug_touch_pages": [_vp, i, _vp, ll, _vp, ll],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_spmk": [_vp, i, _vp, _vp],
@@ -602,7 +604,11 @@ def rel_error(ref, test):
     return out.value
 
 
-def flush_cache():
-    """mpk/utils.cpp:146-154 evicts the CPU caches before a timed call.  The GPU
-    analogue (evicting the 256 MiB Infinity Cache) is a 512 MiB device memset."""
-    check(lib().mi_flush_cache())
+def flush_cache(sync=True):
+    """mpk/utils.cpp:146-154 evicts the CPU caches before a timed call.  The GPU analogue evicts the L2s and the 256 MiB
+    Infinity Cache (512 MiB device fill + 512 MiB read sweep).  sync=False: enqueued on the current stream without the
+    closing synchronise, so that the next launch starts on cold caches but not on an idle GPU (mi_flush_cache_async)."""
+    if sync:
+        check(lib().mi_flush_cache())
+    else:
+        check(lib().mi_flush_cache_async(_stream_ptr()))

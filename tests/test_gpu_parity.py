@@ -98,6 +98,35 @@ def test_seeded_vs_oracle(kind, n, w, kernel):
         assert O.rel_error(O.spmv(p, c, v, x, "x87"), y.cpu().numpy()) <= 1e-15
 
 
+@pytest.mark.parametrize("depth", ["2", "3", "4"])
+def test_ring_prefetch_depths_give_the_same_bits(depth, monkeypatch):
+    """mi_csr_create picks the ring kernel's blocks of prefetch by run length (4 for long runs); every depth is the same
+    arithmetic.  Forced here on matrices whose runs are short, where the pipeline is mostly sentinel blocks, and on one with
+    empty and long rows (PLAIN blocks behind the loop)."""
+    monkeypatch.setenv("MI355_RING_DEPTH", depth)
+    for kind, n, w in (("s15", 120_000, 2000), ("svar", 90_000, 1500), ("s15", 3_000, 300)):
+        p, c, v = synth.rows(kind, n, w=w)
+        A = mpk.csrmatrix(n, p, c, v).set_kernel("ring")
+        assert f", {depth}, 160," in A.kernel_name()
+        x = synth.x_sin(0, n)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(y, dev(x), A)
+        assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v, x), f"{kind} depth {depth}")
+    rng = np.random.default_rng(5)
+    n = 40_000
+    lens = rng.integers(0, 30, n)
+    lens[1234] = 3000
+    p = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    c = np.concatenate([np.sort(np.clip(i + rng.choice(np.arange(-1500, 1500), l, replace=False), 0, n - 1)) if l < 3000
+                        else np.sort(rng.choice(n, l, replace=False)) for i, l in enumerate(lens)]).astype(np.int32)
+    v = rng.uniform(-1, 1, p[-1])
+    x = rng.uniform(-1, 1, n)
+    A = mpk.csrmatrix(n, p, c, v).set_kernel("ring")
+    y = np.full(n, np.nan)
+    mpk.SpMV_CSR(y, x, A)
+    assert_bit_equal(y, O.spmv(p, c, v, x), f"ragged depth {depth}")
+
+
 def test_empty_rows_long_rows_and_degenerate_shapes():
     rng = np.random.default_rng(3)
     n = 5000
