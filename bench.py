@@ -457,6 +457,14 @@ def main():
                                              frac_of_peak_if_fused_bytes=round(B_fused / step_s / 1e9 / HBM_PEAK_GBS, 4),
                                              note="time of the whole k-step over the bytes a perfectly fused kernel would move; "
                                                   "the gap to `frac` is what fusing the k sweeps could still buy")
+    if world == 1 and not args.no_extras:
+        # this box's own streaming rate: a plain read sweep over as many bytes as the kernel's format holds (MI355X boxes of one
+        # pool differ by 10-20 % in it); NOT the roofline's peak — `frac` stays priced against the 8 TB/s spec
+        us_stream = mpk.stream_read_us(B_exec)
+        roofline["this_box_stream_read"] = dict(bytes=B_exec, launch_us=round(us_stream, 2), gbs=round(B_exec / us_stream / 1e3, 1),
+                                                kernel_over_stream=round(us_stream / (launch_s * 1e6), 4),
+                                                note="plain non-temporal read sweep of the same number of bytes, same process, back to back: "
+                                                     "kernel_over_stream = the kernel's rate as a fraction of it")
     if extra:
         if "cold_us" in extra:
             roofline["cold_single_shot"] = dict(launch_us=round(extra["cold_us"], 2),

@@ -169,6 +169,10 @@ int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_
 int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt);
 /* diagnostic: host_out[b] = XCD (HW_REG_XCC_ID) that workgroup b of a `wgs`-workgroup launch ran on */
 int mi_debug_xcc_map(int wgs, int* host_out);
+/* diagnostic / calibration: microseconds per launch of a plain non-temporal read sweep over `bytes` of device memory (16-byte
+ * loads, 2048 workgroups, back to back): the rate THIS GPU streams from HBM at.  MI355X boxes of one pool differ by 10-20 %
+ * here; bench.py prints it beside the kernel's rate so that a roofline fraction can be read against the box it was taken on. */
+int mi_debug_stream_read(long long bytes, int launches, double* us_per_launch);
 /* diagnostic: one 4-byte read every stride_bytes of each device array the handle's kernels stream (and of up to two caller
  * buffers, e.g. x and y), then a synchronise.  Behind mi_flush_cache() this brings the address translations back without
  * bringing the data back (one line per stride): it separates "cold caches" from "cold TLB" in a cold-start measurement. */

@@ -1023,6 +1023,57 @@ extern "C" int mi_debug_xcc_map(int wgs, int* host_out)
     return MI_OK;
 }
 
+// plain read sweep, 16 bytes per lane and step, grid-stride: what this very GPU streams from HBM when nothing else is asked of it
+template <bool NT>
+__global__ __launch_bounds__(256) void stream_read_kernel(const double2* __restrict__ p, size_t n16, double* __restrict__ sink)
+{
+    double s = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        double2 v;
+        if (NT) {
+            v.x = __builtin_nontemporal_load(&p[i].x);
+            v.y = __builtin_nontemporal_load(&p[i].y);
+        } else v = p[i];
+        s += v.x + v.y;
+    }
+    if (s == 123.456) sink[0] = s; // never true: keeps the loads alive
+}
+
+extern "C" int mi_debug_stream_read(long long bytes, int launches, double* us_per_launch)
+{
+    CHECK_ARG(bytes >= (1 << 20) && launches >= 1 && us_per_launch, "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    struct Scratch {
+        void* buf = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scratch()
+        {
+            dfree(buf);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } t;
+    HIP_TRY(hipMalloc(&t.buf, (size_t)bytes + 256));
+    HIP_TRY(hipMemset(t.buf, 1, (size_t)bytes + 256));
+    HIP_TRY(hipEventCreate(&t.e0));
+    HIP_TRY(hipEventCreate(&t.e1));
+    double* sink = reinterpret_cast<double*>((char*)t.buf + ((size_t)bytes / 16) * 16);
+    auto launch = [&]() {
+        hipLaunchKernelGGL(stream_read_kernel<true>, dim3(2048), dim3(256), 0, nullptr, (const double2*)t.buf, (size_t)bytes / 16, sink);
+    };
+    for (int i = 0; i < 3; i++) launch();
+    HIP_TRY(hipEventRecord(t.e0, nullptr));
+    for (int i = 0; i < launches; i++) launch();
+    HIP_TRY(hipEventRecord(t.e1, nullptr));
+    HIP_TRY(hipEventSynchronize(t.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t.e0, t.e1));
+    *us_per_launch = ms * 1e3 / launches;
+    return MI_OK;
+}
+
 // one 4-byte read every `stride` bytes of an array: brings its address translations (and 1 line per stride) back after
 // mi_flush_cache() without bringing the data back — separates "cold caches" from "cold TLB" in a cold-start measurement
 __global__ __launch_bounds__(256) void touch_pages_kernel(const char* __restrict__ p, size_t bytes, size_t stride, int* __restrict__ sink)

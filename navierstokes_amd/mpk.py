@@ -103,6 +103,7 @@ def lib():
         "mi_tile_plan_probe": [i, _vp, _vp, i, P(i), P(ll), P(i), P(ll)],
         "mi_debug_xcc_map": [i, _vp],
         "mi_debug_touch_pages": [_vp, i, _vp, ll, _vp, ll],
+        "mi_debug_stream_read": [ll, i, P(d)],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_spmk": [_vp, i, _vp, _vp],
@@ -602,6 +603,13 @@ def rel_error(ref, test):
     out = _c.c_double(0)
     check(lib().mi_rel_error(n, _host_f64(ref).ctypes.data, _host_f64(test, n).ctypes.data, _c.byref(out)))
     return out.value
+
+
+def stream_read_us(nbytes, launches=20):
+    """Microseconds per launch of a plain read sweep over nbytes of device memory (mi_debug_stream_read): this box's HBM rate."""
+    us = _c.c_double()
+    check(lib().mi_debug_stream_read(int(nbytes), int(launches), _c.byref(us)))
+    return us.value
 
 
 def flush_cache(sync=True):
