@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4", "tile"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4", "tile", "mring"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--exchange", default=None, choices=["auto", "native", "push", "torch"], help="N > 1: which halo exchange drives the step")
@@ -495,6 +495,9 @@ def main():
                                   matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else (8.25 if "bcsr4" in kernel_name else
                                                               round(10 + 4 * A.tile_info()["unique_per_nnz"], 2) if "tile" in kernel_name else 12),
                                   autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
+        mi = A.mring_info()
+        if mi["built"]:
+            out["kernel_info"]["mring_plan"] = dict(runs=mi["runs"], runs_on_plain_path=mi["runs_not_served"], nnz_fraction_served=round(mi["nnz_fraction"], 4))
         ti = A.tile_info()
         if ti["built"]:
             out["kernel_info"]["tile_plan"] = dict(row_blocks=ti["nblk"], distinct_columns_per_nnz=round(ti["unique_per_nnz"], 4))

@@ -63,6 +63,8 @@ enum {
     MI_KERNEL_BCSR4 = 4,   /* the BCSR 4x4 kernel on a blocked copy made at mi_csr_create; available only when the
                             * CSR matrix has exact 4x4 node-block structure (FE matrices), where it returns the
                             * same bits from 8.25 instead of 12 matrix bytes per nonzero */
+    MI_KERNEL_MRING = 6,   /* the ring kernel with five independent sliding windows: 3-D mesh operators, whose rows reach into a
+                            * few narrow column clusters whole mesh planes apart (any mesh size) */
     MI_KERNEL_TILE = 5     /* per row block the DISTINCT columns are gathered once into an LDS tile, nonzeros address it
                             * through a 16-bit stream: wide-band matrices whose neighbouring rows share columns (P1
                             * operators on unstructured 3-D meshes), which the ring's contiguous window cannot hold */
@@ -135,7 +137,7 @@ int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringab
  * handle, two interleaved rounds of a few launches each, and keeps the fastest.  All kernels produce
  * the same bits, so the choice never changes a result.  Reports the measured microseconds per launch
  * of the chosen temporal / non-temporal form (0 = candidate not eligible / not timed).
- * MI355_SPMV_KERNEL=ring|stream|rowpar|bcsr4|tile or MI355_SPMV_AUTOTUNE=0 skip the measurement (then: ring
+ * MI355_SPMV_KERNEL=ring|stream|rowpar|bcsr4|tile|mring or MI355_SPMV_AUTOTUNE=0 skip the measurement (then: ring
  * if eligible else stream, BCSR 4x4 if blocked; non-temporal loads for matrices beyond the Infinity Cache). */
 int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream);
 /* Each candidate is timed twice, with temporal and with non-temporal loads of the matrix (a matrix
@@ -161,6 +163,14 @@ int mi_csr_tile_info(mi_csr_t A, int* built, int* nblk, double* unique_per_nnz, 
  * aligned slot segments, over-long rows unlisted) and report its size.  threads = 0: as many as the library would use. */
 int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, int* nblk, long long* distinct_total,
                        int* max_distinct, long long* nnz_listed);
+/* Multi-window ring kernel (MI_KERNEL_MRING, mring_plan.hpp): mi_csr_create plans it for matrices the single ring does not serve
+ * and keeps the plan when it serves >= 90 % of the nonzeros (MI355_MRING=0 never, =1 always keep); mi_csr_set_kernel builds it
+ * on request.  us[0..1] = measured microseconds per launch, temporal / non-temporal value loads (MI355_MRING_NT=0|1 forces). */
+int mi_csr_mring_info(mi_csr_t A, int* built, int* runs, int* runs_not_served, double* nnz_fraction_served, double us[2], int* nt);
+/* host-only: build that plan exactly as mi_csr_create would and REPLAY it (MI_ERR_STATE names the first violation: every
+ * nonzero's 16-bit slot must hold its column when its block runs, runs cover every block once, records are consistent). */
+int mi_mring_plan_probe(int n, const int* ptrow, const int* indcol, int* nblk, int* runs, int* runs_not_served,
+                        double* nnz_fraction_served, long long* window_restarts);
 /* host-only: does this CSR pattern have the exact 4x4 node-block structure mi_csr_create looks for (n % 4 == 0,
  * the four rows of a block row hold the same columns, in aligned groups {4j..4j+3}) — i.e. will a blocked copy be
  * built and the BCSR kernel become an AUTO candidate?  *nblocks = number of 4x4 blocks if so. */

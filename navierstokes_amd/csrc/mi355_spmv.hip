@@ -29,6 +29,7 @@
 #include "spmv_kernels.hpp"
 #include "spmv_ring.hpp"
 #include "spmv_tile.hpp"
+#include "spmv_mring.hpp"
 
 using namespace mi355;
 
@@ -94,6 +95,18 @@ struct RingTable {
     bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
 };
 
+// plan of the multi-window ring kernel (mring_plan.hpp); valid iff d_plan != nullptr
+struct MringTable {
+    int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0, depth = 2;
+    double ok_fraction = 0.0;
+    long long restarts = 0;
+    int* d_plan = nullptr;             // 16 ints per block, read as four int4
+    int* d_ok = nullptr;
+    int* d_rng = nullptr;
+    unsigned short* d_slots = nullptr;
+    bool nt = false, skew = false;
+};
+
 // plan of the tile kernel (tile_plan.hpp); valid iff d_desc != nullptr
 struct TileTable {
     int nblk = 0;
@@ -120,6 +133,8 @@ struct mi_csr_s {
     RingTable ring;           // valid iff ring.d_plan != nullptr
     TileTable tile;           // valid iff tile.d_desc != nullptr
     double tune_us_tile = 0.0, tune_us_tile_nt = 0.0;
+    MringTable mring;         // valid iff mring.d_plan != nullptr
+    double tune_us_mring = 0.0, tune_us_mring_nt = 0.0;
     int kernel = MI_KERNEL_AUTO;
     int auto_kernel = MI_KERNEL_STREAM;
     double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0, tune_us_stream_nt = 0.0;
@@ -346,6 +361,58 @@ static void free_tile(mi_csr_t A)
     A->tile = TileTable();
 }
 
+static void free_mring(mi_csr_t A)
+{
+    dfree(A->mring.d_plan);
+    dfree(A->mring.d_ok);
+    dfree(A->mring.d_rng);
+    dfree(A->mring.d_slots);
+    A->mring = MringTable();
+}
+
+// Plan of the multi-window ring kernel (host arrays of the caller, or nullptr: the handle's device copy is read back)
+static int build_mring(mi_csr_t A, const int* indcol)
+{
+    if (A->mring.d_plan || A->n == 0 || A->nnz == 0) return MI_OK;
+    std::vector<int> back;
+    if (!indcol) {
+        if (!A->d_indcol) return fail(MI_ERR_STATE, "mring plan: the handle no longer holds its column indices");
+        back.resize((size_t)A->nnz);
+        HIP_TRY(hipMemcpy(back.data(), A->d_indcol, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+        indcol = back.data();
+    }
+    MringPlanHost P;
+    build_mring_plan(A->n, A->h_ptrow.data(), indcol, P);
+    MringTable& M = A->mring;
+    hipError_t e;
+    if ((e = hipMalloc(&M.d_plan, sizeof(int) * P.plan.size())) != hipSuccess ||
+        (e = hipMalloc(&M.d_ok, sizeof(int) * P.run_ok.size())) != hipSuccess ||
+        (e = hipMalloc(&M.d_rng, sizeof(int) * P.run_rng.size())) != hipSuccess ||
+        (e = hipMalloc(&M.d_slots, sizeof(unsigned short) * P.slots.size())) != hipSuccess ||
+        (e = hipMemcpy(M.d_plan, P.plan.data(), sizeof(int) * P.plan.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(M.d_ok, P.run_ok.data(), sizeof(int) * P.run_ok.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(M.d_rng, P.run_rng.data(), sizeof(int) * P.run_rng.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(M.d_slots, P.slots.data(), sizeof(unsigned short) * P.slots.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        free_mring(A);
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("mring plan upload: ") + hipGetErrorString(e));
+    }
+    M.nblk = P.nblk;
+    M.wgs = P.wgs;
+    M.bpw = P.bpw;
+    M.bad_runs = P.bad_runs;
+    M.restarts = P.restarts;
+    M.ok_fraction = 1.0 - (double)P.bad_nnz / (double)A->nnz;
+    M.depth = P.bpw >= 40 ? 4 : 2; // as for the single ring (tools/depth_ab.py)
+    long long mult8 = 0;
+    for (int i = 0; i < A->n; i++) {
+        const int len = A->h_ptrow[i + 1] - A->h_ptrow[i];
+        mult8 += len > 0 && len % 8 == 0;
+    }
+    M.skew = 10 * mult8 > A->n;
+    M.nt = 10.0 * (double)A->nnz + 16.0 * (double)A->n > 0.75 * 256e6;
+    return MI_OK;
+}
+
 // Plan of the tile kernel for this handle's pattern (host arrays of the caller, or nullptr: the handle's own device
 // copy is read back — explicit MI_KERNEL_TILE requests on a handle created without it).
 static int build_tile(mi_csr_t A, const int* indcol)
@@ -539,6 +606,20 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             if (!asked && A->tile.unique_per_nnz > 0.6) free_tile(A); // little sharing: nothing to gain over the stream kernel
         }
     }
+    // ... and the multi-window ring's (3-D mesh operators: a few narrow column clusters far apart), kept if it serves >= 90 %
+    {
+        const char* me = getenv("MI355_MRING");
+        const char* ke = getenv("MI355_SPMV_KERNEL");
+        const bool asked = (me && !strcmp(me, "1")) || (ke && !strcmp(ke, "mring"));
+        if (n > 0 && nnz > 0 && !(me && !strcmp(me, "0")) && (asked || (A->auto_kernel != MI_KERNEL_RING && nnz >= 200000))) {
+            const int rcm = build_mring(A, indcol);
+            if (rcm != MI_OK) {
+                mi_csr_destroy(A);
+                return rcm;
+            }
+            if (!asked && A->mring.ok_fraction < 0.90) free_mring(A);
+        }
+    }
     // FE matrices: a blocked copy for the BCSR 4x4 kernel (same bits, 8.25 instead of 12 B per nonzero)
     // (a row map that moves whole nodes — rowmap[4b + q] = rowmap[4b] + q, 4-aligned — becomes a block-row map)
     bool node_map = rowmap != nullptr && !offset_only && n % 4 == 0;
@@ -569,6 +650,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
     A->stream_nt = 12.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
     if (const char* e = getenv("MI355_STREAM_NT")) A->stream_nt = atoi(e) != 0;
     if (const char* e = getenv("MI355_TILE_NT")) A->tile.nt = atoi(e) != 0;
+    if (const char* e = getenv("MI355_MRING_NT")) A->mring.nt = atoi(e) != 0;
     if (A->blocked) A->auto_kernel = MI_KERNEL_BCSR4; // unless measured otherwise below
     A->n_out = n;
     if (rowmap)
@@ -581,6 +663,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         else if (!strcmp(e, "rowpar")) A->auto_kernel = MI_KERNEL_ROWPAR;
         else if (!strcmp(e, "bcsr4") && A->blocked) A->auto_kernel = MI_KERNEL_BCSR4;
         else if (!strcmp(e, "tile") && A->tile.d_desc) A->auto_kernel = MI_KERNEL_TILE;
+        else if (!strcmp(e, "mring") && A->mring.d_plan) A->auto_kernel = MI_KERNEL_MRING;
         else forced_kernel = false;
     }
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
@@ -610,13 +693,19 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         const bool ring_nt0 = A->ring.nt, stream_nt0 = A->stream_nt;
         const bool tile_nt_forced = getenv("MI355_TILE_NT") != nullptr;
         const bool tile_nt0 = A->tile.nt;
-        double us[6] = {0, 0, 0, 0, 0, 0}; // ring, ring nt, stream, stream nt, tile, tile nt
+        const bool mring_nt_forced = getenv("MI355_MRING_NT") != nullptr;
+        const bool mring_nt0 = A->mring.nt;
+        double us[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // ring, ring nt, stream, stream nt, tile, tile nt, mring, mring nt
         // two interleaved rounds, the faster of the two counts: one round is not enough to tell two
         // candidates 5 % apart from each other (clock ramps, what the previous candidate left in the caches)
         for (int round = 0; round < 2; round++)
-            for (int c = 0; c < 6; c++) {
+            for (int c = 0; c < 8; c++) {
                 const bool nt = c & 1;
-                if (c >= 4) {
+                if (c >= 6) {
+                    if (!A->mring.d_plan || (mring_nt_forced && nt != mring_nt0)) continue;
+                    A->mring.nt = nt;
+                    A->kernel = MI_KERNEL_MRING;
+                } else if (c >= 4) {
                     if (!A->tile.d_desc || (tile_nt_forced && nt != tile_nt0)) continue;
                     A->tile.nt = nt;
                     A->kernel = MI_KERNEL_TILE;
@@ -661,6 +750,12 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         const double best_tile = A->tile.nt ? us[5] : us[4];
         if (ring_ok && better(best_stream, best_ring)) A->auto_kernel = MI_KERNEL_STREAM;
         if (better(best_tile, A->auto_kernel == MI_KERNEL_RING ? best_ring : best_stream)) A->auto_kernel = MI_KERNEL_TILE;
+        A->tune_us_mring = us[6];
+        A->tune_us_mring_nt = us[7];
+        A->mring.nt = A->mring.d_plan ? better(us[7], us[6]) : mring_nt0;
+        const double best_mring = A->mring.nt ? us[7] : us[6];
+        if (better(best_mring, A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : best_stream)))
+            A->auto_kernel = MI_KERNEL_MRING;
         if (A->blocked) { // the blocked copy against the best CSR kernel
             A->kernel = MI_KERNEL_BCSR4;
             for (int w = 0; w < 3; w++)
@@ -674,7 +769,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
             A->tune_us_bcsr = ms * 1e3 / 6;
             A->kernel = MI_KERNEL_AUTO;
-            const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : best_stream);
+            const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : (A->auto_kernel == MI_KERNEL_MRING ? best_mring : best_stream));
             if (better(A->tune_us_bcsr, best_csr)) A->auto_kernel = MI_KERNEL_BCSR4;
         }
     }
@@ -733,6 +828,7 @@ static void release_natural_arrays(mi_csr_t A)
     dfree(A->ring.d_slots);
     A->ring = RingTable();
     free_tile(A);
+    free_mring(A);
     mi_bcsr4_destroy(A->blocked);
     A->blocked = nullptr;
 }
@@ -869,6 +965,7 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->ring.d_run_halo);
     dfree(A->ring.d_slots);
     free_tile(A);
+    free_mring(A);
     mi_bcsr4_destroy(A->blocked);
     mi_csr_destroy(A->inner);
     dfree(A->d_iperm);
@@ -973,6 +1070,7 @@ static int resolve_kernel(const mi_csr_s* A)
     if (k == MI_KERNEL_RING && !A->ring.d_plan) k = MI_KERNEL_STREAM; // empty matrix: nothing to plan
     if (k == MI_KERNEL_BCSR4 && !A->blocked) k = MI_KERNEL_STREAM;
     if (k == MI_KERNEL_TILE && !A->tile.d_desc) k = MI_KERNEL_STREAM;
+    if (k == MI_KERNEL_MRING && !A->mring.d_plan) k = MI_KERNEL_STREAM;
     return k;
 }
 
@@ -1275,6 +1373,38 @@ extern "C" int mi_csr_tile_info(mi_csr_t A, int* built, int* nblk, double* uniqu
     return MI_OK;
 }
 
+extern "C" int mi_csr_mring_info(mi_csr_t A, int* built, int* runs, int* runs_not_served, double* nnz_fraction_served, double us[2], int* nt)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (built) *built = A->mring.d_plan != nullptr;
+    if (runs) *runs = A->mring.wgs;
+    if (runs_not_served) *runs_not_served = A->mring.bad_runs;
+    if (nnz_fraction_served) *nnz_fraction_served = A->mring.ok_fraction;
+    if (us) {
+        us[0] = A->tune_us_mring;
+        us[1] = A->tune_us_mring_nt;
+    }
+    if (nt) *nt = A->mring.nt;
+    return MI_OK;
+}
+
+extern "C" int mi_mring_plan_probe(int n, const int* ptrow, const int* indcol, int* nblk, int* runs, int* runs_not_served,
+                                   double* nnz_fraction_served, long long* window_restarts)
+{
+    CHECK_ARG(n >= 0 && ptrow && ptrow[0] == 0, "bad matrix");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    MringPlanHost P;
+    build_mring_plan(n, ptrow, indcol, P);
+    if (const char* bad = check_mring_plan(P, n, ptrow, indcol)) return fail(MI_ERR_STATE, std::string("mring plan: ") + bad);
+    if (nblk) *nblk = P.nblk;
+    if (runs) *runs = P.wgs;
+    if (runs_not_served) *runs_not_served = P.bad_runs;
+    if (nnz_fraction_served) *nnz_fraction_served = ptrow[n] ? 1.0 - (double)P.bad_nnz / (double)ptrow[n] : 0.0;
+    if (window_restarts) *window_restarts = P.restarts;
+    return MI_OK;
+}
+
 extern "C" int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, int* nblk, long long* distinct_total,
                                   int* max_distinct, long long* nnz_listed)
 {
@@ -1294,13 +1424,18 @@ extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
 {
     CHECK_ARG(A, "null handle");
     if (A->inner) A = A->inner;
-    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_TILE, "unknown kernel id");
+    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_MRING, "unknown kernel id");
     if (kernel_id == MI_KERNEL_BCSR4 && !A->blocked)
         return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_BCSR4: this matrix has no exact 4x4 block structure (or is row-mapped)");
     if (kernel_id == MI_KERNEL_TILE) { // the plan is built on first request if mi_csr_create did not keep one
         int rc = need_device();
         if (rc) return rc;
         if ((rc = build_tile(A, nullptr))) return rc;
+    }
+    if (kernel_id == MI_KERNEL_MRING) {
+        int rc = need_device();
+        if (rc) return rc;
+        if ((rc = build_mring(A, nullptr))) return rc;
     }
     A->kernel = kernel_id;
     return MI_OK;
@@ -1329,6 +1464,12 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
     case MI_KERNEL_BCSR4: return "spmv_bcsr4<2>";
+    case MI_KERNEL_MRING: {
+        static thread_local char nm[96];
+        snprintf(nm, sizeof nm, "spmv_csr_mring<%d, %d, %d, %d, %s, %s, %s>", kMringThreads, kMringNnzb, A->mring.depth, kMringMaxB,
+                 A->d_rowmap ? "true" : "false", A->mring.nt ? "true" : "false", A->mring.skew ? "true" : "false");
+        return nm;
+    }
     case MI_KERNEL_TILE: {
         static thread_local char nm[64];
         snprintf(nm, sizeof nm, "spmv_csr_tile<%d, %s, %s>", kTileNnzb, A->tile.nt ? "true" : "false", A->tile.skew ? "true" : "false");
@@ -1425,7 +1566,23 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
         HIP_TRY(hipGetLastError());
         return MI_OK;
     }
-    if (kid == MI_KERNEL_TILE) {
+    if (kid == MI_KERNEL_MRING) {
+        const MringTable& M = A->mring;
+        V.nblk = M.nblk;
+        const int4* plan = reinterpret_cast<const int4*>(M.d_plan);
+        const int2* rng = reinterpret_cast<const int2*>(M.d_rng);
+#define MRING_L(D_, MP_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, D_, kMringMaxB, MP_, NT_, SK_>), dim3(M.wgs), dim3(kMringThreads), 0, s, V, plan, M.d_ok, M.d_slots, d_x, d_y, rng)
+#define MRING_L3(D_, MP_) do { if (M.nt) { if (M.skew) MRING_L(D_, MP_, true, true); else MRING_L(D_, MP_, true, false); } \
+                               else { if (M.skew) MRING_L(D_, MP_, false, true); else MRING_L(D_, MP_, false, false); } } while (0)
+#define MRING_L2(D_) do { if (V.rowmap) MRING_L3(D_, true); else MRING_L3(D_, false); } while (0)
+        int depth = M.depth;
+        if (const char* e = getenv("MI355_RING_DEPTH")) depth = atoi(e);
+        if (depth == 4) MRING_L2(4);
+        else MRING_L2(2);
+#undef MRING_L2
+#undef MRING_L3
+#undef MRING_L
+    } else if (kid == MI_KERNEL_TILE) {
         const TileTable& T = A->tile;
         const int grid = kNXCD * ((T.nblk + kNXCD - 1) / kNXCD);
         const int4* desc = reinterpret_cast<const int4*>(T.d_desc);

@@ -1,0 +1,289 @@
+// mring_plan.hpp — host-side (no HIP) plan of the multi-window ring kernel (spmv_mring.hpp).
+//
+// The ring kernel (spmv_ring.hpp) keeps ONE sliding window of x in LDS: right for a band, useless for a 3-D mesh, whose
+// rows reach into the mesh plane (or Cuthill-McKee level) below, their own, and the one above — three narrow clusters of
+// columns, two whole planes apart (P1 pressure operator on 100^3 cells, natural or relabelled order: one window would
+// have to span 16-21 k columns, THREE windows 0.7-1.0 k in total; tile_plan.hpp's neighbours' measurement).  And the
+// clusters slide: along a plane each moves forward with the rows, and where a level ends the next one begins right behind
+// it in the numbering, so the windows just keep sliding.  So: K = 5 independent sliding windows, each a ring of
+// RING / K entries of the same LDS array; per block the host plan says, per window, which columns enter; every nonzero's
+// LDS slot is precomputed as a 16-bit number exactly as for the single ring.  The kernel is the ring kernel with a
+// K-way refill — same pipeline, same row chains, same bits.
+//
+// Plan, per run (a workgroup's consecutive blocks), per block:
+//   * the block's distinct columns are cut into clusters wherever two neighbours lie kMringGap or more apart;
+//   * a cluster continues the window it starts in (or just above: within kMringGap of its upper end), sliding it; clusters
+//     that continue nothing take windows no cluster of this block uses (their old content is dropped: a restart of that
+//     window alone);
+//   * more than K clusters, or a cluster wider than a window: the block is PLAIN (computed behind the loop, like the single
+//     ring's), and all windows start afresh behind it.
+// Pure integer work; checked by replay in mi_mring_plan_probe (every nonzero's slot holds its column when its block runs).
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "ring_plan.hpp"
+
+namespace mi355 {
+
+constexpr int kMringK = 5;          // windows
+constexpr int kMringRing = 5120;    // doubles of LDS for all windows together
+constexpr int kMringW = kMringRing / kMringK; // entries per window
+constexpr int kMringGap = 256;      // neighbouring distinct columns this far apart belong to different clusters
+// (relabelled 100^3-cell mesh, blocks of 2048 nonzeros: 3 clusters in 92 %, 5 where the rows cross from one Cuthill-McKee level
+// into the next, in 7 %; widest cluster 265 columns median, 461 at the 99th percentile: K = 5 windows of 1024 serve 99.7 %,
+// K = 4 of 1280 only 93 %.)
+// record slots of window w: first new column at plan[kMringLoAt(w)], count | base index << 11 at plan[kMringPkAt(w)]
+constexpr int kMringLoAt(int w) { return w < 4 ? 8 + w : 6; }
+constexpr int kMringPkAt(int w) { return w < 4 ? 12 + w : 7; }
+constexpr int kMringNnzb = 2048, kMringThreads = 256, kMringWgUnit = 512;
+constexpr int kMringMaxB = 96;      // blocks per run: the plan records are 64 bytes each and two workgroups must fit a CU's LDS
+
+struct MringPlanHost {
+    int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0;
+    long long bad_nnz = 0;
+    // 16 ints per block: {r0, p0, rows, nnz} {flags, total new, new_lo[4], pk[4]} {new_lo[0..3]} {pk[0..3]}, pk = count | base index << 11
+    // flags 1 = window-served, 2 = PLAIN {r0, p0, 0, nnz} {2, 0, 0, 0} {rows, 0, 0, 0}, 0 = empty
+    std::vector<int> plan;
+    std::vector<int> run_ok;
+    std::vector<int> run_rng;
+    std::vector<unsigned short> slots; // per block kMringNnzb entries in thread order (as build_ring_slots)
+    long long restarts = 0;            // window restarts in the middle of a run (diagnostic)
+};
+
+inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPlanHost& out)
+{
+    out = MringPlanHost();
+    const int K = kMringK, W = kMringW, T = kMringThreads, nnzb = kMringNnzb, per = nnzb / T;
+    std::vector<int> rows, ptrs;
+    build_row_blocks(n, ptrow, nnzb, 2 * T, rows, ptrs);
+    const int nblk = (int)rows.size() - 1;
+    out.nblk = nblk;
+    if (nblk <= 0) return;
+    // clusters of every block: distinct columns sorted, cut at gaps >= kMringGap
+    struct Cl { int lo, hi; }; // [lo, hi]
+    std::vector<int> cl_ptr((size_t)nblk + 1, 0);
+    std::vector<Cl> cls;
+    std::vector<char> wide((size_t)nblk, 0);
+    {
+        std::vector<int> u;
+        for (int b = 0; b < nblk; b++) {
+            const int p0 = ptrs[b], nn = ptrs[b + 1] - p0;
+            cl_ptr[b] = (int)cls.size();
+            if (nn <= 0) continue;
+            if (nn > nnzb) { wide[b] = 1; continue; }
+            u.assign(indcol + p0, indcol + p0 + nn);
+            std::sort(u.begin(), u.end());
+            u.erase(std::unique(u.begin(), u.end()), u.end());
+            const size_t first = cls.size();
+            Cl cur{u[0], u[0]};
+            for (size_t i = 1; i < u.size(); i++) {
+                if (u[i] - u[i - 1] >= kMringGap) { cls.push_back(cur); cur.lo = u[i]; }
+                cur.hi = u[i];
+            }
+            cls.push_back(cur);
+            bool bad = (int)(cls.size() - first) > K;
+            for (size_t i = first; i < cls.size() && !bad; i++) bad = cls[i].hi - cls[i].lo + 1 > W;
+            if (bad) { cls.resize(first); wide[b] = 1; }
+        }
+        cl_ptr[nblk] = (int)cls.size();
+    }
+    long long weight = 0;
+    int nwide = 0;
+    for (int b = 0; b < nblk; b++) { nwide += wide[b]; weight += wide[b] ? kRingPlainWeight : 1; }
+    const long long per_unit = (long long)(kMringMaxB - kRingPlainWeight) * kMringWgUnit;
+    int wgs = kMringWgUnit * (int)((weight + per_unit - 1) / per_unit);
+    if (wgs < kMringWgUnit) wgs = kMringWgUnit;
+    out.wgs = wgs;
+    out.bpw = (nblk + wgs - 1) / wgs;
+    out.plan.assign((size_t)16 * nblk, 0);
+    out.run_ok.assign(wgs, 1);
+    out.run_rng.assign((size_t)2 * wgs, 0);
+    if (nwide == 0) {
+        for (int g = 0; g < wgs; g++) {
+            out.run_rng[2 * g] = std::min(nblk, g * out.bpw);
+            out.run_rng[2 * g + 1] = std::min(nblk, (g + 1) * out.bpw);
+        }
+    } else { // runs of equal weight (ring_plan.hpp)
+        long long cum = 0;
+        int g = 0, start = 0;
+        for (int b = 0; b < nblk; b++) {
+            cum += wide[b] ? kRingPlainWeight : 1;
+            while (g < wgs - 1 && cum * wgs >= (long long)(g + 1) * weight) {
+                out.run_rng[2 * g] = start;
+                out.run_rng[2 * g + 1] = b + 1;
+                start = b + 1;
+                g++;
+            }
+        }
+        out.run_rng[2 * g] = start;
+        out.run_rng[2 * g + 1] = nblk;
+        for (g++; g < wgs; g++) out.run_rng[2 * g] = out.run_rng[2 * g + 1] = nblk;
+    }
+    out.slots.assign((size_t)nblk * nnzb, 0);
+    std::vector<int> win_of; // per cluster of the current block: its window
+    for (int g = 0; g < wgs; g++) {
+        int wlo[kMringK], whi[kMringK], wbase[kMringK]; // window w holds columns [wlo, whi); slot = (c - wbase) mod W
+        bool live[kMringK];
+        for (int w = 0; w < K; w++) { wlo[w] = whi[w] = wbase[w] = 0; live[w] = false; }
+        long long run_nnz = 0, plain_nnz = 0;
+        int nplain = 0;
+        bool first_served = true;
+        for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1]; b++) {
+            const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b];
+            int* P = &out.plan[(size_t)16 * b];
+            P[0] = rows[b]; P[1] = ptrs[b]; P[2] = nrows; P[3] = nn;
+            run_nnz += nn;
+            if (nn == 0) continue;
+            if (wide[b]) {
+                P[2] = 0; P[4] = 2; P[8] = nrows;
+                for (int w = 0; w < K; w++) live[w] = false;
+                nplain++;
+                plain_nnz += nn;
+                continue;
+            }
+            const Cl* C = &cls[cl_ptr[b]];
+            const int nc = cl_ptr[b + 1] - cl_ptr[b];
+            // which window does each cluster continue?
+            win_of.assign(nc, -1);
+            bool used[kMringK] = {};
+            for (int j = 0; j < nc; j++)
+                for (int w = 0; w < K; w++)
+                    if (live[w] && !used[w] && C[j].lo >= wlo[w] && C[j].lo < whi[w] + kMringGap) { win_of[j] = w; used[w] = true; break; }
+            for (int j = 0; j < nc; j++) { // the others: a window nobody uses in this block (prefer one that holds nothing)
+                if (win_of[j] >= 0) continue;
+                int pick = -1;
+                for (int w = 0; w < K && pick < 0; w++)
+                    if (!used[w] && !live[w]) pick = w;
+                for (int w = 0; w < K && pick < 0; w++)
+                    if (!used[w]) pick = w;
+                win_of[j] = pick; // nc <= K: there is one
+                used[pick] = true;
+                if (live[pick] && !first_served) out.restarts++;
+                live[pick] = false;
+            }
+            int total_new = 0;
+            int nlo_[kMringK] = {}, ncnt_[kMringK] = {};
+            for (int j = 0; j < nc; j++) {
+                const int w = win_of[j], cmin = C[j].lo, cmax = C[j].hi;
+                int lo = live[w] ? wlo[w] : cmin, hi = live[w] ? whi[w] : cmin;
+                bool restart = !live[w];
+                int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - W);
+                if (!restart && cmin < nlo) { // cannot keep the upper end and reach down: start afresh on this cluster
+                    restart = true;
+                    out.restarts++;
+                }
+                if (restart) {
+                    lo = std::max(0, std::min(cmin, cmax + 1 - W));
+                    hi = lo;
+                    nhi = cmax + 1;
+                    nlo = std::max(lo, nhi - W);
+                    wbase[w] = (lo / W) * W;
+                }
+                while (nlo - wbase[w] >= W) wbase[w] += W;
+                nlo_[w] = hi;
+                ncnt_[w] = nhi - hi;
+                total_new += nhi - hi;
+                wlo[w] = nlo; whi[w] = nhi; live[w] = true;
+            }
+            first_served = false;
+            P[4] = 1; P[5] = total_new;
+            for (int w = 0; w < K; w++) {
+                P[kMringLoAt(w)] = nlo_[w];
+                P[kMringPkAt(w)] = ncnt_[w] | ((wbase[w] / W) << 11);
+            }
+            // slots of this block's nonzeros
+            unsigned short* o = &out.slots[(size_t)b * nnzb];
+            const int p0 = ptrs[b];
+            for (int t = 0; t < T; t++)
+                for (int i = 0; i < per; i++) {
+                    const int k = std::min(t + i * T, nn - 1);
+                    const int c = indcol[p0 + k];
+                    int j = 0;
+                    while (j + 1 < nc && c > C[j].hi) j++;
+                    const int w = win_of[j];
+                    int s = c - wbase[w];
+                    if (s >= W) s -= W;
+                    o[t * per + i] = (unsigned short)(w * W + s);
+                }
+        }
+        bool ok = nplain <= kRingMaxPlain;
+        if (!ok) {
+            out.run_ok[g] = 0;
+            out.bad_runs++;
+            out.bad_nnz += run_nnz;
+            for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1]; b++) {
+                int* P = &out.plan[(size_t)16 * b];
+                if (P[4] == 2) { P[2] = P[8]; P[8] = 0; }
+                P[4] = 0;
+            }
+        } else {
+            out.bad_nnz += plain_nnz;
+        }
+    }
+}
+
+// Replay of a plan against its matrix, as the kernel will execute it: returns nullptr or the first violation.
+inline const char* check_mring_plan(const MringPlanHost& P, int n, const int* ptrow, const int* indcol)
+{
+    const int K = kMringK, W = kMringW, T = kMringThreads, nnzb = kMringNnzb, per = nnzb / T;
+    if (P.nblk == 0) return n == 0 ? nullptr : "no blocks for a matrix with rows";
+    std::vector<int> run_of((size_t)P.nblk, -1);
+    for (int g = 0; g < P.wgs; g++) {
+        const int b0 = P.run_rng[2 * g], b1 = P.run_rng[2 * g + 1];
+        if (b0 < 0 || b1 < b0 || b1 > P.nblk || b1 - b0 > kMringMaxB) return "run range out of bounds or longer than the kernel's plan";
+        for (int b = b0; b < b1; b++) {
+            if (run_of[b] >= 0) return "a block belongs to two runs";
+            run_of[b] = g;
+        }
+    }
+    std::vector<int> content((size_t)K * W, -1);
+    int next_row = 0, cur_run = -1;
+    long long next_nz = 0;
+    for (int b = 0; b < P.nblk; b++) {
+        if (run_of[b] < 0) return "a block belongs to no run";
+        const int* Q = &P.plan[(size_t)16 * b];
+        const int brows = Q[4] == 2 ? Q[8] : Q[2];
+        if (Q[0] != next_row || Q[1] != next_nz) return "plan does not cover rows / nonzeros in order";
+        next_row += brows;
+        next_nz += Q[3];
+        if (Q[3] != ptrow[Q[0] + brows] - ptrow[Q[0]]) return "block nonzero count disagrees with ptrow";
+        const int run = run_of[b];
+        if (run != cur_run) {
+            std::fill(content.begin(), content.end(), -1);
+            cur_run = run;
+        }
+        if (!P.run_ok[run]) {
+            if (Q[4] != 0) return "flags of a block in a plain run";
+            continue;
+        }
+        if (Q[3] == 0) continue;
+        if (Q[4] == 2) {
+            if (Q[2] != 0 || Q[5] != 0) return "a PLAIN block is visible to the loop";
+            continue;
+        }
+        if (Q[4] != 1 || Q[3] > nnzb || Q[2] > 2 * T) return "a served run holds a block the kernel cannot take";
+        int total = 0;
+        for (int w = 0; w < K; w++) {
+            const int lo = Q[kMringLoAt(w)], cnt = Q[kMringPkAt(w)] & 2047;
+            const long long base = (long long)((unsigned)Q[kMringPkAt(w)] >> 11) * W;
+            total += cnt;
+            for (int c = lo; c < lo + cnt; c++) {
+                long long sl = c - base;
+                if (sl >= W) sl -= W;
+                if (sl < 0 || sl >= W) return "a new column falls outside its window";
+                content[(size_t)w * W + sl] = c;
+            }
+        }
+        if (total != Q[5]) return "total of new columns disagrees with the windows";
+        for (int k = 0; k < Q[3]; k++) {
+            const int slot = P.slots[(size_t)b * nnzb + (size_t)(k % T) * per + k / T];
+            if (slot < 0 || slot >= K * W) return "slot outside the LDS array";
+            if (content[slot] != indcol[Q[1] + k]) return "a nonzero's slot does not hold its column when its block runs";
+        }
+    }
+    if (next_row != n || next_nz != ptrow[n]) return "plan does not cover the matrix";
+    return nullptr;
+}
+
+} // namespace mi355

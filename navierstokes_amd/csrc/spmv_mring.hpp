@@ -1,0 +1,194 @@
+// spmv_mring.hpp — the multi-window ring kernel: spmv_csr_ring (spmv_ring.hpp) with K = 5 independent sliding x windows in
+// LDS instead of one.  For 3-D mesh operators (the reference's scalar pressure operator, src/solve_newton.c), whose rows
+// reach into three narrow column clusters two mesh planes apart: no single window can hold them, three small ones can, at
+// any mesh size (mring_plan.hpp).  Everything but the refill is the ring kernel: persistent workgroups over runs of row
+// blocks, matrix stream and new x columns D blocks ahead in registers, 16-bit precomputed LDS slots per nonzero, {coef, x}
+// staged in LDS, one thread per row walking its segment with the sequential fma chain of the reference's SpMV_CSR_OPT/_FMA
+// (mpk/SpMV.cpp:23-56) — bit-identical to every other kernel here.
+//
+// Refill: a block's new columns are the concatenation of up to K ranges [lo_w, lo_w + cnt_w) (one per window, from the plan
+// record).  Thread t prefetches entries t and t + T of that concatenation D blocks ahead (decoded arithmetically from the
+// record, which sits in SGPRs: four compares, no extra memory traffic, no dependent load) and writes them to their windows'
+// rings when the block becomes next.  More than 2T new columns at once (a window restart) take an unpipelined loop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mring_plan.hpp"
+#include "spmv_ring.hpp"
+
+namespace mi355 {
+
+// entry idx of the concatenated new-column ranges of a plan record: its column and its LDS slot (slot < 0: idx is past the end).
+// Record: m1 = {flags, total, lo[4], pk[4]}, m2 = lo[0..3], m3 = pk[0..3]; pk = count | base index << 11 (mring_plan.hpp).
+struct MringNew { int col, slot; };
+__device__ __forceinline__ MringNew mring_decode(int idx, const int4& m1, const int4& lo, const int4& pk)
+{
+    const int c0 = pk.x & 2047, c1 = pk.y & 2047, c2 = pk.z & 2047, c3 = pk.w & 2047;
+    const int p1 = c0, p2 = c0 + c1, p3 = p2 + c2, p4 = p3 + c3;
+    const int w = (idx >= p1) + (idx >= p2) + (idx >= p3) + (idx >= p4);
+    const int first = w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : (w == 3 ? p3 : p4)));
+    const int wl = w == 0 ? lo.x : (w == 1 ? lo.y : (w == 2 ? lo.z : (w == 3 ? lo.w : m1.z)));
+    const unsigned pw = (unsigned)(w == 0 ? pk.x : (w == 1 ? pk.y : (w == 2 ? pk.z : (w == 3 ? pk.w : m1.w))));
+    MringNew r;
+    r.col = wl + (idx - first);
+    int s = r.col - (int)(pw >> 11) * kMringW;
+    if (s >= kMringW) s -= kMringW;
+    r.slot = idx < m1.y ? w * kMringW + s : -1;
+    return r;
+}
+
+template <int T, int NNZB, int D, int MAXB, bool MAPPED, bool NT, bool SKEW>
+__global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __restrict__ plan, const int* __restrict__ run_ok,
+                                                    const unsigned short* __restrict__ slots, const double* __restrict__ x,
+                                                    double* __restrict__ y, const int2* __restrict__ run_rng)
+{
+    constexpr int K = kMringK, W = kMringW, RING = K * W, PER = NNZB / T;
+    typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    __shared__ double s_ring[RING];
+    __shared__ int4 s_plan[4 * (MAXB + 2 * D + 2)];
+    const int tid = threadIdx.x;
+    const int bid = (int)blockIdx.x, nwg = (int)gridDim.x;
+    const int gw = (bid & (kNXCD - 1)) * (nwg / kNXCD) + (bid >> 3); // neighbouring runs share an XCD's L2
+    const int2 rng = run_rng[gw];
+    const int b_begin = rng.x, nb = rng.y - rng.x; // <= MAXB by construction of the plan
+    if (nb <= 0) return;
+    const int clast = A.ncols - 1;
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni4 = [&](const int4& v) { return make_int4(uni(v.x), uni(v.y), uni(v.z), uni(v.w)); };
+    const RingComm nocomm{};
+
+    for (int i = tid; i < 4 * nb; i += T) s_plan[i] = plan[4 * (size_t)b_begin + i];
+    __syncthreads();
+    { // empty sentinel blocks behind the run (fixed number of loads per loop iteration, spmv_ring.hpp)
+        const int4 l0 = s_plan[4 * (nb - 1)];
+        const int4 sent = make_int4(l0.x + l0.z, l0.y + l0.w, 0, 0);
+        for (int i = tid; i < 2 * D + 2; i += T) {
+            s_plan[4 * (nb + i)] = sent;
+            s_plan[4 * (nb + i) + 1] = make_int4(0, 0, 0, 0);
+            s_plan[4 * (nb + i) + 2] = make_int4(0, 0, 0, 0);
+            s_plan[4 * (nb + i) + 3] = make_int4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (!run_ok[gw]) {
+        for (int lb = 0; lb < nb; lb++) {
+            const int4 m0 = s_plan[4 * lb];
+            ring_simple_block<T, NNZB, MAPPED, false>(A, x, y, m0.x, m0.y, m0.z, m0.w, s_c, s_x, nocomm);
+        }
+        return;
+    }
+
+    double c[D][PER];
+    SlotVec sl[D];
+    const SlotVec* slotv = reinterpret_cast<const SlotVec*>(slots);
+    const int bslot_last = A.nblk - 1;
+    int2 pr[D];
+    double xr0[D], xr1[D]; // entries tid and tid + T of the staged block's new columns
+    int rm[D];
+
+    auto issue = [&](int lb, int s) {
+        const int4 m0 = s_plan[4 * lb], m1 = uni4(s_plan[4 * lb + 1]);
+        const int4 m2 = uni4(s_plan[4 * lb + 2]), m3 = uni4(s_plan[4 * lb + 3]);
+        const double* cb = A.coef + uni(m0.y) + (tid & ((m1.x & 1) ? -1 : 0));
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (NT) c[s][i] = __builtin_nontemporal_load(&cb[i * T]);
+            else c[s][i] = cb[i * T];
+        }
+        sl[s] = (slotv + (size_t)min(b_begin + lb, bslot_last) * T)[tid];
+        const int* rp = A.ptrow + uni(m0.x) + tid;
+        pr[s] = make_int2(rp[0], rp[1]);
+        if (MAPPED) rm[s] = (A.rowmap + uni(m0.x))[tid];
+        xr0[s] = x[max(0, min(mring_decode(tid, m1, m2, m3).col, clast))];
+        xr1[s] = x[max(0, min(mring_decode(tid + T, m1, m2, m3).col, clast))];
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; s++) issue(s, s);
+    { // the first block's windows, whole: all loads of a thread in flight at once
+        constexpr int FILLW = (W + T - 1) / T;
+        const int4 m1 = uni4(s_plan[1]), m2 = uni4(s_plan[2]), m3 = uni4(s_plan[3]);
+        const bool served = m1.x == 1; // a PLAIN first block keeps its row count where lo[0] lives
+        const int lo[K] = {m2.x, m2.y, m2.z, m2.w, m1.z};
+        const unsigned pk[K] = {served ? (unsigned)m3.x : 0u, served ? (unsigned)m3.y : 0u, served ? (unsigned)m3.z : 0u,
+                                served ? (unsigned)m3.w : 0u, served ? (unsigned)m1.w : 0u};
+        double v[K][FILLW];
+#pragma unroll
+        for (int w = 0; w < K; w++)
+#pragma unroll
+            for (int u = 0; u < FILLW; u++) v[w][u] = x[max(0, min(lo[w] + tid + u * T, clast))];
+#pragma unroll
+        for (int w = 0; w < K; w++) {
+            const int cnt = (int)(pk[w] & 2047u), base = (int)(pk[w] >> 11) * W;
+#pragma unroll
+            for (int u = 0; u < FILLW; u++)
+                if (tid + u * T < cnt) s_ring[w * W + ring_slot<W>(lo[w] + tid + u * T, base)] = v[w][u];
+        }
+    }
+
+    for (int g = 0; g < nb; g += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            const int lb = g + s; // lb >= nb: an empty sentinel block
+            const int4 m0 = s_plan[4 * lb];
+            const int r0 = uni(m0.x), p0 = uni(m0.y), nrows = uni(m0.z);
+            __syncthreads(); // the rings hold block lb's windows; staging is free again
+            double xv[PER];
+#pragma unroll
+            for (int i = 0; i < PER; i++) xv[i] = s_ring[min((unsigned)sl[s][i], (unsigned)(RING - 1))];
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int k = SKEW ? sk(tid + i * T) : tid + i * T;
+                s_c[k] = c[s][i];
+                s_x[k] = xv[i];
+            }
+            const int2 prs = pr[s];
+            const int rms = MAPPED ? rm[s] : 0;
+            issue(lb + D, s); // refill this stage with block lb + D
+            __syncthreads(); // staging complete; nobody gathers block lb from the rings any more
+            { // new columns of block lb + 1 (requested D blocks ago into stage (s+1)%D) into their windows
+                const int4 q1 = uni4(s_plan[4 * (lb + 1) + 1]);
+                const int total = q1.y;
+                const int4 q2 = uni4(s_plan[4 * (lb + 1) + 2]), q3 = uni4(s_plan[4 * (lb + 1) + 3]);
+                if (total <= 2 * T) {
+                    const MringNew n0 = mring_decode(tid, q1, q2, q3), n1 = mring_decode(tid + T, q1, q2, q3);
+                    if (n0.slot >= 0) s_ring[n0.slot] = xr0[(s + 1) % D];
+                    if (n1.slot >= 0) s_ring[n1.slot] = xr1[(s + 1) % D];
+                } else { // a window restart: more than 2T new columns at once, four loads in flight per thread
+                    const int lo[K] = {q2.x, q2.y, q2.z, q2.w, q1.z};
+                    const unsigned pk[K] = {(unsigned)q3.x, (unsigned)q3.y, (unsigned)q3.z, (unsigned)q3.w, (unsigned)q1.w};
+#pragma unroll
+                    for (int w = 0; w < K; w++) {
+                        const int cnt = (int)(pk[w] & 2047u), base = (int)(pk[w] >> 11) * W;
+                        for (int c0 = lo[w] + tid; c0 < lo[w] + cnt; c0 += 4 * T) {
+                            double v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) v[u] = x[max(0, min(c0 + u * T, clast))];
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                                if (c0 + u * T < lo[w] + cnt) s_ring[w * W + ring_slot<W>(c0 + u * T, base)] = v[u];
+                        }
+                    }
+                }
+            }
+            if (tid < nrows) y[MAPPED ? rms : r0 + tid] = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
+            for (int r = r0 + tid + T; r < r0 + nrows; r += T) { // blocks of very short rows
+                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                y[MAPPED ? A.rowmap[r] : r] = ring_row_chain<8, SKEW>(s_c, s_x, a, e);
+            }
+        }
+    }
+    // PLAIN blocks of this run, behind the loop (spmv_ring.hpp)
+    for (int lb = 0; lb < nb; lb++) {
+        const int4 m1 = s_plan[4 * lb + 1];
+        if (uni(m1.x) != 2) continue;
+        const int4 m0 = s_plan[4 * lb];
+        ring_simple_block<T, NNZB, MAPPED, false>(A, x, y, uni(m0.x), uni(m0.y), uni(s_plan[4 * lb + 2].x), uni(m0.w), s_c, s_x, nocomm);
+    }
+}
+
+} // namespace mi355

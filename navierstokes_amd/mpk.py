@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("MI355_SPMV_LIBRARY") or os.path.join(_HERE, "csrc", "
 
 MI_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_RING, KERNEL_ROWPAR = 0, 1, 2, 3
-KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3, "bcsr4": 4, "tile": 5}
+KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3, "bcsr4": 4, "tile": 5, "mring": 6}
 
 _c = ctypes
 _vp = ctypes.c_void_p
@@ -100,6 +100,8 @@ def lib():
         "mi_csr_block4_structure": [i, _vp, _vp, P(i), P(_c.c_longlong)],
         "mi_ring_plan_probe": [i, _vp, _vp, i, P(i), P(i), P(i), P(d), P(i)],
         "mi_csr_tile_info": [_vp, P(i), P(i), P(d), P(d), P(i)],
+        "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
+        "mi_mring_plan_probe": [i, _vp, _vp, P(i), P(i), P(i), P(d), P(ll)],
         "mi_tile_plan_probe": [i, _vp, _vp, i, P(i), P(ll), P(i), P(ll)],
         "mi_debug_xcc_map": [i, _vp],
         "mi_debug_touch_pages": [_vp, i, _vp, ll, _vp, ll],
@@ -256,12 +258,26 @@ class csrmatrix:
         check(lib().mi_csr_tune_detail(self.handle, us, _c.byref(rnt), _c.byref(snt)))
         nt = rnt.value if "ring" in self.kernel_name() else snt.value
         out = dict(ring=us[0], ring_nt=us[1], stream=us[2], stream_nt=us[3], bcsr4=us[4])
+        m = self.mring_info()
+        if m["built"]:
+            out.update(mring=m["us"], mring_nt=m["us_nt"])
+            if "mring" in self.kernel_name():
+                nt = m["nt"]
         t = self.tile_info()
         if t["built"]:
             out.update(tile=t["us"], tile_nt=t["us_nt"])
             if "tile" in self.kernel_name():
                 nt = t["nt"]
         return out, bool(nt)
+
+    def mring_info(self):
+        """dict(built, runs, runs_not_served, nnz_fraction, us, us_nt, nt) — mi_csr_mring_info (multi-window ring plan)."""
+        b, r, bad, nt = _c.c_int(), _c.c_int(), _c.c_int(), _c.c_int()
+        f = _c.c_double()
+        us = (_c.c_double * 2)()
+        check(lib().mi_csr_mring_info(self.handle, _c.byref(b), _c.byref(r), _c.byref(bad), _c.byref(f), us, _c.byref(nt)))
+        return dict(built=bool(b.value), runs=r.value, runs_not_served=bad.value, nnz_fraction=f.value, us=us[0], us_nt=us[1],
+                    nt=bool(nt.value))
 
     def tile_info(self):
         """dict(built, nblk, unique_per_nnz, us, us_nt, nt) — mi_csr_tile_info (the tile kernel's plan on this handle)."""

@@ -14,7 +14,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["stream", "ring", "rowpar", "tile"]
+KERNELS = ["stream", "ring", "rowpar", "tile", "mring"]
 TOL = 1e-10  # north_star: "match the reference CPU SpMV output within 1e-10 relative (fp64)"
 
 

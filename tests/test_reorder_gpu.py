@@ -32,7 +32,7 @@ def _check_all_entry_points(p, c, v, n, expect_reordered, expect_block):
     mpk.SpMV_CSR(yd, dev(x), A)
     assert_bit_equal(yd.cpu().numpy(), yo, "device SpMV_CSR")
     # every kernel of the relabelled twin
-    for kern in ("stream", "ring", "rowpar", "tile") + (("bcsr4",) if expect_block == 4 else ()):
+    for kern in ("stream", "ring", "rowpar", "tile", "mring") + (("bcsr4",) if expect_block == 4 else ()):
         A.set_kernel(kern)
         mpk.SpMV_CSR(yd.fill_(float("nan")), dev(x), A)
         assert_bit_equal(yd.cpu().numpy(), yo, f"kernel {kern} -> {A.kernel_name()}")
@@ -83,7 +83,7 @@ def test_scrambled_mesh_operator_is_relabelled_and_served_by_the_tile_kernel(mon
     p0, c0, v0 = synth.pressure_matrix(30, 28, 26)
     n = len(p0) - 1
     p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=1, seed=5)
-    for forced in ("tile", None):
+    for forced in ("tile", "mring", None):
         if forced:
             monkeypatch.setenv("MI355_SPMV_KERNEL", forced)
         else:
