@@ -90,6 +90,7 @@ struct RingTable {
     int* d_run_halo = nullptr; // per run: touches a ghost column (fused multi-GPU step)
     std::vector<int> h_run_halo;
     bool uniform = true;       // runs are consecutive ranges of bpw blocks (the kernel then computes them)
+    bool lean = false;         // the plan allows the LEAN instantiation (spmv_ring.hpp)
     unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block
     bool nt = false;                   // non-temporal loads of the values (chosen by measurement)
     bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
@@ -558,6 +559,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         A->ring.bpw = best.bpw;
         A->ring.bad_runs = best.bad_runs;
         A->ring.ok_fraction = 1.0 - (double)best.bad_nnz / (double)nnz;
+        A->ring.lean = best.lean && best.cfg.id == 4 && !(getenv("MI355_RING_LEAN") && !strcmp(getenv("MI355_RING_LEAN"), "0"));
         if (best.nblk > 0) {
             TRY_OR_CLEAN(hipMalloc(&A->ring.d_plan, sizeof(int) * best.plan.size()));
             TRY_OR_CLEAN(hipMemcpy(A->ring.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
@@ -1277,6 +1279,7 @@ extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, in
         next_nz += Q[3];
         if (Q[3] != ptrow[Q[0] + brows] - ptrow[Q[0]]) return fail(MI_ERR_STATE, "block nonzero count disagrees with ptrow");
         const int run = run_of[b];
+        if (P.lean && P.run_ok[run] && brows > T) return fail(MI_ERR_STATE, "a LEAN plan holds a block of more than T rows");
         if (!P.run_ok[run] || Q[3] == 0) {
             if (Q[7] == 2 || (Q[7] && Q[3] == 0)) return fail(MI_ERR_STATE, "flags of a block outside the ring loop");
             continue;
@@ -1294,6 +1297,7 @@ extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, in
         if (cmax - cmin + 1 > c.ring) return fail(MI_ERR_STATE, "block window wider than the ring");
         if (cmin - Q[6] < 0 || cmax - Q[6] >= 2 * c.ring) return fail(MI_ERR_STATE, "ring base out of range for the block's columns");
         if (Q[4] + Q[5] < cmax + 1) return fail(MI_ERR_STATE, "window does not reach the block's last column");
+        if (P.lean && Q[5] > T && b != P.run_rng[2 * run]) return fail(MI_ERR_STATE, "a LEAN plan brings more than T new columns into a block inside a run");
         if (run != cur_run) { // a new workgroup: nothing in its ring yet
             std::fill(content.begin(), content.end(), -1);
             cur_run = run;
@@ -1458,8 +1462,9 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     case MI_KERNEL_RING: { // the name rocprofv3 prints for the instantiation launch_ring picks
         static thread_local char nm[112];
         const RingConfig& c = A->ring.cfg;
-        snprintf(nm, sizeof nm, "spmv_csr_ring<%d, %d, %d, %d, %d, %s, %s, %s, false>", c.threads, c.nnzb, c.ring, c.depth, kRingMaxB,
-                 A->d_rowmap ? "true" : "false", A->ring.nt ? "true" : "false", A->ring.skew ? "true" : "false");
+        snprintf(nm, sizeof nm, "spmv_csr_ring<%d, %d, %d, %d, %d, %s, %s, %s, false, %s>", c.threads, c.nnzb, c.ring, c.depth, kRingMaxB,
+                 A->d_rowmap ? "true" : "false", A->ring.nt ? "true" : "false", A->ring.skew ? "true" : "false",
+                 A->ring.lean && c.threads == 256 && c.depth != 3 ? "true" : "false");
         return nm;
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
@@ -1480,16 +1485,24 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
 }
 
 // ---------------------------------------------------------------- SpMV launch
-template <int T, int NNZB, int RING, int D, bool MAPPED, bool NT, bool SKEW>
-static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm)
+template <int T, int NNZB, int RING, int D, bool MAPPED, bool NT, bool SKEW, bool LEAN>
+static void launch_ring3(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm)
 {
     if (!MAPPED && comm) { // the fused multi-GPU step: push workgroups in front of the grid (spmv_ring.hpp)
-        hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, true>), dim3(A->ring.wgs + comm->push_wgs), dim3(T), 0, s,
+        hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, true, LEAN>), dim3(A->ring.wgs + comm->push_wgs), dim3(T), 0, s,
                            V, reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, reinterpret_cast<const int2*>(A->ring.d_rng), A->ring.uniform ? A->ring.bpw : 0, *comm);
         return;
     }
-    hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, false>), dim3(A->ring.wgs), dim3(T), 0, s, V,
+    hipLaunchKernelGGL((spmv_csr_ring<T, NNZB, RING, D, kRingMaxB, MAPPED, NT, SKEW, false, LEAN>), dim3(A->ring.wgs), dim3(T), 0, s, V,
                        reinterpret_cast<const int4*>(A->ring.d_plan), A->ring.d_ok, A->ring.d_slots, d_x, d_y, reinterpret_cast<const int2*>(A->ring.d_rng), A->ring.uniform ? A->ring.bpw : 0, RingComm{});
+}
+
+template <int T, int NNZB, int RING, int D, bool MAPPED, bool NT, bool SKEW>
+static void launch_ring2(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm)
+{
+    // the LEAN instantiation exists for the configuration that runs in practice (4: 256 threads) at depths 2 and 4
+    if (T == 256 && D != 3 && A->ring.lean) launch_ring3<T, NNZB, RING, D, MAPPED, NT, SKEW, (T == 256 && D != 3)>(A, V, d_x, d_y, s, comm);
+    else launch_ring3<T, NNZB, RING, D, MAPPED, NT, SKEW, false>(A, V, d_x, d_y, s, comm);
 }
 
 template <int T, int NNZB, int RING, int D, bool MAPPED>

@@ -27,15 +27,17 @@
 namespace mi355 {
 
 constexpr int kMringK = 5;          // windows
-constexpr int kMringRing = 5120;    // doubles of LDS for all windows together
+constexpr int kMringRing = 4800;    // doubles of LDS for all windows together (with staging and the plan records 78 992 B per
+                                    // workgroup: two per CU, like the single ring's 80 224)
 constexpr int kMringW = kMringRing / kMringK; // entries per window
 constexpr int kMringGap = 256;      // neighbouring distinct columns this far apart belong to different clusters
 // (relabelled 100^3-cell mesh, blocks of 2048 nonzeros: 3 clusters in 92 %, 5 where the rows cross from one Cuthill-McKee level
-// into the next, in 7 %; widest cluster 265 columns median, 461 at the 99th percentile: K = 5 windows of 1024 serve 99.7 %,
+// into the next, in 7 %; widest cluster 265 columns median, 461 at the 99th percentile: K = 5 windows of 1024 (960: the same) serve 99.7 %,
 // K = 4 of 1280 only 93 %.)
 // record slots of window w: first new column at plan[kMringLoAt(w)], count | base index << 11 at plan[kMringPkAt(w)]
 constexpr int kMringLoAt(int w) { return w < 4 ? 8 + w : 6; }
 constexpr int kMringPkAt(int w) { return w < 4 ? 12 + w : 7; }
+static_assert(kMringW % 64 == 0, "windows are refilled in groups of 64 columns");
 constexpr int kMringNnzb = 2048, kMringThreads = 256, kMringWgUnit = 512;
 constexpr int kMringMaxB = 96;      // blocks per run: the plan records are 64 bytes each and two workgroups must fit a CU's LDS
 
@@ -166,9 +168,13 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
             int nlo_[kMringK] = {}, ncnt_[kMringK] = {};
             for (int j = 0; j < nc; j++) {
                 const int w = win_of[j], cmin = C[j].lo, cmax = C[j].hi;
+                // New columns come in whole groups of 64 (the window simply runs a little ahead of what the block needs): a
+                // wave of the kernel then refills ONE window, and its share of the record is decoded with scalar instructions
+                // (per-lane decoding of up to five ranges cost 0.3 us of VALU time per block, a tenth of the block's time).
+                auto pad64 = [](int from, int to) { return from + ((to - from + 63) & ~63); };
                 int lo = live[w] ? wlo[w] : cmin, hi = live[w] ? whi[w] : cmin;
                 bool restart = !live[w];
-                int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - W);
+                int nhi = pad64(hi, std::max(hi, cmax + 1)), nlo = std::max(lo, nhi - W);
                 if (!restart && cmin < nlo) { // cannot keep the upper end and reach down: start afresh on this cluster
                     restart = true;
                     out.restarts++;
@@ -176,7 +182,7 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
                 if (restart) {
                     lo = std::max(0, std::min(cmin, cmax + 1 - W));
                     hi = lo;
-                    nhi = cmax + 1;
+                    nhi = pad64(lo, cmax + 1); // <= lo + W: W is a multiple of 64
                     nlo = std::max(lo, nhi - W);
                     wbase[w] = (lo / W) * W;
                 }
@@ -268,6 +274,7 @@ inline const char* check_mring_plan(const MringPlanHost& P, int n, const int* pt
             const int lo = Q[kMringLoAt(w)], cnt = Q[kMringPkAt(w)] & 2047;
             const long long base = (long long)((unsigned)Q[kMringPkAt(w)] >> 11) * W;
             total += cnt;
+            if (cnt % 64 != 0 || cnt > W) return "a window's new columns are not whole groups of 64";
             for (int c = lo; c < lo + cnt; c++) {
                 long long sl = c - base;
                 if (sl >= W) sl -= W;

@@ -58,6 +58,7 @@ struct RingPlanHost {
     std::vector<int> run_ok;   // per run
     std::vector<int> run_rng;  // per run: {first block, end block} — a run is a contiguous block range, runs need not be in order
     std::vector<int> run_halo; // per run: touches a ghost column (fused multi-GPU step only)
+    bool lean = true;          // no served block but a run's first brings > T new columns, no block holds > T rows (spmv_ring.hpp: LEAN)
 };
 
 // The fused multi-GPU step (spmv_ring.hpp, FUSED): columns outside [ghost_lo, ghost_hi) are ghosts that arrive from the
@@ -204,6 +205,7 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
             P[0] = rows[b]; P[1] = ptrs[b]; P[2] = nrows; P[3] = nn;
             P[4] = 0; P[5] = 0; P[6] = base; P[7] = 0;
             run_nnz += nn;
+            if (nrows > cfg.threads) out.lean = false; // (empty rows included: their zeros are stored by the loop's second pass)
             if (nn == 0) continue;
             const int cmin = bmin[b], cmax = bmax[b];
             bool use = !wide[b];
@@ -231,6 +233,7 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
                     if (restart) base = (lo / ring) * ring;
                     while (nlo - base >= ring) base += ring;
                     P[4] = hi; P[5] = nhi - hi; P[6] = base; P[7] = 1;
+                    if ((nhi - hi > cfg.threads && b != out.run_rng[2 * g]) || nrows > cfg.threads) out.lean = false;
                     wlo = nlo; whi = nhi; live = true;
                 }
             }

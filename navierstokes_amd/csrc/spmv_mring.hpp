@@ -7,9 +7,10 @@
 // (mpk/SpMV.cpp:23-56) — bit-identical to every other kernel here.
 //
 // Refill: a block's new columns are the concatenation of up to K ranges [lo_w, lo_w + cnt_w) (one per window, from the plan
-// record).  Thread t prefetches entries t and t + T of that concatenation D blocks ahead (decoded arithmetically from the
-// record, which sits in SGPRs: four compares, no extra memory traffic, no dependent load) and writes them to their windows'
-// rings when the block becomes next.  More than 2T new columns at once (a window restart) take an unpipelined loop.
+// record), each a whole number of 64-column groups — so a wave refills one window at a time and decodes its share of the
+// record with scalar instructions.  Every wave prefetches three such groups D blocks ahead (768 columns per block on this
+// path; no extra memory traffic, no dependent load) and writes them to their windows' rings when the block becomes next.
+// More new columns at once (several windows restarting) take an unpipelined loop.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,22 +20,27 @@
 
 namespace mi355 {
 
-// entry idx of the concatenated new-column ranges of a plan record: its column and its LDS slot (slot < 0: idx is past the end).
-// Record: m1 = {flags, total, lo[4], pk[4]}, m2 = lo[0..3], m3 = pk[0..3]; pk = count | base index << 11 (mring_plan.hpp).
+// The refill part of a block's plan record, wave-uniform (SGPRs): m1 = {flags, total, lo[4], pk[4]}, lo = lo[0..3],
+// pk = pk[0..3]; pk = count | base index << 11, counts are multiples of 64 (mring_plan.hpp).
+struct MringRec { int4 m1, lo, pk; };
+// Group g (64 consecutive entries of the concatenated new-column ranges) belongs to ONE window: everything about it is
+// scalar; a lane adds its lane id.  slot < 0: the group lies past the record's last new column.
 struct MringNew { int col, slot; };
-__device__ __forceinline__ MringNew mring_decode(int idx, const int4& m1, const int4& lo, const int4& pk)
+__device__ __forceinline__ MringNew mring_decode(int g /* uniform */, int lane, const MringRec& R)
 {
-    const int c0 = pk.x & 2047, c1 = pk.y & 2047, c2 = pk.z & 2047, c3 = pk.w & 2047;
+    const int i0 = g * 64;
+    const int c0 = R.pk.x & 2047, c1 = R.pk.y & 2047, c2 = R.pk.z & 2047, c3 = R.pk.w & 2047;
     const int p1 = c0, p2 = c0 + c1, p3 = p2 + c2, p4 = p3 + c3;
-    const int w = (idx >= p1) + (idx >= p2) + (idx >= p3) + (idx >= p4);
+    const int w = (i0 >= p1) + (i0 >= p2) + (i0 >= p3) + (i0 >= p4);
     const int first = w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : (w == 3 ? p3 : p4)));
-    const int wl = w == 0 ? lo.x : (w == 1 ? lo.y : (w == 2 ? lo.z : (w == 3 ? lo.w : m1.z)));
-    const unsigned pw = (unsigned)(w == 0 ? pk.x : (w == 1 ? pk.y : (w == 2 ? pk.z : (w == 3 ? pk.w : m1.w))));
+    const int wl = w == 0 ? R.lo.x : (w == 1 ? R.lo.y : (w == 2 ? R.lo.z : (w == 3 ? R.lo.w : R.m1.z)));
+    const unsigned pw = (unsigned)(w == 0 ? R.pk.x : (w == 1 ? R.pk.y : (w == 2 ? R.pk.z : (w == 3 ? R.pk.w : R.m1.w))));
+    const int col0 = wl + (i0 - first), s0 = col0 - (int)(pw >> 11) * kMringW, off = w * kMringW; // scalar
     MringNew r;
-    r.col = wl + (idx - first);
-    int s = r.col - (int)(pw >> 11) * kMringW;
+    r.col = col0 + lane;
+    int s = s0 + lane;
     if (s >= kMringW) s -= kMringW;
-    r.slot = idx < m1.y ? w * kMringW + s : -1;
+    r.slot = i0 < R.m1.y ? off + s : -1;
     return r;
 }
 
@@ -87,13 +93,18 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
     const SlotVec* slotv = reinterpret_cast<const SlotVec*>(slots);
     const int bslot_last = A.nblk - 1;
     int2 pr[D];
-    double xr0[D], xr1[D]; // entries tid and tid + T of the staged block's new columns
+    constexpr int NX = 3;  // groups of 64 new columns a wave prefetches per block: 4 waves x NX x 64 = 768 columns on the fast path
+    double xr[D][NX];      // entries (wave + 4 j) * 64 + lane of the staged block's new columns
     int rm[D];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
     auto issue = [&](int lb, int s) {
-        const int4 m0 = s_plan[4 * lb], m1 = uni4(s_plan[4 * lb + 1]);
-        const int4 m2 = uni4(s_plan[4 * lb + 2]), m3 = uni4(s_plan[4 * lb + 3]);
-        const double* cb = A.coef + uni(m0.y) + (tid & ((m1.x & 1) ? -1 : 0));
+        const int4 m0 = s_plan[4 * lb];
+        MringRec R;
+        R.m1 = uni4(s_plan[4 * lb + 1]);
+        R.lo = uni4(s_plan[4 * lb + 2]);
+        R.pk = uni4(s_plan[4 * lb + 3]);
+        const double* cb = A.coef + uni(m0.y) + (tid & ((R.m1.x & 1) ? -1 : 0));
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             if (NT) c[s][i] = __builtin_nontemporal_load(&cb[i * T]);
@@ -103,8 +114,8 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
         const int* rp = A.ptrow + uni(m0.x) + tid;
         pr[s] = make_int2(rp[0], rp[1]);
         if (MAPPED) rm[s] = (A.rowmap + uni(m0.x))[tid];
-        xr0[s] = x[max(0, min(mring_decode(tid, m1, m2, m3).col, clast))];
-        xr1[s] = x[max(0, min(mring_decode(tid + T, m1, m2, m3).col, clast))];
+#pragma unroll
+        for (int j = 0; j < NX; j++) xr[s][j] = x[max(0, min(mring_decode(wave + (T / 64) * j, lane, R).col, clast))];
     };
 
 #pragma unroll
@@ -151,16 +162,20 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
             issue(lb + D, s); // refill this stage with block lb + D
             __syncthreads(); // staging complete; nobody gathers block lb from the rings any more
             { // new columns of block lb + 1 (requested D blocks ago into stage (s+1)%D) into their windows
-                const int4 q1 = uni4(s_plan[4 * (lb + 1) + 1]);
-                const int total = q1.y;
-                const int4 q2 = uni4(s_plan[4 * (lb + 1) + 2]), q3 = uni4(s_plan[4 * (lb + 1) + 3]);
-                if (total <= 2 * T) {
-                    const MringNew n0 = mring_decode(tid, q1, q2, q3), n1 = mring_decode(tid + T, q1, q2, q3);
-                    if (n0.slot >= 0) s_ring[n0.slot] = xr0[(s + 1) % D];
-                    if (n1.slot >= 0) s_ring[n1.slot] = xr1[(s + 1) % D];
-                } else { // a window restart: more than 2T new columns at once, four loads in flight per thread
-                    const int lo[K] = {q2.x, q2.y, q2.z, q2.w, q1.z};
-                    const unsigned pk[K] = {(unsigned)q3.x, (unsigned)q3.y, (unsigned)q3.z, (unsigned)q3.w, (unsigned)q1.w};
+                MringRec Q; // (re-read from LDS: keeping D records in SGPRs spills)
+                Q.m1 = uni4(s_plan[4 * (lb + 1) + 1]);
+                Q.lo = uni4(s_plan[4 * (lb + 1) + 2]);
+                Q.pk = uni4(s_plan[4 * (lb + 1) + 3]);
+                const int total = Q.m1.y;
+                if (total <= NX * T) {
+#pragma unroll
+                    for (int j = 0; j < NX; j++) {
+                        const MringNew nw = mring_decode(wave + (T / 64) * j, lane, Q);
+                        if (nw.slot >= 0) s_ring[nw.slot] = xr[(s + 1) % D][j];
+                    }
+                } else { // window restarts: more than NX * T new columns at once, four loads in flight per thread
+                    const int lo[K] = {Q.lo.x, Q.lo.y, Q.lo.z, Q.lo.w, Q.m1.z};
+                    const unsigned pk[K] = {(unsigned)Q.pk.x, (unsigned)Q.pk.y, (unsigned)Q.pk.z, (unsigned)Q.pk.w, (unsigned)Q.m1.w};
 #pragma unroll
                     for (int w = 0; w < K; w++) {
                         const int cnt = (int)(pk[w] & 2047u), base = (int)(pk[w] >> 11) * W;

@@ -195,7 +195,15 @@ __device__ __forceinline__ double ring_row_chain(const double* s_c, const double
 // displacing x, the plan and the y lines being written (C4: 190 -> 169 us).  A matrix that fits
 // the cache is better served by it across repeated products (C2: 38 us temporal, 44 us NT), so
 // mi_csr_create times both and keeps the faster.
-template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool NT, bool SKEW, bool FUSED = false>
+//
+// LEAN: the plan guarantees that no block of a served run (but a run's first) brings more than T new columns and that no
+// block holds more than T rows — then the steady-state loop has NO global load under a condition (no unpipelined refill, no
+// second pass over the rows), and that is what lets hipcc's waitcnt pass count across iterations: with either fallback
+// compiled in, every block's row chains sit behind an s_waitcnt vmcnt(0) — the loads just issued for block lb + D are
+// drained before block lb is reduced, so the "D blocks ahead" are never in flight together (ISA of the general form: vmcnt(0)
+// in front of the chains of every stage; of the LEAN form: vmcnt(33) with D = 4, one full drain per D blocks at the loop
+// header).  mi_csr_create launches the LEAN instantiation whenever the plan allows (all natural-order bands do).
+template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool NT, bool SKEW, bool FUSED = false, bool LEAN = false>
 __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __restrict__ plan,
                                                    const int* __restrict__ run_ok,
                                                    const unsigned short* __restrict__ slots,
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
                 const int4 q4 = s_plan[2 * (lb + 1) + 1];
                 const int qx = uni(q4.x), qy = uni(q4.y), qz = uni(q4.z);
                 const double xn = xr[(s + 1) % D];
-                if (qy <= T) {
+                if (LEAN || qy <= T) {
                     if (tid < qy) s_ring[ring_slot<RING>(qx + tid, qz)] = xn;
                 } else { // more than T new columns at once: a window restart, or the ragged edge of a relabelled band.  Four
                          // loads in flight per thread and round trip (one per round trip made this path 4x as long)
@@ -364,10 +372,11 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
             }
             // ---- row chains
             if (tid < nrows) y[MAPPED ? rms : r0 + tid] = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
-            for (int r = r0 + tid + T; r < r0 + nrows; r += T) { // blocks of very short rows
-                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
-                y[MAPPED ? A.rowmap[r] : r] = ring_row_chain<8, SKEW>(s_c, s_x, a, e);
-            }
+            if (!LEAN)
+                for (int r = r0 + tid + T; r < r0 + nrows; r += T) { // blocks of very short rows
+                    const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
+                    y[MAPPED ? A.rowmap[r] : r] = ring_row_chain<8, SKEW>(s_c, s_x, a, e);
+                }
         }
     }
     // PLAIN blocks of this run (ring_plan.hpp: a row the window cannot hold, at most kRingMaxPlain per run): the loop above
