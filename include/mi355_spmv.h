@@ -171,6 +171,10 @@ int mi_csr_mring_info(mi_csr_t A, int* built, int* runs, int* runs_not_served, d
  * nonzero's 16-bit slot must hold its column when its block runs, runs cover every block once, records are consistent). */
 int mi_mring_plan_probe(int n, const int* ptrow, const int* indcol, int* nblk, int* runs, int* runs_not_served,
                         double* nnz_fraction_served, long long* window_restarts);
+/* host-only: would the ring plan of this pattern (configuration config_id) run the LEAN instantiation of the kernel — no block
+ * inside a run bringing more than T new columns, none holding more than T rows (spmv_ring.hpp)?  The planner cuts its runs
+ * at window restarts to make it so; only configuration 4 has the instantiation. */
+int mi_ring_plan_lean(int n, const int* ptrow, const int* indcol, int config_id, int* lean);
 /* host-only: does this CSR pattern have the exact 4x4 node-block structure mi_csr_create looks for (n % 4 == 0,
  * the four rows of a block row hold the same columns, in aligned groups {4j..4j+3}) — i.e. will a blocked copy be
  * built and the BCSR kernel become an AUTO candidate?  *nblocks = number of 4x4 blocks if so. */

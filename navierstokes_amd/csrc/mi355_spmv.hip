@@ -1424,6 +1424,25 @@ extern "C" int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, in
     return MI_OK;
 }
 
+extern "C" int mi_ring_plan_lean(int n, const int* ptrow, const int* indcol, int config_id, int* lean)
+{
+    CHECK_ARG(n >= 0 && ptrow && lean && config_id >= 1 && config_id <= kNumRingConfigs, "bad argument");
+    std::vector<int> row_min((size_t)n), row_max((size_t)n);
+    for (int i = 0; i < n; i++) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) {
+            lo = std::min(lo, indcol[k]);
+            hi = std::max(hi, indcol[k]);
+        }
+        row_min[i] = lo;
+        row_max[i] = hi;
+    }
+    RingPlanHost P;
+    build_ring_plan(kRingConfigs[config_id - 1], n, ptrow, row_min.data(), row_max.data(), P);
+    *lean = P.lean && P.cfg.id == 4 && P.bad_runs == 0;
+    return MI_OK;
+}
+
 extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
 {
     CHECK_ARG(A, "null handle");

@@ -39,6 +39,7 @@ constexpr int kMringLoAt(int w) { return w < 4 ? 8 + w : 6; }
 constexpr int kMringPkAt(int w) { return w < 4 ? 12 + w : 7; }
 static_assert(kMringW % 64 == 0, "windows are refilled in groups of 64 columns");
 constexpr int kMringNnzb = 2048, kMringThreads = 256, kMringWgUnit = 512;
+constexpr int kMringFast = 3 * kMringThreads; // new columns a block inside a run may bring (the kernel prefetches 3 per thread)
 constexpr int kMringMaxB = 96;      // blocks per run: the plan records are 64 bytes each and two workgroups must fit a CU's LDS
 
 struct MringPlanHost {
@@ -58,7 +59,7 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
     out = MringPlanHost();
     const int K = kMringK, W = kMringW, T = kMringThreads, nnzb = kMringNnzb, per = nnzb / T;
     std::vector<int> rows, ptrs;
-    build_row_blocks(n, ptrow, nnzb, 2 * T, rows, ptrs);
+    build_row_blocks(n, ptrow, nnzb, T, rows, ptrs); // <= T rows per block: the kernel makes one pass over a block's rows
     const int nblk = (int)rows.size() - 1;
     out.nblk = nblk;
     if (nblk <= 0) return;
@@ -91,116 +92,67 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
         cl_ptr[nblk] = (int)cls.size();
     }
     long long weight = 0;
-    int nwide = 0;
-    for (int b = 0; b < nblk; b++) { nwide += wide[b]; weight += wide[b] ? kRingPlainWeight : 1; }
+    for (int b = 0; b < nblk; b++) weight += wide[b] ? kRingPlainWeight : 1;
     const long long per_unit = (long long)(kMringMaxB - kRingPlainWeight) * kMringWgUnit;
     int wgs = kMringWgUnit * (int)((weight + per_unit - 1) / per_unit);
     if (wgs < kMringWgUnit) wgs = kMringWgUnit;
-    out.wgs = wgs;
-    out.bpw = (nblk + wgs - 1) / wgs;
     out.plan.assign((size_t)16 * nblk, 0);
-    out.run_ok.assign(wgs, 1);
-    out.run_rng.assign((size_t)2 * wgs, 0);
-    if (nwide == 0) {
-        for (int g = 0; g < wgs; g++) {
-            out.run_rng[2 * g] = std::min(nblk, g * out.bpw);
-            out.run_rng[2 * g + 1] = std::min(nblk, (g + 1) * out.bpw);
-        }
-    } else { // runs of equal weight (ring_plan.hpp)
-        long long cum = 0;
-        int g = 0, start = 0;
-        for (int b = 0; b < nblk; b++) {
-            cum += wide[b] ? kRingPlainWeight : 1;
-            while (g < wgs - 1 && cum * wgs >= (long long)(g + 1) * weight) {
-                out.run_rng[2 * g] = start;
-                out.run_rng[2 * g + 1] = b + 1;
-                start = b + 1;
-                g++;
-            }
-        }
-        out.run_rng[2 * g] = start;
-        out.run_rng[2 * g + 1] = nblk;
-        for (g++; g < wgs; g++) out.run_rng[2 * g] = out.run_rng[2 * g + 1] = nblk;
-    }
     out.slots.assign((size_t)nblk * nnzb, 0);
-    std::vector<int> win_of; // per cluster of the current block: its window
-    for (int g = 0; g < wgs; g++) {
-        int wlo[kMringK], whi[kMringK], wbase[kMringK]; // window w holds columns [wlo, whi); slot = (c - wbase) mod W
-        bool live[kMringK];
-        for (int w = 0; w < K; w++) { wlo[w] = whi[w] = wbase[w] = 0; live[w] = false; }
-        long long run_nnz = 0, plain_nnz = 0;
-        int nplain = 0;
-        bool first_served = true;
-        for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1]; b++) {
-            const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b];
-            int* P = &out.plan[(size_t)16 * b];
-            P[0] = rows[b]; P[1] = ptrs[b]; P[2] = nrows; P[3] = nn;
-            run_nnz += nn;
-            if (nn == 0) continue;
-            if (wide[b]) {
-                P[2] = 0; P[4] = 2; P[8] = nrows;
-                for (int w = 0; w < K; w++) live[w] = false;
-                nplain++;
-                plain_nnz += nn;
-                continue;
+
+    struct Win { int lo[kMringK], hi[kMringK], base[kMringK]; bool live[kMringK]; };
+    auto reset = [&](Win& S) { for (int w = 0; w < K; w++) { S.lo[w] = S.hi[w] = S.base[w] = 0; S.live[w] = false; } };
+    std::vector<int> win_of;
+    long long restarts = 0;
+    // one served block against window state S: fills its record P (and, if o != nullptr, its slots); returns the new columns
+    auto plan_block = [&](int b, Win& S, int* P, unsigned short* o) {
+        const Cl* C = &cls[cl_ptr[b]];
+        const int nc = cl_ptr[b + 1] - cl_ptr[b], nn = ptrs[b + 1] - ptrs[b], p0 = ptrs[b];
+        win_of.assign(nc, -1);
+        bool used[kMringK] = {};
+        for (int j = 0; j < nc; j++) // which window does each cluster continue?
+            for (int w = 0; w < K; w++)
+                if (S.live[w] && !used[w] && C[j].lo >= S.lo[w] && C[j].lo < S.hi[w] + kMringGap) { win_of[j] = w; used[w] = true; break; }
+        for (int j = 0; j < nc; j++) { // the others: a window nobody uses in this block (prefer one that holds nothing)
+            if (win_of[j] >= 0) continue;
+            int pick = -1;
+            for (int w = 0; w < K && pick < 0; w++)
+                if (!used[w] && !S.live[w]) pick = w;
+            for (int w = 0; w < K && pick < 0; w++)
+                if (!used[w]) pick = w;
+            win_of[j] = pick; // nc <= K: there is one
+            used[pick] = true;
+            S.live[pick] = false;
+        }
+        int total_new = 0;
+        int nlo_[kMringK] = {}, ncnt_[kMringK] = {};
+        // New columns come in whole groups of 64 (the window simply runs a little ahead of what the block needs): a wave of
+        // the kernel then refills ONE window and decodes its share of the record with scalar instructions.
+        auto pad64 = [](int from, int to) { return from + ((to - from + 63) & ~63); };
+        for (int j = 0; j < nc; j++) {
+            const int w = win_of[j], cmin = C[j].lo, cmax = C[j].hi;
+            int lo = S.live[w] ? S.lo[w] : cmin, hi = S.live[w] ? S.hi[w] : cmin;
+            bool restart = !S.live[w];
+            int nhi = pad64(hi, std::max(hi, cmax + 1)), nlo = std::max(lo, nhi - W);
+            if (!restart && cmin < nlo) restart = true; // cannot keep the upper end and reach down: start afresh on this cluster
+            if (restart) {
+                lo = std::max(0, std::min(cmin, cmax + 1 - W));
+                hi = lo;
+                nhi = pad64(lo, cmax + 1); // <= lo + W: W is a multiple of 64
+                nlo = std::max(lo, nhi - W);
+                S.base[w] = (lo / W) * W;
             }
-            const Cl* C = &cls[cl_ptr[b]];
-            const int nc = cl_ptr[b + 1] - cl_ptr[b];
-            // which window does each cluster continue?
-            win_of.assign(nc, -1);
-            bool used[kMringK] = {};
-            for (int j = 0; j < nc; j++)
-                for (int w = 0; w < K; w++)
-                    if (live[w] && !used[w] && C[j].lo >= wlo[w] && C[j].lo < whi[w] + kMringGap) { win_of[j] = w; used[w] = true; break; }
-            for (int j = 0; j < nc; j++) { // the others: a window nobody uses in this block (prefer one that holds nothing)
-                if (win_of[j] >= 0) continue;
-                int pick = -1;
-                for (int w = 0; w < K && pick < 0; w++)
-                    if (!used[w] && !live[w]) pick = w;
-                for (int w = 0; w < K && pick < 0; w++)
-                    if (!used[w]) pick = w;
-                win_of[j] = pick; // nc <= K: there is one
-                used[pick] = true;
-                if (live[pick] && !first_served) out.restarts++;
-                live[pick] = false;
-            }
-            int total_new = 0;
-            int nlo_[kMringK] = {}, ncnt_[kMringK] = {};
-            for (int j = 0; j < nc; j++) {
-                const int w = win_of[j], cmin = C[j].lo, cmax = C[j].hi;
-                // New columns come in whole groups of 64 (the window simply runs a little ahead of what the block needs): a
-                // wave of the kernel then refills ONE window, and its share of the record is decoded with scalar instructions
-                // (per-lane decoding of up to five ranges cost 0.3 us of VALU time per block, a tenth of the block's time).
-                auto pad64 = [](int from, int to) { return from + ((to - from + 63) & ~63); };
-                int lo = live[w] ? wlo[w] : cmin, hi = live[w] ? whi[w] : cmin;
-                bool restart = !live[w];
-                int nhi = pad64(hi, std::max(hi, cmax + 1)), nlo = std::max(lo, nhi - W);
-                if (!restart && cmin < nlo) { // cannot keep the upper end and reach down: start afresh on this cluster
-                    restart = true;
-                    out.restarts++;
-                }
-                if (restart) {
-                    lo = std::max(0, std::min(cmin, cmax + 1 - W));
-                    hi = lo;
-                    nhi = pad64(lo, cmax + 1); // <= lo + W: W is a multiple of 64
-                    nlo = std::max(lo, nhi - W);
-                    wbase[w] = (lo / W) * W;
-                }
-                while (nlo - wbase[w] >= W) wbase[w] += W;
-                nlo_[w] = hi;
-                ncnt_[w] = nhi - hi;
-                total_new += nhi - hi;
-                wlo[w] = nlo; whi[w] = nhi; live[w] = true;
-            }
-            first_served = false;
-            P[4] = 1; P[5] = total_new;
-            for (int w = 0; w < K; w++) {
-                P[kMringLoAt(w)] = nlo_[w];
-                P[kMringPkAt(w)] = ncnt_[w] | ((wbase[w] / W) << 11);
-            }
-            // slots of this block's nonzeros
-            unsigned short* o = &out.slots[(size_t)b * nnzb];
-            const int p0 = ptrs[b];
+            while (nlo - S.base[w] >= W) S.base[w] += W;
+            nlo_[w] = hi;
+            ncnt_[w] = nhi - hi;
+            total_new += nhi - hi;
+            S.lo[w] = nlo; S.hi[w] = nhi; S.live[w] = true;
+        }
+        P[4] = 1; P[5] = total_new;
+        for (int w = 0; w < K; w++) {
+            P[kMringLoAt(w)] = nlo_[w];
+            P[kMringPkAt(w)] = ncnt_[w] | ((S.base[w] / W) << 11);
+        }
+        if (o)
             for (int t = 0; t < T; t++)
                 for (int i = 0; i < per; i++) {
                     const int k = std::min(t + i * T, nn - 1);
@@ -208,13 +160,67 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
                     int j = 0;
                     while (j + 1 < nc && c > C[j].hi) j++;
                     const int w = win_of[j];
-                    int s = c - wbase[w];
-                    if (s >= W) s -= W;
-                    o[t * per + i] = (unsigned short)(w * W + s);
+                    int sl = c - S.base[w];
+                    if (sl >= W) sl -= W;
+                    o[t * per + i] = (unsigned short)(w * W + sl);
                 }
+        return total_new;
+    };
+    // Runs are formed on the way: a run ends where its weight is used up, and — the kernel's loop has no unpipelined refill —
+    // in front of every block that would bring more than kMringFast new columns at once (several windows starting afresh):
+    // such a block starts a run, whose first block's windows the kernel fills whole.
+    std::vector<int> cuts;
+    // (forced cuts ADD runs — short ones — instead of lengthening the others: the grid grows by whole rounds of workgroups, and
+    // the hardware deals the later rounds out as the first workgroups finish)
+    const long long target = (weight + wgs - 1) / wgs;
+    {
+        cuts.assign(1, 0);
+        restarts = 0;
+        Win S;
+        reset(S);
+        long long cum = 0;
+        int count = 0, forced = 0;
+        for (int b = 0; b < nblk; b++) {
+            const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b], wb = wide[b] ? kRingPlainWeight : 1;
+            auto fresh = [&]() { if (b > cuts.back()) cuts.push_back(b); cum = 0; count = 0; reset(S); };
+            if (count > 0 && (count >= kMringMaxB || cum + wb > target)) fresh();
+            int* P = &out.plan[(size_t)16 * b];
+            for (int q = 0; q < 16; q++) P[q] = 0;
+            P[0] = rows[b]; P[1] = ptrs[b]; P[2] = nrows; P[3] = nn;
+            if (nn > 0 && wide[b]) {
+                P[2] = 0; P[4] = 2; P[8] = nrows;
+                reset(S);
+            } else if (nn > 0) {
+                Win trial = S;
+                int tn = plan_block(b, trial, P, nullptr);
+                if (tn > kMringFast && count > 0) { fresh(); forced++; } // this block starts a run: its windows are filled whole
+                plan_block(b, S, P, &out.slots[(size_t)b * nnzb]);        // commit: advances S
+            }
+            cum += wb;
+            count++;
         }
-        bool ok = nplain <= kRingMaxPlain;
-        if (!ok) {
+        restarts = forced;
+    }
+    while ((int)cuts.size() > wgs) wgs += kMringWgUnit;
+    const int nruns = (int)cuts.size();
+    out.wgs = wgs;
+    out.bpw = (nblk + wgs - 1) / wgs;
+    out.restarts = restarts;
+    out.run_ok.assign(wgs, 1);
+    out.run_rng.assign((size_t)2 * wgs, 0);
+    for (int g = 0; g < wgs; g++) {
+        out.run_rng[2 * g] = g < nruns ? cuts[g] : nblk;
+        out.run_rng[2 * g + 1] = g + 1 < nruns ? cuts[g + 1] : nblk;
+    }
+    for (int g = 0; g < nruns; g++) { // runs with too many PLAIN blocks go down the plain path as a whole
+        int nplain = 0;
+        long long run_nnz = 0, plain_nnz = 0;
+        for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1]; b++) {
+            const int* P = &out.plan[(size_t)16 * b];
+            run_nnz += P[3];
+            if (P[4] == 2) { nplain++; plain_nnz += P[3]; }
+        }
+        if (nplain > kRingMaxPlain) {
             out.run_ok[g] = 0;
             out.bad_runs++;
             out.bad_nnz += run_nnz;
@@ -268,7 +274,7 @@ inline const char* check_mring_plan(const MringPlanHost& P, int n, const int* pt
             if (Q[2] != 0 || Q[5] != 0) return "a PLAIN block is visible to the loop";
             continue;
         }
-        if (Q[4] != 1 || Q[3] > nnzb || Q[2] > 2 * T) return "a served run holds a block the kernel cannot take";
+        if (Q[4] != 1 || Q[3] > nnzb || Q[2] > T) return "a served run holds a block the kernel cannot take";
         int total = 0;
         for (int w = 0; w < K; w++) {
             const int lo = Q[kMringLoAt(w)], cnt = Q[kMringPkAt(w)] & 2047;
@@ -283,6 +289,7 @@ inline const char* check_mring_plan(const MringPlanHost& P, int n, const int* pt
             }
         }
         if (total != Q[5]) return "total of new columns disagrees with the windows";
+        if (total > kMringFast && b != P.run_rng[2 * run]) return "a block inside a run brings more new columns than the kernel prefetches";
         for (int k = 0; k < Q[3]; k++) {
             const int slot = P.slots[(size_t)b * nnzb + (size_t)(k % T) * per + k / T];
             if (slot < 0 || slot >= K * W) return "slot outside the LDS array";

@@ -110,11 +110,13 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     out = RingPlanHost();
     out.cfg = cfg;
     std::vector<int> rows, ptrs;
-    build_row_blocks(n, ptrow, cfg.nnzb, 2 * cfg.threads, rows, ptrs);
+    // (configuration 4 keeps its blocks to T rows: one pass over the rows per block is a condition of the LEAN kernel)
+    const int max_rows = cfg.id == 4 ? cfg.threads : 2 * cfg.threads;
+    build_row_blocks(n, ptrow, cfg.nnzb, max_rows, rows, ptrs);
     {   // span-limited blocks where that takes only a few cuts; a matrix whose rows themselves outspan the ring would
         // fall apart into one-row blocks — it is not the ring's to serve, keep the plain blocks (its runs go plain)
         std::vector<int> rows2, ptrs2;
-        build_ring_blocks(n, ptrow, row_min, row_max, cfg.nnzb, 2 * cfg.threads, cfg.ring, rows2, ptrs2);
+        build_ring_blocks(n, ptrow, row_min, row_max, cfg.nnzb, max_rows, cfg.ring, rows2, ptrs2);
         if (rows2.size() <= rows.size() + rows.size() / 8 + 16) {
             rows.swap(rows2);
             ptrs.swap(ptrs2);
@@ -167,6 +169,58 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
         out.run_rng[2 * g] = start;
         out.run_rng[2 * g + 1] = nblk;
         for (g++; g < wgs; g++) out.run_rng[2 * g] = out.run_rng[2 * g + 1] = nblk;
+    }
+    // LEAN runs (spmv_ring.hpp): inside a run no block may bring more than T new columns — only a run's FIRST block may (the
+    // kernel fills its whole window up front).  So runs are cut where the window would restart or jump (a relabelled band has a
+    // few dozen such places), the other cuts are placed by weight as before.  Replays the window exactly as the plan loop
+    // below; gives up (keeps the runs above: general kernel) if that needs more runs than workgroups.
+    if (!(ghost_lo < ghost_hi) && cfg.id == 4) {
+        const int ring = cfg.ring, T = cfg.threads;
+        std::vector<int> cuts; // first block of every run
+        auto simulate = [&](long long target) {
+            cuts.clear();
+            cuts.push_back(0);
+            long long cum = 0;
+            int count = 0, wlo = 0, whi = 0;
+            bool live = false;
+            for (int b = 0; b < nblk; b++) {
+                const int nn = ptrs[b + 1] - ptrs[b], wb = wide[b] ? kRingPlainWeight : 1;
+                auto fresh = [&]() { if (b > cuts.back()) cuts.push_back(b); cum = 0; count = 0; live = false; };
+                if (count >= kRingMaxB || (count > 0 && cum + wb > target)) fresh();
+                if (nn > 0 && !wide[b]) {
+                    const int cmin = bmin[b], cmax = bmax[b];
+                    for (int pass = 0; pass < 2; pass++) {
+                        int lo = live ? wlo : cmin, hi = live ? whi : cmin;
+                        bool restart = !live || cmin < lo || cmin > hi;
+                        if (restart) { lo = std::max(0, std::min(cmin, cmax + 1 - ring)); hi = lo; }
+                        int nhi = std::max(hi, cmax + 1), nlo = std::max(lo, nhi - ring);
+                        if (cmin < nlo) { lo = std::max(0, std::min(cmin, cmax + 1 - ring)); hi = lo; nhi = cmax + 1; nlo = std::max(lo, nhi - ring); }
+                        if (nhi - hi > T && count > 0 && pass == 0) { fresh(); continue; } // must start a run
+                        wlo = nlo; whi = nhi; live = true;
+                        break;
+                    }
+                } else if (wide[b]) {
+                    live = false;
+                }
+                cum += wb;
+                count++;
+            }
+            return (int)cuts.size();
+        };
+        long long target = (weight + wgs - 1) / wgs;
+        int nruns = simulate(target);
+        for (int it = 0; it < 4 && nruns > wgs; it++) { // forced cuts cost runs: make the weight cuts rarer
+            const long long spare = (long long)wgs - (nruns - (weight + target - 1) / target);
+            if (spare <= 0) break;
+            target = (weight + spare - 1) / spare;
+            nruns = simulate(target);
+        }
+        if (nruns <= wgs) {
+            for (int g = 0; g < wgs; g++) {
+                out.run_rng[2 * g] = g < nruns ? cuts[g] : nblk;
+                out.run_rng[2 * g + 1] = g + 1 < nruns ? cuts[g + 1] : nblk;
+            }
+        }
     }
     if (ghost_lo < ghost_hi) {
         std::vector<char> gh((size_t)nblk, 0);

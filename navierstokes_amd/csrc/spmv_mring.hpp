@@ -10,7 +10,8 @@
 // record), each a whole number of 64-column groups — so a wave refills one window at a time and decodes its share of the
 // record with scalar instructions.  Every wave prefetches three such groups D blocks ahead (768 columns per block on this
 // path; no extra memory traffic, no dependent load) and writes them to their windows' rings when the block becomes next.
-// More new columns at once (several windows restarting) take an unpipelined loop.
+// A block that would bring more starts a run (mring_plan.hpp), whose first block's windows are filled whole up front: the
+// steady-state loop has no global load under a condition, which is what keeps the prefetched blocks in flight (spmv_ring.hpp, LEAN).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -167,34 +168,14 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
                 Q.lo = uni4(s_plan[4 * (lb + 1) + 2]);
                 Q.pk = uni4(s_plan[4 * (lb + 1) + 3]);
                 const int total = Q.m1.y;
-                if (total <= NX * T) {
 #pragma unroll
-                    for (int j = 0; j < NX; j++) {
-                        const MringNew nw = mring_decode(wave + (T / 64) * j, lane, Q);
-                        if (nw.slot >= 0) s_ring[nw.slot] = xr[(s + 1) % D][j];
-                    }
-                } else { // window restarts: more than NX * T new columns at once, four loads in flight per thread
-                    const int lo[K] = {Q.lo.x, Q.lo.y, Q.lo.z, Q.lo.w, Q.m1.z};
-                    const unsigned pk[K] = {(unsigned)Q.pk.x, (unsigned)Q.pk.y, (unsigned)Q.pk.z, (unsigned)Q.pk.w, (unsigned)Q.m1.w};
-#pragma unroll
-                    for (int w = 0; w < K; w++) {
-                        const int cnt = (int)(pk[w] & 2047u), base = (int)(pk[w] >> 11) * W;
-                        for (int c0 = lo[w] + tid; c0 < lo[w] + cnt; c0 += 4 * T) {
-                            double v[4];
-#pragma unroll
-                            for (int u = 0; u < 4; u++) v[u] = x[max(0, min(c0 + u * T, clast))];
-#pragma unroll
-                            for (int u = 0; u < 4; u++)
-                                if (c0 + u * T < lo[w] + cnt) s_ring[w * W + ring_slot<W>(c0 + u * T, base)] = v[u];
-                        }
-                    }
+                for (int j = 0; j < NX; j++) { // (the plan guarantees total <= NX * T inside a run: no unpipelined refill here)
+                    const MringNew nw = mring_decode(wave + (T / 64) * j, lane, Q);
+                    if (nw.slot >= 0) s_ring[nw.slot] = xr[(s + 1) % D][j];
                 }
+                (void)total;
             }
             if (tid < nrows) y[MAPPED ? rms : r0 + tid] = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
-            for (int r = r0 + tid + T; r < r0 + nrows; r += T) { // blocks of very short rows
-                const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
-                y[MAPPED ? A.rowmap[r] : r] = ring_row_chain<8, SKEW>(s_c, s_x, a, e);
-            }
         }
     }
     // PLAIN blocks of this run, behind the loop (spmv_ring.hpp)

@@ -99,6 +99,7 @@ def lib():
         "mi_csr_set_nontemporal": [_vp, i, i],
         "mi_csr_block4_structure": [i, _vp, _vp, P(i), P(_c.c_longlong)],
         "mi_ring_plan_probe": [i, _vp, _vp, i, P(i), P(i), P(i), P(d), P(i)],
+        "mi_ring_plan_lean": [i, _vp, _vp, i, P(i)],
         "mi_csr_tile_info": [_vp, P(i), P(i), P(d), P(d), P(i)],
         "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
         "mi_mring_plan_probe": [i, _vp, _vp, P(i), P(i), P(i), P(d), P(ll)],

@@ -21,6 +21,15 @@ def probe(p, c, cfg):
     return nblk.value, runs.value, bad.value, frac.value, mslot.value
 
 
+def is_lean(p, c, cfg=4):
+    L = mpk.lib()
+    p = np.ascontiguousarray(p, np.int32)
+    c = np.ascontiguousarray(c, np.int32)
+    out = ctypes.c_int()
+    mpk.check(L.mi_ring_plan_lean(len(p) - 1, p.ctypes.data, c.ctypes.data, cfg, ctypes.byref(out)))
+    return bool(out.value)
+
+
 RING = {1: 5120, 2: 5120, 3: 11264, 4: 5120}
 NNZB = {1: 2048, 2: 4096, 3: 4096, 4: 2048}
 
@@ -112,6 +121,7 @@ def test_relabelled_band_keeps_every_run_in_the_ring_loop():
     p2, c2 = relabelled(np.ascontiguousarray(ps, np.int32), np.ascontiguousarray(cs, np.int32))
     nblk, runs, bad, frac, mslot = probe(p2, c2, 4)    # the probe also fails if a run carries > 2x the mean weight
     assert bad == 0 and 0.97 < frac < 1.0
+    assert is_lean(p2, c2) and is_lean(p, c)           # runs cut at the window restarts: the LEAN kernel runs both
     assert nblk <= int(p2[-1]) // 2048 + 1 + nblk // 50    # only a few extra cuts
 
 
@@ -125,3 +135,18 @@ def test_window_restarts_instead_of_giving_up():
     p = (np.arange(n + 1) * per).astype(np.int32)
     nblk, runs, bad, frac, mslot = probe(p, c, 4)
     assert bad == 0 and frac == 1.0
+
+
+def test_lean_plans():
+    """LEAN = no block inside a run brings > T new columns or holds > T rows (the replay in mi_ring_plan_probe checks the
+    invariants of a plan that claims it).  Bands are; a matrix of very short rows is (blocks are cut at T rows); the
+    alternating-ends matrix restarts its window at every block and still is — every block starts its own run or the
+    planner gives up and says so."""
+    p, c, _ = synth.rows("s15", 60_000, w=2000)
+    assert is_lean(p, c) and not is_lean(p, c, 1)          # only configuration 4 has the instantiation
+    p, c, _ = synth.rows("svar", 50_000, w=2000)
+    assert is_lean(p, c)
+    n = 40_000
+    p = np.arange(n + 1, dtype=np.int32) * 2                # two entries per row: blocks of 256 rows, not 1024
+    c = np.stack([np.arange(n), np.minimum(np.arange(n) + 3, n - 1)], 1).astype(np.int32).ravel()
+    assert is_lean(p, c) and probe(p, c, 4)[2:4] == (0, 1.0)
