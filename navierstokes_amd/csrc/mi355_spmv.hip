@@ -613,7 +613,9 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         const char* me = getenv("MI355_MRING");
         const char* ke = getenv("MI355_SPMV_KERNEL");
         const bool asked = (me && !strcmp(me, "1")) || (ke && !strcmp(ke, "mring"));
-        if (n > 0 && nnz > 0 && !(me && !strcmp(me, "0")) && (asked || (A->auto_kernel != MI_KERNEL_RING && nnz >= 200000))) {
+        // (opt-in: measured 1.3x the single ring on identical bands and behind the stream / tile kernels on meshes so far —
+        // DESIGN 4.10 — so mi_csr_create does not spend its time on it unless asked)
+        if (n > 0 && nnz > 0 && asked) {
             const int rcm = build_mring(A, indcol);
             if (rcm != MI_OK) {
                 mi_csr_destroy(A);
@@ -1286,6 +1288,7 @@ extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, in
         }
         if (Q[7] == 2) { // computed behind the loop: the loop must see an empty block
             if (Q[2] != 0 || Q[5] != 0) return fail(MI_ERR_STATE, "a PLAIN block is visible to the ring loop");
+            if (P.run_ok[run] != 3) return fail(MI_ERR_STATE, "a run with a PLAIN block does not tell the kernel to look behind its loop");
             continue;
         }
         if (Q[7] != 1 || Q[3] > c.nnzb || Q[2] > 2 * T) return fail(MI_ERR_STATE, "a served run holds a block the kernel cannot take");

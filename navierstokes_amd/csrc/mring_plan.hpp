@@ -39,7 +39,8 @@ constexpr int kMringLoAt(int w) { return w < 4 ? 8 + w : 6; }
 constexpr int kMringPkAt(int w) { return w < 4 ? 12 + w : 7; }
 static_assert(kMringW % 64 == 0, "windows are refilled in groups of 64 columns");
 constexpr int kMringNnzb = 2048, kMringThreads = 256, kMringWgUnit = 512;
-constexpr int kMringFast = 3 * kMringThreads; // new columns a block inside a run may bring (the kernel prefetches 3 per thread)
+constexpr int kMringFast = 4 * kMringThreads; // new columns a block inside a run may bring (the kernel prefetches 4 per thread:
+                                              // three windows advancing by a block's <= 256 rows, padded to 64, stay below)
 constexpr int kMringMaxB = 96;      // blocks per run: the plan records are 64 bytes each and two workgroups must fit a CU's LDS
 
 struct MringPlanHost {
@@ -231,6 +232,7 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
             }
         } else {
             out.bad_nnz += plain_nnz;
+            if (nplain > 0) out.run_ok[g] = 3; // tells the kernel to look for PLAIN blocks behind its loop
         }
     }
 }
@@ -272,6 +274,7 @@ inline const char* check_mring_plan(const MringPlanHost& P, int n, const int* pt
         if (Q[3] == 0) continue;
         if (Q[4] == 2) {
             if (Q[2] != 0 || Q[5] != 0) return "a PLAIN block is visible to the loop";
+            if (P.run_ok[run] != 3) return "a run with a PLAIN block does not tell the kernel to look behind its loop";
             continue;
         }
         if (Q[4] != 1 || Q[3] > nnzb || Q[2] > T) return "a served run holds a block the kernel cannot take";

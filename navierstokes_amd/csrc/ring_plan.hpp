@@ -55,7 +55,7 @@ struct RingPlanHost {
     long long bad_nnz = 0;     // nonzeros living in runs that take the plain path
     std::vector<int> plan;     // 8 ints per block: {r0, p0, rows, nnz, new_lo, new_cnt, base, flags}; flags 1 = window-served,
                                // 2 = PLAIN: {r0, p0, 0, nnz, rows, 0, base, 2} (rows moved out of the loop's sight), 0 = empty
-    std::vector<int> run_ok;   // per run
+    std::vector<int> run_ok;   // per run: 0 plain path, 1 ring loop, 3 ring loop + PLAIN blocks behind it
     std::vector<int> run_rng;  // per run: {first block, end block} — a run is a contiguous block range, runs need not be in order
     std::vector<int> run_halo; // per run: touches a ghost column (fused multi-GPU step only)
     bool lean = true;          // no served block but a run's first brings > T new columns, no block holds > T rows (spmv_ring.hpp: LEAN)
@@ -309,6 +309,7 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
             }
         } else {
             out.bad_nnz += plain_nnz;
+            if (nplain > 0) out.run_ok[g] = 3; // tells the kernel to look for PLAIN blocks behind its loop
         }
     }
 }

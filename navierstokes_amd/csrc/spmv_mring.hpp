@@ -8,7 +8,7 @@
 //
 // Refill: a block's new columns are the concatenation of up to K ranges [lo_w, lo_w + cnt_w) (one per window, from the plan
 // record), each a whole number of 64-column groups — so a wave refills one window at a time and decodes its share of the
-// record with scalar instructions.  Every wave prefetches three such groups D blocks ahead (768 columns per block on this
+// record with scalar instructions.  Every wave prefetches four such groups D blocks ahead (1024 columns per block on this
 // path; no extra memory traffic, no dependent load) and writes them to their windows' rings when the block becomes next.
 // A block that would bring more starts a run (mring_plan.hpp), whose first block's windows are filled whole up front: the
 // steady-state loop has no global load under a condition, which is what keeps the prefetched blocks in flight (spmv_ring.hpp, LEAN).
@@ -29,19 +29,31 @@ struct MringRec { int4 m1, lo, pk; };
 struct MringNew { int col, slot; };
 __device__ __forceinline__ MringNew mring_decode(int g /* uniform */, int lane, const MringRec& R)
 {
+    // branch-free on purpose: written with ?: chains hipcc turns the (scalar) window selection into a dozen s_cbranch per
+    // call, six calls per block — measured as +50 % on the whole kernel.  Masks keep it a straight run of SALU instructions.
     const int i0 = g * 64;
-    const int c0 = R.pk.x & 2047, c1 = R.pk.y & 2047, c2 = R.pk.z & 2047, c3 = R.pk.w & 2047;
-    const int p1 = c0, p2 = c0 + c1, p3 = p2 + c2, p4 = p3 + c3;
-    const int w = (i0 >= p1) + (i0 >= p2) + (i0 >= p3) + (i0 >= p4);
-    const int first = w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : (w == 3 ? p3 : p4)));
-    const int wl = w == 0 ? R.lo.x : (w == 1 ? R.lo.y : (w == 2 ? R.lo.z : (w == 3 ? R.lo.w : R.m1.z)));
-    const unsigned pw = (unsigned)(w == 0 ? R.pk.x : (w == 1 ? R.pk.y : (w == 2 ? R.pk.z : (w == 3 ? R.pk.w : R.m1.w))));
-    const int col0 = wl + (i0 - first), s0 = col0 - (int)(pw >> 11) * kMringW, off = w * kMringW; // scalar
+    const int lo[kMringK] = {R.lo.x, R.lo.y, R.lo.z, R.lo.w, R.m1.z};
+    const unsigned pk[kMringK] = {(unsigned)R.pk.x, (unsigned)R.pk.y, (unsigned)R.pk.z, (unsigned)R.pk.w, (unsigned)R.m1.w};
+    int first = 0, col0 = 0, s0 = 0, off = 0, hit = 0;
+#pragma unroll
+    for (int w = 0; w < kMringK; w++) {
+        const int cnt = (int)(pk[w] & 2047u);
+        const int in = -(int)((unsigned)(i0 - first) < (unsigned)cnt); // all ones if group g lies in window w's range
+        const int c = lo[w] + (i0 - first);
+        col0 |= in & c;
+        s0 |= in & (c - (int)(pk[w] >> 11) * kMringW);
+        off |= in & (w * kMringW);
+        hit |= in;
+        first += cnt;
+    }
     MringNew r;
-    r.col = col0 + lane;
-    int s = s0 + lane;
-    if (s >= kMringW) s -= kMringW;
-    r.slot = i0 < R.m1.y ? off + s : -1;
+    // (a group past the record's last new column still loads — a fixed number of loads per block — but from the neighbourhood of
+    // this workgroup's own columns: x[lane] for everybody is one cache line asked for by every wave of the GPU at once, measured
+    // as +0.3 us per block and unused group)
+    r.col = (hit ? col0 : lo[0] + i0) + lane;
+    int sl = s0 + lane;
+    if (sl >= kMringW) sl -= kMringW;
+    r.slot = hit ? off + sl : -1;
     return r;
 }
 
@@ -81,7 +93,8 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
         }
     }
     __syncthreads();
-    if (!run_ok[gw]) {
+    const int run_kind = uni(run_ok[gw]); // 0: plain path for the whole run; 1: loop; 3: loop + PLAIN blocks behind it
+    if (!(run_kind & 1)) {
         for (int lb = 0; lb < nb; lb++) {
             const int4 m0 = s_plan[4 * lb];
             ring_simple_block<T, NNZB, MAPPED, false>(A, x, y, m0.x, m0.y, m0.z, m0.w, s_c, s_x, nocomm);
@@ -94,7 +107,7 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
     const SlotVec* slotv = reinterpret_cast<const SlotVec*>(slots);
     const int bslot_last = A.nblk - 1;
     int2 pr[D];
-    constexpr int NX = 3;  // groups of 64 new columns a wave prefetches per block: 4 waves x NX x 64 = 768 columns on the fast path
+    constexpr int NX = kMringFast / T; // groups of 64 new columns a wave prefetches per block: 4 waves x NX x 64 columns in all
     double xr[D][NX];      // entries (wave + 4 j) * 64 + lane of the staged block's new columns
     int rm[D];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
         }
     }
     // PLAIN blocks of this run, behind the loop (spmv_ring.hpp)
+    if (!(run_kind & 2)) return;
     for (int lb = 0; lb < nb; lb++) {
         const int4 m1 = s_plan[4 * lb + 1];
         if (uni(m1.x) != 2) continue;
