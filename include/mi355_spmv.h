@@ -163,9 +163,9 @@ int mi_csr_tile_info(mi_csr_t A, int* built, int* nblk, double* unique_per_nnz, 
  * aligned slot segments, over-long rows unlisted) and report its size.  threads = 0: as many as the library would use. */
 int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, int* nblk, long long* distinct_total,
                        int* max_distinct, long long* nnz_listed);
-/* Multi-window ring kernel (MI_KERNEL_MRING, mring_plan.hpp): opt-in — MI355_MRING=1 (or MI355_SPMV_KERNEL=mring) makes
- * mi_csr_create plan and time it, mi_csr_set_kernel(A, MI_KERNEL_MRING) builds the plan on request; same bits as every other
- * kernel, not yet faster than the stream / tile kernels on the meshes it was written for.  us[0..1] = measured microseconds per launch, temporal / non-temporal value loads (MI355_MRING_NT=0|1 forces). */
+/* Multi-window ring kernel (MI_KERNEL_MRING, mring_plan.hpp): mi_csr_create plans it for matrices the single ring does not serve
+ * and keeps the plan when it serves >= 90 % of the nonzeros (MI355_MRING=0 never, =1 always keep); mi_csr_set_kernel builds it
+ * on request.  us[0..1] = measured microseconds per launch, temporal / non-temporal value loads (MI355_MRING_NT=0|1 forces). */
 int mi_csr_mring_info(mi_csr_t A, int* built, int* runs, int* runs_not_served, double* nnz_fraction_served, double us[2], int* nt);
 /* host-only: build that plan exactly as mi_csr_create would and REPLAY it (MI_ERR_STATE names the first violation: every
  * nonzero's 16-bit slot must hold its column when its block runs, runs cover every block once, records are consistent). */

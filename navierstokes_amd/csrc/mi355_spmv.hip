@@ -101,7 +101,8 @@ struct MringTable {
     int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0, depth = 2;
     double ok_fraction = 0.0;
     long long restarts = 0;
-    int* d_plan = nullptr;             // 16 ints per block, read as four int4
+    int* d_plan = nullptr;             // kMringRec ints per block, read as int4
+    int* d_first = nullptr;            // kMringFirst ints per run: the first block's windows
     int* d_ok = nullptr;
     int* d_rng = nullptr;
     unsigned short* d_slots = nullptr;
@@ -365,6 +366,7 @@ static void free_tile(mi_csr_t A)
 static void free_mring(mi_csr_t A)
 {
     dfree(A->mring.d_plan);
+    dfree(A->mring.d_first);
     dfree(A->mring.d_ok);
     dfree(A->mring.d_rng);
     dfree(A->mring.d_slots);
@@ -387,6 +389,8 @@ static int build_mring(mi_csr_t A, const int* indcol)
     MringTable& M = A->mring;
     hipError_t e;
     if ((e = hipMalloc(&M.d_plan, sizeof(int) * P.plan.size())) != hipSuccess ||
+        (e = hipMalloc(&M.d_first, sizeof(int) * P.first.size())) != hipSuccess ||
+        (e = hipMemcpy(M.d_first, P.first.data(), sizeof(int) * P.first.size(), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMalloc(&M.d_ok, sizeof(int) * P.run_ok.size())) != hipSuccess ||
         (e = hipMalloc(&M.d_rng, sizeof(int) * P.run_rng.size())) != hipSuccess ||
         (e = hipMalloc(&M.d_slots, sizeof(unsigned short) * P.slots.size())) != hipSuccess ||
@@ -613,9 +617,7 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         const char* me = getenv("MI355_MRING");
         const char* ke = getenv("MI355_SPMV_KERNEL");
         const bool asked = (me && !strcmp(me, "1")) || (ke && !strcmp(ke, "mring"));
-        // (opt-in: measured 1.3x the single ring on identical bands and behind the stream / tile kernels on meshes so far —
-        // DESIGN 4.10 — so mi_csr_create does not spend its time on it unless asked)
-        if (n > 0 && nnz > 0 && asked) {
+        if (n > 0 && nnz > 0 && !(me && !strcmp(me, "0")) && (asked || (A->auto_kernel != MI_KERNEL_RING && nnz >= 200000))) {
             const int rcm = build_mring(A, indcol);
             if (rcm != MI_OK) {
                 mi_csr_destroy(A);
@@ -1606,7 +1608,7 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
         V.nblk = M.nblk;
         const int4* plan = reinterpret_cast<const int4*>(M.d_plan);
         const int2* rng = reinterpret_cast<const int2*>(M.d_rng);
-#define MRING_L(D_, MP_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, D_, kMringMaxB, MP_, NT_, SK_>), dim3(M.wgs), dim3(kMringThreads), 0, s, V, plan, M.d_ok, M.d_slots, d_x, d_y, rng)
+#define MRING_L(D_, MP_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, D_, kMringMaxB, MP_, NT_, SK_>), dim3(M.wgs), dim3(kMringThreads), 0, s, V, plan, reinterpret_cast<const int4*>(M.d_first), M.d_ok, M.d_slots, d_x, d_y, rng)
 #define MRING_L3(D_, MP_) do { if (M.nt) { if (M.skew) MRING_L(D_, MP_, true, true); else MRING_L(D_, MP_, true, false); } \
                                else { if (M.skew) MRING_L(D_, MP_, false, true); else MRING_L(D_, MP_, false, false); } } while (0)
 #define MRING_L2(D_) do { if (V.rowmap) MRING_L3(D_, true); else MRING_L3(D_, false); } while (0)
