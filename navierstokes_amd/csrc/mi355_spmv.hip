@@ -98,7 +98,7 @@ struct RingTable {
 
 // plan of the multi-window ring kernel (mring_plan.hpp); valid iff d_plan != nullptr
 struct MringTable {
-    int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0, depth = 2;
+    int nblk = 0, wgs = 0, nruns = 0, bpw = 0, bad_runs = 0, depth = 2;
     double ok_fraction = 0.0;
     long long restarts = 0;
     int* d_plan = nullptr;             // kMringRec ints per block, read as int4
@@ -403,6 +403,7 @@ static int build_mring(mi_csr_t A, const int* indcol)
     }
     M.nblk = P.nblk;
     M.wgs = P.wgs;
+    M.nruns = P.nruns;
     M.bpw = P.bpw;
     M.bad_runs = P.bad_runs;
     M.restarts = P.restarts;
@@ -1608,7 +1609,7 @@ static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s
         V.nblk = M.nblk;
         const int4* plan = reinterpret_cast<const int4*>(M.d_plan);
         const int2* rng = reinterpret_cast<const int2*>(M.d_rng);
-#define MRING_L(D_, MP_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, D_, kMringMaxB, MP_, NT_, SK_>), dim3(M.wgs), dim3(kMringThreads), 0, s, V, plan, reinterpret_cast<const int4*>(M.d_first), M.d_ok, M.d_slots, d_x, d_y, rng)
+#define MRING_L(D_, MP_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, D_, kMringMaxB, MP_, NT_, SK_>), dim3(kNXCD * ((M.nruns + kNXCD - 1) / kNXCD)), dim3(kMringThreads), 0, s, V, plan, reinterpret_cast<const int4*>(M.d_first), M.d_ok, M.d_slots, d_x, d_y, rng, M.nruns)
 #define MRING_L3(D_, MP_) do { if (M.nt) { if (M.skew) MRING_L(D_, MP_, true, true); else MRING_L(D_, MP_, true, false); } \
                                else { if (M.skew) MRING_L(D_, MP_, false, true); else MRING_L(D_, MP_, false, false); } } while (0)
 #define MRING_L2(D_) do { if (V.rowmap) MRING_L3(D_, true); else MRING_L3(D_, false); } while (0)

@@ -50,7 +50,7 @@ constexpr int kMringFirst = 16;     // ints per run: first block's windows {lo[5
 static_assert(kMringW % 64 == 0, "windows are refilled in groups of 64 columns");
 
 struct MringPlanHost {
-    int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0;
+    int nblk = 0, wgs = 0, nruns = 0, bpw = 0, bad_runs = 0; // wgs: array lengths (>= nruns); the kernel's grid is 8 * ceil(nruns / 8)
     long long bad_nnz = 0;
     std::vector<int> plan;   // kMringRec ints per block; flags 1 = window-served, 2 = PLAIN {r0, p0, 0, nnz} {2, 0, rows, 0}, 0 = empty
     std::vector<int> first;  // kMringFirst ints per run
@@ -182,14 +182,21 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
             while (S.live[w] && S.lo[w] - S.base[w] >= W) S.base[w] += W;
     };
 
-    std::vector<int> cuts(1, 0), first(kMringFirst, 0);
-    // (forced cuts ADD runs — short ones — instead of lengthening the others: the grid grows by whole rounds of workgroups, and
-    // the hardware deals the later rounds out as the first workgroups finish)
-    const long long target = (weight + wgs - 1) / wgs;
+    std::vector<int> cuts, first;
+    int forced = 0;
+    // One pass over the blocks with a given weight per run; returns the number of runs.  Cuts forced by blocks that need more
+    // groups than the loop refills come on top of the weight cuts, so the pass is repeated with heavier runs until everything
+    // fits ONE round of workgroups: a second round starts when the first workgroups finish, and a long run dealt to it is the
+    // launch's tail (measured on a relabelled 100^3-cell mesh: 626 runs in two rounds 51 us).
+    auto pass = [&](long long target) {
+        cuts.assign(1, 0);
+        first.assign(kMringFirst, 0);
+        forced = 0;
+        std::fill(out.plan.begin(), out.plan.end(), 0);
     Win S;
     reset(S);
     long long cum = 0;
-    int count = 0, forced = 0;
+    int count = 0;
     for (int b = 0; b < nblk; b++) {
         const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b], wb = wide[b] ? kRingPlainWeight : 1;
         auto fresh = [&]() {
@@ -249,10 +256,21 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
         cum += wb;
         count++;
     }
+        return (int)cuts.size();
+    };
+    long long target = (weight + wgs - 1) / wgs;
+    int nr = pass(target);
+    for (int it = 0; it < 4 && nr > wgs; it++) {
+        const long long spare = (long long)wgs - forced;
+        if (spare < wgs / 4) break; // mostly forced cuts: more rounds it is
+        target = (weight + spare - 1) / spare + it;
+        nr = pass(target);
+    }
     while ((int)cuts.size() > wgs) wgs += kMringWgUnit;
     const int nruns = (int)cuts.size();
     out.wgs = wgs;
-    out.bpw = (nblk + wgs - 1) / wgs;
+    out.nruns = nruns;
+    out.bpw = (nblk + nruns - 1) / nruns;
     out.restarts = forced;
     out.run_ok.assign(wgs, 1);
     out.run_rng.assign((size_t)2 * wgs, 0);

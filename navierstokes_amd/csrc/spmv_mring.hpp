@@ -24,7 +24,7 @@ template <int T, int NNZB, int D, int MAXB, bool MAPPED, bool NT, bool SKEW>
 __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __restrict__ plan, const int4* __restrict__ first,
                                                     const int* __restrict__ run_ok, const unsigned short* __restrict__ slots,
                                                     const double* __restrict__ x, double* __restrict__ y,
-                                                    const int2* __restrict__ run_rng)
+                                                    const int2* __restrict__ run_rng, int nruns)
 {
     constexpr int K = kMringK, W = kMringW, RING = K * W, PER = NNZB / T, R4 = kMringRec / 4;
     static_assert(T == 256 && kMringGroups == 8 && kMringRec == 20 && kMringFirst == 16, "two groups per wave; record layout");
@@ -36,8 +36,11 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
     __shared__ int4 s_plan[R4 * (MAXB + 2 * D + 2)];
     const int* s_rec = reinterpret_cast<const int*>(s_plan);
     const int tid = threadIdx.x;
-    const int bid = (int)blockIdx.x, nwg = (int)gridDim.x;
-    const int gw = (bid & (kNXCD - 1)) * (nwg / kNXCD) + (bid >> 3); // neighbouring runs share an XCD's L2
+    // neighbouring runs share an XCD's L2; the runs that exist (forced cuts make their number irregular) are dealt out evenly
+    // over the eight XCDs — dealing out grid slots instead left whole XCDs idle when the grid was rounded up
+    const int bid = (int)blockIdx.x, per_xcd = (nruns + kNXCD - 1) / kNXCD;
+    const int gw = (bid & (kNXCD - 1)) * per_xcd + (bid >> 3);
+    if ((bid >> 3) >= per_xcd || gw >= nruns) return;
     const int2 rng = run_rng[gw];
     const int b_begin = rng.x, nb = rng.y - rng.x; // <= MAXB by construction of the plan
     if (nb <= 0) return;
