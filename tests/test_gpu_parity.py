@@ -575,3 +575,21 @@ def test_unsorted_and_repeated_columns():
         y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
         mpk.SpMV_CSR(y, dev(x), A)
         assert_bit_equal(y.cpu().numpy(), yr, f"unsorted/repeated columns, {kernel} -> {A.kernel_name()}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_patterns_every_kernel(seed):
+    """the planner fuzz (tests/test_planner_fuzz.py) on the GPU: rows of wildly different lengths, wandering / jumping / scattered
+    column clusters, unsorted rows, duplicates — every kernel against the oracle's fma chain, bit for bit"""
+    from test_planner_fuzz import random_pattern
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([7, 300, 5000, 20000, 60000]))
+    p, c = random_pattern(rng, n)
+    v = rng.uniform(-1, 1, len(c))
+    x = rng.uniform(-1, 1, n)
+    yr = O.spmv(p, c, v, x)
+    for kernel in KERNELS + ["auto"]:
+        A = mpk.csrmatrix(n, p, c, v).set_kernel(kernel)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(y, dev(x), A)
+        assert_bit_equal(y.cpu().numpy(), yr, f"seed {seed} n {n} {kernel} -> {A.kernel_name()}")
