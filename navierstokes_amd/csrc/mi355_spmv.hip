@@ -1388,7 +1388,7 @@ extern "C" int mi_csr_mring_info(mi_csr_t A, int* built, int* runs, int* runs_no
     CHECK_ARG(A, "null handle");
     if (A->inner) A = A->inner;
     if (built) *built = A->mring.d_plan != nullptr;
-    if (runs) *runs = A->mring.wgs;
+    if (runs) *runs = A->mring.nruns;
     if (runs_not_served) *runs_not_served = A->mring.bad_runs;
     if (nnz_fraction_served) *nnz_fraction_served = A->mring.ok_fraction;
     if (us) {
@@ -1408,7 +1408,7 @@ extern "C" int mi_mring_plan_probe(int n, const int* ptrow, const int* indcol, i
     build_mring_plan(n, ptrow, indcol, P);
     if (const char* bad = check_mring_plan(P, n, ptrow, indcol)) return fail(MI_ERR_STATE, std::string("mring plan: ") + bad);
     if (nblk) *nblk = P.nblk;
-    if (runs) *runs = P.wgs;
+    if (runs) *runs = P.nruns;
     if (runs_not_served) *runs_not_served = P.bad_runs;
     if (nnz_fraction_served) *nnz_fraction_served = ptrow[n] ? 1.0 - (double)P.bad_nnz / (double)ptrow[n] : 0.0;
     if (window_restarts) *window_restarts = P.restarts;

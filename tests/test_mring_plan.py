@@ -27,7 +27,7 @@ def test_mesh_operator_is_served_in_natural_and_in_relabelled_order():
     (test_ring_plan), the five small windows all of it — in the mesher-free natural order and after scramble + relabel."""
     p, c, v = synth.pressure_matrix(48, 44, 40)
     nblk, runs, bad, frac, restarts = probe(p, c)
-    assert bad == 0 and frac == 1.0 and restarts <= nblk // 100 and runs % 8 == 0   # (a handful of blocks at the mesh faces need > 8 groups)
+    assert bad == 0 and frac == 1.0 and restarts <= nblk // 100 and 0 < runs <= 512   # (a handful of blocks at the mesh faces need > 8 groups; one round of workgroups)
     ps, cs, _ = synth.permute_nodes(p, c, v, block=1)[:3]
     assert probe(ps, cs)[3] < 0.05                                      # scrambled: nothing to hold on to
     p2, c2 = relabelled(np.ascontiguousarray(ps, np.int32), np.ascontiguousarray(cs, np.int32))
