@@ -65,7 +65,9 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
     out = MringPlanHost();
     const int K = kMringK, W = kMringW, T = kMringThreads, nnzb = kMringNnzb, per = nnzb / T, G = kMringGroups;
     std::vector<int> rows, ptrs;
-    build_row_blocks(n, ptrow, nnzb, T, rows, ptrs); // <= T rows per block: the kernel makes one pass over a block's rows
+    // <= T rows per block (the kernel makes one pass over a block's rows), whole waves of rows where that keeps 7/8 of the block
+    // (ring_plan.hpp: the row-chain phase is the LDS-bound part)
+    build_row_blocks(n, ptrow, nnzb, T, rows, ptrs, 64, 7);
     const int nblk = (int)rows.size() - 1;
     out.nblk = nblk;
     if (nblk <= 0) return;

@@ -198,8 +198,10 @@ struct PartPlan {
 // out: {first row, first nnz} per block plus the terminator {n, nnz}.
 // row_align > 1: block boundaries are pulled back to multiples of row_align rows where possible,
 // so that the y segment a block writes starts on a 128-byte line (row_align = 16).
+// row_align > 1: blocks end on multiples of row_align rows; keep_eighths > 0: only where the shortened block keeps at least that
+// many eighths of its nonzeros (the one-thread-per-row kernels want whole waves of rows, but not half-empty blocks)
 inline void build_row_blocks(int n, const int* ptrow, int nnzb, int max_rows, std::vector<int>& out_rows,
-                             std::vector<int>& out_ptr, int row_align = 1)
+                             std::vector<int>& out_ptr, int row_align = 1, int keep_eighths = 0)
 {
     out_rows.clear();
     out_ptr.clear();
@@ -211,7 +213,7 @@ inline void build_row_blocks(int n, const int* ptrow, int nnzb, int max_rows, st
         while (e < n && (e - start) < max_rows && (long long)ptrow[e + 1] - p0 <= nnzb) e++;
         if (row_align > 1 && e < n) {
             const int ea = (e / row_align) * row_align;
-            if (ea > start) e = ea;
+            if (ea > start && 8 * (long long)(ptrow[ea] - p0) >= (long long)keep_eighths * (ptrow[e] - p0)) e = ea;
         }
         out_rows.push_back(start);
         out_ptr.push_back(p0);

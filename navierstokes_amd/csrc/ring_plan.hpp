@@ -3,6 +3,7 @@
 // matrix at mi_csr_create; testable on a CPU-only machine.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "partition.hpp"
@@ -75,7 +76,7 @@ constexpr int kGhostRunSlack = 2; // blocks (~2.5 us each at 2048 nonzeros) — 
 // is then the tail of the launch (measured on the relabelled 1 M-row S15 matrix: 39 such blocks of 7353, 81-88 us against
 // 34 us for the natural order).
 inline void build_ring_blocks(int n, const int* ptrow, const int* row_min, const int* row_max, int nnzb, int max_rows, int ring,
-                              std::vector<int>& out_rows, std::vector<int>& out_ptr)
+                              std::vector<int>& out_rows, std::vector<int>& out_ptr, int row_align = 1)
 {
     out_rows.clear();
     out_ptr.clear();
@@ -93,6 +94,10 @@ inline void build_ring_blocks(int n, const int* ptrow, const int* row_min, const
                 cmax = nmax;
             }
             e++;
+        }
+        if (row_align > 1 && e < n) { // whole waves of rows (see build_ring_plan)
+            const int ea = (e / row_align) * row_align;
+            if (ea > start && 8 * (long long)(ptrow[ea] - p0) >= 7 * (long long)(ptrow[e] - p0)) e = ea;
         }
         out_rows.push_back(start);
         out_ptr.push_back(p0);
@@ -112,11 +117,16 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     std::vector<int> rows, ptrs;
     // (configuration 4 keeps its blocks to T rows: one pass over the rows per block is a condition of the LEAN kernel)
     const int max_rows = cfg.id == 4 ? cfg.threads : 2 * cfg.threads;
-    build_row_blocks(n, ptrow, cfg.nnzb, max_rows, rows, ptrs);
+    // Row-chain phase: one thread per row, so a block of 137 rows keeps THREE waves busy for 2.14 waves of work, and the kernel's
+    // busiest unit is the LDS.  Blocks are therefore ended on multiples of 64 rows where that gives up less than an eighth of the
+    // block's nonzeros (S15: 128 rows / 1920 nonzeros instead of 136 / 2040).  MI355_RING_ROW_ALIGN=1 switches it off (A/B).
+    int row_align = cfg.id == 4 ? 64 : 1;
+    if (const char* e = getenv("MI355_RING_ROW_ALIGN")) row_align = std::max(1, atoi(e));
+    build_ring_blocks(n, ptrow, row_min, row_max, cfg.nnzb, max_rows, 0x7fffffff, rows, ptrs, row_align);
     {   // span-limited blocks where that takes only a few cuts; a matrix whose rows themselves outspan the ring would
         // fall apart into one-row blocks — it is not the ring's to serve, keep the plain blocks (its runs go plain)
         std::vector<int> rows2, ptrs2;
-        build_ring_blocks(n, ptrow, row_min, row_max, cfg.nnzb, max_rows, cfg.ring, rows2, ptrs2);
+        build_ring_blocks(n, ptrow, row_min, row_max, cfg.nnzb, max_rows, cfg.ring, rows2, ptrs2, row_align);
         if (rows2.size() <= rows.size() + rows.size() / 8 + 16) {
             rows.swap(rows2);
             ptrs.swap(ptrs2);

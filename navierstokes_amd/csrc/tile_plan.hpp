@@ -42,7 +42,7 @@ inline void build_tile_plan(int n, const int* ptrow, const int* indcol, TilePlan
     out = TilePlanHost();
     out.nnzb = nnzb;
     std::vector<int> rows, ptrs;
-    build_row_blocks(n, ptrow, nnzb, 4 * kTileThreads, rows, ptrs);
+    build_row_blocks(n, ptrow, nnzb, 4 * kTileThreads, rows, ptrs, 64, 7); // whole waves of rows for the row-chain phase (ring_plan.hpp)
     const int nblk = (int)rows.size() - 1;
     out.nblk = nblk;
     out.desc.assign((size_t)4 * (nblk + 1), 0);

@@ -56,7 +56,7 @@ def test_windows_restart_and_swap_roles():
     block and the replay still finds every column in its slot; six clusters in a block: PLAIN"""
     n, per = 6000, 15
     rows = np.arange(n)
-    blk = rows // 136
+    blk = rows // 128                                                   # blocks end on multiples of 64 rows: 128 x 15 nonzeros
     a = (blk * 7919) % 50 * 3000                                        # two clusters per block, wandering
     b = a + 150_000
     c = np.where(np.arange(per)[None, :] < 8, a[:, None], b[:, None]) + (rows[:, None] * 13 + np.arange(per)[None, :] * 17) % 600
