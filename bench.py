@@ -495,9 +495,16 @@ def main():
                                   matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else (8.25 if "bcsr4" in kernel_name else
                                                               round(10 + 4 * A.tile_info()["unique_per_nnz"], 2) if "tile" in kernel_name else 12),
                                   autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
+        if "ring<" in kernel_name:
+            rs = A.ring_shape_info()
+            out["kernel_info"]["ring_plan"] = dict(row_blocks=rs["blocks"], lean=rs["lean"], prefetch_depth=rs["depth"],
+                                                   us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
         mi = A.mring_info()
         if mi["built"]:
             out["kernel_info"]["mring_plan"] = dict(runs=mi["runs"], runs_on_plain_path=mi["runs_not_served"], nnz_fraction_served=round(mi["nnz_fraction"], 4))
+            if "mring<" in kernel_name:
+                rs = A.ring_shape_info()
+                out["kernel_info"]["mring_plan"].update(us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
         ti = A.tile_info()
         if ti["built"]:
             out["kernel_info"]["tile_plan"] = dict(row_blocks=ti["nblk"], distinct_columns_per_nnz=round(ti["unique_per_nnz"], 4))

@@ -132,6 +132,10 @@ int mi_reorder_probe(int n, const int* ptrow, const int* indcol, int* block, int
  * per-block path); mi_csr_ring_info reports how much of the matrix the ring serves. */
 int mi_csr_set_kernel(mi_csr_t A, int kernel_id);
 int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable);
+/* Shape of the ring plan in use: row blocks, whether the LEAN instantiation runs, blocks of prefetch; and, for matrices of
+ * >= 20 M nonzeros, the create-time measurement that chose between row blocks ending on multiples of 64 rows and unaligned
+ * ones (microseconds per launch; 0 = not compared; which is faster depends on the box). */
+int mi_csr_ring_shape_info(mi_csr_t A, int* blocks, int* lean, int* depth, double* us_aligned, double* us_unaligned);
 /* MI_KERNEL_AUTO is decided by measurement: mi_csr_create times the candidate kernels (ring if
  * >= 90 % of the nonzeros are ring-served, stream, tile if a plan was kept, BCSR 4x4 if a blocked copy exists) on the new
  * handle, two interleaved rounds of a few launches each, and keeps the fastest.  All kernels produce

@@ -140,6 +140,7 @@ struct mi_csr_s {
     int kernel = MI_KERNEL_AUTO;
     int auto_kernel = MI_KERNEL_STREAM;
     double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0, tune_us_stream_nt = 0.0;
+    double tune_us_ring_aligned = 0.0, tune_us_ring_unaligned = 0.0; // large matrices: the two block shapes (0 = not compared)
     bool stream_nt = false; // non-temporal matrix loads in the stream kernel
     mi_bcsr4_t blocked = nullptr; // BCSR 4x4 copy (exact 4x4 node-block structure only), else null
     double tune_us_bcsr = 0.0;
@@ -374,7 +375,7 @@ static void free_mring(mi_csr_t A)
 }
 
 // Plan of the multi-window ring kernel (host arrays of the caller, or nullptr: the handle's device copy is read back)
-static int build_mring(mi_csr_t A, const int* indcol)
+static int build_mring(mi_csr_t A, const int* indcol, int row_align = 0)
 {
     if (A->mring.d_plan || A->n == 0 || A->nnz == 0) return MI_OK;
     std::vector<int> back;
@@ -385,7 +386,7 @@ static int build_mring(mi_csr_t A, const int* indcol)
         indcol = back.data();
     }
     MringPlanHost P;
-    build_mring_plan(A->n, A->h_ptrow.data(), indcol, P);
+    build_mring_plan(A->n, A->h_ptrow.data(), indcol, P, row_align);
     MringTable& M = A->mring;
     hipError_t e;
     if ((e = hipMalloc(&M.d_plan, sizeof(int) * P.plan.size())) != hipSuccess ||
@@ -459,6 +460,77 @@ static int build_tile(mi_csr_t A, const int* indcol)
 static int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr);
 static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);
 static int resolve_kernel(const mi_csr_s* A);
+
+static void free_ring_table(RingTable& R)
+{
+    dfree(R.d_plan);
+    dfree(R.d_ok);
+    dfree(R.d_rng);
+    dfree(R.d_run_halo);
+    dfree(R.d_slots);
+    R = RingTable();
+}
+
+// device copy of a ring plan (plan records, run tables, 16-bit column stream) and what the launch needs to know about it
+static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const int* ptrow, const int* indcol, long long nnz, bool ghosts)
+{
+    R.cfg = best.cfg;
+    // Blocks of prefetch: with long runs (C4: 72 blocks per workgroup) four blocks in flight instead of two hide more of
+    // the HBM latency — same handle, same box, back to back 172.8 / 168.8 / 167.5 us at depth 2 / 3 / 4, cold caches
+    // 198.2 / 194.2 / 191.9 us; with short runs (1 M rows: 14 blocks) the longer pipeline fill costs more than it hides:
+    // 34.7 / 35.1 / 37.3 us (tools/depth_ab.py, profiles/r02_ring_depth_ab.txt).  Configuration 4 only.
+    if (best.cfg.id == 4 && best.bpw >= 40) R.cfg.depth = 4;
+    if (const char* e = getenv("MI355_RING_DEPTH")) {
+        const int d = atoi(e);
+        if (best.cfg.id == 4 && d >= 2 && d <= 4) R.cfg.depth = d;
+    }
+    R.nblk = best.nblk;
+    R.wgs = best.wgs;
+    R.bpw = best.bpw;
+    R.bad_runs = best.bad_runs;
+    R.ok_fraction = nnz ? 1.0 - (double)best.bad_nnz / (double)nnz : 0.0;
+    R.lean = best.lean && best.cfg.id == 4 && !(getenv("MI355_RING_LEAN") && !strcmp(getenv("MI355_RING_LEAN"), "0"));
+    if (best.nblk <= 0) return MI_OK;
+    hipError_t e;
+#define RING_TRY(expr)                                                                                                      \
+    if ((e = (expr)) != hipSuccess) {                                                                                       \
+        free_ring_table(R);                                                                                                 \
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e)); \
+    }
+    RING_TRY(hipMalloc(&R.d_plan, sizeof(int) * best.plan.size()));
+    RING_TRY(hipMemcpy(R.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
+    RING_TRY(hipMalloc(&R.d_ok, sizeof(int) * best.run_ok.size()));
+    RING_TRY(hipMemcpy(R.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
+    for (int g = 0; g < best.wgs; g++)
+        R.uniform = R.uniform && best.run_rng[2 * g] == std::min(best.nblk, g * best.bpw) &&
+                    best.run_rng[2 * g + 1] == std::min(best.nblk, (g + 1) * best.bpw);
+    RING_TRY(hipMalloc(&R.d_rng, sizeof(int) * best.run_rng.size()));
+    RING_TRY(hipMemcpy(R.d_rng, best.run_rng.data(), sizeof(int) * best.run_rng.size(), hipMemcpyHostToDevice));
+    if (ghosts) {
+        R.h_run_halo = best.run_halo;
+        RING_TRY(hipMalloc(&R.d_run_halo, sizeof(int) * best.run_halo.size()));
+        RING_TRY(hipMemcpy(R.d_run_halo, best.run_halo.data(), sizeof(int) * best.run_halo.size(), hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<unsigned short> slots;
+        build_ring_slots(best, indcol, slots);
+        RING_TRY(hipMalloc(&R.d_slots, sizeof(unsigned short) * slots.size()));
+        RING_TRY(hipMemcpy(R.d_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice));
+    }
+#undef RING_TRY
+    // staging layout of the row chains: plain unless more than a tenth of the rows have a length
+    // that is a multiple of 8 (their LDS segments would start on the same two banks)
+    long long mult8 = 0;
+    for (int i = 0; i < n; i++) {
+        const int len = ptrow[i + 1] - ptrow[i];
+        mult8 += len > 0 && len % 8 == 0;
+    }
+    R.skew = 10 * mult8 > n;
+    if (const char* e2 = getenv("MI355_RING_SKEW")) R.skew = atoi(e2) != 0;
+    return MI_OK;
+}
+
+static int time_handle(mi_csr_t A, int warm, int timed, double* us);
 
 static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
                            const int* rowmap, mi_csr_t* out, int ghost_lo = 0, int ghost_hi = 0)
@@ -549,52 +621,12 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             }
             if (forced) break;
         }
-        A->ring.cfg = best.cfg;
-        // Blocks of prefetch: with long runs (C4: 72 blocks per workgroup) four blocks in flight instead of two hide more of
-        // the HBM latency — same handle, same box, back to back 172.8 / 168.8 / 167.5 us at depth 2 / 3 / 4, cold caches
-        // 198.2 / 194.2 / 191.9 us; with short runs (1 M rows: 14 blocks) the longer pipeline fill costs more than it hides:
-        // 34.7 / 35.1 / 37.3 us (tools/depth_ab.py, profiles/r02_ring_depth_ab.txt).  Configuration 4 only.
-        if (best.cfg.id == 4 && best.bpw >= 40) A->ring.cfg.depth = 4;
-        if (const char* e = getenv("MI355_RING_DEPTH")) {
-            const int d = atoi(e);
-            if (best.cfg.id == 4 && d >= 2 && d <= 4) A->ring.cfg.depth = d;
-        }
-        A->ring.nblk = best.nblk;
-        A->ring.wgs = best.wgs;
-        A->ring.bpw = best.bpw;
-        A->ring.bad_runs = best.bad_runs;
-        A->ring.ok_fraction = 1.0 - (double)best.bad_nnz / (double)nnz;
-        A->ring.lean = best.lean && best.cfg.id == 4 && !(getenv("MI355_RING_LEAN") && !strcmp(getenv("MI355_RING_LEAN"), "0"));
-        if (best.nblk > 0) {
-            TRY_OR_CLEAN(hipMalloc(&A->ring.d_plan, sizeof(int) * best.plan.size()));
-            TRY_OR_CLEAN(hipMemcpy(A->ring.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
-            TRY_OR_CLEAN(hipMalloc(&A->ring.d_ok, sizeof(int) * best.run_ok.size()));
-            TRY_OR_CLEAN(hipMemcpy(A->ring.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
-            for (int g = 0; g < best.wgs; g++)
-                A->ring.uniform = A->ring.uniform && best.run_rng[2 * g] == std::min(best.nblk, g * best.bpw) &&
-                                  best.run_rng[2 * g + 1] == std::min(best.nblk, (g + 1) * best.bpw);
-            TRY_OR_CLEAN(hipMalloc(&A->ring.d_rng, sizeof(int) * best.run_rng.size()));
-            TRY_OR_CLEAN(hipMemcpy(A->ring.d_rng, best.run_rng.data(), sizeof(int) * best.run_rng.size(), hipMemcpyHostToDevice));
-            if (ghost_lo < ghost_hi) {
-                A->ring.h_run_halo = best.run_halo;
-                TRY_OR_CLEAN(hipMalloc(&A->ring.d_run_halo, sizeof(int) * best.run_halo.size()));
-                TRY_OR_CLEAN(hipMemcpy(A->ring.d_run_halo, best.run_halo.data(), sizeof(int) * best.run_halo.size(), hipMemcpyHostToDevice));
+        {
+            const int rcr = fill_ring_table(A->ring, best, n, ptrow, indcol, nnz, ghost_lo < ghost_hi);
+            if (rcr != MI_OK) {
+                mi_csr_destroy(A);
+                return rcr;
             }
-            {
-                std::vector<unsigned short> slots;
-                build_ring_slots(best, indcol, slots);
-                TRY_OR_CLEAN(hipMalloc(&A->ring.d_slots, sizeof(unsigned short) * slots.size()));
-                TRY_OR_CLEAN(hipMemcpy(A->ring.d_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice));
-            }
-            // staging layout of the row chains: plain unless more than a tenth of the rows have a length
-            // that is a multiple of 8 (their LDS segments would start on the same two banks)
-            long long mult8 = 0;
-            for (int i = 0; i < n; i++) {
-                const int len = ptrow[i + 1] - ptrow[i];
-                mult8 += len > 0 && len % 8 == 0;
-            }
-            A->ring.skew = 10 * mult8 > n;
-            if (const char* e = getenv("MI355_RING_SKEW")) A->ring.skew = atoi(e) != 0;
         }
         A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     }
@@ -778,6 +810,50 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
             A->kernel = MI_KERNEL_AUTO;
             const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : (A->auto_kernel == MI_KERNEL_MRING ? best_mring : best_stream));
             if (better(A->tune_us_bcsr, best_csr)) A->auto_kernel = MI_KERNEL_BCSR4;
+        }
+        // Large ring-served matrices: blocks ending on multiples of 64 rows (the default plan) against unaligned blocks — which
+        // is faster depends on the box (ring_plan.hpp), so both are built and timed; the loser is released.
+        if (A->auto_kernel == MI_KERNEL_RING && A->ring.cfg.id == 4 && nnz >= 20000000 && !(ghost_lo < ghost_hi) &&
+            !getenv("MI355_RING_ROW_ALIGN")) {
+            RingPlanHost alt;
+            build_ring_plan(kRingConfigs[3], n, ptrow, row_min.data(), row_max.data(), alt, 0, 0, 1);
+            RingTable T2;
+            if (nnz > 0 && 1.0 - (double)alt.bad_nnz / (double)nnz >= 0.90 && fill_ring_table(T2, alt, n, ptrow, indcol, nnz, false) == MI_OK) {
+                T2.nt = A->ring.nt;
+                double us64 = 0.0, us1 = 0.0;
+                A->kernel = MI_KERNEL_RING;
+                int rct = time_handle(A, 3, 8, &us64);
+                std::swap(A->ring, T2);
+                if (rct == MI_OK) rct = time_handle(A, 3, 8, &us1);
+                A->kernel = MI_KERNEL_AUTO;
+                A->tune_us_ring_aligned = us64;
+                A->tune_us_ring_unaligned = us1;
+                if (rct != MI_OK || !(us1 < 0.98 * us64)) std::swap(A->ring, T2); // keep the default unless the other is clearly faster
+                free_ring_table(T2);
+            }
+        }
+        if (A->auto_kernel == MI_KERNEL_MRING && nnz >= 20000000 && !getenv("MI355_RING_ROW_ALIGN")) { // the same for the multi-window ring
+            MringTable keep = A->mring;
+            A->mring = MringTable();
+            if (build_mring(A, indcol, 1) == MI_OK && A->mring.d_plan && A->mring.ok_fraction >= 0.90) {
+                A->mring.nt = keep.nt;
+                double us64 = 0.0, us1 = 0.0;
+                A->kernel = MI_KERNEL_MRING;
+                int rct = time_handle(A, 3, 8, &us1);
+                std::swap(A->mring, keep);
+                if (rct == MI_OK) rct = time_handle(A, 3, 8, &us64);
+                A->kernel = MI_KERNEL_AUTO;
+                A->tune_us_ring_aligned = us64;
+                A->tune_us_ring_unaligned = us1;
+                if (rct == MI_OK && us1 < 0.98 * us64) std::swap(A->mring, keep); // the unaligned plan is clearly faster here
+            } else {
+                std::swap(A->mring, keep);
+            }
+            MringTable loser = keep; // release the plan not kept
+            keep = A->mring;
+            A->mring = loser;
+            free_mring(A);
+            A->mring = keep;
         }
     }
 #undef TRY_OR_CLEAN
@@ -1446,6 +1522,18 @@ extern "C" int mi_ring_plan_lean(int n, const int* ptrow, const int* indcol, int
     RingPlanHost P;
     build_ring_plan(kRingConfigs[config_id - 1], n, ptrow, row_min.data(), row_max.data(), P);
     *lean = P.lean && P.cfg.id == 4 && P.bad_runs == 0;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_ring_shape_info(mi_csr_t A, int* blocks, int* lean, int* depth, double* us_aligned, double* us_unaligned)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (blocks) *blocks = A->ring.nblk;
+    if (lean) *lean = A->ring.lean;
+    if (depth) *depth = A->ring.cfg.depth;
+    if (us_aligned) *us_aligned = A->tune_us_ring_aligned;
+    if (us_unaligned) *us_unaligned = A->tune_us_ring_unaligned;
     return MI_OK;
 }
 

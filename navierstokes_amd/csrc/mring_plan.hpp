@@ -31,6 +31,7 @@
 // Pure integer work; checked by replay in mi_mring_plan_probe (every nonzero's slot holds its column when its block runs).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "ring_plan.hpp"
@@ -60,14 +61,16 @@ struct MringPlanHost {
     long long restarts = 0;            // runs started because a block needed more groups than the loop refills (diagnostic)
 };
 
-inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPlanHost& out)
+inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPlanHost& out, int row_align_arg = 0)
 {
     out = MringPlanHost();
     const int K = kMringK, W = kMringW, T = kMringThreads, nnzb = kMringNnzb, per = nnzb / T, G = kMringGroups;
     std::vector<int> rows, ptrs;
     // <= T rows per block (the kernel makes one pass over a block's rows), whole waves of rows where that keeps 7/8 of the block
     // (ring_plan.hpp: the row-chain phase is the LDS-bound part)
-    build_row_blocks(n, ptrow, nnzb, T, rows, ptrs, 64, 7);
+    int row_align = row_align_arg > 0 ? row_align_arg : 64; // (large matrices: mi_csr_create times both shapes, ring_plan.hpp)
+    if (const char* e = getenv("MI355_RING_ROW_ALIGN")) row_align = std::max(1, atoi(e)); // (A/B: tools/rowalign_ab.py)
+    build_row_blocks(n, ptrow, nnzb, T, rows, ptrs, row_align, 7);
     const int nblk = (int)rows.size() - 1;
     out.nblk = nblk;
     if (nblk <= 0) return;

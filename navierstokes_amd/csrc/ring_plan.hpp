@@ -109,8 +109,9 @@ inline void build_ring_blocks(int n, const int* ptrow, const int* row_min, const
 
 // row_min/row_max: smallest / largest column of each row (row_min > row_max for an empty row)
 // ghost_lo < ghost_hi: shape the runs for the fused step as described above (and fill run_halo)
+// row_align: blocks end on multiples of that many rows (1: no alignment; 0: the default — 64 for configuration 4, see below)
 inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, const int* row_min, const int* row_max,
-                            RingPlanHost& out, int ghost_lo = 0, int ghost_hi = 0)
+                            RingPlanHost& out, int ghost_lo = 0, int ghost_hi = 0, int row_align_arg = 0)
 {
     out = RingPlanHost();
     out.cfg = cfg;
@@ -119,8 +120,11 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
     const int max_rows = cfg.id == 4 ? cfg.threads : 2 * cfg.threads;
     // Row-chain phase: one thread per row, so a block of 137 rows keeps THREE waves busy for 2.14 waves of work, and the kernel's
     // busiest unit is the LDS.  Blocks are therefore ended on multiples of 64 rows where that gives up less than an eighth of the
-    // block's nonzeros (S15: 128 rows / 1920 nonzeros instead of 136 / 2040).  MI355_RING_ROW_ALIGN=1 switches it off (A/B).
-    int row_align = cfg.id == 4 ? 64 : 1;
+    // block's nonzeros (S15: 128 rows / 1920 nonzeros instead of 136 / 2040): 2-5 % faster at 1 M rows on every box tried; at
+    // 5 M rows 150 -> 140 us on one box and 151 -> 158 us on another (in-process A/B, profiles/r02_ring_rowalign_ab.txt) — so for
+    // large matrices mi_csr_create builds both plans and keeps the one that measures faster on the box at hand.
+    // MI355_RING_ROW_ALIGN=1|64 forces one.
+    int row_align = row_align_arg > 0 ? row_align_arg : (cfg.id == 4 ? 64 : 1);
     if (const char* e = getenv("MI355_RING_ROW_ALIGN")) row_align = std::max(1, atoi(e));
     build_ring_blocks(n, ptrow, row_min, row_max, cfg.nnzb, max_rows, 0x7fffffff, rows, ptrs, row_align);
     {   // span-limited blocks where that takes only a few cuts; a matrix whose rows themselves outspan the ring would

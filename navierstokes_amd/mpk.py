@@ -94,6 +94,7 @@ def lib():
         "mi_csr_set_kernel": [_vp, i],
         "mi_csr_get_kernel": [_vp, P(i)],
         "mi_csr_ring_info": [_vp, P(i), P(i), P(i), P(d)],
+        "mi_csr_ring_shape_info": [_vp, P(i), P(i), P(i), P(d), P(d)],
         "mi_csr_tune_info": [_vp, P(d), P(d)],
         "mi_csr_tune_detail": [_vp, P(d), P(_c.c_int), P(_c.c_int)],
         "mi_csr_set_nontemporal": [_vp, i, i],
@@ -244,6 +245,13 @@ class csrmatrix:
         frac = _c.c_double()
         check(lib().mi_csr_ring_info(self.handle, _c.byref(cfg), _c.byref(runs), _c.byref(bad), _c.byref(frac)))
         return cfg.value, runs.value, bad.value, frac.value
+
+    def ring_shape_info(self):
+        """dict(blocks, lean, depth, us_aligned, us_unaligned) — mi_csr_ring_shape_info."""
+        b, l, dd = _c.c_int(), _c.c_int(), _c.c_int()
+        ua, uu = _c.c_double(), _c.c_double()
+        check(lib().mi_csr_ring_shape_info(self.handle, _c.byref(b), _c.byref(l), _c.byref(dd), _c.byref(ua), _c.byref(uu)))
+        return dict(blocks=b.value, lean=bool(l.value), depth=dd.value, us_aligned=ua.value, us_unaligned=uu.value)
 
     def tune_info(self):
         """(us per launch measured for ring, for stream) at create time; zeros if not measured."""
