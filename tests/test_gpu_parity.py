@@ -382,7 +382,11 @@ def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MI355_DIST_FORCE_SELFCHECK="1", MI355_TEST_EXCHANGE=exchange)
+    # (ranks SHARING a card is a test arrangement, not a supported deployment: a rank's kernel may sit out whole time slices of
+    # the other processes, so the in-kernel wait for a neighbour's push gets 2^23 polls (~30 s) here instead of the default ~4 s —
+    # once in a dozen runs of the four-process case the default gave up; a wait that gives up is still loud and fails the run)
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MI355_DIST_FORCE_SELFCHECK="1", MI355_TEST_EXCHANGE=exchange,
+               MI355_PUSH_SPIN_LOG2=os.environ.get("MI355_PUSH_SPIN_LOG2", "23"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_gpu_worker.py"), kind, str(n), str(w)]
