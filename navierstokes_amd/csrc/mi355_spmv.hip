@@ -344,7 +344,12 @@ static int get_table(mi_csr_t A, int nnzb, BlockTable** out)
     BlockTable& T = A->tables[nnzb];
     if (!T.d_blk) {
         std::vector<int> rows, ptrs;
-        build_row_blocks(A->n, A->h_ptrow.data(), nnzb, 4 * kWG, rows, ptrs);
+        // whole waves of rows for the one-thread-per-row chain phase where that keeps 7/8 of the block (ring_plan.hpp) — for
+        // matrices that live in the Infinity Cache: S15 1 M rows 61 -> 56 us, but the 5 M-row mesh 180 -> 193 us
+        // (tools/stream_align_ab.py); MI355_STREAM_ROW_ALIGN=1|64 forces (A/B)
+        int row_align = A->nnz < 20000000 ? 64 : 1;
+        if (const char* e = getenv("MI355_STREAM_ROW_ALIGN")) row_align = std::max(1, atoi(e));
+        build_row_blocks(A->n, A->h_ptrow.data(), nnzb, 4 * kWG, rows, ptrs, row_align, 7);
         T.nnzb = nnzb;
         T.nblk = (int)rows.size() - 1;
         std::vector<int2> h(rows.size());
@@ -433,7 +438,7 @@ static int build_tile(mi_csr_t A, const int* indcol)
         indcol = back.data();
     }
     TilePlanHost P;
-    build_tile_plan(A->n, A->h_ptrow.data(), indcol, P);
+    build_tile_plan(A->n, A->h_ptrow.data(), indcol, P, kTileNnzb, 0, A->nnz < 20000000 ? 64 : 1);
     TileTable& T = A->tile;
     hipError_t e;
     if ((e = hipMalloc(&T.d_desc, sizeof(int) * P.desc.size())) != hipSuccess ||

@@ -37,12 +37,14 @@ struct TilePlanHost {
     int max_unique = 0;
 };
 
-inline void build_tile_plan(int n, const int* ptrow, const int* indcol, TilePlanHost& out, int nnzb = kTileNnzb, int threads = 0)
+inline void build_tile_plan(int n, const int* ptrow, const int* indcol, TilePlanHost& out, int nnzb = kTileNnzb, int threads = 0,
+                            int row_align = 64)
 {
     out = TilePlanHost();
     out.nnzb = nnzb;
     std::vector<int> rows, ptrs;
-    build_row_blocks(n, ptrow, nnzb, 4 * kTileThreads, rows, ptrs, 64, 7); // whole waves of rows for the row-chain phase (ring_plan.hpp)
+    build_row_blocks(n, ptrow, nnzb, 4 * kTileThreads, rows, ptrs, row_align, 7); // whole waves of rows for the row-chain phase
+                                                                                   // (ring_plan.hpp; the caller decides by matrix size)
     const int nblk = (int)rows.size() - 1;
     out.nblk = nblk;
     out.desc.assign((size_t)4 * (nblk + 1), 0);
