@@ -355,6 +355,9 @@ int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_st
  * touch ghosts, which are ordered last) live inside that kernel (spmv_ring.hpp, FUSED; MI355_PUSH_FUSED=0 disables).
  * In the fused form the halo part of d_x_ext is neither read nor written. */
 int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
+/* Step down from the one-launch form to the four-launch form (push, interior rows, wait + copy, boundary rows).  All ranks must
+ * drive the step the same way; the caller compares mi_part_push_info's `fused` across ranks and calls this where they differ. */
+int mi_part_push_unfuse(mi_part_t P);
 /* give the push exchange up again (e.g. after a failed collective self-check): windows released, sticky give-ups cleared */
 int mi_part_push_disable(mi_part_t P);
 /* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */

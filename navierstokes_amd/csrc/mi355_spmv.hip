@@ -2966,6 +2966,25 @@ extern "C" int mi_part_push_disable(mi_part_t P)
     return MI_OK;
 }
 
+// All ranks must drive the step the same way: whether the one-launch form is available is decided per rank (it needs the ring
+// kernel to be the measured choice for the rank's combined piece), so the caller makes the decision collective and the ranks
+// that could have fused step down to the four-launch form when a neighbour cannot.  (Ranks mixing the two forms passed the
+// bitwise checks but, four processes sharing one card, a fused rank's in-kernel wait gave up in one run of four.)
+extern "C" int mi_part_push_unfuse(mi_part_t P)
+{
+    CHECK_ARG(P, "null handle");
+    if (!P->fused) return MI_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    P->fused = P->fused_bcsr = false;
+    dfree(P->d_run_link);
+    dfree(P->d_wg_halo);
+    P->d_run_link = nullptr;
+    P->d_wg_halo = nullptr;
+    mi_csr_destroy(P->piece_all);
+    P->piece_all = nullptr;
+    return MI_OK;
+}
+
 extern "C" int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours)
 {
     CHECK_ARG(P, "null handle");

@@ -205,7 +205,12 @@ class DistCSR:
         if all(flags):
             fused = _c.c_int()
             mpk.check(L.mi_part_push_info(self._h, None, _c.byref(fused), None))
-            self.push_fused = bool(fused.value)
+            # one form for everybody: the one-launch step only if EVERY rank can run it (it depends on each rank's measured kernel)
+            every = [None] * self.nranks
+            dist.all_gather_object(every, bool(fused.value), group=self.group)
+            if fused.value and not all(every):
+                mpk.check(L.mi_part_push_unfuse(self._h))
+            self.push_fused = bool(fused.value) and all(every)
         return all(flags)
 
     def update_values(self, coef):

@@ -84,6 +84,7 @@ def lib():
         "mi_part_push_info": [_vp, P(i), P(i), P(i)],
         "mi_part_combined_info": [_vp, P(i)],
         "mi_part_push_disable": [_vp],
+        "mi_part_push_unfuse": [_vp],
         "mi_bcsr4_spmm": [_vp, i, _vp, ll, _vp, ll, i],
         "mi_bcsr4_spmm_dev": [_vp, i, _vp, ll, _vp, ll, i, _vp],
         "mi_spmm_dev": [_vp, i, _vp, ll, _vp, ll, _vp],

@@ -27,14 +27,22 @@ def main():
     p, c, v = synth.rows(kind, n, lo, hi, w=w)
     ok = True
     exchange = os.environ.get("MI355_TEST_EXCHANGE", "torch")
+    trace = os.environ.get("MI355_TEST_TRACE") == "1"
+
+    def mark(what):  # stage markers for a post-mortem of a stalled rank (MI355_TEST_TRACE=1)
+        if trace:
+            print(f"[rank {rank}] {what}", file=sys.stderr, flush=True)
     for kernel in (None, "ring", "stream"):
+        mark(f"kernel={kernel}: create")
         dc = D.DistCSR(rs, p, c, v, kernel=kernel, exchange=exchange)
+        mark(f"kernel={kernel}: created push={dc.push} fused={dc.push_fused} n_halo={dc.n_halo}")
         assert not dc.native  # gloo: no RCCL
         assert dc.push == (exchange in ("push", "auto")), "peer-push exchange was requested but did not come up (or vice versa)"
         x_ext = dc.new_x_ext()
         x_ext[: dc.n_local] = torch.from_numpy(synth.x_sin(lo, hi)).cuda()
         ys = dc.spmk(x_ext, dc.new_power_buffers(3))
         torch.cuda.synchronize()
+        mark("powers done")
         Y = O.spmk_chain(3, Pg, Cg, Vg, synth.x_sin(0, n))
         ok = ok and all(np.array_equal(ys[k].cpu().numpy().view(np.uint64), Y[k][lo:hi].view(np.uint64)) for k in range(3))
         if dc.push:  # many unsynchronised repetitions of one step into the same buffers: the windows' two parities at work
@@ -42,6 +50,7 @@ def main():
             for _ in range(50):
                 dc.spmv(x_ext, y)
             torch.cuda.synchronize()
+            mark("50 repetitions done")
             dc.status()
             ok = ok and np.array_equal(y.cpu().numpy().view(np.uint64), Y[0][lo:hi].view(np.uint64))
             # the step protocol under skew: 36 steps that alternate between THREE different x vectors (so a ghost taken from the
@@ -61,6 +70,7 @@ def main():
                     time.sleep(rnd.random() * 0.004)
                 dc.spmv(xs[t % 3], outs[t])
             torch.cuda.synchronize()
+            mark("skew steps done")
             dc.status()
             refs = [O.spmv(Pg, Cg, Vg, g_)[lo:hi] for g_ in xg]
             ok = ok and all(np.array_equal(outs[t].cpu().numpy().view(np.uint64), refs[t % 3].view(np.uint64)) for t in range(36))
@@ -74,6 +84,7 @@ def main():
         full_v2[Pg[lo]:Pg[hi]] = v2
         ok = ok and np.array_equal(y2.cpu().numpy().view(np.uint64), O.spmv(Pg, Cg, full_v2, synth.x_sin(0, n))[lo:hi].view(np.uint64))
         dc.update_values(v)
+        mark("update_values done")
         g = float(dc.dot(ys[0], ys[0]))
         ref = float(np.dot(Y[0], Y[0]))
         ok = ok and abs(g - ref) <= 1e-12 * ref
