@@ -2892,6 +2892,11 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
         if (rc) return rc;
         mi_csr_t A = P->piece_all;
         if (P->kernel != MI_KERNEL_AUTO && P->kernel != MI_KERNEL_RING) A->kernel = P->kernel;
+        // Where the ring serves the combined piece it is taken even if another kernel measured a hair faster on this rank: the
+        // one-launch step saves three launches, and it only happens if EVERY rank has it (mi_part_push_unfuse) — a rank whose
+        // create-time measurement tipped the other way by noise would cost all of them the fused step.
+        if (P->kernel == MI_KERNEL_AUTO && A->ring.d_plan && A->ring.d_run_halo && A->ring.ok_fraction >= 0.90 && !A->blocked)
+            A->kernel = MI_KERNEL_RING;
         P->fused = resolve_kernel(A) == MI_KERNEL_RING && A->ring.d_run_halo;
         if (P->fused) { // push duty goes to the ghost-touching runs (short by construction): link l to the (l mod k)-th of them
             std::vector<int> link((size_t)A->ring.wgs, -1);
