@@ -517,10 +517,10 @@ def main():
         tune, nt = A.tune_detail()
         out["kernel_info"] = dict(kernel=kernel_name, ring_config=ring_cfg, runs=ring_runs, runs_on_plain_path=ring_bad,
                                   nnz_fraction_ring=round(ring_frac, 4), nontemporal_values=nt,
-                                  matrix_stream_bytes_per_nnz=10 if "ring" in kernel_name else (8.25 if "bcsr4" in kernel_name else
+                                  matrix_stream_bytes_per_nnz=10 if "ring<" in kernel_name else (8.25 if "bcsr4" in kernel_name else
                                                               round(10 + 4 * A.tile_info()["unique_per_nnz"], 2) if "tile" in kernel_name else 12),
                                   autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
-        if "ring<" in kernel_name:
+        if "spmv_csr_ring<" in kernel_name:
             rs = A.ring_shape_info()
             out["kernel_info"]["ring_plan"] = dict(row_blocks=rs["blocks"], lean=rs["lean"], prefetch_depth=rs["depth"],
                                                    us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
