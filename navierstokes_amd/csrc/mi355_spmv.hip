@@ -818,12 +818,13 @@ static int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol
         }
         // Large ring-served matrices: blocks ending on multiples of 64 rows (the default plan) against unaligned blocks — which
         // is faster depends on the box (ring_plan.hpp), so both are built and timed; the loser is released.
-        if (A->auto_kernel == MI_KERNEL_RING && A->ring.cfg.id == 4 && nnz >= 20000000 && !(ghost_lo < ghost_hi) &&
-            !getenv("MI355_RING_ROW_ALIGN")) {
+        // (a rank's combined piece of the fused multi-GPU step included: timed here without the exchange, as a plain product)
+        if (A->auto_kernel == MI_KERNEL_RING && A->ring.cfg.id == 4 && nnz >= 20000000 && !getenv("MI355_RING_ROW_ALIGN")) {
             RingPlanHost alt;
-            build_ring_plan(kRingConfigs[3], n, ptrow, row_min.data(), row_max.data(), alt, 0, 0, 1);
+            build_ring_plan(kRingConfigs[3], n, ptrow, row_min.data(), row_max.data(), alt, ghost_lo, ghost_hi, 1);
             RingTable T2;
-            if (nnz > 0 && 1.0 - (double)alt.bad_nnz / (double)nnz >= 0.90 && fill_ring_table(T2, alt, n, ptrow, indcol, nnz, false) == MI_OK) {
+            if (nnz > 0 && 1.0 - (double)alt.bad_nnz / (double)nnz >= 0.90 &&
+                fill_ring_table(T2, alt, n, ptrow, indcol, nnz, ghost_lo < ghost_hi) == MI_OK) {
                 T2.nt = A->ring.nt;
                 double us64 = 0.0, us1 = 0.0;
                 A->kernel = MI_KERNEL_RING;
