@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+import ctypes as _ct
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -211,7 +213,9 @@ def main():
         bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
         A = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
         _ = A.handle
-        kernel_name = "spmv_bcsr4<2>"
+        bt = [_ct.c_int(), _ct.c_int(), _ct.c_double(), _ct.c_double()]
+        mpk.check(mpk.lib().mi_bcsr4_tile_info(A.handle, _ct.byref(bt[0]), _ct.byref(bt[1]), _ct.byref(bt[2]), _ct.byref(bt[3])))
+        kernel_name = "spmv_bcsr4_tile<2>" if bt[1].value else "spmv_bcsr4<2>"
         ring_cfg, ring_runs, ring_bad, ring_frac = 0, 0, 0, 0.0
         x = torch.from_numpy(x_host).cuda()
         ys = [torch.empty(n, dtype=torch.float64, device="cuda")]

@@ -245,6 +245,11 @@ int mi_gather_dev(int m, const int* d_idx, const double* d_src, double* d_dst, m
 int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
                     mi_bcsr4_t* out);
 int mi_bcsr4_destroy(mi_bcsr4_t A);
+/* The blocked kernel exists in two forms: x blocks gathered through L1/L2 per block (spmv_bcsr4), or each workgroup's distinct
+ * block columns gathered once into an LDS tile and addressed through a 16-bit stream (spmv_bcsr4_tile; built when no group of 64
+ * block rows touches more than 1024 block columns).  mi_bcsr4_create times both and keeps the faster; same bits.
+ * MI355_BCSR_TILE=0|1 forces. */
+int mi_bcsr4_tile_info(mi_bcsr4_t A, int* built, int* in_use, double* us_plain, double* us_tile);
 /* new block values (16 per block, row-major) for an unchanged block pattern; see mi_csr_update_values */
 int mi_bcsr4_update_values(mi_bcsr4_t A, const double* coef);
 int mi_bcsr4_update_values_dev(mi_bcsr4_t A, const double* d_coef, mi_stream_t s);

@@ -170,6 +170,12 @@ struct mi_bcsr4_s {
     int* d_indcol = nullptr;
     double* d_coef = nullptr;
     int* d_browmap = nullptr; // block-row map of a reordered matrix's blocked copy, else null
+    // x tile per workgroup (spmv_bcsr4_tile): lists of distinct block columns and 16-bit positions; null if not built
+    int* d_tl_ptr = nullptr;
+    unsigned* d_tl_nodes = nullptr;
+    unsigned short* d_tl_slots = nullptr;
+    bool use_tile = false;    // the measured choice between the two kernels (MI355_BCSR_TILE=0|1 forces)
+    double tune_us_plain = 0.0, tune_us_tile = 0.0;
     double* d_x = nullptr;
     double* d_y = nullptr;
     std::vector<double*> d_pow;
@@ -1587,7 +1593,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
         return nm;
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
-    case MI_KERNEL_BCSR4: return "spmv_bcsr4<2>";
+    case MI_KERNEL_BCSR4: return A->blocked && A->blocked->use_tile && A->blocked->d_tl_ptr ? "spmv_bcsr4_tile<2>" : "spmv_bcsr4<2>";
     case MI_KERNEL_MRING: {
         static thread_local char nm[96];
         snprintf(nm, sizeof nm, "spmv_csr_mring<%d, %d, %d, %d, %s, %s, %s>", kMringThreads, kMringNnzb, A->mring.depth, kMringMaxB,
@@ -2113,7 +2119,82 @@ extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const i
         mi_bcsr4_destroy(A);
         return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 upload: ") + hipGetErrorString(e));
     }
+    // The x tile per workgroup (spmv_bcsr4_tile): the distinct block columns of each group of 64 block rows, and every block's
+    // position in its group's list.  Built when no group needs more than the tile holds; then both kernels are timed and the
+    // faster is kept (MI355_BCSR_TILE=0 never builds it, =1 takes it unmeasured).
+    const char* te = getenv("MI355_BCSR_TILE");
+    if (nb >= 4096 && !(te && !strcmp(te, "0"))) {
+        const int per = kWG / 4, nwg = (nbrows + per - 1) / per;
+        std::vector<int> wg_ptr((size_t)nwg + 1, 0);
+        std::vector<unsigned> nodes;
+        std::vector<unsigned short> slots((size_t)nb + 1, 0);
+        std::vector<unsigned> u;
+        bool fits = true;
+        for (int w = 0; w < nwg && fits; w++) {
+            const int b0 = ptrow[(size_t)w * per], b1 = ptrow[std::min<long long>((long long)(w + 1) * per, nbrows)];
+            u.assign(indcol + b0, indcol + b1);
+            std::sort(u.begin(), u.end());
+            u.erase(std::unique(u.begin(), u.end()), u.end());
+            fits = (int)u.size() <= kBtileNodes;
+            for (int k = b0; k < b1 && fits; k++) slots[k] = (unsigned short)(std::lower_bound(u.begin(), u.end(), (unsigned)indcol[k]) - u.begin());
+            nodes.insert(nodes.end(), u.begin(), u.end());
+            wg_ptr[w + 1] = (int)nodes.size();
+        }
+        if (fits) {
+            nodes.push_back(0);
+            if ((e = hipMalloc(&A->d_tl_ptr, sizeof(int) * wg_ptr.size())) != hipSuccess ||
+                (e = hipMalloc(&A->d_tl_nodes, sizeof(unsigned) * nodes.size())) != hipSuccess ||
+                (e = hipMalloc(&A->d_tl_slots, sizeof(unsigned short) * slots.size())) != hipSuccess ||
+                (e = hipMemcpy(A->d_tl_ptr, wg_ptr.data(), sizeof(int) * wg_ptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->d_tl_nodes, nodes.data(), sizeof(unsigned) * nodes.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->d_tl_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+                mi_bcsr4_destroy(A);
+                return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 tile upload: ") + hipGetErrorString(e));
+            }
+            const char* at = getenv("MI355_SPMV_AUTOTUNE");
+            if (te && !strcmp(te, "1")) A->use_tile = true;
+            else if (!(at && !strcmp(at, "0")) && nb >= 100000) { // measure both (x = 0: timing does not depend on the values)
+                double *tx = nullptr, *ty = nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                const size_t nx = 4 * (size_t)std::max(nbcols, 1), ny = 4 * (size_t)std::max(nbrows, 1);
+                if (hipMalloc(&tx, sizeof(double) * nx) == hipSuccess && hipMalloc(&ty, sizeof(double) * ny) == hipSuccess &&
+                    hipMemset(tx, 0, sizeof(double) * nx) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                    double us[2] = {0, 0};
+                    for (int round = 0; round < 2; round++)
+                        for (int c = 0; c < 2; c++) {
+                            A->use_tile = c == 1;
+                            for (int w = 0; w < 3; w++) (void)launch_bcsr4(A, tx, ty, nullptr, false);
+                            (void)hipEventRecord(e0, nullptr);
+                            for (int w = 0; w < 8; w++) (void)launch_bcsr4(A, tx, ty, nullptr, false);
+                            (void)hipEventRecord(e1, nullptr);
+                            (void)hipEventSynchronize(e1);
+                            float ms = 0.f;
+                            (void)hipEventElapsedTime(&ms, e0, e1);
+                            const double t = ms * 1e3 / 8;
+                            us[c] = us[c] > 0 ? std::min(us[c], t) : t;
+                        }
+                    A->tune_us_plain = us[0];
+                    A->tune_us_tile = us[1];
+                    A->use_tile = us[1] > 0 && us[1] < us[0];
+                }
+                dfree(tx);
+                dfree(ty);
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+            }
+        }
+    }
     *out = A;
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_tile_info(mi_bcsr4_t A, int* built, int* in_use, double* us_plain, double* us_tile)
+{
+    CHECK_ARG(A, "null handle");
+    if (built) *built = A->d_tl_ptr != nullptr;
+    if (in_use) *in_use = A->use_tile && A->d_tl_ptr;
+    if (us_plain) *us_plain = A->tune_us_plain;
+    if (us_tile) *us_tile = A->tune_us_tile;
     return MI_OK;
 }
 
@@ -2143,6 +2224,9 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     dfree(A->d_indcol);
     dfree(A->d_coef);
     dfree(A->d_browmap);
+    dfree(A->d_tl_ptr);
+    dfree(A->d_tl_nodes);
+    dfree(A->d_tl_slots);
     dfree(A->d_x);
     dfree(A->d_y);
     for (double* p : A->d_pow) dfree(p);
@@ -2161,6 +2245,12 @@ static int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_
     const int nwg = (int)((threads + kWG - 1) / kWG);
     static const int chunk = getenv("MI355_BCSR_XCD_CHUNK") ? atoi(getenv("MI355_BCSR_XCD_CHUNK")) : 0;
     const int grid = nwg;
+    if (A->use_tile && A->d_tl_ptr) {
+        Bcsr4Tile Tl{A->d_tl_ptr, A->d_tl_nodes, A->d_tl_slots};
+        hipLaunchKernelGGL(spmv_bcsr4_tile<kBcsrDepth>, dim3((unsigned)grid), dim3(kWG), 0, (hipStream_t)s, V, Tl, d_x, d_y, nwg);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
     hipLaunchKernelGGL(spmv_bcsr4<kBcsrDepth>, dim3((unsigned)grid), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y, chunk, nwg);
     HIP_TRY(hipGetLastError());
     return MI_OK;

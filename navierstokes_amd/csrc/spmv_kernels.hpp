@@ -292,6 +292,76 @@ __global__ __launch_bounds__(kWG) void spmv_bcsr4(Bcsr4View A, const double* __r
     y[4 * (size_t)(A.browmap ? A.browmap[bi] : bi) + q] = s;
 }
 
+// ---------------------------------------------------------------------------
+// spmv_bcsr4 with the x nodes of a workgroup's 64 block rows gathered ONCE into an LDS tile (the tile kernel's idea,
+// spmv_tile.hpp, at node granularity): the host lists each workgroup's distinct block columns (ascending) and gives every block
+// the 16-bit position of its column in that list.  The inner loop then waits for coefficients only — no column -> x round trip
+// through L1/L2 per block — and x is fetched once per workgroup instead of once per block (spmv_bcsr4 moves 1.14-1.17x its
+// format's bytes, the excess being x).  Same lanes, same fma order, same bits.  UMAX nodes of tile (32 bytes each).
+// ---------------------------------------------------------------------------
+constexpr int kBtileNodes = 1024;
+struct Bcsr4Tile {
+    const int* wg_ptr;            // [nwg + 1] first list entry of each workgroup
+    const unsigned* nodes;        // distinct block columns per workgroup
+    const unsigned short* slots;  // per block: position of its column in its workgroup's list
+};
+
+template <int P>
+__global__ __launch_bounds__(kWG) void spmv_bcsr4_tile(Bcsr4View A, Bcsr4Tile Tl, const double* __restrict__ x, double* __restrict__ y, int nwg)
+{
+    __shared__ __attribute__((aligned(16))) double s_x[4 * kBtileNodes];
+    const int wg = (int)blockIdx.x;
+    if (wg >= nwg) return;
+    const int tid = threadIdx.x;
+    const int g = wg * kWG + tid;
+    const int bi = min(g >> 2, A.nbrows - 1), q = g & 3; // (lanes past the last block row shadow it and store nothing)
+    const bool live = (g >> 2) < A.nbrows;
+    const int u0 = Tl.wg_ptr[wg], U = Tl.wg_ptr[wg + 1] - u0;
+    // the tile: every thread fetches whole nodes (two 16-byte loads), list first
+    for (int i = tid; i < U; i += kWG) {
+        const unsigned node = Tl.nodes[u0 + i];
+        const double2* xb = reinterpret_cast<const double2*>(x + 4 * (size_t)node);
+        const double2 v0 = xb[0], v1 = xb[1];
+        reinterpret_cast<double2*>(s_x)[2 * i] = v0;
+        reinterpret_cast<double2*>(s_x)[2 * i + 1] = v1;
+    }
+    const int ia0 = A.ptrow[bi], ia1 = A.ptrow[bi + 1];
+    const int last = max(ia1 - 1, ia0);
+    const double* cq = A.coef + 4 * q;
+    double2 a01[P], a23[P];
+    unsigned sl[P];
+#pragma unroll
+    for (int t = 0; t < P; t++) { // the first coefficient stages are in flight across the barrier
+        const int blk = min(ia0 + t, last);
+        const double2* row = reinterpret_cast<const double2*>(cq + 16 * (size_t)blk);
+        a01[t] = row[0];
+        a23[t] = row[1];
+        sl[t] = Tl.slots[blk];
+    }
+    __syncthreads();
+    double s = 0.0;
+    for (int ia = ia0; ia < ia1; ia += P) {
+#pragma unroll
+        for (int t = 0; t < P; t++) {
+            const double2 c01 = a01[t], c23 = a23[t];
+            const double2* xs = reinterpret_cast<const double2*>(s_x + 4 * sl[t]);
+            const double2 v01 = xs[0], v23 = xs[1];
+            const int nb = min(ia + t + P, last);
+            const double2* nrow = reinterpret_cast<const double2*>(cq + 16 * (size_t)nb);
+            a01[t] = nrow[0];
+            a23[t] = nrow[1];
+            sl[t] = Tl.slots[nb];
+            if (ia + t < ia1) {
+                s = fma(c01.x, v01.x, s);
+                s = fma(c01.y, v01.y, s);
+                s = fma(c23.x, v23.x, s);
+                s = fma(c23.y, v23.y, s);
+            }
+        }
+    }
+    if (live) y[4 * (size_t)(A.browmap ? A.browmap[bi] : bi) + q] = s;
+}
+
 } // namespace mi355
 
 namespace mi355 {

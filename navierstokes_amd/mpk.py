@@ -103,6 +103,7 @@ def lib():
         "mi_ring_plan_probe": [i, _vp, _vp, i, P(i), P(i), P(i), P(d), P(i)],
         "mi_ring_plan_lean": [i, _vp, _vp, i, P(i)],
         "mi_csr_tile_info": [_vp, P(i), P(i), P(d), P(d), P(i)],
+        "mi_bcsr4_tile_info": [_vp, P(i), P(i), P(d), P(d)],
         "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
         "mi_mring_plan_probe": [i, _vp, _vp, P(i), P(i), P(i), P(d), P(ll)],
         "mi_tile_plan_probe": [i, _vp, _vp, i, P(i), P(ll), P(i), P(ll)],

@@ -597,3 +597,35 @@ def test_random_patterns_every_kernel(seed):
         y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
         mpk.SpMV_CSR(y, dev(x), A)
         assert_bit_equal(y.cpu().numpy(), yr, f"seed {seed} n {n} {kernel} -> {A.kernel_name()}")
+
+
+@pytest.mark.parametrize("force", ["0", "1"])
+def test_blocked_kernel_with_and_without_the_x_tile(force, monkeypatch):
+    """spmv_bcsr4 (x blocks through L1/L2) and spmv_bcsr4_tile (each workgroup's distinct block columns once into LDS): the same
+    lanes and fma order, so the same bits — on an FE matrix whose block-row count is no multiple of 64, with empty block rows, and
+    through the CSR entry point that runs the blocked copy."""
+    monkeypatch.setenv("MI355_BCSR_TILE", force)
+    p, c, v = synth.fe_matrix(9, 7, 5)                       # 480 nodes: 7.5 workgroups of 64 block rows
+    n = len(p) - 1
+    x = synth.x_sin(0, n)
+    yr = O.spmv(p, c, v, x)
+    bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+    B = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
+    y = np.full(n, np.nan)
+    mpk.SpMV_BCSR(y, x, B)
+    assert_bit_equal(y, yr, f"BCSR API, tile={force}")
+    A = mpk.csrmatrix(n, p, c, v).set_kernel("bcsr4")
+    assert ("tile" in A.kernel_name()) == (force == "1")
+    yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(yd, dev(x), A)
+    assert_bit_equal(yd.cpu().numpy(), yr, f"CSR API on the blocked copy, tile={force}")
+    # empty block rows in the middle and at the end
+    keep = np.ones(n // 4, bool)
+    keep[[3, 100, 101, n // 4 - 1]] = False
+    lens = np.diff(bp) * keep
+    bp2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    sel = np.repeat(keep, np.diff(bp))
+    bc2, bv2 = bc[sel], bv.reshape(-1, 16)[sel].ravel()
+    B2 = mpk.bcsr4x4_matrix(n // 4, bp2, bc2, bv2, nbcols=n // 4)
+    mpk.SpMV_BCSR(y, x, B2)
+    assert_bit_equal(y, O.spmv_bcsr4(bp2, bc2, bv2, x), f"empty block rows, tile={force}")
