@@ -1,0 +1,24 @@
+/*
+ * mi355_devtools.h — diagnostics for tools/ (XCD map, page touch, flag preset).  NOT part of the product
+ * library: these entry points exist only in libmi355spmv_dev.so (`make devtools` in navierstokes_amd/csrc),
+ * which is libmi355spmv.so plus devtools.hip.  the tools (tools/sim_rank.py, xcc_probe.py, cold_probe.py) load it through MI355_SPMV_LIBRARY.
+ */
+#ifndef MI355_DEVTOOLS_H
+#define MI355_DEVTOOLS_H
+#include "mi355_spmv.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* diagnostic: host_out[b] = XCD (HW_REG_XCC_ID) that workgroup b of a `wgs`-workgroup launch ran on */
+int mi_debug_xcc_map(int wgs, int* host_out);
+/* diagnostic: one 4-byte read every stride_bytes of each device array the handle's kernels stream (and of up to two caller
+ * buffers, e.g. x and y), then a synchronise.  Behind mi_flush_cache() this brings the address translations back without
+ * bringing the data back (one line per stride): it separates "cold caches" from "cold TLB" in a cold-start measurement. */
+int mi_debug_touch_pages(mi_csr_t A, int stride_bytes, const void* d_extra0, long long bytes0, const void* d_extra1, long long bytes1);
+/* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
+int mi_part_push_debug_preset(mi_part_t P, unsigned value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_DEVTOOLS_H */

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 201 /* 0.2.1 */
+#define MI355_SPMV_VERSION 300 /* 0.3.0 */
 
 enum {
     MI_OK = 0,
@@ -185,16 +185,10 @@ int mi_ring_plan_lean(int n, const int* ptrow, const int* indcol, int config_id,
 int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_blocked, long long* nblocks);
 /* override the measured choice: 1 = non-temporal matrix loads, 0 = temporal, -1 = leave as is */
 int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt);
-/* diagnostic: host_out[b] = XCD (HW_REG_XCC_ID) that workgroup b of a `wgs`-workgroup launch ran on */
-int mi_debug_xcc_map(int wgs, int* host_out);
-/* diagnostic / calibration: microseconds per launch of a plain non-temporal read sweep over `bytes` of device memory (16-byte
+/* calibration: microseconds per launch of a plain non-temporal read sweep over `bytes` of device memory (16-byte
  * loads, 2048 workgroups, back to back): the rate THIS GPU streams from HBM at.  MI355X boxes of one pool differ by 10-20 %
  * here; bench.py prints it beside the kernel's rate so that a roofline fraction can be read against the box it was taken on. */
-int mi_debug_stream_read(long long bytes, int launches, double* us_per_launch);
-/* diagnostic: one 4-byte read every stride_bytes of each device array the handle's kernels stream (and of up to two caller
- * buffers, e.g. x and y), then a synchronise.  Behind mi_flush_cache() this brings the address translations back without
- * bringing the data back (one line per stride): it separates "cold caches" from "cold TLB" in a cold-start measurement. */
-int mi_debug_touch_pages(mi_csr_t A, int stride_bytes, const void* d_extra0, long long bytes0, const void* d_extra1, long long bytes1);
+int mi_stream_read_probe(long long bytes, int launches, double* us_per_launch);
 int mi_csr_get_kernel(mi_csr_t A, int* kernel_id);
 /* name of the HIP kernel the next mi_spmv*(A) launches (for matching rocprof rows) */
 const char* mi_csr_kernel_name(mi_csr_t A);
@@ -365,9 +359,6 @@ int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
 int mi_part_push_unfuse(mi_part_t P);
 /* give the push exchange up again (e.g. after a failed collective self-check): windows released, sticky give-ups cleared */
 int mi_part_push_disable(mi_part_t P);
-/* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
-int mi_part_push_debug_preset(mi_part_t P, unsigned value);
-
 /* development check of the RCCL plumbing on ONE GPU: a communicator of size 1 sends
  * `count` doubles to itself through the same send/recv/stream/event code path
  * (the per-step cost measurements of this path live in tools/comm_timing.hip) */

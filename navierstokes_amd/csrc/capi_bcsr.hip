@@ -1,0 +1,411 @@
+// capi_bcsr.hip: BCSR 4x4 handles and products, multi-vector products, Krylov basis — part of libmi355spmv.so (see capi_internal.hpp for the layout of the library).
+// Built for gfx950 only; no CPU fallback anywhere: every compute entry point needs a HIP device.
+#include "capi_internal.hpp"
+
+// ---------------------------------------------------------------- BCSR 4x4
+extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
+                               mi_bcsr4_t* out)
+{
+    CHECK_ARG(out, "out is null");
+    *out = nullptr;
+    CHECK_ARG(nbrows >= 0 && nbcols >= 0 && ptrow && ptrow[0] == 0, "bad argument");
+    for (int i = 0; i < nbrows; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
+    const long long nb = ptrow[nbrows];
+    CHECK_ARG(nb == 0 || (indcol && coef), "indcol/coef is null");
+    for (long long k = 0; k < nb; k++) CHECK_ARG(indcol[k] >= 0 && indcol[k] < nbcols, "block column outside [0, nbcols)");
+    int rc = need_device();
+    if (rc) return rc;
+    mi_bcsr4_t A = new (std::nothrow) mi_bcsr4_s();
+    if (!A) return fail(MI_ERR_ALLOC, "host allocation failed");
+    A->nbrows = nbrows;
+    A->nbcols = nbcols;
+    A->nblocks = nb;
+    hipError_t e;
+    if ((e = hipGetDevice(&A->device)) != hipSuccess ||
+        (e = hipMalloc(&A->d_ptrow, sizeof(int) * ((size_t)nbrows + 1))) != hipSuccess ||
+        (e = hipMalloc(&A->d_indcol, sizeof(int) * ((size_t)nb + 1))) != hipSuccess ||
+        (e = hipMalloc(&A->d_coef, sizeof(double) * 16 * ((size_t)nb + 1))) != hipSuccess ||
+        (e = hipMemcpy(A->d_ptrow, ptrow, sizeof(int) * ((size_t)nbrows + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+        (nb && (e = hipMemcpy(A->d_indcol, indcol, sizeof(int) * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess) ||
+        (nb && (e = hipMemcpy(A->d_coef, coef, sizeof(double) * 16 * (size_t)nb, hipMemcpyHostToDevice)) != hipSuccess)) {
+        mi_bcsr4_destroy(A);
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 upload: ") + hipGetErrorString(e));
+    }
+    // The x tile per workgroup (spmv_bcsr4_tile): the distinct block columns of each group of 64 block rows, and every block's
+    // position in its group's list.  Built when no group needs more than the tile holds; then both kernels are timed and the
+    // faster is kept (MI355_BCSR_TILE=0 never builds it, =1 takes it unmeasured).
+    const char* te = getenv("MI355_BCSR_TILE");
+    if (nb >= 4096 && !(te && !strcmp(te, "0"))) {
+        const int per = kWG / 4, nwg = (nbrows + per - 1) / per;
+        std::vector<int> wg_ptr((size_t)nwg + 1, 0);
+        std::vector<unsigned> nodes;
+        std::vector<unsigned short> slots((size_t)nb + 1, 0);
+        std::vector<unsigned> u;
+        bool fits = true;
+        for (int w = 0; w < nwg && fits; w++) {
+            const int b0 = ptrow[(size_t)w * per], b1 = ptrow[std::min<long long>((long long)(w + 1) * per, nbrows)];
+            u.assign(indcol + b0, indcol + b1);
+            std::sort(u.begin(), u.end());
+            u.erase(std::unique(u.begin(), u.end()), u.end());
+            fits = (int)u.size() <= kBtileNodes;
+            for (int k = b0; k < b1 && fits; k++) slots[k] = (unsigned short)(std::lower_bound(u.begin(), u.end(), (unsigned)indcol[k]) - u.begin());
+            nodes.insert(nodes.end(), u.begin(), u.end());
+            wg_ptr[w + 1] = (int)nodes.size();
+        }
+        if (fits) {
+            nodes.push_back(0);
+            if ((e = hipMalloc(&A->d_tl_ptr, sizeof(int) * wg_ptr.size())) != hipSuccess ||
+                (e = hipMalloc(&A->d_tl_nodes, sizeof(unsigned) * nodes.size())) != hipSuccess ||
+                (e = hipMalloc(&A->d_tl_slots, sizeof(unsigned short) * slots.size())) != hipSuccess ||
+                (e = hipMemcpy(A->d_tl_ptr, wg_ptr.data(), sizeof(int) * wg_ptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->d_tl_nodes, nodes.data(), sizeof(unsigned) * nodes.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->d_tl_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+                mi_bcsr4_destroy(A);
+                return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 tile upload: ") + hipGetErrorString(e));
+            }
+            const char* at = getenv("MI355_SPMV_AUTOTUNE");
+            if (te && !strcmp(te, "1")) A->use_tile = true;
+            else if (!(at && !strcmp(at, "0")) && nb >= 100000) { // measure both (x = 0: timing does not depend on the values)
+                double *tx = nullptr, *ty = nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                const size_t nx = 4 * (size_t)std::max(nbcols, 1), ny = 4 * (size_t)std::max(nbrows, 1);
+                if (hipMalloc(&tx, sizeof(double) * nx) == hipSuccess && hipMalloc(&ty, sizeof(double) * ny) == hipSuccess &&
+                    hipMemset(tx, 0, sizeof(double) * nx) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                    double us[2] = {0, 0};
+                    for (int round = 0; round < 2; round++)
+                        for (int c = 0; c < 2; c++) {
+                            A->use_tile = c == 1;
+                            for (int w = 0; w < 3; w++) (void)launch_bcsr4(A, tx, ty, nullptr, false);
+                            (void)hipEventRecord(e0, nullptr);
+                            for (int w = 0; w < 8; w++) (void)launch_bcsr4(A, tx, ty, nullptr, false);
+                            (void)hipEventRecord(e1, nullptr);
+                            (void)hipEventSynchronize(e1);
+                            float ms = 0.f;
+                            (void)hipEventElapsedTime(&ms, e0, e1);
+                            const double t = ms * 1e3 / 8;
+                            us[c] = us[c] > 0 ? std::min(us[c], t) : t;
+                        }
+                    A->tune_us_plain = us[0];
+                    A->tune_us_tile = us[1];
+                    A->use_tile = us[1] > 0 && us[1] < us[0];
+                }
+                dfree(tx);
+                dfree(ty);
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+            }
+        }
+    }
+    *out = A;
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_tile_info(mi_bcsr4_t A, int* built, int* in_use, double* us_plain, double* us_tile)
+{
+    CHECK_ARG(A, "null handle");
+    if (built) *built = A->d_tl_ptr != nullptr;
+    if (in_use) *in_use = A->use_tile && A->d_tl_ptr;
+    if (us_plain) *us_plain = A->tune_us_plain;
+    if (us_tile) *us_tile = A->tune_us_tile;
+    return MI_OK;
+}
+
+// new block values (16 per block, row-major) for an unchanged block pattern
+extern "C" int mi_bcsr4_update_values(mi_bcsr4_t A, const double* coef)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nblocks == 0) return MI_OK;
+    CHECK_ARG(coef, "null coef");
+    HIP_TRY(hipMemcpy(A->d_coef, coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyHostToDevice));
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_update_values_dev(mi_bcsr4_t A, const double* d_coef, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nblocks == 0) return MI_OK;
+    CHECK_ARG(d_coef, "null coef");
+    HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
+{
+    if (!A) return MI_OK;
+    dfree(A->d_ptrow);
+    dfree(A->d_indcol);
+    dfree(A->d_coef);
+    dfree(A->d_browmap);
+    dfree(A->d_tl_ptr);
+    dfree(A->d_tl_nodes);
+    dfree(A->d_tl_slots);
+    dfree(A->d_x);
+    dfree(A->d_y);
+    for (double* p : A->d_pow) dfree(p);
+    delete A;
+    return MI_OK;
+}
+
+int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nbrows == 0) return MI_OK;
+    CHECK_ARG(d_x && d_y, "null vector");
+    CHECK_ARG((((uintptr_t)d_x) & 15) == 0, "x must be 16-byte aligned");
+    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map ? A->d_browmap : nullptr};
+    const long long threads = 4LL * A->nbrows;
+    const int nwg = (int)((threads + kWG - 1) / kWG);
+    static const int chunk = getenv("MI355_BCSR_XCD_CHUNK") ? atoi(getenv("MI355_BCSR_XCD_CHUNK")) : 0;
+    const int grid = nwg;
+    if (A->use_tile && A->d_tl_ptr) {
+        Bcsr4Tile Tl{A->d_tl_ptr, A->d_tl_nodes, A->d_tl_slots};
+        hipLaunchKernelGGL(spmv_bcsr4_tile<kBcsrDepth>, dim3((unsigned)grid), dim3(kWG), 0, (hipStream_t)s, V, Tl, d_x, d_y, nwg);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
+    hipLaunchKernelGGL(spmv_bcsr4<kBcsrDepth>, dim3((unsigned)grid), dim3(kWG), 0, (hipStream_t)s, V, d_x, d_y, chunk, nwg);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s)
+{
+    return launch_bcsr4(A, d_x, d_y, s, true);
+}
+
+extern "C" int mi_bcsr4_spmv(mi_bcsr4_t A, const double* x, double* y)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nbrows == 0) return MI_OK;
+    CHECK_ARG(x && y, "null vector");
+    if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * 4 * (size_t)(A->nbcols > 0 ? A->nbcols : 1)));
+    if (!A->d_y) HIP_TRY(hipMalloc(&A->d_y, sizeof(double) * 4 * (size_t)A->nbrows));
+    HIP_TRY(hipMemcpy(A->d_x, x, sizeof(double) * 4 * (size_t)A->nbcols, hipMemcpyHostToDevice));
+    int rc = mi_bcsr4_spmv_dev(A, A->d_x, A->d_y, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(y, A->d_y, sizeof(double) * 4 * (size_t)A->nbrows, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmk_dev(mi_bcsr4_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(A->nbrows == A->nbcols, "matrix powers need a square matrix");
+    CHECK_ARG(d_y_out, "null output array");
+    const double* src = d_x;
+    for (int p = 0; p < k; p++) {
+        CHECK_ARG(A->nbrows == 0 || d_y_out[p], "null output vector");
+        int rc = mi_bcsr4_spmv_dev(A, src, d_y_out[p], s);
+        if (rc) return rc;
+        src = d_y_out[p];
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmk(mi_bcsr4_t A, int k, const double* x, double* const* y_out)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(A->nbrows == A->nbcols, "matrix powers need a square matrix");
+    if (A->nbrows == 0) return MI_OK;
+    CHECK_ARG(x && y_out, "null vector");
+    const size_t n = 4 * (size_t)A->nbrows;
+    if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * n));
+    while ((int)A->d_pow.size() < k) {
+        double* p = nullptr;
+        HIP_TRY(hipMalloc(&p, sizeof(double) * n));
+        A->d_pow.push_back(p);
+    }
+    HIP_TRY(hipMemcpy(A->d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = mi_bcsr4_spmk_dev(A, k, A->d_x, A->d_pow.data(), nullptr);
+    if (rc) return rc;
+    for (int p = 0; p < k; p++) {
+        CHECK_ARG(y_out[p], "null output vector");
+        HIP_TRY(hipMemcpy(y_out[p], A->d_pow[p], sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- multi-vector products, Krylov basis
+template <int S>
+static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t s)
+{
+    const long long threads = 4LL * V.nbrows;
+    const int nwg = (int)((threads + kWG - 1) / kWG);
+    // measured on the FE matrix (bench.py --workload fe_spmm4 / fe_spmm8, MI355_SPMM_XCD=0|1): 8 columns 284 us in XCD order
+    // against 343 in dispatch order (x traffic is 8x a single product's and every L2 fetched all of it); 4 columns 179
+    // against 173 (not bound by x traffic yet) — so XCD order from five columns on.  MI355_SPMM_XCD=0|1 forces.
+    static const int xcd_env = getenv("MI355_SPMM_XCD") ? atoi(getenv("MI355_SPMM_XCD")) : -1;
+    const bool xcd = xcd_env >= 0 ? xcd_env != 0 : S > 4;
+    const dim3 grid((unsigned)(xcd ? kNXCD * ((nwg + kNXCD - 1) / kNXCD) : nwg)), block(kWG);
+    constexpr bool PF = S <= 4; // beyond four columns the prefetch stage costs more occupancy than it hides latency
+    static const bool quad = !(getenv("MI355_SPMM_QUAD") && !strcmp(getenv("MI355_SPMM_QUAD"), "0"));
+    if (S % 4 == 0 && quad) { // the quad of a block row shares its x blocks through DPP (spmv_kernels.hpp: spmm_bcsr4_quad)
+        constexpr int SQ = S % 4 == 0 ? S : 4;
+        static const int depth_env = getenv("MI355_SPMM_DEPTH") ? atoi(getenv("MI355_SPMM_DEPTH")) : 0;
+        // measured on the FE matrix (bench.py fe_spmm4 / fe_spmm8, MI355_SPMM_DEPTH): 4 columns 254 / 168 / 168 / 173 us at depth 1 / 2 / 3 / 4
+        // (registers cost occupancy: 7 / 5 / 4 / 3 waves per SIMD), 8 columns 223 / 232 / 237 us at depth 1 / 2 / 3
+        const int depth = depth_env >= 1 && depth_env <= 4 ? depth_env : (S == 4 ? 2 : 1);
+#define MI_SPMM_QUAD(PD)                                                                                                               \
+    do {                                                                                                                               \
+        if (xcd) {                                                                                                                     \
+            if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 1, true, PD>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg); \
+            else hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 0, true, PD>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);                    \
+        } else {                                                                                                                       \
+            if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 1, false, PD>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg); \
+            else hipLaunchKernelGGL((spmm_bcsr4_quad<SQ, 0, false, PD>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);                   \
+        }                                                                                                                              \
+    } while (0)
+        if (depth == 1) MI_SPMM_QUAD(1);
+        else if (depth == 2) MI_SPMM_QUAD(2);
+        else if (depth == 3) MI_SPMM_QUAD(3);
+        else MI_SPMM_QUAD(4);
+#undef MI_SPMM_QUAD
+        return;
+    }
+    if (xcd) {
+        if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4<S, 1, PF, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+        else hipLaunchKernelGGL((spmm_bcsr4<S, 0, PF, true>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+    } else {
+        if (arith == MI_ARITH_BLOCKACC) hipLaunchKernelGGL((spmm_bcsr4<S, 1, PF, false>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+        else hipLaunchKernelGGL((spmm_bcsr4<S, 0, PF, false>), grid, block, 0, s, V, X, ldx, Y, ldy, nwg);
+    }
+}
+
+static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t st,
+                       bool use_map)
+{
+    Bcsr4View V{A->nbrows, A->nbcols, A->d_ptrow, A->d_indcol, A->d_coef, use_map ? A->d_browmap : nullptr};
+    for (int j0 = 0; j0 < s; j0 += 8) { // more than eight columns: batches of eight (the matrix is read once per batch)
+        const int m = std::min(8, s - j0);
+        const double* Xj = X + (size_t)j0 * ldx;
+        double* Yj = Y + (size_t)j0 * ldy;
+        switch (m) {
+        case 1: launch_spmm_s<1>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 2: launch_spmm_s<2>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 3: launch_spmm_s<3>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 4: launch_spmm_s<4>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 5: launch_spmm_s<5>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 6: launch_spmm_s<6>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        case 7: launch_spmm_s<7>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        default: launch_spmm_s<8>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_spmm_dev(mi_bcsr4_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, int arith,
+                                 mi_stream_t st)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(s >= 0, "negative column count");
+    CHECK_ARG(arith == MI_ARITH_CHAIN || arith == MI_ARITH_BLOCKACC, "unknown arithmetic id");
+    if (s == 0 || A->nbrows == 0) return MI_OK;
+    CHECK_ARG(d_X && d_Y, "null matrix");
+    CHECK_ARG(ldx >= 4LL * A->nbcols && ldy >= 4LL * A->nbrows, "leading dimension shorter than a column");
+    CHECK_ARG((((uintptr_t)d_X) & 15) == 0 && (ldx & 1) == 0, "X columns must be 16-byte aligned (even ldx)");
+    return launch_spmm(A, s, arith, d_X, ldx, d_Y, ldy, (hipStream_t)st, true);
+}
+
+extern "C" int mi_bcsr4_spmm(mi_bcsr4_t A, int s, const double* X, long long ldx, double* Y, long long ldy, int arith)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(s >= 0, "negative column count");
+    if (s == 0 || A->nbrows == 0) return MI_OK;
+    CHECK_ARG(X && Y, "null matrix");
+    CHECK_ARG(ldx >= 4LL * A->nbcols && ldy >= 4LL * A->nbrows, "leading dimension shorter than a column");
+    int rc = need_device();
+    if (rc) return rc;
+    Scratch S;
+    double *dX = nullptr, *dY = nullptr;
+    const size_t nx = 4 * (size_t)A->nbcols, ny = 4 * (size_t)A->nbrows;
+    if ((rc = S.up(nullptr, nx * s, &dX)) || (rc = S.up(nullptr, ny * s, &dY))) return rc;
+    for (int j = 0; j < s; j++) HIP_TRY(hipMemcpy(dX + nx * j, X + (size_t)ldx * j, sizeof(double) * nx, hipMemcpyHostToDevice));
+    if ((rc = mi_bcsr4_spmm_dev(A, s, dX, (long long)nx, dY, (long long)ny, arith, nullptr))) return rc;
+    for (int j = 0; j < s; j++) HIP_TRY(hipMemcpy(Y + (size_t)ldy * j, dY + ny * j, sizeof(double) * ny, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// CSR handle: through the blocked copy when the matrix has one (matrix read once for all columns; a BCSR chain visits
+// the CSR row's terms in CSR order, so every column carries the bits of SpMV_CSR_FMA), else column by column.
+extern "C" int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, mi_stream_t st_)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(s >= 0, "negative column count");
+    CHECK_ARG(!A->mapped, "multi-vector products need an unmapped matrix");
+    if (s == 0 || A->n == 0) return MI_OK;
+    CHECK_ARG(d_X && d_Y, "null matrix");
+    CHECK_ARG(ldx >= A->ncols && ldy >= A->n, "leading dimension shorter than a column");
+    hipStream_t st = (hipStream_t)st_;
+    const bool aligned = (((uintptr_t)d_X) & 15) == 0 && (ldx & 1) == 0;
+    if (A->inner && A->inner->blocked && aligned) { // reordered: gather the s columns into the new numbering first
+        const size_t n = (size_t)A->n;
+        double* Xp = nullptr; // the gathered columns as one dense block, stream-ordered allocation
+        HIP_TRY(hipMallocAsync((void**)&Xp, sizeof(double) * n * s, st));
+        int rc = MI_OK;
+        for (int j = 0; j < s && !rc; j++) rc = gather_perm(A, d_X + (size_t)j * ldx, Xp + n * j, st);
+        if (!rc) rc = launch_spmm(A->inner->blocked, s, MI_ARITH_CHAIN, Xp, (long long)n, d_Y, ldy, st, true);
+        (void)hipFreeAsync(Xp, st);
+        return rc;
+    }
+    if (!A->inner && A->blocked && aligned) return launch_spmm(A->blocked, s, MI_ARITH_CHAIN, d_X, ldx, d_Y, ldy, st, true);
+    for (int j = 0; j < s; j++) {
+        int rc = launch_spmv(A, d_X + (size_t)j * ldx, d_Y + (size_t)j * ldy, st);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
+// y[i] /= *d (IEEE division by a scalar read from device memory)
+__global__ __launch_bounds__(256) void div_by_scalar_kernel(int n, const double* __restrict__ d, double* __restrict__ y)
+{
+    const double q = d[0];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = __ddiv_rn(y[i], q);
+}
+
+// V[:, 0] = v0, V[:, k+1] = A V[:, k] for k < s: BuildKrylovBasis_AVX2, src/kernels/spmm_avx2.c:112-168 (a dense n x (s+1)
+// column-major V, each new column one product) — that is orth == 0, the monomial basis, bit-equal to the matrix-powers
+// chain.  orth != 0 builds the ORTHONORMAL (Arnoldi) basis an s-step GMRES needs out of the reference's own pieces:
+// V[:, 0] = v0 / ||v0||; each product is passed through orthonormalize_against_basis (mpk/2SpMV.cpp:13-28) against the
+// columns before it and then divided by its norm2 (mpk/utils.cpp:131-136) — the normalisation that helper computes and
+// drops (:23-26), without which its projections y -= (y.v) v are only meaningful for unit v.  Coefficients (the Hessenberg
+// column of step k) go to d_coef[k * (s + 2) + j]: j <= k the dots in the order taken, j = k + 1 the norm;
+// d_coef[s * (s + 2)] = ||v0||.  d_coef: s * (s + 2) + 1 doubles.
+extern "C" int mi_krylov_basis_dev(mi_csr_t A, int s, const double* d_v0, double* d_V, long long ldv, int orth, double* d_coef,
+                                   mi_stream_t st_)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(s >= 0 && s <= 64, "s must be in 0..64");
+    CHECK_ARG(A->n == A->ncols && !A->mapped, "a Krylov basis needs a square, unmapped matrix");
+    if (A->n == 0) return MI_OK;
+    CHECK_ARG(d_v0 && d_V && ldv >= A->n, "bad argument");
+    CHECK_ARG(!orth || d_coef, "null coefficient array");
+    hipStream_t st = (hipStream_t)st_;
+    const int n = A->n;
+    int grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    int rc;
+    if (d_V != d_v0) HIP_TRY(hipMemcpyAsync(d_V, d_v0, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (orth) {
+        double* nrm0 = d_coef + (size_t)s * (s + 2);
+        if ((rc = mi_norm2_dev(n, d_V, nrm0, st))) return rc;
+        hipLaunchKernelGGL(div_by_scalar_kernel, dim3(grid), dim3(256), 0, st, n, nrm0, d_V);
+    }
+    std::vector<const double*> cols;
+    for (int k = 0; k < s; k++) {
+        double* next = d_V + (size_t)(k + 1) * ldv;
+        if ((rc = launch_spmv(A, d_V + (size_t)k * ldv, next, st))) return rc;
+        if (orth) {
+            double* h = d_coef + (size_t)k * (s + 2);
+            cols.push_back(d_V + (size_t)k * ldv);
+            if ((rc = mi_orthonormalize_against_basis_dev(n, (int)cols.size(), cols.data(), next, h, st))) return rc;
+            if ((rc = mi_norm2_dev(n, next, h + k + 1, st))) return rc;
+            hipLaunchKernelGGL(div_by_scalar_kernel, dim3(grid), dim3(256), 0, st, n, h + k + 1, next);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}

@@ -1,0 +1,1228 @@
+// capi_csr.hip: CSR handles — create (plans, autotuner, relabelling), update, info, products — part of libmi355spmv.so (see capi_internal.hpp for the layout of the library).
+// Built for gfx950 only; no CPU fallback anywhere: every compute entry point needs a HIP device.
+#include "capi_internal.hpp"
+#include "reorder.hpp"
+#include "mring_plan.hpp"
+#include "tile_plan.hpp"
+
+// ---------------------------------------------------------------- CSR create
+int get_table(mi_csr_t A, int nnzb, BlockTable** out)
+{
+    BlockTable& T = A->tables[nnzb];
+    if (!T.d_blk) {
+        std::vector<int> rows, ptrs;
+        // whole waves of rows for the one-thread-per-row chain phase where that keeps 7/8 of the block (ring_plan.hpp) — for
+        // matrices that live in the Infinity Cache: S15 1 M rows 61 -> 56 us, but the 5 M-row mesh 180 -> 193 us
+        // (tools/stream_align_ab.py); MI355_STREAM_ROW_ALIGN=1|64 forces (A/B)
+        int row_align = A->nnz < 20000000 ? 64 : 1;
+        if (const char* e = getenv("MI355_STREAM_ROW_ALIGN")) row_align = std::max(1, atoi(e));
+        build_row_blocks(A->n, A->h_ptrow.data(), nnzb, 4 * kWG, rows, ptrs, row_align, 7);
+        T.nnzb = nnzb;
+        T.nblk = (int)rows.size() - 1;
+        std::vector<int2> h(rows.size());
+        for (size_t i = 0; i < rows.size(); i++) h[i] = make_int2(rows[i], ptrs[i]);
+        HIP_TRY(hipMalloc(&T.d_blk, sizeof(int2) * h.size()));
+        HIP_TRY(hipMemcpy(T.d_blk, h.data(), sizeof(int2) * h.size(), hipMemcpyHostToDevice));
+    }
+    *out = &T;
+    return MI_OK;
+}
+
+static void free_tile(mi_csr_t A)
+{
+    dfree(A->tile.d_desc);
+    dfree(A->tile.d_ulist);
+    dfree(A->tile.d_slots);
+    A->tile = TileTable();
+}
+
+static void free_mring(mi_csr_t A)
+{
+    dfree(A->mring.d_plan);
+    dfree(A->mring.d_first);
+    dfree(A->mring.d_ok);
+    dfree(A->mring.d_rng);
+    dfree(A->mring.d_slots);
+    A->mring = MringTable();
+}
+
+// Plan of the multi-window ring kernel (host arrays of the caller, or nullptr: the handle's device copy is read back)
+static int build_mring(mi_csr_t A, const int* indcol, int row_align = 0)
+{
+    if (A->mring.d_plan || A->n == 0 || A->nnz == 0) return MI_OK;
+    std::vector<int> back;
+    if (!indcol) {
+        if (!A->d_indcol) return fail(MI_ERR_STATE, "mring plan: the handle no longer holds its column indices");
+        back.resize((size_t)A->nnz);
+        HIP_TRY(hipMemcpy(back.data(), A->d_indcol, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+        indcol = back.data();
+    }
+    MringPlanHost P;
+    build_mring_plan(A->n, A->h_ptrow.data(), indcol, P, row_align);
+    MringTable& M = A->mring;
+    hipError_t e;
+    if ((e = hipMalloc(&M.d_plan, sizeof(int) * P.plan.size())) != hipSuccess ||
+        (e = hipMalloc(&M.d_first, sizeof(int) * P.first.size())) != hipSuccess ||
+        (e = hipMemcpy(M.d_first, P.first.data(), sizeof(int) * P.first.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMalloc(&M.d_ok, sizeof(int) * P.run_ok.size())) != hipSuccess ||
+        (e = hipMalloc(&M.d_rng, sizeof(int) * P.run_rng.size())) != hipSuccess ||
+        (e = hipMalloc(&M.d_slots, sizeof(unsigned short) * P.slots.size())) != hipSuccess ||
+        (e = hipMemcpy(M.d_plan, P.plan.data(), sizeof(int) * P.plan.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(M.d_ok, P.run_ok.data(), sizeof(int) * P.run_ok.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(M.d_rng, P.run_rng.data(), sizeof(int) * P.run_rng.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(M.d_slots, P.slots.data(), sizeof(unsigned short) * P.slots.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        free_mring(A);
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("mring plan upload: ") + hipGetErrorString(e));
+    }
+    M.nblk = P.nblk;
+    M.wgs = P.wgs;
+    M.nruns = P.nruns;
+    M.bpw = P.bpw;
+    M.bad_runs = P.bad_runs;
+    M.restarts = P.restarts;
+    M.ok_fraction = 1.0 - (double)P.bad_nnz / (double)A->nnz;
+    M.depth = P.bpw >= 40 ? 4 : 2; // as for the single ring (tools/depth_ab.py)
+    long long mult8 = 0;
+    for (int i = 0; i < A->n; i++) {
+        const int len = A->h_ptrow[i + 1] - A->h_ptrow[i];
+        mult8 += len > 0 && len % 8 == 0;
+    }
+    M.skew = 10 * mult8 > A->n;
+    M.nt = 10.0 * (double)A->nnz + 16.0 * (double)A->n > 0.75 * 256e6;
+    return MI_OK;
+}
+
+// Plan of the tile kernel for this handle's pattern (host arrays of the caller, or nullptr: the handle's own device
+// copy is read back — explicit MI_KERNEL_TILE requests on a handle created without it).
+static int build_tile(mi_csr_t A, const int* indcol)
+{
+    if (A->tile.d_desc || A->n == 0 || A->nnz == 0) return MI_OK;
+    std::vector<int> back;
+    if (!indcol) {
+        if (!A->d_indcol) return fail(MI_ERR_STATE, "tile plan: the handle no longer holds its column indices");
+        back.resize((size_t)A->nnz);
+        HIP_TRY(hipMemcpy(back.data(), A->d_indcol, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+        indcol = back.data();
+    }
+    TilePlanHost P;
+    build_tile_plan(A->n, A->h_ptrow.data(), indcol, P, kTileNnzb, 0, A->nnz < 20000000 ? 64 : 1);
+    TileTable& T = A->tile;
+    hipError_t e;
+    if ((e = hipMalloc(&T.d_desc, sizeof(int) * P.desc.size())) != hipSuccess ||
+        (e = hipMalloc(&T.d_ulist, sizeof(unsigned) * P.ulist.size())) != hipSuccess ||
+        (e = hipMalloc(&T.d_slots, sizeof(unsigned short) * P.slots.size())) != hipSuccess ||
+        (e = hipMemcpy(T.d_desc, P.desc.data(), sizeof(int) * P.desc.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_ulist, P.ulist.data(), sizeof(unsigned) * P.ulist.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_slots, P.slots.data(), sizeof(unsigned short) * P.slots.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        free_tile(A);
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("tile plan upload: ") + hipGetErrorString(e));
+    }
+    T.nblk = P.nblk;
+    T.unique_per_nnz = (double)(P.ulist.size() - kTileThreads) / (double)A->nnz;
+    long long mult8 = 0;
+    for (int i = 0; i < A->n; i++) {
+        const int len = A->h_ptrow[i + 1] - A->h_ptrow[i];
+        mult8 += len > 0 && len % 8 == 0;
+    }
+    T.skew = 10 * mult8 > A->n;
+    T.nt = 10.0 * (double)A->nnz + 16.0 * (double)A->n > 0.75 * 256e6;
+    return MI_OK;
+}
+
+
+static void free_ring_table(RingTable& R)
+{
+    dfree(R.d_plan);
+    dfree(R.d_ok);
+    dfree(R.d_rng);
+    dfree(R.d_run_halo);
+    dfree(R.d_slots);
+    R = RingTable();
+}
+
+// device copy of a ring plan (plan records, run tables, 16-bit column stream) and what the launch needs to know about it
+static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const int* ptrow, const int* indcol, long long nnz, bool ghosts)
+{
+    R.cfg = best.cfg;
+    // Blocks of prefetch: with long runs (C4: 72 blocks per workgroup) four blocks in flight instead of two hide more of
+    // the HBM latency — same handle, same box, back to back 172.8 / 168.8 / 167.5 us at depth 2 / 3 / 4, cold caches
+    // 198.2 / 194.2 / 191.9 us; with short runs (1 M rows: 14 blocks) the longer pipeline fill costs more than it hides:
+    // 34.7 / 35.1 / 37.3 us (tools/depth_ab.py, profiles/r02_ring_depth_ab.txt).  Configuration 4 only.
+    if (best.cfg.id == 4 && best.bpw >= 40) R.cfg.depth = 4;
+    if (const char* e = getenv("MI355_RING_DEPTH")) {
+        const int d = atoi(e);
+        if (best.cfg.id == 4 && d >= 2 && d <= 4) R.cfg.depth = d;
+    }
+    R.nblk = best.nblk;
+    R.wgs = best.wgs;
+    R.bpw = best.bpw;
+    R.bad_runs = best.bad_runs;
+    R.ok_fraction = nnz ? 1.0 - (double)best.bad_nnz / (double)nnz : 0.0;
+    R.lean = best.lean && best.cfg.id == 4 && !(getenv("MI355_RING_LEAN") && !strcmp(getenv("MI355_RING_LEAN"), "0"));
+    if (best.nblk <= 0) return MI_OK;
+    hipError_t e;
+#define RING_TRY(expr)                                                                                                      \
+    if ((e = (expr)) != hipSuccess) {                                                                                       \
+        free_ring_table(R);                                                                                                 \
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e)); \
+    }
+    RING_TRY(hipMalloc(&R.d_plan, sizeof(int) * best.plan.size()));
+    RING_TRY(hipMemcpy(R.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
+    RING_TRY(hipMalloc(&R.d_ok, sizeof(int) * best.run_ok.size()));
+    RING_TRY(hipMemcpy(R.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
+    for (int g = 0; g < best.wgs; g++)
+        R.uniform = R.uniform && best.run_rng[2 * g] == std::min(best.nblk, g * best.bpw) &&
+                    best.run_rng[2 * g + 1] == std::min(best.nblk, (g + 1) * best.bpw);
+    RING_TRY(hipMalloc(&R.d_rng, sizeof(int) * best.run_rng.size()));
+    RING_TRY(hipMemcpy(R.d_rng, best.run_rng.data(), sizeof(int) * best.run_rng.size(), hipMemcpyHostToDevice));
+    if (ghosts) {
+        R.h_run_halo = best.run_halo;
+        RING_TRY(hipMalloc(&R.d_run_halo, sizeof(int) * best.run_halo.size()));
+        RING_TRY(hipMemcpy(R.d_run_halo, best.run_halo.data(), sizeof(int) * best.run_halo.size(), hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<unsigned short> slots;
+        build_ring_slots(best, indcol, slots);
+        RING_TRY(hipMalloc(&R.d_slots, sizeof(unsigned short) * slots.size()));
+        RING_TRY(hipMemcpy(R.d_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice));
+    }
+#undef RING_TRY
+    // staging layout of the row chains: plain unless more than a tenth of the rows have a length
+    // that is a multiple of 8 (their LDS segments would start on the same two banks)
+    long long mult8 = 0;
+    for (int i = 0; i < n; i++) {
+        const int len = ptrow[i + 1] - ptrow[i];
+        mult8 += len > 0 && len % 8 == 0;
+    }
+    R.skew = 10 * mult8 > n;
+    if (const char* e2 = getenv("MI355_RING_SKEW")) R.skew = atoi(e2) != 0;
+    return MI_OK;
+}
+
+static int time_handle(mi_csr_t A, int warm, int timed, double* us);
+
+int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
+                    const int* rowmap, mi_csr_t* out, int ghost_lo, int ghost_hi)
+{
+    CHECK_ARG(out, "out is null");
+    *out = nullptr;
+    CHECK_ARG(n >= 0 && ncols >= 0, "negative dimension");
+    CHECK_ARG(ptrow, "ptrow is null");
+    CHECK_ARG(ptrow[0] == 0, "ptrow[0] must be 0");
+    for (int i = 0; i < n; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
+    const long long nnz = ptrow[n];
+    CHECK_ARG(nnz == 0 || (indcol && coef), "indcol/coef is null");
+    // 32-bit element offsets inside the kernels, padding included (ring_plan.hpp)
+    CHECK_ARG(nnz <= 0x7fffffffLL - 2 * kRingPadNnz && n <= 0x7fffffff - 2 * kRingPadRows, "matrix too large for 32-bit offsets: partition it (mi_part_*)");
+    std::vector<int> row_min((size_t)n), row_max((size_t)n);
+    for (int i = 0; i < n; i++) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) {
+            const int c = indcol[k];
+            CHECK_ARG(c >= 0 && c < ncols, "column index outside [0, ncols)");
+            lo = c < lo ? c : lo;
+            hi = c > hi ? c : hi;
+        }
+        row_min[i] = lo;
+        row_max[i] = hi;
+    }
+    int rc = need_device();
+    if (rc) return rc;
+
+    mi_csr_t A = new (std::nothrow) mi_csr_s();
+    if (!A) return fail(MI_ERR_ALLOC, "host allocation failed");
+    A->n = n;
+    A->ncols = ncols;
+    A->nnz = nnz;
+    A->h_ptrow.assign(ptrow, ptrow + n + 1);
+    hipError_t e = hipGetDevice(&A->device);
+    // zero padding behind the arrays: the kernels' unclamped / vector loads may touch it (ring_plan.hpp)
+    const size_t pad = 8, padv = kRingPadNnz, padr = kRingPadRows;
+    auto cleanup = [&]() { mi_csr_destroy(A); };
+#define TRY_OR_CLEAN(expr)                                                          \
+    do {                                                                            \
+        hipError_t e2_ = (expr);                                                    \
+        if (e2_ != hipSuccess) {                                                    \
+            cleanup();                                                              \
+            return fail(e2_ == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP,     \
+                        std::string(#expr) + ": " + hipGetErrorString(e2_));        \
+        }                                                                           \
+    } while (0)
+    TRY_OR_CLEAN(e);
+    TRY_OR_CLEAN(hipMalloc(&A->d_ptrow, sizeof(int) * ((size_t)n + 1 + padr)));
+    TRY_OR_CLEAN(hipMalloc(&A->d_indcol, sizeof(int) * ((size_t)nnz + pad)));
+    TRY_OR_CLEAN(hipMalloc(&A->d_coef, sizeof(double) * ((size_t)nnz + padv)));
+    TRY_OR_CLEAN(hipMemset(A->d_ptrow + n + 1, 0, sizeof(int) * padr));
+    TRY_OR_CLEAN(hipMemset(A->d_indcol + nnz, 0, sizeof(int) * pad));
+    TRY_OR_CLEAN(hipMemset(A->d_coef + nnz, 0, sizeof(double) * padv));
+    TRY_OR_CLEAN(hipMemcpy(A->d_ptrow, ptrow, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    if (nnz) {
+        TRY_OR_CLEAN(hipMemcpy(A->d_indcol, indcol, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        TRY_OR_CLEAN(hipMemcpy(A->d_coef, coef, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    A->mapped = rowmap != nullptr;
+    bool offset_only = rowmap != nullptr && n > 0;
+    for (int i = 1; offset_only && i < n; i++) offset_only = rowmap[i] == rowmap[0] + i;
+    if (offset_only) A->y_offset = rowmap[0]; // e.g. the interior rows of a banded partition: one contiguous range
+    if (rowmap && n > 0 && !offset_only) {
+        TRY_OR_CLEAN(hipMalloc(&A->d_rowmap, sizeof(int) * ((size_t)n + padr)));
+        TRY_OR_CLEAN(hipMemset(A->d_rowmap + n, 0, sizeof(int) * padr));
+        TRY_OR_CLEAN(hipMemcpy(A->d_rowmap, rowmap, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    // window plan of the ring kernel: first configuration (in preference order) that
+    // serves at least 90 % of the nonzeros; MI355_RING_CONFIG=1..4 forces one
+    if (n > 0 && nnz > 0) {
+        const int* order = kRingConfigOrder;
+        int forced = 0;
+        if (const char* e = getenv("MI355_RING_CONFIG")) forced = atoi(e);
+        RingPlanHost best;
+        bool have = false;
+        for (int t = 0; t < kNumRingConfigs && !have; t++) {
+            const int id = forced >= 1 && forced <= kNumRingConfigs ? forced : order[t];
+            RingPlanHost P;
+            build_ring_plan(kRingConfigs[id - 1], n, ptrow, row_min.data(), row_max.data(), P, ghost_lo, ghost_hi);
+            const double okf = 1.0 - (double)P.bad_nnz / (double)nnz;
+            if (forced || okf >= 0.90) {
+                best = std::move(P);
+                have = true;
+            } else if (t == 0) {
+                best = std::move(P); // remember the preferred one for explicit MI_KERNEL_RING requests
+            }
+            if (forced) break;
+        }
+        {
+            const int rcr = fill_ring_table(A->ring, best, n, ptrow, indcol, nnz, ghost_lo < ghost_hi);
+            if (rcr != MI_OK) {
+                mi_csr_destroy(A);
+                return rcr;
+            }
+        }
+        A->auto_kernel = (have && A->ring.ok_fraction >= 0.90) ? MI_KERNEL_RING : MI_KERNEL_STREAM;
+    }
+    // wide-band matrices (the ring does not serve them): the tile kernel's plan, kept if neighbouring rows share
+    // enough columns for it to pay (tile_plan.hpp); MI355_TILE=0 never, =1 always
+    {
+        const char* te = getenv("MI355_TILE");
+        const char* ke = getenv("MI355_SPMV_KERNEL");
+        const bool asked = (te && !strcmp(te, "1")) || (ke && !strcmp(ke, "tile"));
+        if (n > 0 && nnz > 0 && !(te && !strcmp(te, "0")) && (asked || (A->auto_kernel != MI_KERNEL_RING && nnz >= 200000))) {
+            const int rct = build_tile(A, indcol);
+            if (rct != MI_OK) {
+                mi_csr_destroy(A);
+                return rct;
+            }
+            if (!asked && A->tile.unique_per_nnz > 0.6) free_tile(A); // little sharing: nothing to gain over the stream kernel
+        }
+    }
+    // ... and the multi-window ring's (3-D mesh operators: a few narrow column clusters far apart), kept if it serves >= 90 %
+    {
+        const char* me = getenv("MI355_MRING");
+        const char* ke = getenv("MI355_SPMV_KERNEL");
+        const bool asked = (me && !strcmp(me, "1")) || (ke && !strcmp(ke, "mring"));
+        if (n > 0 && nnz > 0 && !(me && !strcmp(me, "0")) && (asked || (A->auto_kernel != MI_KERNEL_RING && nnz >= 200000))) {
+            const int rcm = build_mring(A, indcol);
+            if (rcm != MI_OK) {
+                mi_csr_destroy(A);
+                return rcm;
+            }
+            if (!asked && A->mring.ok_fraction < 0.90) free_mring(A);
+        }
+    }
+    // FE matrices: a blocked copy for the BCSR 4x4 kernel (same bits, 8.25 instead of 12 B per nonzero)
+    // (a row map that moves whole nodes — rowmap[4b + q] = rowmap[4b] + q, 4-aligned — becomes a block-row map)
+    bool node_map = rowmap != nullptr && !offset_only && n % 4 == 0;
+    for (int b = 0; node_map && b < n / 4; b++)
+        node_map = rowmap[4 * b] % 4 == 0 && rowmap[4 * b + 1] == rowmap[4 * b] + 1 && rowmap[4 * b + 2] == rowmap[4 * b] + 2 &&
+                   rowmap[4 * b + 3] == rowmap[4 * b] + 3;
+    if ((!rowmap || offset_only || node_map) && n >= 4 && nnz >= 16 && ncols % 4 == 0 && !(getenv("MI355_AUTO_BCSR") && !strcmp(getenv("MI355_AUTO_BCSR"), "0"))) {
+        std::vector<int> bptr, bcol;
+        std::vector<double> bval;
+        if (csr_to_bcsr4_exact(n, ptrow, indcol, coef, bptr, bcol, bval)) {
+            const int rcb = mi_bcsr4_create(n / 4, ncols / 4, bptr.data(), bcol.data(), bval.data(), &A->blocked);
+            if (rcb != MI_OK) {
+                mi_csr_destroy(A);
+                return rcb;
+            }
+            if (node_map) {
+                std::vector<int> bmap((size_t)n / 4);
+                for (int b = 0; b < n / 4; b++) bmap[b] = rowmap[4 * b] / 4;
+                TRY_OR_CLEAN(hipMalloc(&A->blocked->d_browmap, sizeof(int) * bmap.size()));
+                TRY_OR_CLEAN(hipMemcpy(A->blocked->d_browmap, bmap.data(), sizeof(int) * bmap.size(), hipMemcpyHostToDevice));
+            }
+        }
+    }
+    // default for the value loads when nothing is measured: non-temporal once the matrix stream
+    // (10 B per nonzero) no longer fits the 256 MB Infinity Cache with room for the vectors
+    A->ring.nt = A->ring.d_slots && 10.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
+    if (const char* e = getenv("MI355_RING_NT")) A->ring.nt = A->ring.d_slots && atoi(e) != 0;
+    A->stream_nt = 12.0 * (double)nnz + 16.0 * (double)n > 0.75 * 256e6;
+    if (const char* e = getenv("MI355_STREAM_NT")) A->stream_nt = atoi(e) != 0;
+    if (const char* e = getenv("MI355_TILE_NT")) A->tile.nt = atoi(e) != 0;
+    if (const char* e = getenv("MI355_MRING_NT")) A->mring.nt = atoi(e) != 0;
+    if (A->blocked) A->auto_kernel = MI_KERNEL_BCSR4; // unless measured otherwise below
+    A->n_out = n;
+    if (rowmap)
+        for (int i = 0; i < n; i++) A->n_out = rowmap[i] + 1 > A->n_out ? rowmap[i] + 1 : A->n_out;
+    bool forced_kernel = false;
+    if (const char* e = getenv("MI355_SPMV_KERNEL")) {
+        forced_kernel = true;
+        if (!strcmp(e, "stream")) A->auto_kernel = MI_KERNEL_STREAM;
+        else if (!strcmp(e, "ring") && A->ring.d_plan) A->auto_kernel = MI_KERNEL_RING;
+        else if (!strcmp(e, "rowpar")) A->auto_kernel = MI_KERNEL_ROWPAR;
+        else if (!strcmp(e, "bcsr4") && A->blocked) A->auto_kernel = MI_KERNEL_BCSR4;
+        else if (!strcmp(e, "tile") && A->tile.d_desc) A->auto_kernel = MI_KERNEL_TILE;
+        else if (!strcmp(e, "mring") && A->mring.d_plan) A->auto_kernel = MI_KERNEL_MRING;
+        else forced_kernel = false;
+    }
+    const char* at = getenv("MI355_SPMV_AUTOTUNE");
+    if (!forced_kernel && !(at && !strcmp(at, "0")) && nnz >= 200000) {
+        // measure the candidates on this very matrix (x = 0: timing does not depend on the values):
+        // ring (if it serves the matrix) and stream, each with temporal and non-temporal matrix loads
+        struct TuneScratch { // released on every exit path, the early error returns of TRY_OR_CLEAN included
+            double *tx = nullptr, *ty = nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~TuneScratch()
+            {
+                dfree(tx);
+                dfree(ty);
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+            }
+        } ts;
+        double *&tx = ts.tx, *&ty = ts.ty;
+        hipEvent_t &e0 = ts.e0, &e1 = ts.e1;
+        TRY_OR_CLEAN(hipMalloc(&tx, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
+        TRY_OR_CLEAN(hipMalloc(&ty, sizeof(double) * (size_t)(A->n_out > 0 ? A->n_out : 1)));
+        TRY_OR_CLEAN(hipMemset(tx, 0, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
+        TRY_OR_CLEAN(hipEventCreate(&e0));
+        TRY_OR_CLEAN(hipEventCreate(&e1));
+        const bool ring_ok = A->auto_kernel == MI_KERNEL_RING;
+        const bool ring_nt_forced = getenv("MI355_RING_NT") != nullptr, stream_nt_forced = getenv("MI355_STREAM_NT") != nullptr;
+        const bool ring_nt0 = A->ring.nt, stream_nt0 = A->stream_nt;
+        const bool tile_nt_forced = getenv("MI355_TILE_NT") != nullptr;
+        const bool tile_nt0 = A->tile.nt;
+        const bool mring_nt_forced = getenv("MI355_MRING_NT") != nullptr;
+        const bool mring_nt0 = A->mring.nt;
+        double us[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // ring, ring nt, stream, stream nt, tile, tile nt, mring, mring nt
+        // two interleaved rounds, the faster of the two counts: one round is not enough to tell two
+        // candidates 5 % apart from each other (clock ramps, what the previous candidate left in the caches)
+        for (int round = 0; round < 2; round++)
+            for (int c = 0; c < 8; c++) {
+                const bool nt = c & 1;
+                if (c >= 6) {
+                    if (!A->mring.d_plan || (mring_nt_forced && nt != mring_nt0)) continue;
+                    A->mring.nt = nt;
+                    A->kernel = MI_KERNEL_MRING;
+                } else if (c >= 4) {
+                    if (!A->tile.d_desc || (tile_nt_forced && nt != tile_nt0)) continue;
+                    A->tile.nt = nt;
+                    A->kernel = MI_KERNEL_TILE;
+                } else if (c < 2) {
+                    if (!ring_ok || (nt && !A->ring.d_slots) || (ring_nt_forced && nt != ring_nt0)) continue;
+                    A->ring.nt = nt;
+                    A->kernel = MI_KERNEL_RING;
+                } else {
+                    if (stream_nt_forced && nt != stream_nt0) continue;
+                    if (round == 1 && ring_ok && us[c] > 1.25 * std::min(us[0] > 0 ? us[0] : us[1], us[1] > 0 ? us[1] : us[0]))
+                        continue; // stream is out of the race already
+                    A->stream_nt = nt;
+                    A->kernel = MI_KERNEL_STREAM;
+                }
+                // warm launches first: a temporal candidate is judged with the Infinity Cache holding
+                // what it can of the matrix, as it would between the iterations of a solver
+                const int warm = 3, timed = nnz < 40000000 ? 12 : 6;
+                for (int w = 0; w < warm; w++)
+                    if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+                TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+                for (int w = 0; w < timed; w++)
+                    if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+                TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+                TRY_OR_CLEAN(hipEventSynchronize(e1));
+                float ms = 0.f;
+                TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+                const double t = ms * 1e3 / timed;
+                us[c] = us[c] > 0 ? std::min(us[c], t) : t;
+            }
+        A->kernel = MI_KERNEL_AUTO;
+        A->tune_us_ring = us[0];
+        A->tune_us_ring_nt = us[1];
+        A->tune_us_stream = us[2];
+        A->tune_us_stream_nt = us[3];
+        auto better = [](double a, double b) { return a > 0 && (b <= 0 || a < b); }; // a measured and faster than b
+        A->ring.nt = ring_ok ? better(us[1], us[0]) : ring_nt0;
+        A->stream_nt = better(us[3], us[2]);
+        A->tune_us_tile = us[4];
+        A->tune_us_tile_nt = us[5];
+        A->tile.nt = A->tile.d_desc ? better(us[5], us[4]) : tile_nt0;
+        const double best_ring = A->ring.nt ? us[1] : us[0], best_stream = A->stream_nt ? us[3] : us[2];
+        const double best_tile = A->tile.nt ? us[5] : us[4];
+        if (ring_ok && better(best_stream, best_ring)) A->auto_kernel = MI_KERNEL_STREAM;
+        if (better(best_tile, A->auto_kernel == MI_KERNEL_RING ? best_ring : best_stream)) A->auto_kernel = MI_KERNEL_TILE;
+        A->tune_us_mring = us[6];
+        A->tune_us_mring_nt = us[7];
+        A->mring.nt = A->mring.d_plan ? better(us[7], us[6]) : mring_nt0;
+        const double best_mring = A->mring.nt ? us[7] : us[6];
+        if (better(best_mring, A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : best_stream)))
+            A->auto_kernel = MI_KERNEL_MRING;
+        if (A->blocked) { // the blocked copy against the best CSR kernel
+            A->kernel = MI_KERNEL_BCSR4;
+            for (int w = 0; w < 3; w++)
+                if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+            TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+            for (int w = 0; w < 6; w++)
+                if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+            TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+            TRY_OR_CLEAN(hipEventSynchronize(e1));
+            float ms = 0.f;
+            TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+            A->tune_us_bcsr = ms * 1e3 / 6;
+            A->kernel = MI_KERNEL_AUTO;
+            const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : (A->auto_kernel == MI_KERNEL_MRING ? best_mring : best_stream));
+            if (better(A->tune_us_bcsr, best_csr)) A->auto_kernel = MI_KERNEL_BCSR4;
+        }
+        // Large ring-served matrices: blocks ending on multiples of 64 rows (the default plan) against unaligned blocks — which
+        // is faster depends on the box (ring_plan.hpp), so both are built and timed; the loser is released.
+        // (a rank's combined piece of the fused multi-GPU step included: timed here without the exchange, as a plain product)
+        if (A->auto_kernel == MI_KERNEL_RING && A->ring.cfg.id == 4 && nnz >= 20000000 && !getenv("MI355_RING_ROW_ALIGN")) {
+            RingPlanHost alt;
+            build_ring_plan(kRingConfigs[3], n, ptrow, row_min.data(), row_max.data(), alt, ghost_lo, ghost_hi, 1);
+            RingTable T2;
+            if (nnz > 0 && 1.0 - (double)alt.bad_nnz / (double)nnz >= 0.90 &&
+                fill_ring_table(T2, alt, n, ptrow, indcol, nnz, ghost_lo < ghost_hi) == MI_OK) {
+                T2.nt = A->ring.nt;
+                double us64 = 0.0, us1 = 0.0;
+                A->kernel = MI_KERNEL_RING;
+                int rct = time_handle(A, 3, 8, &us64);
+                std::swap(A->ring, T2);
+                if (rct == MI_OK) rct = time_handle(A, 3, 8, &us1);
+                A->kernel = MI_KERNEL_AUTO;
+                A->tune_us_ring_aligned = us64;
+                A->tune_us_ring_unaligned = us1;
+                if (rct != MI_OK || !(us1 < 0.98 * us64)) std::swap(A->ring, T2); // keep the default unless the other is clearly faster
+                free_ring_table(T2);
+            }
+        }
+        if (A->auto_kernel == MI_KERNEL_MRING && nnz >= 20000000 && !getenv("MI355_RING_ROW_ALIGN")) { // the same for the multi-window ring
+            MringTable keep = A->mring;
+            A->mring = MringTable();
+            if (build_mring(A, indcol, 1) == MI_OK && A->mring.d_plan && A->mring.ok_fraction >= 0.90) {
+                A->mring.nt = keep.nt;
+                double us64 = 0.0, us1 = 0.0;
+                A->kernel = MI_KERNEL_MRING;
+                int rct = time_handle(A, 3, 8, &us1);
+                std::swap(A->mring, keep);
+                if (rct == MI_OK) rct = time_handle(A, 3, 8, &us64);
+                A->kernel = MI_KERNEL_AUTO;
+                A->tune_us_ring_aligned = us64;
+                A->tune_us_ring_unaligned = us1;
+                if (rct == MI_OK && us1 < 0.98 * us64) std::swap(A->mring, keep); // the unaligned plan is clearly faster here
+            } else {
+                std::swap(A->mring, keep);
+            }
+            MringTable loser = keep; // release the plan not kept
+            keep = A->mring;
+            A->mring = loser;
+            free_mring(A);
+            A->mring = keep;
+        }
+    }
+#undef TRY_OR_CLEAN
+    *out = A;
+    return MI_OK;
+}
+
+// mean launch time of A's current choice over `timed` launches after `warm` (x = 0: timing does not depend on values)
+static int time_handle(mi_csr_t A, int warm, int timed, double* us)
+{
+    struct Scratch2 {
+        double *tx = nullptr, *ty = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scratch2()
+        {
+            dfree(tx);
+            dfree(ty);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } t;
+    const size_t nx = (size_t)(A->ncols > 0 ? A->ncols : 1), ny = (size_t)(A->n_out > 0 ? A->n_out : 1);
+    HIP_TRY(hipMalloc(&t.tx, sizeof(double) * nx));
+    HIP_TRY(hipMalloc(&t.ty, sizeof(double) * ny));
+    HIP_TRY(hipMemset(t.tx, 0, sizeof(double) * nx));
+    HIP_TRY(hipEventCreate(&t.e0));
+    HIP_TRY(hipEventCreate(&t.e1));
+    int rc;
+    for (int w = 0; w < warm; w++)
+        if ((rc = launch_spmv(A, t.tx, t.ty, nullptr))) return rc;
+    HIP_TRY(hipEventRecord(t.e0, nullptr));
+    for (int w = 0; w < timed; w++)
+        if ((rc = launch_spmv(A, t.tx, t.ty, nullptr))) return rc;
+    HIP_TRY(hipEventRecord(t.e1, nullptr));
+    HIP_TRY(hipEventSynchronize(t.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t.e0, t.e1));
+    *us = ms * 1e3 / timed;
+    return MI_OK;
+}
+
+static void release_natural_arrays(mi_csr_t A)
+{
+    dfree(A->d_ptrow);
+    dfree(A->d_indcol);
+    dfree(A->d_coef);
+    A->d_ptrow = A->d_indcol = nullptr;
+    A->d_coef = nullptr;
+    for (auto& kv : A->tables) dfree(kv.second.d_blk);
+    A->tables.clear();
+    dfree(A->ring.d_plan);
+    dfree(A->ring.d_ok);
+    dfree(A->ring.d_rng);
+    dfree(A->ring.d_run_halo);
+    dfree(A->ring.d_slots);
+    A->ring = RingTable();
+    free_tile(A);
+    free_mring(A);
+    mi_bcsr4_destroy(A->blocked);
+    A->blocked = nullptr;
+}
+
+// Locality reordering at create time (reorder.hpp).  Tried when the matrix is square, not row-mapped, large enough
+// to matter, NOT already served by the ring kernel, and its nonzeros lie far from the diagonal for its size (an
+// unstructured node numbering); kept when the reordered twin — x gather included — measures faster.
+// MI355_REORDER=0 never, =1 always try and keep (tests), unset: as described.
+static int maybe_reorder(mi_csr_t A, const int* ptrow, const int* indcol, const double* coef)
+{
+    const char* env = getenv("MI355_REORDER");
+    const bool force = env && !strcmp(env, "1");
+    if (env && !strcmp(env, "0")) return MI_OK;
+    const int n = A->n;
+    if (A->mapped || n != A->ncols || n < 8 || A->nnz == 0) return MI_OK;
+    if (!force && (n < 100000 || resolve_kernel(A) == MI_KERNEL_RING)) return MI_OK;
+    const int block = csr_has_block4_pattern(n, ptrow, indcol) ? 4 : 1;
+    const double nn = (double)n / block;
+    const double spread = mean_column_distance(n, ptrow, indcol, block);
+    A->spread_before = spread;
+    // a mesh of nn nodes in d >= 2 dimensions cannot be numbered with a mean distance much below nn^(1 - 1/d);
+    // far above the 3-D figure means the numbering, not the mesh, spreads the columns
+    if (!force && spread < 2.0 * std::pow(nn, 2.0 / 3.0)) return MI_OK;
+    Reorder R;
+    rcm_reorder(n, ptrow, indcol, block, R);
+    A->reorder_block = block;
+    A->spread_after = R.spread_after;
+    if (!force && R.spread_after > 0.5 * spread) return MI_OK; // nothing gained
+    std::vector<int> p2, c2, src_start;
+    std::vector<double> v2;
+    permute_csr(n, ptrow, indcol, coef, R, p2, c2, v2, src_start);
+    mi_csr_t inner = nullptr;
+    int rc = csr_create_impl(n, n, p2.data(), c2.data(), v2.data(), R.iperm.data(), &inner);
+    if (rc) return rc;
+    A->inner = inner; // from here on launch_spmv(A) goes through the twin; destroy releases it
+    hipError_t e;
+    if ((e = hipMalloc(&A->d_iperm, sizeof(int) * (size_t)n)) != hipSuccess ||
+        (e = hipMalloc(&A->d_src_start, sizeof(int) * (size_t)n)) != hipSuccess ||
+        (e = hipMalloc(&A->d_xp, sizeof(double) * (size_t)n)) != hipSuccess ||
+        (e = hipMemcpy(A->d_iperm, R.iperm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(A->d_src_start, src_start.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("reorder upload: ") + hipGetErrorString(e));
+    const char* at = getenv("MI355_SPMV_AUTOTUNE");
+    bool keep = true;
+    if (!force && !(at && !strcmp(at, "0"))) { // measure: natural choice against the twin (gather included)
+        const int timed = A->nnz < 40000000 ? 12 : 6;
+        A->inner = nullptr;
+        rc = time_handle(A, 3, timed, &A->us_natural);
+        A->inner = inner;
+        if (rc) return rc;
+        if ((rc = time_handle(A, 3, timed, &A->us_reordered))) return rc;
+        keep = A->us_reordered < 0.97 * A->us_natural;
+    }
+    if (!keep) {
+        mi_csr_destroy(A->inner);
+        A->inner = nullptr;
+        dfree(A->d_iperm);
+        dfree(A->d_src_start);
+        dfree(A->d_xp);
+        A->d_iperm = A->d_src_start = nullptr;
+        A->d_xp = nullptr;
+        return MI_OK;
+    }
+    release_natural_arrays(A);
+    return MI_OK;
+}
+
+extern "C" int mi_csr_create(int n, int ncols, const int* ptrow, const int* indcol, const double* coef, mi_csr_t* out)
+{
+    int rc = csr_create_impl(n, ncols, ptrow, indcol, coef, nullptr, out);
+    if (rc) return rc;
+    if ((rc = maybe_reorder(*out, ptrow, indcol, coef))) {
+        mi_csr_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+// host-only: the relabelling maybe_reorder would compute (reverse Cuthill-McKee on the node graph), for CPU tests
+extern "C" int mi_reorder_probe(int n, const int* ptrow, const int* indcol, int* block, int* perm, double* spread_before,
+                                double* spread_after)
+{
+    CHECK_ARG(n >= 0 && ptrow && (ptrow[n] == 0 || indcol), "bad argument");
+    for (int i = 0; i < n; i++) {
+        CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) CHECK_ARG(indcol[k] >= 0 && indcol[k] < n, "column index outside [0, n)");
+    }
+    const int b = csr_has_block4_pattern(n, ptrow, indcol) ? 4 : 1;
+    Reorder R;
+    rcm_reorder(n, ptrow, indcol, b, R);
+    if (block) *block = b;
+    if (perm)
+        for (int i = 0; i < n; i++) perm[i] = R.perm[i];
+    if (spread_before) *spread_before = R.spread_before;
+    if (spread_after) *spread_after = R.spread_after;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_reorder_info(mi_csr_t A, int* reordered, int* block, double* spread_before, double* spread_after,
+                                   double* us_natural, double* us_reordered)
+{
+    CHECK_ARG(A, "null handle");
+    if (reordered) *reordered = A->inner ? 1 : 0;
+    if (block) *block = A->reorder_block;
+    if (spread_before) *spread_before = A->spread_before;
+    if (spread_after) *spread_after = A->spread_after;
+    if (us_natural) *us_natural = A->us_natural;
+    if (us_reordered) *us_reordered = A->us_reordered;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_create_mapped(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
+                                    const int* rowmap, mi_csr_t* out)
+{
+    return csr_create_impl(n, ncols, ptrow, indcol, coef, rowmap, out);
+}
+
+extern "C" int mi_csr_destroy(mi_csr_t A)
+{
+    if (!A) return MI_OK;
+    dfree(A->d_ptrow);
+    dfree(A->d_indcol);
+    dfree(A->d_coef);
+    dfree(A->d_rowmap);
+    dfree(A->d_x);
+    dfree(A->d_y);
+    for (double* p : A->d_pow) dfree(p);
+    for (auto& kv : A->tables) {
+        dfree(kv.second.d_blk);
+    }
+    dfree(A->ring.d_plan);
+    dfree(A->ring.d_ok);
+    dfree(A->ring.d_rng);
+    dfree(A->ring.d_run_halo);
+    dfree(A->ring.d_slots);
+    free_tile(A);
+    free_mring(A);
+    mi_bcsr4_destroy(A->blocked);
+    mi_csr_destroy(A->inner);
+    dfree(A->d_iperm);
+    dfree(A->d_src_start);
+    dfree(A->d_xp);
+    dfree(A->d_vtmp);
+    for (double* p : A->d_pp) dfree(p);
+    delete A;
+    return MI_OK;
+}
+
+// Blocked copy's values from the CSR values already on the device: lane q of block row bi copies its
+// row's four coefficients of every block (32 B per lane and block; setup-time traffic).
+__global__ __launch_bounds__(kWG) void bcsr4_values_from_csr_kernel(int nbrows, const int* __restrict__ csr_ptrow,
+                                                                     const double* __restrict__ csr_coef,
+                                                                     const int* __restrict__ bptr, double* __restrict__ bval)
+{
+    const int g = blockIdx.x * kWG + threadIdx.x;
+    const int bi = g >> 2, q = g & 3;
+    if (bi >= nbrows) return;
+    const double* src = csr_coef + csr_ptrow[4 * bi + q];
+    const int b0 = bptr[bi], b1 = bptr[bi + 1];
+    for (int blk = b0; blk < b1; blk++) {
+        double* dst = bval + 16 * (size_t)blk + 4 * q;
+        const double* sp = src + 4 * (size_t)(blk - b0);
+        dst[0] = sp[0]; dst[1] = sp[1]; dst[2] = sp[2]; dst[3] = sp[3];
+    }
+}
+
+static int refresh_blocked_values(mi_csr_t A, hipStream_t s)
+{
+    if (!A->blocked || A->blocked->nbrows == 0) return MI_OK;
+    const long long threads = 4LL * A->blocked->nbrows;
+    hipLaunchKernelGGL(bcsr4_values_from_csr_kernel, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, s,
+                       A->blocked->nbrows, A->d_ptrow, A->d_coef, A->blocked->d_ptrow, A->blocked->d_coef);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// New coefficients for an unchanged sparsity pattern (what a Newton loop does to its Jacobian every
+// iteration, src/solve_newton.c:1245-1247): only the value array is replaced.  Row-block tables, the
+// ring plan, the 16-bit column stream and the kernel choice depend on the pattern alone and are kept;
+// the blocked copy's values are regenerated on the device.
+// values of a reordered twin from the caller's (original order) values: new row r' copies its segment
+__global__ __launch_bounds__(kWG) void permute_values_kernel(int n, const int* __restrict__ new_ptrow, const int* __restrict__ src_start,
+                                                              const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int r = blockIdx.x * kWG + threadIdx.x;
+    if (r >= n) return;
+    const int b = new_ptrow[r], len = new_ptrow[r + 1] - b, a = src_start[r];
+    for (int k = 0; k < len; k++) dst[b + k] = src[a + k];
+}
+
+extern "C" int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_stream_t s_)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nnz == 0) return MI_OK;
+    CHECK_ARG(d_coef, "null coef");
+    hipStream_t s = (hipStream_t)s_;
+    if (A->inner) {
+        mi_csr_t I = A->inner;
+        hipLaunchKernelGGL(permute_values_kernel, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, A->n, I->d_ptrow, A->d_src_start, d_coef, I->d_coef);
+        HIP_TRY(hipGetLastError());
+        return refresh_blocked_values(I, s);
+    }
+    HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
+    return refresh_blocked_values(A, s);
+}
+
+extern "C" int mi_csr_update_values(mi_csr_t A, const double* coef)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->nnz == 0) return MI_OK;
+    CHECK_ARG(coef, "null coef");
+    if (A->inner) {
+        if (!A->d_vtmp) HIP_TRY(hipMalloc(&A->d_vtmp, sizeof(double) * (size_t)A->nnz));
+        HIP_TRY(hipMemcpy(A->d_vtmp, coef, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice));
+        int rc = mi_csr_update_values_dev(A, A->d_vtmp, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return MI_OK;
+    }
+    HIP_TRY(hipMemcpy(A->d_coef, coef, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice));
+    int rc = refresh_blocked_values(A, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return MI_OK;
+}
+
+extern "C" int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz)
+{
+    CHECK_ARG(A, "null handle");
+    if (n) *n = A->n;
+    if (ncols) *ncols = A->ncols;
+    if (nnz) *nnz = A->nnz;
+    return MI_OK;
+}
+
+int resolve_kernel(const mi_csr_s* A)
+{
+    int k = A->kernel != MI_KERNEL_AUTO ? A->kernel : A->auto_kernel;
+    if (k == MI_KERNEL_RING && !A->ring.d_plan) k = MI_KERNEL_STREAM; // empty matrix: nothing to plan
+    if (k == MI_KERNEL_BCSR4 && !A->blocked) k = MI_KERNEL_STREAM;
+    if (k == MI_KERNEL_TILE && !A->tile.d_desc) k = MI_KERNEL_STREAM;
+    if (k == MI_KERNEL_MRING && !A->mring.d_plan) k = MI_KERNEL_STREAM;
+    return k;
+}
+
+extern "C" int mi_csr_tune_info(mi_csr_t A, double* us_ring, double* us_stream)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (us_ring) *us_ring = A->ring.nt ? A->tune_us_ring_nt : A->tune_us_ring;
+    if (us_stream) *us_stream = A->stream_nt ? A->tune_us_stream_nt : A->tune_us_stream;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_tune_detail(mi_csr_t A, double us[5], int* ring_nt, int* stream_nt)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (us) {
+        us[0] = A->tune_us_ring;
+        us[1] = A->tune_us_ring_nt;
+        us[2] = A->tune_us_stream;
+        us[3] = A->tune_us_stream_nt;
+        us[4] = A->tune_us_bcsr;
+    }
+    if (ring_nt) *ring_nt = A->ring.nt ? 1 : 0;
+    if (stream_nt) *stream_nt = A->stream_nt ? 1 : 0;
+    return MI_OK;
+}
+// host-only: build the ring plan and the 16-bit column stream for one configuration exactly as
+// mi_csr_create would, and check their invariants (every block of a served run keeps its columns
+// inside one window of at most RING entries, distinct columns of a block get distinct slots, slots
+// are < RING, rows/nonzeros are covered once and in order).  For CPU-side tests of the planner.
+extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, int config_id, int* nblk, int* runs,
+                                  int* runs_not_ringable, double* nnz_fraction_ringable, int* max_slot)
+{
+    CHECK_ARG(n >= 0 && ptrow && config_id >= 1 && config_id <= kNumRingConfigs, "bad argument");
+    const long long nnz = ptrow[n];
+    CHECK_ARG(nnz == 0 || indcol, "indcol is null");
+    std::vector<int> row_min((size_t)n), row_max((size_t)n);
+    for (int i = 0; i < n; i++) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) {
+            lo = std::min(lo, indcol[k]);
+            hi = std::max(hi, indcol[k]);
+        }
+        row_min[i] = lo;
+        row_max[i] = hi;
+    }
+    RingPlanHost P;
+    build_ring_plan(kRingConfigs[config_id - 1], n, ptrow, row_min.data(), row_max.data(), P);
+    std::vector<unsigned short> slots;
+    if (P.nblk > 0) build_ring_slots(P, indcol, slots);
+    const RingConfig& c = P.cfg;
+    const int T = c.threads, per = c.nnzb / T;
+    int next_row = 0, mslot = -1;
+    long long next_nz = 0;
+    // replay of the window as the kernel keeps it: content[s] = the column whose x value slot s holds
+    std::vector<int> content((size_t)c.ring, -1);
+    int cur_run = -1;
+    // the runs: every block in exactly one, none longer than the kernel's LDS plan, dealt out by weight (ring_plan.hpp)
+    std::vector<int> run_of((size_t)P.nblk, -1);
+    long long wmax = 0, wsum = 0;
+    for (int g = 0; g < P.wgs; g++) {
+        const int b0 = P.run_rng[2 * g], b1 = P.run_rng[2 * g + 1];
+        if (b0 < 0 || b1 < b0 || b1 > P.nblk || b1 - b0 > kRingMaxB) return fail(MI_ERR_STATE, "run range out of bounds or longer than the kernel's plan");
+        long long w = 0;
+        for (int b = b0; b < b1; b++) {
+            if (run_of[b] >= 0) return fail(MI_ERR_STATE, "a block belongs to two runs");
+            run_of[b] = g;
+            w += !P.run_ok[g] || P.plan[(size_t)8 * b + 7] == 2 ? kRingPlainWeight : 1;
+        }
+        wmax = std::max(wmax, w);
+        wsum += w;
+    }
+    for (int b = 0; b < P.nblk; b++)
+        if (run_of[b] < 0) return fail(MI_ERR_STATE, "a block belongs to no run");
+    if (P.wgs > 0 && wmax > 2 * (wsum / P.wgs) + 4 * kRingPlainWeight) return fail(MI_ERR_STATE, "one run carries more than twice the mean weight");
+    for (int b = 0; b < P.nblk; b++) {
+        const int* Q = &P.plan[(size_t)8 * b];
+        if (Q[0] != next_row || Q[1] != next_nz) return fail(MI_ERR_STATE, "plan does not cover rows / nonzeros in order");
+        const int brows = Q[7] == 2 ? Q[4] : Q[2]; // a PLAIN block keeps its row count out of the loop's sight
+        next_row += brows;
+        next_nz += Q[3];
+        if (Q[3] != ptrow[Q[0] + brows] - ptrow[Q[0]]) return fail(MI_ERR_STATE, "block nonzero count disagrees with ptrow");
+        const int run = run_of[b];
+        if (P.lean && P.run_ok[run] && brows > T) return fail(MI_ERR_STATE, "a LEAN plan holds a block of more than T rows");
+        if (!P.run_ok[run] || Q[3] == 0) {
+            if (Q[7] == 2 || (Q[7] && Q[3] == 0)) return fail(MI_ERR_STATE, "flags of a block outside the ring loop");
+            continue;
+        }
+        if (Q[7] == 2) { // computed behind the loop: the loop must see an empty block
+            if (Q[2] != 0 || Q[5] != 0) return fail(MI_ERR_STATE, "a PLAIN block is visible to the ring loop");
+            if (P.run_ok[run] != 3) return fail(MI_ERR_STATE, "a run with a PLAIN block does not tell the kernel to look behind its loop");
+            continue;
+        }
+        if (Q[7] != 1 || Q[3] > c.nnzb || Q[2] > 2 * T) return fail(MI_ERR_STATE, "a served run holds a block the kernel cannot take");
+        int cmin = 0x7fffffff, cmax = -1;
+        for (long long k = Q[1]; k < (long long)Q[1] + Q[3]; k++) {
+            cmin = std::min(cmin, indcol[k]);
+            cmax = std::max(cmax, indcol[k]);
+        }
+        if (cmax - cmin + 1 > c.ring) return fail(MI_ERR_STATE, "block window wider than the ring");
+        if (cmin - Q[6] < 0 || cmax - Q[6] >= 2 * c.ring) return fail(MI_ERR_STATE, "ring base out of range for the block's columns");
+        if (Q[4] + Q[5] < cmax + 1) return fail(MI_ERR_STATE, "window does not reach the block's last column");
+        if (P.lean && Q[5] > T && b != P.run_rng[2 * run]) return fail(MI_ERR_STATE, "a LEAN plan brings more than T new columns into a block inside a run");
+        if (run != cur_run) { // a new workgroup: nothing in its ring yet
+            std::fill(content.begin(), content.end(), -1);
+            cur_run = run;
+        }
+        for (int col = Q[4]; col < Q[4] + Q[5]; col++) { // the columns this block brings in
+            int sl = col - Q[6];
+            if (sl >= c.ring) sl -= c.ring;
+            if (sl < 0 || sl >= c.ring) return fail(MI_ERR_STATE, "a new column falls outside the ring");
+            content[sl] = col;
+        }
+        for (int k = 0; k < Q[3]; k++)
+            if (content[(indcol[Q[1] + k] - Q[6]) >= c.ring ? indcol[Q[1] + k] - Q[6] - c.ring : indcol[Q[1] + k] - Q[6]] != indcol[Q[1] + k])
+                return fail(MI_ERR_STATE, "a nonzero's column is not in the window when its block runs");
+        for (int k = 0; k < Q[3]; k++) { // slot of nonzero k as the kernel's thread (k % T), element k / T reads it
+            const int slot = slots[(size_t)b * c.nnzb + (size_t)(k % T) * per + k / T];
+            int want = indcol[Q[1] + k] - Q[6];
+            if (want >= c.ring) want -= c.ring;
+            if (slot != want || slot < 0 || slot >= c.ring) return fail(MI_ERR_STATE, "16-bit slot disagrees with the column");
+            mslot = std::max(mslot, slot);
+        }
+    }
+    if (next_row != n || next_nz != nnz) return fail(MI_ERR_STATE, "plan does not cover the matrix");
+    if (nblk) *nblk = P.nblk;
+    if (runs) *runs = P.wgs;
+    if (runs_not_ringable) *runs_not_ringable = P.bad_runs;
+    if (nnz_fraction_ringable) *nnz_fraction_ringable = nnz ? 1.0 - (double)P.bad_nnz / (double)nnz : 0.0;
+    if (max_slot) *max_slot = mslot;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_blocked, long long* nblocks)
+{
+    CHECK_ARG(n >= 0 && ptrow && is_blocked, "bad argument");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    // values are irrelevant to the structure test: hand the converter a dummy array of the right length
+    std::vector<double> dummy((size_t)ptrow[n], 0.0);
+    std::vector<int> bptr, bcol;
+    std::vector<double> bval;
+    const bool ok = csr_to_bcsr4_exact(n, ptrow, indcol, dummy.data(), bptr, bcol, bval);
+    *is_blocked = ok ? 1 : 0;
+    if (nblocks) *nblocks = ok ? (long long)bcol.size() : 0;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_set_nontemporal(mi_csr_t A, int ring_nt, int stream_nt)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (ring_nt >= 0) A->ring.nt = ring_nt != 0 && A->ring.d_slots;
+    if (stream_nt >= 0) A->stream_nt = stream_nt != 0;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (config_id) *config_id = A->ring.cfg.id;
+    if (runs) *runs = A->ring.wgs;
+    if (runs_not_ringable) *runs_not_ringable = A->ring.bad_runs;
+    if (nnz_fraction_ringable) *nnz_fraction_ringable = A->ring.ok_fraction;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_tile_info(mi_csr_t A, int* built, int* nblk, double* unique_per_nnz, double us[2], int* nt)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (built) *built = A->tile.d_desc != nullptr;
+    if (nblk) *nblk = A->tile.nblk;
+    if (unique_per_nnz) *unique_per_nnz = A->tile.unique_per_nnz;
+    if (us) {
+        us[0] = A->tune_us_tile;
+        us[1] = A->tune_us_tile_nt;
+    }
+    if (nt) *nt = A->tile.nt;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_mring_info(mi_csr_t A, int* built, int* runs, int* runs_not_served, double* nnz_fraction_served, double us[2], int* nt)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (built) *built = A->mring.d_plan != nullptr;
+    if (runs) *runs = A->mring.nruns;
+    if (runs_not_served) *runs_not_served = A->mring.bad_runs;
+    if (nnz_fraction_served) *nnz_fraction_served = A->mring.ok_fraction;
+    if (us) {
+        us[0] = A->tune_us_mring;
+        us[1] = A->tune_us_mring_nt;
+    }
+    if (nt) *nt = A->mring.nt;
+    return MI_OK;
+}
+
+extern "C" int mi_mring_plan_probe(int n, const int* ptrow, const int* indcol, int* nblk, int* runs, int* runs_not_served,
+                                   double* nnz_fraction_served, long long* window_restarts)
+{
+    CHECK_ARG(n >= 0 && ptrow && ptrow[0] == 0, "bad matrix");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    MringPlanHost P;
+    build_mring_plan(n, ptrow, indcol, P);
+    if (const char* bad = check_mring_plan(P, n, ptrow, indcol)) return fail(MI_ERR_STATE, std::string("mring plan: ") + bad);
+    if (nblk) *nblk = P.nblk;
+    if (runs) *runs = P.nruns;
+    if (runs_not_served) *runs_not_served = P.bad_runs;
+    if (nnz_fraction_served) *nnz_fraction_served = ptrow[n] ? 1.0 - (double)P.bad_nnz / (double)ptrow[n] : 0.0;
+    if (window_restarts) *window_restarts = P.restarts;
+    return MI_OK;
+}
+
+extern "C" int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, int* nblk, long long* distinct_total,
+                                  int* max_distinct, long long* nnz_listed)
+{
+    CHECK_ARG(n >= 0 && ptrow && ptrow[0] == 0, "bad matrix");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    TilePlanHost P;
+    build_tile_plan(n, ptrow, indcol, P, kTileNnzb, threads);
+    if (const char* bad = check_tile_plan(P, n, ptrow, indcol)) return fail(MI_ERR_STATE, std::string("tile plan: ") + bad);
+    if (nblk) *nblk = P.nblk;
+    if (distinct_total) *distinct_total = P.nblk > 0 ? (long long)P.ulist.size() - kTileThreads : 0;
+    if (max_distinct) *max_distinct = P.max_unique;
+    if (nnz_listed) *nnz_listed = P.listed;
+    return MI_OK;
+}
+
+extern "C" int mi_ring_plan_lean(int n, const int* ptrow, const int* indcol, int config_id, int* lean)
+{
+    CHECK_ARG(n >= 0 && ptrow && lean && config_id >= 1 && config_id <= kNumRingConfigs, "bad argument");
+    std::vector<int> row_min((size_t)n), row_max((size_t)n);
+    for (int i = 0; i < n; i++) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) {
+            lo = std::min(lo, indcol[k]);
+            hi = std::max(hi, indcol[k]);
+        }
+        row_min[i] = lo;
+        row_max[i] = hi;
+    }
+    RingPlanHost P;
+    build_ring_plan(kRingConfigs[config_id - 1], n, ptrow, row_min.data(), row_max.data(), P);
+    *lean = P.lean && P.cfg.id == 4 && P.bad_runs == 0;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_ring_shape_info(mi_csr_t A, int* blocks, int* lean, int* depth, double* us_aligned, double* us_unaligned)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (blocks) *blocks = A->ring.nblk;
+    if (lean) *lean = A->ring.lean;
+    if (depth) *depth = A->ring.cfg.depth;
+    if (us_aligned) *us_aligned = A->tune_us_ring_aligned;
+    if (us_unaligned) *us_unaligned = A->tune_us_ring_unaligned;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_MRING, "unknown kernel id");
+    if (kernel_id == MI_KERNEL_BCSR4 && !A->blocked)
+        return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_BCSR4: this matrix has no exact 4x4 block structure (or is row-mapped)");
+    if (kernel_id == MI_KERNEL_TILE) { // the plan is built on first request if mi_csr_create did not keep one
+        int rc = need_device();
+        if (rc) return rc;
+        if ((rc = build_tile(A, nullptr))) return rc;
+    }
+    if (kernel_id == MI_KERNEL_MRING) {
+        int rc = need_device();
+        if (rc) return rc;
+        if ((rc = build_mring(A, nullptr))) return rc;
+    }
+    A->kernel = kernel_id;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_get_kernel(mi_csr_t A, int* kernel_id)
+{
+    CHECK_ARG(A && kernel_id, "null argument");
+    if (A->inner) A = A->inner;
+    *kernel_id = resolve_kernel(A);
+    return MI_OK;
+}
+
+extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
+{
+    if (!A) return "";
+    if (A->inner) A = A->inner;
+    switch (resolve_kernel(A)) {
+    case MI_KERNEL_STREAM: return A->stream_nt ? "spmv_csr_stream<1024, true>" : "spmv_csr_stream<1024, false>";
+    case MI_KERNEL_RING: { // the name rocprofv3 prints for the instantiation launch_ring picks
+        static thread_local char nm[112];
+        const RingConfig& c = A->ring.cfg;
+        snprintf(nm, sizeof nm, "spmv_csr_ring<%d, %d, %d, %d, %d, %s, %s, %s, false, %s>", c.threads, c.nnzb, c.ring, c.depth, kRingMaxB,
+                 A->d_rowmap ? "true" : "false", A->ring.nt ? "true" : "false", A->ring.skew ? "true" : "false",
+                 A->ring.lean && c.threads == 256 && c.depth != 3 ? "true" : "false");
+        return nm;
+    }
+    case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
+    case MI_KERNEL_BCSR4: return A->blocked && A->blocked->use_tile && A->blocked->d_tl_ptr ? "spmv_bcsr4_tile<2>" : "spmv_bcsr4<2>";
+    case MI_KERNEL_MRING: {
+        static thread_local char nm[96];
+        snprintf(nm, sizeof nm, "spmv_csr_mring<%d, %d, %d, %d, %s, %s, %s>", kMringThreads, kMringNnzb, A->mring.depth, kMringMaxB,
+                 A->d_rowmap ? "true" : "false", A->mring.nt ? "true" : "false", A->mring.skew ? "true" : "false");
+        return nm;
+    }
+    case MI_KERNEL_TILE: {
+        static thread_local char nm[64];
+        snprintf(nm, sizeof nm, "spmv_csr_tile<%d, %s, %s>", kTileNnzb, A->tile.nt ? "true" : "false", A->tile.skew ? "true" : "false");
+        return nm;
+    }
+    default: return "";
+    }
+}
+extern "C" int mi_spmv_dev(mi_csr_t A, const double* d_x, double* d_y, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(A->n == 0 || (d_x && d_y), "null vector");
+    return launch_spmv(A, d_x, d_y, (hipStream_t)s);
+}
+
+extern "C" int mi_spmv(mi_csr_t A, const double* x, double* y)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(A->n == 0 || (x && y), "null vector");
+    if (A->mapped) return fail(MI_ERR_UNSUPPORTED, "mapped matrices are device-only (use mi_spmv_dev)");
+    if (A->n == 0) return MI_OK;
+    if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * (size_t)(A->ncols > 0 ? A->ncols : 1)));
+    if (!A->d_y) HIP_TRY(hipMalloc(&A->d_y, sizeof(double) * (size_t)A->n));
+    HIP_TRY(hipMemcpy(A->d_x, x, sizeof(double) * (size_t)A->ncols, hipMemcpyHostToDevice));
+    int rc = launch_spmv(A, A->d_x, A->d_y, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(y, A->d_y, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- matrix powers
+extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(A->n == A->ncols, "matrix powers need a square matrix");
+    CHECK_ARG(!A->mapped, "matrix powers need an unmapped matrix");
+    CHECK_ARG(d_y_out, "null output array");
+    if (A->inner && A->n > 0) {
+        // the whole chain in the new numbering (each power feeds the next without leaving it), every power scattered
+        // to the caller's numbering as it completes
+        while ((int)A->d_pp.size() < k) {
+            double* p = nullptr;
+            HIP_TRY(hipMalloc(&p, sizeof(double) * (size_t)A->n));
+            A->d_pp.push_back(p);
+        }
+        int rc = gather_perm(A, d_x, A->d_xp, (hipStream_t)s);
+        if (rc) return rc;
+        const double* src = A->d_xp;
+        for (int p = 0; p < k; p++) {
+            CHECK_ARG(d_y_out[p], "null output vector");
+            if ((rc = launch_spmv(A->inner, src, A->d_pp[p], (hipStream_t)s, false))) return rc;
+            if ((rc = scatter_perm(A, A->d_pp[p], d_y_out[p], (hipStream_t)s))) return rc;
+            src = A->d_pp[p];
+        }
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
+    const double* src = d_x;
+    for (int p = 0; p < k; p++) {
+        CHECK_ARG(A->n == 0 || d_y_out[p], "null output vector");
+        int rc = launch_spmv(A, src, d_y_out[p], (hipStream_t)s);
+        if (rc) return rc;
+        src = d_y_out[p];
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_spmk(mi_csr_t A, int k, const double* x, double* const* y_out)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(A->n == A->ncols, "matrix powers need a square matrix");
+    CHECK_ARG(A->n == 0 || (x && y_out), "null vector");
+    if (A->n == 0) return MI_OK;
+    if (!A->d_x) HIP_TRY(hipMalloc(&A->d_x, sizeof(double) * (size_t)A->ncols));
+    while ((int)A->d_pow.size() < k) {
+        double* p = nullptr;
+        HIP_TRY(hipMalloc(&p, sizeof(double) * (size_t)A->n));
+        A->d_pow.push_back(p);
+    }
+    HIP_TRY(hipMemcpy(A->d_x, x, sizeof(double) * (size_t)A->ncols, hipMemcpyHostToDevice));
+    int rc = mi_spmk_dev(A, k, A->d_x, A->d_pow.data(), nullptr);
+    if (rc) return rc;
+    for (int p = 0; p < k; p++) {
+        CHECK_ARG(y_out[p], "null output vector");
+        HIP_TRY(hipMemcpy(y_out[p], A->d_pow[p], sizeof(double) * (size_t)A->n, hipMemcpyDeviceToHost));
+    }
+    return MI_OK;
+}

@@ -1,0 +1,253 @@
+// capi_internal.hpp — state shared by the translation units that implement include/mi355_spmv.h:
+// error helpers, the handle structs, and the few functions one unit needs from another.  The library is
+// built from capi_lib.hip (library / device / cache flush), capi_csr.hip (CSR handles: create, plans,
+// autotuner, products), launch_csr.hip (the CSR kernels' instantiations and launch_spmv), capi_blas1.hip,
+// capi_bcsr.hip (BCSR 4x4, multi-vector products, Krylov basis) and capi_part.hip (partition, RCCL and
+// peer-push exchange); devtools.hip (mi355_devtools.h) is linked into libmi355spmv_dev.so only.
+#pragma once
+#include "mi355_spmv.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "partition.hpp"
+#include "push_exchange.hpp"
+#include "ring_plan.hpp"
+#include "spmv_kernels.hpp"
+#include "spmv_ring.hpp"
+
+using namespace mi355;
+
+// ---------------------------------------------------------------- errors
+extern thread_local std::string g_err; // capi_lib.hip
+
+static inline void dfree(void* p)
+{
+    if (p) (void)hipFree(p);
+}
+
+static inline int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            int code_ = (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver) \
+                            ? MI_ERR_NODEVICE                                                           \
+                            : (e_ == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP);                  \
+            return fail(code_, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+        }                                                                                               \
+    } while (0)
+
+#define CHECK_ARG(cond, msg)                        \
+    do {                                            \
+        if (!(cond)) return fail(MI_ERR_ARG, msg);  \
+    } while (0)
+
+
+int need_device(); // capi_lib.hip
+
+// ---------------------------------------------------------------- handles
+struct BlockTable {
+    int nnzb = 0;
+    int nblk = 0;
+    int2* d_blk = nullptr;  // [nblk+1]
+};
+
+struct RingTable {
+    RingConfig cfg{};
+    int nblk = 0, wgs = 0, bpw = 0, bad_runs = 0;
+    double ok_fraction = 0.0; // share of the nonzeros in ring-served runs
+    int* d_plan = nullptr; // 8 ints per block, read as two int4
+    int* d_ok = nullptr;
+    int* d_rng = nullptr;      // {first block, end block} per run
+    int* d_run_halo = nullptr; // per run: touches a ghost column (fused multi-GPU step)
+    std::vector<int> h_run_halo;
+    bool uniform = true;       // runs are consecutive ranges of bpw blocks (the kernel then computes them)
+    bool lean = false;         // the plan allows the LEAN instantiation (spmv_ring.hpp)
+    unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block
+    bool nt = false;                   // non-temporal loads of the values (chosen by measurement)
+    bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
+};
+
+// plan of the multi-window ring kernel (mring_plan.hpp); valid iff d_plan != nullptr
+struct MringTable {
+    int nblk = 0, wgs = 0, nruns = 0, bpw = 0, bad_runs = 0, depth = 2;
+    double ok_fraction = 0.0;
+    long long restarts = 0;
+    int* d_plan = nullptr;             // kMringRec ints per block, read as int4
+    int* d_first = nullptr;            // kMringFirst ints per run: the first block's windows
+    int* d_ok = nullptr;
+    int* d_rng = nullptr;
+    unsigned short* d_slots = nullptr;
+    bool nt = false, skew = false;
+};
+
+// plan of the tile kernel (tile_plan.hpp); valid iff d_desc != nullptr
+struct TileTable {
+    int nblk = 0;
+    int* d_desc = nullptr;             // 4 ints per block, read as int4
+    unsigned* d_ulist = nullptr;       // distinct columns per block
+    unsigned short* d_slots = nullptr; // 16-bit column stream: position in the block's list
+    double unique_per_nnz = 0.0;       // distinct columns per nonzero, averaged over the matrix
+    bool nt = false;                   // non-temporal loads of the values
+    bool skew = false;                 // padded staging layout (see RingTable::skew)
+};
+
+struct mi_csr_s {
+    int device = 0;
+    int n = 0, ncols = 0;
+    long long nnz = 0;
+    int* d_ptrow = nullptr;
+    int* d_indcol = nullptr;
+    double* d_coef = nullptr;
+    int* d_rowmap = nullptr;
+    bool mapped = false;  // created with a rowmap (device-only entry points, no powers)
+    int y_offset = 0;     // a rowmap that is just "row r -> y[r + offset]" is applied as a pointer offset, not as a gather
+    std::vector<int> h_ptrow; // kept to (re)build row-block tables
+    std::map<int, BlockTable> tables;
+    RingTable ring;           // valid iff ring.d_plan != nullptr
+    TileTable tile;           // valid iff tile.d_desc != nullptr
+    double tune_us_tile = 0.0, tune_us_tile_nt = 0.0;
+    MringTable mring;         // valid iff mring.d_plan != nullptr
+    double tune_us_mring = 0.0, tune_us_mring_nt = 0.0;
+    int kernel = MI_KERNEL_AUTO;
+    int auto_kernel = MI_KERNEL_STREAM;
+    double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0, tune_us_stream_nt = 0.0;
+    double tune_us_ring_aligned = 0.0, tune_us_ring_unaligned = 0.0; // large matrices: the two block shapes (0 = not compared)
+    bool stream_nt = false; // non-temporal matrix loads in the stream kernel
+    mi_bcsr4_t blocked = nullptr; // BCSR 4x4 copy (exact 4x4 node-block structure only), else null
+    double tune_us_bcsr = 0.0;
+    int n_out = 0; // length of the y a launch may write (n, or max rowmap + 1)
+    // Locality reordering (reorder.hpp): when `inner` is set, this handle is a front for A' = P A P^T, a row-mapped
+    // handle in the new numbering; products gather x into d_xp (new numbering) and inner writes y through its row
+    // map straight into the caller's numbering.  The natural-order device arrays are released then.
+    mi_csr_t inner = nullptr;
+    int* d_iperm = nullptr;     // [n] caller's index of new row / column
+    int* d_src_start = nullptr; // [n] offset of new row r' in the caller's coef (values refresh)
+    double* d_xp = nullptr;     // x in the new numbering (one product at a time per handle)
+    std::vector<double*> d_pp;  // powers in the new numbering
+    double* d_vtmp = nullptr;   // staging for mi_csr_update_values (host values)
+    double spread_before = 0.0, spread_after = 0.0, us_natural = 0.0, us_reordered = 0.0;
+    int reorder_block = 0;      // 0: no reordering attempted
+    // scratch for the host-pointer entry points
+    double* d_x = nullptr;
+    double* d_y = nullptr;
+    std::vector<double*> d_pow;
+};
+
+struct mi_bcsr4_s {
+    int device = 0;
+    int nbrows = 0, nbcols = 0;
+    long long nblocks = 0;
+    int* d_ptrow = nullptr;
+    int* d_indcol = nullptr;
+    double* d_coef = nullptr;
+    int* d_browmap = nullptr; // block-row map of a reordered matrix's blocked copy, else null
+    // x tile per workgroup (spmv_bcsr4_tile): lists of distinct block columns and 16-bit positions; null if not built
+    int* d_tl_ptr = nullptr;
+    unsigned* d_tl_nodes = nullptr;
+    unsigned short* d_tl_slots = nullptr;
+    bool use_tile = false;    // the measured choice between the two kernels (MI355_BCSR_TILE=0|1 forces)
+    double tune_us_plain = 0.0, tune_us_tile = 0.0;
+    double* d_x = nullptr;
+    double* d_y = nullptr;
+    std::vector<double*> d_pow;
+};
+
+struct mi_part_s {
+    PartPlan plan;
+    mi_csr_t piece[2] = {nullptr, nullptr};
+    int* d_send_idx = nullptr;
+    bool finalized = false;
+    int kernel = MI_KERNEL_AUTO;
+    // native exchange (mi_part_comm_init)
+    void* comm = nullptr; // ncclComm_t
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
+    double* d_sendbuf = nullptr;
+    unsigned* d_flags = nullptr; // [0] "x ready" (set on the caller's stream), [1] "halo rows done" (set on the comm stream)
+    unsigned* h_timeouts = nullptr; // pinned, device-mapped: hand-off waits that gave up (read by the host at every entry point)
+    unsigned* d_timeouts = nullptr; // the device address of h_timeouts
+    unsigned step_no = 0;
+    // Hand-offs between the two streams: HIP events by default.  Flag kernels (handoff_kernels.hpp) are ~8 us per
+    // step cheaper in the one-GPU harness but have not run against real multi-GPU RCCL yet: opt in with
+    // MI355_PART_HANDOFF=flags.
+    bool flag_handoff = false;
+    // peer-push exchange (push_exchange.hpp): my receive window, the peers' windows I write to
+    void* win = nullptr;          // [flags: nranks x 64 B][pad][data: 2 x n_halo doubles]
+    bool win_uncached = false, win_registered = false;
+    std::string win_key;          // the IPC handle bytes (key of the in-process registry)
+    unsigned* win_flags = nullptr;
+    double* win_data = nullptr;
+    std::vector<void*> ipc_opened; // mappings to close
+    PushLink* d_links = nullptr;
+    int n_links = 0;
+    int2* d_push_work = nullptr;   // stand-alone push kernel: {link, chunk} per workgroup
+    int* d_link_chunks = nullptr;  // chunks per link
+    unsigned* d_tickets = nullptr; // per link: chunks out so far
+    int n_push_work = 0;
+    int* d_nb = nullptr;           // ranks whose flags I wait for
+    int n_nb = 0;
+    unsigned push_step = 0;
+    bool push_ready = false;
+    // the one-launch form of the push step (spmv_ring.hpp, FUSED): all local rows in one ring-served, row-mapped piece
+    mi_csr_t piece_all = nullptr;
+    int* d_run_link = nullptr; // per run of piece_all: first push link it serves, or -1
+    int npush_runs = 0;
+    bool fused = false;
+    bool fused_bcsr = false;   // piece_all is served by the BCSR kernel: spmv_bcsr4_fused
+    int* d_wg_halo = nullptr;  // per workgroup of that launch: its block rows touch a ghost node
+};
+
+static inline size_t win_data_offset(int nranks) { return ((size_t)nranks * kWinFlagStride * sizeof(unsigned) + 255) / 256 * 256; }
+
+// g_mu guards every process-wide table of the library (reduction workspaces, flush buffers, window registry)
+extern std::mutex g_mu; // capi_lib.hip
+int get_ws(hipStream_t s, double** out); // capi_blas1.hip: reduction workspace of (device, stream)
+
+// host-pointer helper: upload vectors, run on the device copies, download
+struct Scratch {
+    std::vector<double*> bufs;
+    ~Scratch()
+    {
+        for (double* p : bufs) dfree(p);
+    }
+    int up(const double* h, size_t n, double** d)
+    {
+        *d = nullptr;
+        HIP_TRY(hipMalloc(d, sizeof(double) * (n ? n : 1)));
+        bufs.push_back(*d);
+        if (h && n) HIP_TRY(hipMemcpy(*d, h, sizeof(double) * n, hipMemcpyHostToDevice));
+        return MI_OK;
+    }
+};
+
+// capi_csr.hip
+int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef, const int* rowmap, mi_csr_t* out,
+                    int ghost_lo = 0, int ghost_hi = 0);
+int resolve_kernel(const mi_csr_s* A);
+int get_table(mi_csr_t A, int nnzb, BlockTable** out);
+// launch_csr.hip
+int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr);
+// launch_ring.hip
+void launch_ring_cfg(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm);
+// capi_blas1.hip
+int gather_perm(mi_csr_t A, const double* d_x, double* d_xp, hipStream_t s);
+int scatter_perm(mi_csr_t A, const double* d_src, double* d_dst, hipStream_t s);
+// capi_bcsr.hip
+int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);

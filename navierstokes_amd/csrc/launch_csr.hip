@@ -1,0 +1,82 @@
+// launch_csr.hip: instantiations of the CSR kernels and launch_spmv — part of libmi355spmv.so (see capi_internal.hpp for the layout of the library).
+// Built for gfx950 only; no CPU fallback anywhere: every compute entry point needs a HIP device.
+#include "capi_internal.hpp"
+#include "spmv_rowpar.hpp"
+#include "spmv_tile.hpp"
+#include "spmv_mring.hpp"
+
+// ---------------------------------------------------------------- SpMV launch
+int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm)
+{
+    if (A->n == 0) return MI_OK;
+    if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
+        int rc = gather_perm(A, d_x, A->d_xp, s);
+        if (rc) return rc;
+        return launch_spmv(A->inner, A->d_xp, d_y, s, true);
+    }
+    const int kid = resolve_kernel(A);
+    if (use_map) d_y += A->y_offset;
+    CsrView V;
+    V.n = A->n;
+    V.ncols = A->ncols;
+    V.ptrow = A->d_ptrow;
+    V.indcol = A->d_indcol;
+    V.coef = A->d_coef;
+    V.rowmap = use_map ? A->d_rowmap : nullptr;
+    V.blk = nullptr;
+    V.blk_span = nullptr;
+    V.nblk = 0;
+    if (kid == MI_KERNEL_BCSR4 && (((uintptr_t)d_x) & 15) == 0) return launch_bcsr4(A->blocked, d_x, d_y, (mi_stream_t)s, use_map);
+    if (kid == MI_KERNEL_BCSR4) { // x not 16-byte aligned: the blocked kernel's paired loads cannot be used
+        BlockTable* T = nullptr;
+        int rc = get_table(A, 1024, &T);
+        if (rc) return rc;
+        V.blk = T->d_blk;
+        V.nblk = T->nblk;
+        const int grid = kNXCD * ((T->nblk + kNXCD - 1) / kNXCD);
+        hipLaunchKernelGGL((spmv_csr_stream<1024, false>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
+    if (kid == MI_KERNEL_MRING) {
+        const MringTable& M = A->mring;
+        V.nblk = M.nblk;
+        const int4* plan = reinterpret_cast<const int4*>(M.d_plan);
+        const int2* rng = reinterpret_cast<const int2*>(M.d_rng);
+#define MRING_L(D_, MP_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, D_, kMringMaxB, MP_, NT_, SK_>), dim3(kNXCD * ((M.nruns + kNXCD - 1) / kNXCD)), dim3(kMringThreads), 0, s, V, plan, reinterpret_cast<const int4*>(M.d_first), M.d_ok, M.d_slots, d_x, d_y, rng, M.nruns)
+#define MRING_L3(D_, MP_) do { if (M.nt) { if (M.skew) MRING_L(D_, MP_, true, true); else MRING_L(D_, MP_, true, false); } \
+                               else { if (M.skew) MRING_L(D_, MP_, false, true); else MRING_L(D_, MP_, false, false); } } while (0)
+#define MRING_L2(D_) do { if (V.rowmap) MRING_L3(D_, true); else MRING_L3(D_, false); } while (0)
+        int depth = M.depth;
+        if (const char* e = getenv("MI355_RING_DEPTH")) depth = atoi(e);
+        if (depth == 4) MRING_L2(4);
+        else MRING_L2(2);
+#undef MRING_L2
+#undef MRING_L3
+#undef MRING_L
+    } else if (kid == MI_KERNEL_TILE) {
+        const TileTable& T = A->tile;
+        const int grid = kNXCD * ((T.nblk + kNXCD - 1) / kNXCD);
+        const int4* desc = reinterpret_cast<const int4*>(T.d_desc);
+#define TILE_LAUNCH(NT_, SK_) hipLaunchKernelGGL((spmv_csr_tile<kTileNnzb, NT_, SK_>), dim3(grid), dim3(kTileThreads), 0, s, V, desc, T.nblk, T.d_ulist, T.d_slots, d_x, d_y)
+        if (T.nt) { if (T.skew) TILE_LAUNCH(true, true); else TILE_LAUNCH(true, false); }
+        else { if (T.skew) TILE_LAUNCH(false, true); else TILE_LAUNCH(false, false); }
+#undef TILE_LAUNCH
+    } else if (kid == MI_KERNEL_ROWPAR) {
+        hipLaunchKernelGGL(spmv_csr_rowpar, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y);
+    } else if (kid == MI_KERNEL_RING) {
+        V.nblk = A->ring.nblk;
+        launch_ring_cfg(A, V, d_x, d_y, s, comm); // launch_ring.hip
+    } else {
+        BlockTable* T = nullptr;
+        int rc = get_table(A, 1024, &T);
+        if (rc) return rc;
+        V.blk = T->d_blk;
+        V.nblk = T->nblk;
+        const int grid = kNXCD * ((T->nblk + kNXCD - 1) / kNXCD);
+        if (A->stream_nt) hipLaunchKernelGGL((spmv_csr_stream<1024, true>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+        else hipLaunchKernelGGL((spmv_csr_stream<1024, false>), dim3(grid), dim3(kWG), 0, s, V, d_x, d_y);
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}

@@ -80,7 +80,6 @@ def lib():
         "mi_part_push_export": [_vp, _vp, _vp],
         "mi_part_push_connect": [_vp, _vp, _vp],
         "mi_part_spmv_push_dev": [_vp, _vp, _vp, _vp],
-        "mi_part_push_debug_preset": [_vp, _c.c_uint],
         "mi_part_push_info": [_vp, P(i), P(i), P(i)],
         "mi_part_combined_info": [_vp, P(i)],
         "mi_part_push_disable": [_vp],
@@ -107,9 +106,7 @@ def lib():
         "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
         "mi_mring_plan_probe": [i, _vp, _vp, P(i), P(i), P(i), P(d), P(ll)],
         "mi_tile_plan_probe": [i, _vp, _vp, i, P(i), P(ll), P(i), P(ll)],
-        "mi_debug_xcc_map": [i, _vp],
-        "mi_debug_touch_pages": [_vp, i, _vp, ll, _vp, ll],
-        "mi_debug_stream_read": [ll, i, P(d)],
+        "mi_stream_read_probe": [ll, i, P(d)],
         "mi_spmv": [_vp, _vp, _vp],
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_spmk": [_vp, i, _vp, _vp],
@@ -156,6 +153,14 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = argt
         fn.restype = _c.c_int
+    # diagnostics of include/mi355_devtools.h: present only in libmi355spmv_dev.so (`make devtools`; tools/ load it through
+    # MI355_SPMV_LIBRARY), never in the product library
+    for name, argt in {"mi_debug_xcc_map": [i, _vp], "mi_debug_touch_pages": [_vp, i, _vp, ll, _vp, ll],
+                       "mi_part_push_debug_preset": [_vp, _c.c_uint]}.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.argtypes = argt
+            fn.restype = _c.c_int
     _LIB = L
     return L
 
@@ -633,9 +638,9 @@ def rel_error(ref, test):
 
 
 def stream_read_us(nbytes, launches=20):
-    """Microseconds per launch of a plain read sweep over nbytes of device memory (mi_debug_stream_read): this box's HBM rate."""
+    """Microseconds per launch of a plain read sweep over nbytes of device memory (mi_stream_read_probe): this box's HBM rate."""
     us = _c.c_double()
-    check(lib().mi_debug_stream_read(int(nbytes), int(launches), _c.byref(us)))
+    check(lib().mi_stream_read_probe(int(nbytes), int(launches), _c.byref(us)))
     return us.value
 
 

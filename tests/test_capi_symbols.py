@@ -37,7 +37,17 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     assert not missing, f"declared in include/mi355_spmv.h but not exported: {missing}"
     L.mi_version.restype = ctypes.c_int
-    assert L.mi_version() == 201
+    assert L.mi_version() == 300
+
+
+def test_product_library_carries_no_debug_entry_points():
+    """mi_debug_* and the flag preset live in libmi355spmv_dev.so (include/mi355_devtools.h, `make devtools`) only."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", LIB], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    dev_hdr = open(os.path.join(ROOT, "include", "mi355_devtools.h")).read()
+    dev_syms = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", dev_hdr, flags=re.S)))
+    assert dev_syms and not (dev_syms & exported), sorted(dev_syms & exported)
+    assert not [s for s in exported if s.startswith("mi_debug_")]
 
 
 def test_python_binding_covers_the_header():

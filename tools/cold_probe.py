@@ -4,6 +4,8 @@ before each), and cold launches with the address translations brought back first
 import sys, os, ctypes
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# diagnostics live in the devtools build of the library (make -C navierstokes_amd/csrc devtools; include/mi355_devtools.h)
+os.environ.setdefault("MI355_SPMV_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "navierstokes_amd", "csrc", "libmi355spmv_dev.so"))
 from navierstokes_amd import mpk, synth
 what = sys.argv[1] if len(sys.argv) > 1 else "c4"
 if what == "fe":

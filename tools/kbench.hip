@@ -22,6 +22,7 @@
 
 #include "partition.hpp"
 #include "spmv_kernels.hpp"
+#include "spmv_rowpar.hpp"
 #include "spmv_experimental.hpp"
 
 extern "C" long long synth_count(int kind, unsigned long long seed, int n, int w, long long rb, long long re);
