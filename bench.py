@@ -3,15 +3,24 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3] [--kernel ...]
 
+With --gpus N > 1 and no torchrun environment (RANK unset) the script starts its N ranks ITSELF, as a child process
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, decided before anything touches the GPU), relays the
+child's output and exits with its code; started by torch.distributed.run it is one of the ranks.
+
 A "step" is one pass of the hot path over the whole (global) matrix: y = A x
 (workloads c2, c4) or the k=4 matrix-powers chain y1..y4 (workload c3).  The
 matrix is synthetic (no matrix ships with the reference):
 generator S15 of SURVEY.md §8d, seed 0x5EED — c4 = 5 M rows / 75 M nnz (the
 configuration BASELINE.json's target is quoted on; it fits one GPU), c2 = 1 M
-rows / 15 M nnz.  For N > 1 (launched by torch.distributed.run, one rank per
-GPU) the SAME global matrix is row-partitioned by nnz, each rank generates only
-its rows, and every step exchanges the packed halo x entries over RCCL while the
-interior rows compute — strong scaling.
+rows / 15 M nnz.  For N > 1 (one rank per GPU) the SAME global matrix is
+row-partitioned by nnz, each rank generates only its rows, and every step
+exchanges the packed halo x entries while the interior rows compute — strong
+scaling.  Which exchange drives the step is MEASURED: each candidate (peer push
+over HIP IPC windows, the C++ step over RCCL send/recv, torch.distributed
+all_to_all) is brought up, checked bit for bit against the torch.distributed
+exchange, dry-run and timed on every rank; the fastest one that survived runs
+the timed region and the line reports all of them (`halo.exchanges`), the bytes
+exchanged per step and how much of the step is compute (`halo.overlap`).
 
 Rank 0 prints ONE JSON line.  `value` = 2*nnz*k*K / wall (GFLOP/s, the
 reference's convention, src/benchmark_spmv.c:234), inputs resident in HBM.
@@ -138,6 +147,43 @@ def cpu_baseline(p, c, v, x, seconds_budget=20.0):
     return out
 
 
+def self_launch(ngpus):
+    """`bench.py --gpus N` started plainly: run the N ranks as a CHILD process (torch.distributed.run on 127.0.0.1, a free
+    port), let it write to our stdout/stderr, return its exit code.  Nothing here touches the GPU (no torch import): a
+    process that has initialised the GPU must neither exec nor be re-launched on this pool."""
+    import signal
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL, the push windows)
+    limit = int(os.environ.get("MI355_BENCH_LAUNCH_TIMEOUT", "1500"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {ngpus}-rank child did not finish within {limit} s; stopping its process group", file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)  # exactly the group started above
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=15)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+    except KeyboardInterrupt:
+        os.killpg(child.pid, signal.SIGTERM)
+        return 130
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +197,8 @@ def main():
     ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold single-shot and in-pipeline measurements")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -161,10 +209,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
-        args.gpus = world
+    args.gpus = world  # under torch.distributed.run the environment says how many ranks there are
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if "MI355_FORCE_DEVICE" in os.environ:  # development only: several ranks on one card
         local_rank = int(os.environ["MI355_FORCE_DEVICE"])
@@ -173,10 +218,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MI355_BENCH_BACKEND", "nccl")  # "gloo": development runs only
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("MI355_BENCH_COLLECTIVE_TIMEOUT", "300")))  # a stuck rank fails the run, not the day
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     W = WORKLOADS[args.workload]
     n, k, kind = W["n"], W["k"], W["kind"]
@@ -252,49 +299,133 @@ def main():
     else:
         kernel_name = "interior+boundary pieces, kernel=" + args.kernel
         sp = mpk._stream_ptr()  # the bench stays on one stream: look it up once, not per step
-        exchange_note = None
-        for attempt_exchange in ([args.exchange, "torch"] if args.exchange in ("auto", "push", "native") else [args.exchange]):
-            dc = D.DistCSR(rs, p, c, v, kernel=None if args.kernel == "auto" else args.kernel, exchange=attempt_exchange)
-            x_ext = dc.new_x_ext()
-            x_ext[: dc.n_local] = torch.from_numpy(x_host).cuda()
+        red_dev0 = "cuda" if backend == "nccl" else "cpu"
+
+        def agree_min(v):  # collective: the smallest of every rank's integer
+            t = torch.tensor([int(v)], dtype=torch.int32, device=red_dev0)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t)
+
+        def timed_max_us(fn, reps):  # collective: microseconds per call, the slowest rank's
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0_) / reps * 1e6], dtype=torch.float64, device=red_dev0)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t)
+
+        # Every candidate exchange is brought up (collective), must equal the torch.distributed exchange bit for bit (DistCSR's
+        # self-check), survive a dry run without a wait giving up on any rank, and is then timed; the fastest survivor runs the
+        # timed region.  --exchange push|native|torch restricts the candidates to one (plus torch as the way out).
+        want = [args.exchange] if args.exchange in ("push", "native", "torch") else ["push", "native", "torch"]
+        if "torch" not in want:
+            want.append("torch")
+        probe_steps = max(5, min(args.steps, 50))
+        probes, alive = {}, {}
+        rccl_ranks = None
+        for ex in want:
+            try:
+                dcx = D.DistCSR(rs, p, c, v, kernel=None if args.kernel == "auto" else args.kernel, exchange=ex)
+            except D.DistSetupError as e:  # raised on every rank alike
+                probes[ex] = dict(ok=False, note=str(e)[:200])
+                continue
+            got = "push" if dcx.push else ("native" if dcx.native else "torch")
+            if ex == "native" or dcx.rccl_ranks:
+                rccl_ranks = dcx.rccl_ranks
+            if got != ex:  # (a collective outcome: the same on every rank)
+                probes[ex] = dict(ok=False, note=f"did not come up on every rank, or failed its bitwise self-check against the torch.distributed exchange (DistCSR fell to '{got}')")
+                dcx.close()
+                continue
+            xx = dcx.new_x_ext()
+            xx[: dcx.n_local] = torch.from_numpy(x_host).cuda()
             if k == 1:
-                y = dc.new_y()
+                yy = dcx.new_y()
+                pb = None
 
-                def step(dc=dc, x_ext=x_ext, y=y):
-                    dc.spmv(x_ext, y, sp)
+                def stepx(dcx=dcx, xx=xx, yy=yy):
+                    dcx.spmv(xx, yy, sp)
             else:  # matrix powers across ranks: one halo exchange per power
-                pbufs = dc.new_power_buffers(k)
+                yy = None
+                pb = dcx.new_power_buffers(k)
 
-                def step(dc=dc, x_ext=x_ext, pbufs=pbufs):
-                    dc.spmk(x_ext, pbufs, sp)
-            # A dry run of the chosen exchange BEFORE anything is timed: a hand-off or halo wait that gives up (sticky, loud) on
-            # any rank sends every rank down to the torch.distributed exchange instead of losing the run.  The self-check inside
-            # DistCSR covers the first product only.
-            fine = 1
+                def stepx(dcx=dcx, xx=xx, pb=pb):
+                    dcx.spmk(xx, pb, sp)
+            fine, why = 1, ""
             try:
                 for _ in range(max(3, args.warmup)):
-                    step()
+                    stepx()
                 torch.cuda.synchronize()
-                dc.status()
+                dcx.status()
             except Exception as e:  # noqa: BLE001
-                fine = 0
-                exchange_note = f"exchange '{attempt_exchange}' failed in the dry run ({type(e).__name__}: {str(e)[:120]}); fell back to torch.distributed"
-            t_fine = torch.tensor([fine], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(t_fine, op=dist.ReduceOp.MIN)
-            if int(t_fine) == 1:
-                break
-            if exchange_note is None:
-                exchange_note = f"exchange '{attempt_exchange}' failed in the dry run on another rank; fell back to torch.distributed"
+                fine, why = 0, f"{type(e).__name__}: {str(e)[:160]}"
+            if agree_min(fine) == 0:
+                probes[ex] = dict(ok=False, note="failed in the dry run" + (f" on this rank ({why})" if why else " on another rank"))
+                try:
+                    dcx.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                continue
+            us = timed_max_us(stepx, probe_steps)
+            fine = 1
             try:
-                dc.close()
+                dcx.status()
             except Exception:  # noqa: BLE001
-                pass
+                fine = 0
+            if agree_min(fine) == 0:
+                probes[ex] = dict(ok=False, note="a halo wait gave up while the exchange was being timed")
+                try:
+                    dcx.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                continue
+            probes[ex] = dict(ok=True, step_us=round(us, 2),
+                              form=("ONE launch per step" if dcx.push_fused else "four launches per step") if ex == "push" else
+                                   ("RCCL send/recv on the partition's comm stream, events" if ex == "native" else
+                                    ("all_to_all_single over RCCL" if dcx._nccl else "host-staged (non-NCCL backend, development)")))
+            alive[ex] = (dcx, stepx, xx, yy, pb)
+        if not alive:
+            sys.exit("no halo exchange survived its checks on every rank: " + json.dumps(probes))
+        chosen = args.exchange if args.exchange in alive else min(alive, key=lambda e: probes[e]["step_us"])
+        for ex in list(alive):
+            if ex != chosen:
+                alive.pop(ex)[0].close()
+        dc, step, x_ext, y, pbufs = alive[chosen]
+        # what the same rank's kernels cost WITHOUT any exchange (pack + interior rows + boundary rows, back to back), slowest rank
+        L_ = mpk.lib()
+        ybuf = dc.new_y()
+        sbuf = torch.empty(max(dc.n_send, 1), dtype=torch.float64, device="cuda")
+        vp_ = _ct.c_void_p
+
+        def compute_only():
+            for _ in range(k):
+                mpk.check(L_.mi_part_pack_dev(dc._h, vp_(x_ext.data_ptr()), vp_(sbuf.data_ptr()), sp))
+                mpk.check(L_.mi_part_spmv_interior_dev(dc._h, vp_(x_ext.data_ptr()), vp_(ybuf.data_ptr()), sp))
+                mpk.check(L_.mi_part_spmv_boundary_dev(dc._h, vp_(x_ext.data_ptr()), vp_(ybuf.data_ptr()), sp))
+        for _ in range(3):
+            compute_only()
+        us_compute = timed_max_us(compute_only, probe_steps)
+        tb = torch.tensor([8.0 * dc.n_send * k, 8.0 * dc.n_halo * k], dtype=torch.float64, device=red_dev0)
+        tb_max = tb.clone()
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tb_max, op=dist.ReduceOp.MAX)
+        us_step = probes[chosen]["step_us"]
         halo_info = dict(n_halo=dc.n_halo, n_send=dc.n_send, interior_rows=dc.n_interior, boundary_rows=dc.n_boundary,
-                         exchange="native RCCL send/recv (mi_part_spmv_dev)" if dc.native
-                         else ("peer push over HIP IPC windows, no RCCL (mi_part_spmv_push_dev), " + ("ONE launch per step" if dc.push_fused else "four launches per step")) if dc.push
-                         else ("torch.distributed all_to_all_single" if dc._nccl else "host-staged (non-NCCL backend, development)"))
-        if exchange_note:
-            halo_info["exchange_fallback"] = exchange_note
+                         exchange=("peer push over HIP IPC windows, no RCCL (mi_part_spmv_push_dev), " + probes[chosen]["form"]) if chosen == "push"
+                         else ("native RCCL send/recv (mi_part_spmv_dev)" if chosen == "native" else "torch.distributed " + probes[chosen]["form"]),
+                         chosen=chosen, chosen_by=("--exchange" if args.exchange in alive else f"fastest of the survivors over {probe_steps} steps, slowest rank's time"),
+                         exchanges=probes,
+                         exchange_bytes_per_step=dict(sent_all_ranks=int(tb[0]), received_all_ranks=int(tb[1]), sent_max_rank=int(tb_max[0]),
+                                                      received_max_rank=int(tb_max[1]), note="8 B per halo entry, once per product"),
+                         overlap=dict(step_us=us_step, compute_only_us=round(us_compute, 2), exchange_exposed_us=round(us_step - us_compute, 2),
+                                      compute_over_step=round(us_compute / us_step, 4),
+                                      note="compute_only = pack + interior rows + boundary rows of the same rank with NO exchange, slowest rank; "
+                                           "exposed = what the exchange adds to the step (negative: the one-launch step is cheaper than the three kernels it replaces)"),
+                         rccl_ranks=rccl_ranks, torch_backend=backend, torch_world=world)
+        del ybuf, sbuf
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
@@ -329,8 +460,15 @@ def main():
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
     barrier()
-    if world > 1:
-        dc.status()  # a hand-off / halo wait that gave up during the timed region fails the run here, loudly
+    if world > 1:  # a hand-off / halo wait that gave up during the timed region fails the run here, loudly and on every rank
+        fine = 1
+        try:
+            dc.status()
+        except Exception as e:  # noqa: BLE001
+            fine = 0
+            print(f"[rank {rank}] {e}", file=sys.stderr, flush=True)
+        if agree_min(fine) == 0:
+            sys.exit("a halo wait gave up during the timed region: no number to report")
     # ---- the same kernel in two other regimes (N = 1, y = A x workloads only; never `value`) -------------------
     extra = {}
     if world == 1 and k == 1 and not args.cold and not args.no_extras and not W.get("spmm"):

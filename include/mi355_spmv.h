@@ -328,6 +328,10 @@ int mi_part_spmv_boundary_dev(mi_part_t P, const double* d_x_ext, double* d_y_lo
 int mi_comm_available(void); /* MI_OK iff librccl could be resolved in this process */
 int mi_comm_unique_id(void* id128);
 int mi_part_comm_init(mi_part_t P, const void* id128);
+/* what the communicator made by mi_part_comm_init says about itself (ncclCommCount / ncclCommUserRank): *comm_ranks = 0 and
+ * *comm_rank = -1 when the handle has none.  bench.py prints it as `rccl_ranks`, so that a multi-GPU line shows how many ranks
+ * RCCL really connected. */
+int mi_part_comm_info(mi_part_t P, int* comm_ranks, int* comm_rank);
 /* y_local = (A x)_local: d_x_ext = [x_local | halo], the halo part is overwritten.
  * Cross-stream hand-offs are HIP events; MI355_PART_HANDOFF=flags selects one-wave flag kernels instead
  * (cheaper, but a wait on a stalled peer then spins on the GPU: it gives up after minutes and the give-up is

@@ -211,6 +211,7 @@ struct mi_part_s {
     int npush_runs = 0;
     bool fused = false;
     bool fused_bcsr = false;   // piece_all is served by the BCSR kernel: spmv_bcsr4_fused
+    bool ghost_readers = true; // some run / workgroup of the fused launch waits for the neighbours (false: the pushers wait)
     int* d_wg_halo = nullptr;  // per workgroup of that launch: its block rows touch a ghost node
 };
 

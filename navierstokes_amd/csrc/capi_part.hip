@@ -317,6 +317,17 @@ extern "C" int mi_part_comm_init(mi_part_t P, const void* id128)
     return MI_OK;
 }
 
+extern "C" int mi_part_comm_info(mi_part_t P, int* comm_ranks, int* comm_rank)
+{
+    CHECK_ARG(P, "null handle");
+    if (comm_ranks) *comm_ranks = 0;
+    if (comm_rank) *comm_rank = -1;
+    if (!P->comm) return MI_OK; // no communicator: zeros
+    if (comm_ranks && g_rccl.CommCount) NCCL_TRY(g_rccl.CommCount(P->comm, comm_ranks));
+    if (comm_rank && g_rccl.CommUserRank) NCCL_TRY(g_rccl.CommUserRank(P->comm, comm_rank));
+    return MI_OK;
+}
+
 extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s_)
 {
     CHECK_ARG(P, "null handle");
@@ -425,6 +436,9 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
     if (rc) return rc;
     std::vector<PushLink> links;
     std::vector<int> nb;
+    // MI355_PUSH_LOOPBACK=1 (tools/sim_rank.py only): a handle may map windows of its own process — one rank's step timed on
+    // one GPU with its pushes looped back and every flag preset, so that nothing ever waits
+    const bool loopback = getenv("MI355_PUSH_LOOPBACK") && !strcmp(getenv("MI355_PUSH_LOOPBACK"), "1");
     for (int p = 0; p < R; p++) {
         if (p == me) continue;
         const long long* Lp = layouts + (size_t)p * LW;
@@ -437,8 +451,15 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
         {
             std::lock_guard<std::mutex> lock(g_mu);
             auto it = g_win_registry.find(key);
-            if (it != g_win_registry.end()) base = it->second; // a rank of this very process
+            if (it != g_win_registry.end()) base = it->second; // a window of this very process
         }
+        if (base && !loopback)
+            // Ranks as threads of one process cannot use this exchange: their streams share the process's few hardware queues
+            // (GPU_MAX_HW_QUEUES, 4 by default), a queue runs its kernels in order, and a kernel that spins on a peer's flag can
+            // sit in the queue in front of the very kernel that would raise it — seen as a hang of four rank threads
+            // (gpurun_out/t_dist.log, round 2).  Nothing the library does can order another rank's launches, so it refuses.
+            return fail(MI_ERR_UNSUPPORTED, "peer push needs one PROCESS per rank: a peer's window belongs to this process "
+                                            "(rank threads share hardware queues and can deadlock in the wait); use the RCCL or torch exchange");
         if (!base) {
             hipIpcMemHandle_t h;
             memcpy(&h, key.data(), sizeof h);
@@ -506,6 +527,8 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
             for (int g = 0; g < A->ring.wgs && k < P->n_links; g++)
                 if (A->ring.h_run_halo[g]) link[g] = k++;
             P->npush_runs = k; // 0: no ghost runs in the plan -> dedicated push workgroups in front of the grid
+            P->ghost_readers = false;
+            for (int v : A->ring.h_run_halo) P->ghost_readers = P->ghost_readers || v != 0;
             HIP_TRY(hipMalloc(&P->d_run_link, sizeof(int) * link.size()));
             HIP_TRY(hipMemcpy(P->d_run_link, link.data(), sizeof(int) * link.size(), hipMemcpyHostToDevice));
         }
@@ -526,6 +549,8 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
             HIP_TRY(hipMalloc(&P->d_wg_halo, sizeof(int) * wg_halo.size()));
             HIP_TRY(hipMemcpy(P->d_wg_halo, wg_halo.data(), sizeof(int) * wg_halo.size(), hipMemcpyHostToDevice));
             P->fused = P->fused_bcsr = true;
+            P->ghost_readers = false;
+            for (int v : wg_halo) P->ghost_readers = P->ghost_readers || v != 0;
         }
         if (!P->fused) {
             mi_csr_destroy(P->piece_all);
@@ -614,7 +639,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
     if (!P->push_ready) return fail(MI_ERR_STATE, "mi_part_push_connect was not called");
     if ((rc = part_handoff_status(P))) return rc;
     const unsigned step = ++P->push_step;
-    static const unsigned spin_max = 1u << (getenv("MI355_PUSH_SPIN_LOG2") ? std::max(8, std::min(30, atoi(getenv("MI355_PUSH_SPIN_LOG2")))) : 20); // 2^20 polls: ~4 s
+    static const unsigned spin_max = 1u << (getenv("MI355_PUSH_SPIN_LOG2") ? std::max(8, std::min(30, atoi(getenv("MI355_PUSH_SPIN_LOG2")))) : kPushSpinLog2Default);
     if (P->fused) { // ONE launch: push workgroups first, then the ring kernel over all rows, ghost readers waiting in-kernel
         RingComm C;
         C.links = P->d_links;
@@ -633,6 +658,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.push_wgs = (P->npush_runs == 0 && P->n_links > 0) ? kNXCD : 0; // fallback only; a multiple of the XCD count keeps the run-to-XCD mapping
         C.step = step;
         C.spin_max = spin_max;
+        C.gate_push = P->ghost_readers ? 0 : 1; // nobody in this launch waits for the neighbours: the pushers do (push_exchange.hpp)
         if (P->fused_bcsr) {
             if ((((uintptr_t)d_x_ext) & 15) != 0) return fail(MI_ERR_ARG, "the fused blocked step needs a 16-byte aligned x");
             mi_bcsr4_t B = P->piece_all->blocked;
@@ -682,6 +708,7 @@ extern "C" int mi_part_update_values(mi_part_t P, const double* coef)
     }
     if (P->piece_all) {
         LocalPiece& L = P->plan.all;
+        CHECK_ARG(coef || L.coef.empty(), "null coef");
         for (size_t k = 0; k < L.coef.size(); k++) L.coef[k] = coef[k];
         int rc = mi_csr_update_values(P->piece_all, coef);
         if (rc) return rc;

@@ -9,6 +9,10 @@
 int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm)
 {
     if (A->n == 0) return MI_OK;
+    // The fused multi-GPU step hands over a RingComm: its piece is numbered [ghosts | owned | ghosts], which only the ring
+    // kernel's FUSED instantiation understands.  Any other launch would index x with that numbering — refuse, never drop it.
+    if (comm && (A->inner || A->d_rowmap || resolve_kernel(A) != MI_KERNEL_RING))
+        return fail(MI_ERR_STATE, "fused multi-GPU step: the combined piece must be an unmapped, unreordered, ring-served handle");
     if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
         int rc = gather_perm(A, d_x, A->d_xp, s);
         if (rc) return rc;

@@ -21,6 +21,16 @@
 //   * neighbours are made symmetric (a rank also flags peers it only receives from): a sender can then
 //     only reach step t + 2 — and overwrite parity t & 1 — after it saw the receiver's flag of step
 //     t + 1, which the receiver raises after its copy of step t in stream order.  Two parities suffice.
+//     THE INVARIANT every form of the step keeps (tests/test_push_protocol.py is its executable model: random
+//     interleavings of {push, flag, wait, read} per rank, the one-launch and four-launch forms mixed, asymmetric
+//     couplings, ranks that send but receive nothing): a rank's kernels of step t + 1 start only after SOME kernel of
+//     its step t has seen every neighbour's flag >= t.  In the four-launch form that is the wait + copy kernel (it runs
+//     whenever the rank has a neighbour, halo or not); in the one-launch forms it is a ghost-reading run / workgroup —
+//     and a rank WITHOUT ghosts (it only sends: an upwind coupling, the last rank of a triangular band) has none, so its
+//     pushing workgroups themselves wait for flag >= t - 1 before they store step t (push_wait_flags with lag 1).
+//     Without that a sender could run any number of steps ahead and overwrite a parity its peer was still reading.
+//   * the two forms may be mixed freely across ranks (both raise and await the same flags; the model checks it).
+//     DistCSR still makes the form collective — a matter of balanced step times, not of correctness.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -43,6 +53,36 @@ struct PushLink {
     int count;       // entries to push (0: flag only)
     int first;       // >= 0: the list is the contiguous slice x[first .. first+count)
 };
+
+// Polls before a wait gives up: 2^kPushSpinLog2Default (the back-off sleeps ~4 us per poll, so ~4 s; MI355_PUSH_SPIN_LOG2
+// overrides, 8..30).  THE one place this default is written down.
+constexpr int kPushSpinLog2Default = 20;
+
+// Wait (threads tid, tid + nthreads, ... take one neighbour each) until every neighbour's flag in MY window shows
+// >= step - lag.  Flags are monotone step numbers; "behind" is computed modulo 2^32, so a wrap after 4e9 steps is
+// harmless.  Bounded: a give-up is counted in `timeouts` (host-visible, sticky, fails every later call on the handle) —
+// and a wait that is not satisfied at once looks at that counter after a few dozen polls and gives up with it, so that the
+// steps already queued behind a stalled peer cost microseconds each, not spin_max polls each (a healthy wait never
+// reads host memory).  The caller follows with a barrier and a system-scope acquire fence before it reads the window.
+__device__ __forceinline__ void push_wait_flags(const unsigned* flags, const int* __restrict__ nb, int n_nb, unsigned step, unsigned lag,
+                                                unsigned* timeouts, unsigned spin_max, int tid, int nthreads)
+{
+    for (int j = tid; j < n_nb; j += nthreads) {
+        const unsigned* f = flags + (size_t)nb[j] * kWinFlagStride;
+        const unsigned want = step - lag;
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+            if (spins < 4096) __builtin_amdgcn_s_sleep(2);
+            else __builtin_amdgcn_s_sleep(127);
+            ++spins;
+            if (spins == 64 && __hip_atomic_load(timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break; // an earlier wait gave up already
+            if (spins > spin_max) {
+                __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+}
 
 // (the stand-alone push and wait + copy kernels of the four-launch form live in push_kernels.hpp)
 

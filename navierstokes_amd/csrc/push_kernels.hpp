@@ -52,19 +52,7 @@ __global__ __launch_bounds__(256) void halo_wait_copy_kernel(const unsigned* fla
                                                              const double* src, double* __restrict__ dst, int n_halo,
                                                              unsigned* timeouts /* host-visible */, unsigned spin_max)
 {
-    for (int j = threadIdx.x; j < n_nb; j += 256) {
-        const unsigned* f = flags + (size_t)nb[j] * kWinFlagStride;
-        unsigned spins = 0;
-        // flags are monotone step numbers; "behind" is computed modulo 2^32 so that a wrap after 4e9 steps is harmless
-        while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
-            if (spins < 4096) __builtin_amdgcn_s_sleep(2);
-            else __builtin_amdgcn_s_sleep(127);
-            if (++spins > spin_max) { // default 2^23: ~30 s
-                __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-    }
+    push_wait_flags(flags, nb, n_nb, step, 0u, timeouts, spin_max, threadIdx.x, 256);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // system scope: the data the flags announce
     const long long stride = (long long)gridDim.x * 256;

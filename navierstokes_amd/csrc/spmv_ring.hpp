@@ -75,8 +75,9 @@ struct RingComm {
     const int* run_link;   // per run: first push link this run serves (then every npush_runs-th), or -1
     unsigned* timeouts;    // host-visible
     int n_links, n_nb, n_local, n_left, push_wgs, npush_runs;
+    int gate_push;         // this rank has no ghost reader: its push workgroups wait for flag >= step - 1 themselves
     unsigned step;
-    unsigned spin_max; // polls before a wait gives up (MI355_PUSH_SPIN_LOG2, default 23: ~30 s)
+    unsigned spin_max; // polls before a wait gives up (2^kPushSpinLog2Default unless MI355_PUSH_SPIN_LOG2 says otherwise)
 };
 
 // one push link by the T threads of a workgroup (push_exchange.hpp: halo_push_kernel's body)
@@ -94,6 +95,18 @@ __device__ __forceinline__ void ring_push_link(const RingComm& C, const double* 
     push_drain();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(L.flag, C.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Dedicated push workgroups (a plan without ghost runs; the blocked form): if NO run / workgroup of this rank's launch waits for
+// the neighbours — the rank receives nothing, C.gate_push — the pushers themselves wait until every neighbour has flagged
+// step - 1 before they overwrite this step's parity (push_exchange.hpp: THE INVARIANT).  A rank with ghosts skips this: its
+// ghost readers of the previous step's launch waited already.
+template <int T>
+__device__ __forceinline__ void ring_push_gate(const RingComm& C)
+{
+    if (!C.gate_push) return;
+    push_wait_flags(C.flags, C.nb, C.n_nb, C.step, 1u, C.timeouts, C.spin_max, threadIdx.x, T);
+    __syncthreads();
 }
 
 template <bool FUSED>
@@ -220,6 +233,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
     const int tid = threadIdx.x;
     if (FUSED && (int)blockIdx.x < C.push_wgs) { // fallback: dedicated push workgroups in front of the grid
+        if ((int)blockIdx.x < C.n_links) ring_push_gate<T>(C); // (uniform per workgroup)
         for (int l = blockIdx.x; l < C.n_links; l += C.push_wgs) ring_push_link<T>(C, x, l);
         return;
     }
@@ -259,18 +273,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     }
     __syncthreads();
     if (FUSED && C.run_halo[gw]) { // this run reads ghosts: every neighbour's entries of this step must have landed
-        for (int j = tid; j < C.n_nb; j += T) {
-            const unsigned* f = C.flags + (size_t)C.nb[j] * kWinFlagStride;
-            unsigned spins = 0;
-            while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - C.step) < 0) {
-                if (spins < 4096) __builtin_amdgcn_s_sleep(2);
-                else __builtin_amdgcn_s_sleep(127);
-                if (++spins > C.spin_max) {
-                    __hip_atomic_fetch_add(C.timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-        }
+        push_wait_flags(C.flags, C.nb, C.n_nb, C.step, 0u, C.timeouts, C.spin_max, tid, T);
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
@@ -405,23 +408,13 @@ __global__ __launch_bounds__(T) void spmv_bcsr4_fused(Bcsr4View A, const double*
                                                       const int* __restrict__ wg_halo)
 {
     if ((int)blockIdx.x < C.push_wgs) {
+        if ((int)blockIdx.x < C.n_links) ring_push_gate<T>(C);
         for (int l = blockIdx.x; l < C.n_links; l += C.push_wgs) ring_push_link<T>(C, x, l);
         return;
     }
     const int wg = (int)blockIdx.x - C.push_wgs;
     if (wg_halo[wg]) {
-        for (int j = threadIdx.x; j < C.n_nb; j += T) {
-            const unsigned* f = C.flags + (size_t)C.nb[j] * kWinFlagStride;
-            unsigned spins = 0;
-            while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - C.step) < 0) {
-                if (spins < 4096) __builtin_amdgcn_s_sleep(2);
-                else __builtin_amdgcn_s_sleep(127);
-                if (++spins > C.spin_max) {
-                    __hip_atomic_fetch_add(C.timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-        }
+        push_wait_flags(C.flags, C.nb, C.n_nb, C.step, 0u, C.timeouts, C.spin_max, threadIdx.x, T);
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }

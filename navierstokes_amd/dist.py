@@ -53,13 +53,51 @@ def balanced_row_starts(n, nranks, nnz_per_row=None, align=1):
     return np.concatenate([[0], cuts, [n]]).astype(np.int64)
 
 
+class DistSetupError(RuntimeError):
+    """Raised on EVERY rank when a set-up phase of DistCSR failed on ANY rank (the message names the first failing rank's
+    error): a caller may catch it and go on collectively — nobody is left waiting in a collective for a rank that died."""
+
+
 class DistCSR:
     """This rank's share of a row-partitioned csrmatrix."""
+
+    def _agree(self, err, phase):
+        """Collective: every rank learns whether `phase` failed anywhere.  err: None or this rank's exception."""
+        if self.nranks == 1:
+            if err is not None:
+                raise err
+            return
+        mine = None if err is None else f"rank {self.rank}: {type(err).__name__}: {str(err)[:300]}"
+        every = [None] * self.nranks
+        dist.all_gather_object(every, mine, group=self.group)
+        bad = [e for e in every if e is not None]
+        if bad:
+            raise DistSetupError(f"DistCSR set-up failed in phase '{phase}' on {len(bad)} of {self.nranks} ranks; first: {bad[0]}")
 
     def __init__(self, row_starts, ptrow, indcol_global, coef, group=None, device=None, compute=None, kernel=None, exchange=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.nranks = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._h = None
+        # Set-up is a sequence of LOCAL phases (library calls that can fail on one rank alone: an allocation, a plan) and
+        # COLLECTIVE ones; each local phase ends with _agree(), so that a failure anywhere raises DistSetupError everywhere
+        # instead of leaving the other ranks in the next collective until the process group times out.
+        err = None
+        try:
+            self._init_local(row_starts, ptrow, indcol_global, coef, device, compute)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        self._agree(err, "plan")
+        self._init_exchange_ids()
+        err = None
+        try:
+            self._init_finalize(compute, kernel, exchange)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        self._agree(err, "finalize")
+        self._init_choose_exchange(compute)
+
+    def _init_local(self, row_starts, ptrow, indcol_global, coef, device, compute):
         self.row_starts = np.ascontiguousarray(row_starts, dtype=np.int64)
         assert len(self.row_starts) == self.nranks + 1
         ptrow = np.ascontiguousarray(ptrow, dtype=np.int32)
@@ -87,12 +125,16 @@ class DistCSR:
         rc = np.zeros(self.nranks, np.int32)
         mpk.check(L.mi_part_recv_counts(h, rc.ctypes.data))
         self.recv_counts = [int(v) for v in rc]
-        recv_ids = np.empty(self.n_halo, np.int64)
+        recv_ids = self._recv_ids = np.empty(self.n_halo, np.int64)
         off = 0
         for p in range(self.nranks):
             if rc[p]:
                 mpk.check(L.mi_part_recv_ids(h, p, recv_ids[off:].ctypes.data))
                 off += int(rc[p])
+
+    def _init_exchange_ids(self):
+        """Collective: tell every owner which of its entries this rank needs."""
+        L, h, group, recv_ids = mpk.lib(), self._h, self.group, self._recv_ids
         self._nccl = bool(dist.is_initialized() and dist.get_backend(group) == "nccl")
         comm_dev = self.device if self._nccl else torch.device("cpu")
         if self.nranks > 1:
@@ -104,16 +146,24 @@ class DistCSR:
             t_ids_out = torch.empty(sum(self.send_counts), dtype=torch.int64, device=comm_dev)
             dist.all_to_all_single(t_ids_out, t_ids_in, self.send_counts, self.recv_counts, group=group)
             send_ids = t_ids_out.cpu().numpy()
+            self._send_ids = send_ids
+        else:
+            self.send_counts = [0]
+            self._send_ids = None
+        self.n_send = sum(self.send_counts)
+
+
+    def _init_finalize(self, compute, kernel, exchange):
+        """Local: send lists into the plan, pieces to the device."""
+        L, h = mpk.lib(), self._h
+        if self._send_ids is not None:
             off = 0
             for p in range(self.nranks):
                 c = self.send_counts[p]
-                ids = np.ascontiguousarray(send_ids[off:off + c])
+                ids = np.ascontiguousarray(self._send_ids[off:off + c])
                 mpk.check(L.mi_part_set_send_ids(h, p, c, ids.ctypes.data if c else None))
                 off += c
-        else:
-            self.send_counts = [0]
-        self.n_send = sum(self.send_counts)
-
+        self._send_ids = self._recv_ids = None
         if compute is None:
             mpk.check(L.mi_part_finalize(h))
             if kernel is not None:
@@ -127,8 +177,7 @@ class DistCSR:
             # "auto" (default): push, else native, else torch — each step down only after the collective self-check below
             self.exchange = exchange or os.environ.get("MI355_DIST_EXCHANGE", "auto")
             assert self.exchange in ("auto", "native", "push", "torch"), self.exchange
-            self.push = self.exchange in ("auto", "push") and self._try_push_exchange()
-            self.native = False
+            self.push = self.native = False
         else:
             self.native = False
             self.push = False
@@ -137,6 +186,12 @@ class DistCSR:
             mpk.check(L.mi_part_send_index(h, _c.byref(tot), _c.byref(ptr)))
             self._send_idx = (np.ctypeslib.as_array(_c.cast(ptr, _c.POINTER(_c.c_int)), shape=(tot.value,)).copy()
                               if tot.value else np.zeros(0, np.int32))
+
+    def _init_choose_exchange(self, compute):
+        """Collective: bring the requested exchange up; each candidate is self-checked against the torch.distributed exchange."""
+        self.rccl_ranks = 0
+        if compute is None:
+            self.push = self.exchange in ("auto", "push") and self._try_push_exchange()
         self.sendbuf = torch.empty(max(self.n_send, 1), dtype=torch.float64, device=self.device)
         import os
         if self.push and not self._native_selfcheck():
@@ -174,7 +229,11 @@ class DistCSR:
             return False
         dist.broadcast(idt, src=0, group=self.group)
         rc = self._native_init(bytes(idt.cpu().numpy().tobytes()))  # collective inside RCCL
-        flag.fill_(1 if rc == 0 else 0)
+        if rc == 0:
+            cnt = _c.c_int()
+            if L.mi_part_comm_info(self._h, _c.byref(cnt), None) == 0:
+                self.rccl_ranks = cnt.value  # ncclCommCount of the communicator just made
+        flag.fill_(1 if rc == 0 and self.rccl_ranks in (0, self.nranks) else 0)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag) == 1
 
@@ -203,14 +262,20 @@ class DistCSR:
         if not all(flags):
             L.mi_part_push_disable(self._h)
         if all(flags):
+            # one form for everybody: the one-launch step only if EVERY rank can run it (it depends on each rank's measured
+            # kernel).  Mixed forms are legal (tests/test_push_protocol.py); equal forms keep the ranks' step times balanced.
             fused = _c.c_int()
-            mpk.check(L.mi_part_push_info(self._h, None, _c.byref(fused), None))
-            # one form for everybody: the one-launch step only if EVERY rank can run it (it depends on each rank's measured kernel)
+            rc = L.mi_part_push_info(self._h, None, _c.byref(fused), None)
             every = [None] * self.nranks
-            dist.all_gather_object(every, bool(fused.value), group=self.group)
-            if fused.value and not all(every):
-                mpk.check(L.mi_part_push_unfuse(self._h))
-            self.push_fused = bool(fused.value) and all(every)
+            dist.all_gather_object(every, (rc == 0, bool(fused.value)), group=self.group)
+            want = all(f for _, f in every)
+            rc2 = L.mi_part_push_unfuse(self._h) if (rc == 0 and fused.value and not want) else 0
+            fine = [None] * self.nranks
+            dist.all_gather_object(fine, rc == 0 and rc2 == 0, group=self.group)
+            if not all(fine):
+                L.mi_part_push_disable(self._h)
+                return False
+            self.push_fused = bool(fused.value) and want
         return all(flags)
 
     def update_values(self, coef):

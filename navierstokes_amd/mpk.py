@@ -146,6 +146,7 @@ def lib():
         "mi_comm_available": [],
         "mi_comm_unique_id": [_vp],
         "mi_part_comm_init": [_vp, _vp],
+        "mi_part_comm_info": [_vp, P(i), P(i)],
         "mi_part_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_comm_selftest": [i, P(d)],
     }

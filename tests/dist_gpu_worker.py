@@ -16,15 +16,31 @@ from navierstokes_amd import synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402  (checker)
 
 
+def upper_part(p, c, v, row0):
+    """Entries at or above the diagonal only (an upwind coupling): x then flows from higher ranks to lower ones, the LAST rank
+    receives nothing and only sends — the rank the one-launch step's push gate exists for (push_exchange.hpp)."""
+    rows = np.repeat(np.arange(len(p) - 1, dtype=np.int64) + row0, np.diff(p))
+    keep = c >= rows
+    cnt = np.zeros(len(p) - 1, np.int64)
+    np.add.at(cnt, rows[keep] - row0, 1)
+    return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), c[keep].copy(), v[keep].copy()
+
+
 def main():
     kind, n, w = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    upwind = kind.endswith("_up")
+    kind = kind[:-3] if upwind else kind
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     Pg, Cg, Vg = synth.rows(kind, n, w=w)
+    if upwind:
+        Pg, Cg, Vg = upper_part(Pg, Cg, Vg, 0)
     rs = D.balanced_row_starts(n, world, np.diff(Pg), align=4 if kind == "sfe" else 1)  # FE-like: cut at node boundaries
     lo, hi = int(rs[rank]), int(rs[rank + 1])
     p, c, v = synth.rows(kind, n, lo, hi, w=w)
+    if upwind:
+        p, c, v = upper_part(p, c, v, lo)
     ok = True
     exchange = os.environ.get("MI355_TEST_EXCHANGE", "torch")
     trace = os.environ.get("MI355_TEST_TRACE") == "1"
@@ -36,6 +52,8 @@ def main():
         mark(f"kernel={kernel}: create")
         dc = D.DistCSR(rs, p, c, v, kernel=kernel, exchange=exchange)
         mark(f"kernel={kernel}: created push={dc.push} fused={dc.push_fused} n_halo={dc.n_halo}")
+        if upwind:
+            assert (dc.n_halo == 0) == (rank == world - 1) and (dc.n_send == 0) == (rank == 0), (rank, dc.n_halo, dc.n_send)
         assert not dc.native  # gloo: no RCCL
         assert dc.push == (exchange in ("push", "auto")), "peer-push exchange was requested but did not come up (or vice versa)"
         x_ext = dc.new_x_ext()

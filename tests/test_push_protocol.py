@@ -1,0 +1,175 @@
+"""Executable model of the peer-push step protocol (navierstokes_amd/csrc/push_exchange.hpp, spmv_ring.hpp FUSED,
+push_kernels.hpp): host only, no GPU.
+
+What the library does per rank and step t, reduced to the memory operations that matter:
+
+    four-launch form   push kernel:      per neighbour p: payload -> p's window, parity t & 1; then flag[p][me] = t
+                       wait+copy kernel: wait until flag[me][p] >= t for EVERY neighbour p; read parity t & 1
+    one-launch form    ghost-reading runs (ranks that receive something): push their links, wait for every
+                       neighbour's flag >= t, then read parity t & 1 UNTIL THE LAUNCH ENDS;
+                       a rank that receives nothing has no such run: dedicated push workgroups —
+                       gated (this round's fix): wait for every neighbour's flag >= t - 1, then push
+                       ungated (round 2):        push at once
+    both forms         kernels of step t + 1 start when every kernel of step t has finished (stream order)
+
+The model runs these as interleaved atomic actions under an adversarial random scheduler (one rank is let run
+ahead) and checks at every read that the slot holds exactly (sender, t): neither a later step's value (the
+sender overwrote a parity still being read) nor an earlier one (the flag ran ahead of the payload), and that
+no schedule deadlocks.  Neighbour sets are symmetric (the planner's rule: a rank also flags peers it only
+receives from), couplings are random DIRECTED graphs, so ranks that send without receiving — an upwind stencil,
+the last rank of an upper-triangular band — occur, and the two forms are mixed freely across ranks.
+
+Result recorded in DESIGN.md §6: with the gate the protocol holds for every mix of forms (so the round-2 rule
+"one form for all ranks" is a matter of balance, not of safety); without it the model exhibits the overwrite
+the advisor described within a few schedules.
+"""
+import random
+
+import pytest
+
+
+class Sim:
+    def __init__(self, nranks, sends, fused, steps, rnd, gate=True, reads_per_launch=3):
+        self.R, self.steps, self.rnd, self.gate = nranks, steps, rnd, gate
+        self.sends = sends                       # sends[r] = set of peers r pushes payload to
+        self.recv = [set(p for p in range(nranks) if r in sends[p]) for r in range(nranks)]
+        self.nb = [sorted(self.sends[r] | self.recv[r]) for r in range(nranks)]  # symmetric by construction
+        self.fused = fused
+        self.flag = [[0] * nranks for _ in range(nranks)]            # flag[owner][sender]
+        self.win = [[{}, {}] for _ in range(nranks)]                 # win[owner][parity][sender] = step written
+        self.reads_per_launch = reads_per_launch
+        self.errors = []
+        self.threads = [self.rank_program(r) for r in range(nranks)]  # generators yielding "want" predicates
+
+    # -- primitive actions (each `yield` is a scheduling point; a yielded callable must be true to proceed) ----
+    def push_link(self, r, p, t):
+        if p in self.sends[r]:
+            self.win[p][t & 1][r] = t   # payload, write-through, drained ...
+            yield None
+        self.flag[p][r] = t             # ... then the flag
+        yield None
+
+    def wait_flags(self, r, t):
+        for p in self.nb[r]:
+            yield (lambda p=p: self.flag[r][p] >= t)
+
+    def read_window(self, r, t):
+        for p in self.recv[r]:
+            got = self.win[r][t & 1].get(p)
+            if got != t:
+                self.errors.append(f"rank {r} step {t}: slot of sender {p} holds step {got}")
+
+    def rank_program(self, r):
+        for t in range(1, self.steps + 1):
+            if not self.nb[r]:
+                yield None
+                continue
+            if not self.fused[r]:  # four launches, stream-ordered
+                for p in self.nb[r]:
+                    yield from self.push_link(r, p, t)
+                yield from self.wait_flags(r, t)
+                self.read_window(r, t)  # the copy: one pass, the boundary kernel then reads x
+                yield None
+            elif self.recv[r]:  # one launch, ghost readers push first, wait, then read until the launch ends
+                for p in self.nb[r]:
+                    yield from self.push_link(r, p, t)
+                yield from self.wait_flags(r, t)
+                for _ in range(self.reads_per_launch):
+                    self.read_window(r, t)
+                    yield None
+            else:  # one launch, nobody reads ghosts: dedicated push workgroups
+                if self.gate:
+                    yield from self.wait_flags(r, t - 1)
+                for p in self.nb[r]:
+                    yield from self.push_link(r, p, t)
+
+    def run(self):
+        pending = {r: None for r in range(self.R)}  # the predicate a rank is blocked on (None: runnable)
+        alive = set(range(self.R))
+        favourite = self.rnd.randrange(self.R)
+        guard = 0
+        while alive:
+            guard += 1
+            assert guard < 10_000_000
+            runnable = [r for r in alive if pending[r] is None or pending[r]()]
+            if not runnable:
+                return "deadlock"
+            r = favourite if favourite in runnable and self.rnd.random() < 0.8 else self.rnd.choice(runnable)
+            if self.rnd.random() < 0.02:
+                favourite = self.rnd.randrange(self.R)
+            try:
+                pending[r] = next(self.threads[r])
+            except StopIteration:
+                alive.discard(r)
+        return "ok"
+
+
+def random_case(rnd, force_sender_only=False):
+    R = rnd.randint(2, 6)
+    sends = [set() for _ in range(R)]
+    shape = rnd.choice(["band", "upwind", "random"])
+    for r in range(R):
+        for p in range(R):
+            if p == r:
+                continue
+            if shape == "band" and abs(p - r) == 1:
+                sends[r].add(p)
+            elif shape == "upwind" and p == r - 1:   # rows reference columns at or above the diagonal: x flows downwards
+                sends[r].add(p)
+            elif shape == "random" and rnd.random() < 0.35:
+                sends[r].add(p)
+    if force_sender_only:  # the last rank only sends
+        for s in sends:
+            s.discard(R - 1)
+        sends[R - 1].add(R - 2)
+    fused = [rnd.random() < 0.6 for _ in range(R)]
+    if force_sender_only:
+        fused[R - 1] = True
+    return R, sends, fused
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_protocol_holds_for_mixed_forms_asymmetric_couplings_and_skew(seed):
+    rnd = random.Random(1000 + seed)
+    for _ in range(250):
+        R, sends, fused = random_case(rnd, force_sender_only=rnd.random() < 0.3)
+        sim = Sim(R, sends, fused, steps=rnd.randint(3, 9), rnd=rnd)
+        assert sim.run() == "ok", (R, sends, fused)
+        assert not sim.errors, (sim.errors[:3], R, sends, fused)
+
+
+def test_all_ranks_fused_and_all_ranks_unfused_are_covered():
+    rnd = random.Random(7)
+    for fused_all in (True, False):
+        for _ in range(200):
+            R, sends, _ = random_case(rnd)
+            sim = Sim(R, sends, [fused_all] * R, steps=6, rnd=rnd)
+            assert sim.run() == "ok" and not sim.errors, (sim.errors[:3], sends)
+
+
+def test_model_exhibits_the_round2_hole_without_the_gate():
+    """A fused rank that sends but receives nothing, round-2 form (pushers do not wait): the model must find a schedule in
+    which it runs two steps ahead and overwrites the parity its peer is still reading."""
+    rnd = random.Random(3)
+    found = 0
+    for _ in range(300):
+        R, sends, fused = random_case(rnd, force_sender_only=True)
+        sim = Sim(R, sends, fused, steps=6, rnd=rnd, gate=False)
+        sim.run()
+        found += bool(sim.errors)
+    assert found > 0, "the ungated model should overwrite a parity under some schedule"
+
+
+def test_spin_default_is_written_down_once():
+    """The poll budget's default lives in push_exchange.hpp (kPushSpinLog2Default); no comment quotes another number."""
+    import os
+    import re
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, "navierstokes_amd", "csrc")
+    txt = open(os.path.join(csrc, "push_exchange.hpp")).read()
+    m = re.search(r"constexpr int kPushSpinLog2Default = (\d+);", txt)
+    assert m and int(m.group(1)) == 20
+    for f in os.listdir(csrc):
+        if f.endswith((".hpp", ".hip")):
+            body = open(os.path.join(csrc, f)).read()
+            assert "default 23" not in body and "default 2^23" not in body, f
