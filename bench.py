@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--exchange", default=None, choices=["auto", "native", "push", "torch"], help="N > 1: which halo exchange drives the step")
     ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold single-shot and in-pipeline measurements")
+    ap.add_argument("--internal", action="store_true", help="N = 1, y = A x CSR workloads: x and y stay in the library's numbering "
+                    "(mi_spmv_internal_dev: a relabelled matrix pays no gather and no mapped store per product; what a Krylov loop does)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -289,7 +291,13 @@ def main():
         ring_cfg, ring_runs, ring_bad, ring_frac = A.ring_info()
         x = torch.from_numpy(x_host).cuda()
         ys = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(k)]
-        if k == 1:
+        if k == 1 and args.internal:
+            x_caller = x
+            x = A.to_internal(x_caller)  # once per solve, not once per product
+
+            def step():
+                mpk.SpMV_CSR_internal(ys[0], x, A)
+        elif k == 1:
             def step():
                 mpk.SpMV_CSR(ys[0], x, A)
         else:
@@ -471,7 +479,7 @@ def main():
             sys.exit("a halo wait gave up during the timed region: no number to report")
     # ---- the same kernel in two other regimes (N = 1, y = A x workloads only; never `value`) -------------------
     extra = {}
-    if world == 1 and k == 1 and not args.cold and not args.no_extras and not W.get("spmm"):
+    if world == 1 and k == 1 and not args.cold and not args.no_extras and not W.get("spmm") and not args.internal:
         # (1) cold single shot: L2s and the 256 MiB Infinity Cache evicted before EVERY launch (the reference's own
         #     protocol: flush_cache() before each timed call, mpk/SpM2V.cpp:895-904)
         #     Two forms: the eviction ENQUEUED in front of the launch (cold caches, GPU never idle: what "cold cache" means on
@@ -514,8 +522,13 @@ def main():
                 ev1.record()
                 torch.cuda.synchronize()
                 return ev0.elapsed_time(ev1) * 1e3 / reps
+            def pipe_fused():  # the dot rides in the first product's epilogue: two launches + one instead of two + two
+                mpk.SpMV_CSR_orthogonalize(ys[0], x, A, bvec, x3, 1e-8)
+                mpk.SpMV_CSR(z, x3, A)
             t_pipe = timed(pipe, 50)
             t_orth = timed(lambda: mpk.orthogonalize(n, bvec, ys[0], x3, 1e-8), 50)
+            extra["pipeline_fused_pass_us"] = timed(pipe_fused, 50)
+            extra["pipeline_dot_in_epilogue"] = A.dot_in_epilogue()
             extra["pipeline_pass_us"] = t_pipe
             extra["pipeline_orthogonalize_us"] = t_orth
             extra["pipeline_spmv_us"] = (t_pipe - t_orth) / 2
@@ -545,7 +558,7 @@ def main():
                           against="oracle SpMV_BCSR_FMA restatement (bit-pinned to the reference's object code)")
         elif world == 1:
             Y = O.spmk_chain(k, p, c, v, x_host)
-            got = [t.cpu().numpy() for t in ys]
+            got = [(A.from_internal(t) if (args.internal and k == 1) else t).cpu().numpy() for t in ys]
             parity = dict(rel_error=max(O.rel_error(Y[i], got[i]) for i in range(k)),
                           bitwise=all(np.array_equal(Y[i].view(np.uint64), got[i].view(np.uint64)) for i in range(k)),
                           against="oracle/cpu_ref.c fma chain (= reference SpMV_CSR_OPT/_FMA), full vectors")
@@ -647,13 +660,16 @@ def main():
             roofline["in_pipeline"] = dict(spmv_us=round(extra["pipeline_spmv_us"], 2),
                                            frac=round(B_exec / (extra["pipeline_spmv_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                            pass_us=round(extra["pipeline_pass_us"], 2), orthogonalize_us=round(extra["pipeline_orthogonalize_us"], 2),
+                                           pass_dot_in_epilogue_us=round(extra["pipeline_fused_pass_us"], 2), dot_in_epilogue=extra["pipeline_dot_in_epilogue"],
                                            protocol="SpMV -> orthogonalize (dot + AXPY) -> SpMV, mpk/SpMVmulti.cpp:559-574, device-resident, 50 passes; "
-                                                    "spmv_us = (pass - orthogonalize alone) / 2")
+                                                    "spmv_us = (pass - orthogonalize alone) / 2; pass_dot_in_epilogue_us = the same pass through "
+                                                    "mi_spmv_orthogonalize_dev (b . x1 accumulated in the first product's epilogue)")
     out = dict(metric="fp64 CSR SpMV GFLOP/s & % HBM roofline @ nnz; 1/2/4/8 GPU", value=round(value, 2), unit="GFLOP/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(wall * 1e3 / args.steps, 5),
                higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=W["desc"], name=args.workload, n=n, nnz=nnz_global, k=k, seed="0x5EED",
-                           half_bandwidth=synth.DEFAULT_W, partition=f"row-range x{world}", cold=bool(args.cold)),
+                           half_bandwidth=synth.DEFAULT_W, partition=f"row-range x{world}", cold=bool(args.cold),
+                           numbering="internal (mi_spmv_internal_dev; vectors permuted once outside the timed region)" if args.internal else "caller's"),
                roofline=roofline, pct_hbm_roofline=round(100 * achieved / HBM_PEAK_GBS, 2))
     if world == 1 and not bcsr:
         tune, nt = A.tune_detail()

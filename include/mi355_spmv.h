@@ -125,6 +125,24 @@ int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz);
  * us_* = measured launch time of the natural-order choice and of the twin incl. its gather (0 if not measured). */
 int mi_csr_reorder_info(mi_csr_t A, int* reordered, int* block, double* spread_before, double* spread_after,
                         double* us_natural, double* us_reordered);
+/* ---- staying in the library's numbering (callers that own the loop) -----------------------------------------------
+ * A relabelled handle pays an x gather and a mapped y store on EVERY mi_spmv_dev (random 8-byte accesses: 92 + 45 us of
+ * 326 us at 5 M rows).  A caller that runs many products per matrix — a Krylov solve: src/solve_newton.c:1265 KSPSolve, one
+ * MatMult per GMRES iteration on the mesh numbering of :91-197 — permutes its vectors ONCE per solve instead:
+ *   mi_csr_perm              perm[old] = new (identity and *reordered = 0 for a handle that was not relabelled)
+ *   mi_vec_to_internal_dev   x_int[perm[i]] = x[i]     (one gather; out of place)
+ *   mi_vec_from_internal_dev x[i] = x_int[perm[i]]
+ *   mi_spmv_internal_dev     y_int = A' x_int: the twin alone — no gather, no row map, no per-handle scratch
+ *   mi_spmk_internal_dev     the powers chain, every power left in the internal numbering
+ * The BLAS-1 entry points (mi_dot_dev, mi_axpy_dev, mi_orthogonalize_dev, mi_norm2_dev, ...) are numbering-agnostic:
+ * element-wise updates commute with a permutation bit for bit; a reduction sums in index order of whatever numbering it is
+ * given, so its last bits may differ between numberings (inside the bound documented at mi_dot).  Every row of y_int is the
+ * same fma chain as the caller-numbering product's: un-permuting y_int gives mi_spmv_dev's bits. */
+int mi_csr_perm(mi_csr_t A, int* reordered, int* perm /* [n] or NULL */);
+int mi_vec_to_internal_dev(mi_csr_t A, const double* d_x, double* d_x_int, mi_stream_t s);
+int mi_vec_from_internal_dev(mi_csr_t A, const double* d_x_int, double* d_x, mi_stream_t s);
+int mi_spmv_internal_dev(mi_csr_t A, const double* d_x_int, double* d_y_int, mi_stream_t s);
+int mi_spmk_internal_dev(mi_csr_t A, int k, const double* d_x_int, double* const* d_y_int_out, mi_stream_t s);
 /* host-only: the relabelling mi_csr_create would compute; perm[old] = new (n entries) */
 int mi_reorder_probe(int n, const int* ptrow, const int* indcol, int* block, int* perm, double* spread_before,
                      double* spread_after);
@@ -220,6 +238,21 @@ int mi_axpy_dev(int n, double a, const double* d_x, double* d_y, mi_stream_t s);
 int mi_orthogonalize(int n, const double* b, const double* x1, double* x3, double alpha, double* beta_out);
 int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1, double* d_x3, double alpha,
                          double* d_beta_out, mi_stream_t s);
+/* The Krylov-step pipeline of mpk/SpMVmulti.cpp:563-569 — SpMV_CSR(x1, b, a); orthogonalize(nrow, b, x1, x3); SpMV_CSR(x2, x3, a)
+ * — with the dot folded into the product (SURVEY.md §8 f-4 "fuse orthogonalisation with the k-step kernel"):
+ *   mi_spmv_dot_dev            y = A x and *beta = b . y; b . y is accumulated in the product's epilogue, while each row's
+ *                              value is still in its thread's register (ring kernel, LEAN form), so y and b are not read again
+ *                              by a dot kernel of their own.  Handles whose launch cannot carry the epilogue (other kernels,
+ *                              relabelled or blocked matrices) run product and dot as separate launches: same call, same bound.
+ *   mi_spmv_orthogonalize_dev  x1 = A x; beta = b . x1 (epilogue); x3 = fma(-(alpha*beta), b, x1): two launches instead of three.
+ * beta is a fixed-tree reduction like mi_dot's (deterministic run to run; its last bits differ from mi_dot's and from the CPU's
+ * left-to-right sum: |beta - b.y| <= 1e-13 * sum |b_i y_i| is what the tests assert); every row of y / x1 and, given beta, every
+ * element of x3 are the reference's bits.  Square or rectangular, unmapped matrices; device vectors. */
+int mi_spmv_dot_dev(mi_csr_t A, const double* d_x, double* d_y, const double* d_b, double* d_beta_out, mi_stream_t s);
+/* *in_epilogue = 1 if the next mi_spmv_dot_dev / mi_spmv_orthogonalize_dev on this handle carries the dot in the product's launch */
+int mi_csr_dot_epilogue_info(mi_csr_t A, int* in_epilogue);
+int mi_spmv_orthogonalize_dev(mi_csr_t A, const double* d_x, double* d_x1, const double* d_b, double* d_x3, double alpha,
+                              double* d_beta_out, mi_stream_t s);
 /* orthonormalize_against_basis(nrow, basis, y), mpk/2SpMV.cpp:13-28: for each of the m basis vectors IN TURN
  * dots[j] = y . v_j (on the y updated so far), y <- fma(-dots[j], v_j, y).  Like the reference nothing is
  * normalised (its norm is computed and dropped).  basis: HOST array of m pointers (host resp. device vectors).
@@ -239,6 +272,18 @@ int mi_gather_dev(int m, const int* d_idx, const double* d_src, double* d_dst, m
 int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
                     mi_bcsr4_t* out);
 int mi_bcsr4_destroy(mi_bcsr4_t A);
+/* Block layout of the caller's coefficient array.  mpk/ stores a 4x4 block ROW-major (mpk/SpMV.cpp:112: blk[4*i + j]); PETSc's
+ * MATSEQBAIJ — the matrix the reference's solver multiplies with (MatSetOperation(..., MATOP_MULT, ...), src/solve_newton.c:864-879;
+ * kernels src/kernels/baij4_{mad,fma,avx2}.c) — stores it COLUMN-major (baij4_mad.c:73-76: row 0 is v[0], v[4], v[8], v[12]).
+ * The *_layout entry points take either; column-major blocks are transposed on the way to the device (at create and at every
+ * value refresh, never per product), after which the handle is an ordinary one: y is bit-equal to the row-major handle of the
+ * transposed blocks, i.e. each row is the fma chain of SpMV_BCSR_FMA (mpk/SpMV.cpp:150-178).  (That is NOT the summation order of
+ * MatMult_SeqBAIJ_4_AVX2, which keeps four per-column accumulators and adds them at the end, src/kernels/baij4_avx2.c:42-66; that
+ * kernel needs PETSc to run, so against it parity is unpinned here — see INTEGRATION.md §4.) */
+enum { MI_BLOCK_ROWMAJOR = 0, MI_BLOCK_COLMAJOR = 1 };
+int mi_bcsr4_create_layout(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef, int layout, mi_bcsr4_t* out);
+int mi_bcsr4_update_values_layout(mi_bcsr4_t A, const double* coef, int layout);                          /* host values */
+int mi_bcsr4_update_values_layout_dev(mi_bcsr4_t A, const double* d_coef, int layout, mi_stream_t s);     /* device values */
 /* The blocked kernel exists in two forms: x blocks gathered through L1/L2 per block (spmv_bcsr4), or each workgroup's distinct
  * block columns gathered once into an LDS tile and addressed through a 16-bit stream (spmv_bcsr4_tile; built when no group of 64
  * block rows touches more than 1024 block columns).  mi_bcsr4_create times both and keeps the faster; same bits.

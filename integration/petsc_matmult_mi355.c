@@ -1,0 +1,106 @@
+/*
+ * petsc_matmult_mi355.c — the MI355X product behind PETSc's MatMult, for the reference's solver seam.
+ *
+ * The reference installs its hand-written SpMV into the Newton/GMRES loop with
+ *     MatSetOperation(mat, MATOP_MULT, (void(*)(void))MatMult_SeqBAIJ_4_AVX2);      src/solve_newton.c:864-879
+ * on MATSEQBAIJ matrices of block size 4 (S at :1061-1064, J at :1149-1152); KSPSolve (:1265) then calls it once per
+ * GMRES iteration.  This file is the same seam for libmi355spmv.so: OverrideMatMultWithMI355(mat) installs
+ * MatMult_MI355, which keeps one device handle per Mat (composed onto the Mat as a PetscContainer), refreshes the
+ * handle's values when the Mat's object state has moved (the Newton loop rewrites J every iteration:
+ * MatCopy + add_nonlinear_jacobian_terms + MatZeroRows, :1245-1247) and multiplies on the GPU.
+ *
+ * PETSc stores a BAIJ block COLUMN-major (src/kernels/baij4_mad.c:73-76 reads v[0], v[4], v[8], v[12] for row 0);
+ * the arrays go to mi_bcsr4_create_layout(..., MI_BLOCK_COLMAJOR, ...) as they are.
+ *
+ * Build (only where PETSc is installed — it is NOT in this repository's image, so this file is shipped as source and
+ * is compiled by nothing here; it needs the same private header the reference's kernels include,
+ * src/include/kernels.h:8):
+ *     mpicc -c petsc_matmult_mi355.c -I$PETSC_DIR/include -I$PETSC_DIR/$PETSC_ARCH/include -I<repo>/include
+ *     ... link the solver with -L<repo>/navierstokes_amd/csrc -lmi355spmv
+ * In src/solve_newton.c replace OverrideMatMultWithAVX2(J) by OverrideMatMultWithMI355(J) (same signature).
+ *
+ * Arithmetic: each row of y is ONE fma chain over the row's blocks in storage order, columns 0..3 inside a block —
+ * the bits of mpk's SpMV_BCSR_FMA (mpk/SpMV.cpp:150-178).  MatMult_SeqBAIJ_4_AVX2 keeps four per-column accumulators
+ * and adds them at the end (src/kernels/baij4_avx2.c:42-66): the two agree to rounding (rel. 1e-16 per row), not bit
+ * for bit, and since that kernel cannot run without PETSc its order is parity-unpinned in this repository.
+ */
+#include <petscmat.h>
+#include <../src/mat/impls/baij/seq/baij.h> /* Mat_SeqBAIJ: i, j, a, mbs, nbs, bs2 (as src/include/kernels.h:8) */
+
+#include "mi355_spmv.h"
+
+typedef struct {
+    mi_bcsr4_t        h;
+    PetscObjectState  state; /* the Mat's state the device values correspond to */
+} MI355MatCtx;
+
+static PetscErrorCode MI355MatCtxDestroy(void *p)
+{
+    MI355MatCtx *ctx = (MI355MatCtx *)p;
+    PetscFunctionBegin;
+    if (ctx) {
+        (void)mi_bcsr4_destroy(ctx->h);
+        PetscCall(PetscFree(ctx));
+    }
+    PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+#define MI_CALL(expr)                                                                                          \
+    do {                                                                                                       \
+        int mi_rc_ = (expr);                                                                                   \
+        if (mi_rc_ != MI_OK) SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "libmi355spmv: %s (%s)", mi_strerror(mi_rc_), mi_last_error()); \
+    } while (0)
+
+PetscErrorCode MatMult_MI355(Mat A, Vec xx, Vec zz)
+{
+    Mat_SeqBAIJ       *a = (Mat_SeqBAIJ *)A->data;
+    PetscContainer     box = NULL;
+    MI355MatCtx       *ctx = NULL;
+    PetscObjectState   st;
+    const PetscScalar *x;
+    PetscScalar       *z;
+
+    PetscFunctionBegin;
+    PetscCheck(a->bs2 == 16, PETSC_COMM_SELF, PETSC_ERR_ARG_WRONG, "MatMult_MI355 needs block size 4");
+    PetscCheck(sizeof(PetscInt) == sizeof(int) && sizeof(PetscScalar) == sizeof(double), PETSC_COMM_SELF, PETSC_ERR_SUP,
+               "libmi355spmv takes int32 indices and real double values");
+    PetscCall(PetscObjectStateGet((PetscObject)A, &st));
+    PetscCall(PetscObjectQuery((PetscObject)A, "mi355_matmult_ctx", (PetscObject *)&box));
+    if (!box) { /* first product with this Mat: upload pattern and values (a->i is the full row pointer even when
+                   compressedrow.use is set; rows without blocks simply produce 0, as baij4_avx2.c:27-29 arranges) */
+        PetscCall(PetscNew(&ctx));
+        MI_CALL(mi_bcsr4_create_layout((int)a->mbs, (int)a->nbs, (const int *)a->i, (const int *)a->j, (const double *)a->a,
+                                       MI_BLOCK_COLMAJOR, &ctx->h));
+        ctx->state = st;
+        PetscCall(PetscContainerCreate(PETSC_COMM_SELF, &box));
+        PetscCall(PetscContainerSetPointer(box, ctx));
+        PetscCall(PetscContainerSetUserDestroy(box, MI355MatCtxDestroy));
+        PetscCall(PetscObjectCompose((PetscObject)A, "mi355_matmult_ctx", (PetscObject)box));
+        PetscCall(PetscContainerDestroy(&box)); /* the Mat holds the reference now */
+    } else {
+        PetscCall(PetscContainerGetPointer(box, (void **)&ctx));
+        if (ctx->state != st) { /* values changed under an unchanged pattern (MatCopy ... SAME_NONZERO_PATTERN) */
+            MI_CALL(mi_bcsr4_update_values_layout(ctx->h, (const double *)a->a, MI_BLOCK_COLMAJOR));
+            ctx->state = st;
+        }
+    }
+    PetscCall(VecGetArrayRead(xx, &x));
+    PetscCall(VecGetArrayWrite(zz, &z));
+    MI_CALL(mi_bcsr4_spmv(ctx->h, (const double *)x, (double *)z)); /* host vectors in, host vector out (VECSEQ) */
+    PetscCall(VecRestoreArrayRead(xx, &x));
+    PetscCall(VecRestoreArrayWrite(zz, &z));
+    PetscCall(PetscLogFlops(2.0 * a->nz * a->bs2 - 4.0 * a->nonzerorowcnt)); /* as src/kernels/baij4_avx2.c:82 */
+    PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* same shape as OverrideMatMultWithAVX2, src/solve_newton.c:864-879 */
+PetscErrorCode OverrideMatMultWithMI355(Mat mat)
+{
+    PetscBool is_seqbaij;
+
+    PetscFunctionBegin;
+    PetscCall(PetscObjectTypeCompare((PetscObject)mat, MATSEQBAIJ, &is_seqbaij));
+    PetscCheck(is_seqbaij, PETSC_COMM_WORLD, PETSC_ERR_ARG_WRONG, "Matrix must be of type MATSEQBAIJ");
+    PetscCall(MatSetOperation(mat, MATOP_MULT, (void (*)(void))MatMult_MI355));
+    PetscFunctionReturn(PETSC_SUCCESS);
+}

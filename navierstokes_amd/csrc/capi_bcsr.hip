@@ -100,6 +100,65 @@ extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const i
     return MI_OK;
 }
 
+// ---- PETSc BAIJ block layout (column-major 4x4 blocks: v[0], v[4], v[8], v[12] are row 0 — src/kernels/baij4_mad.c:73-76) ------
+// The kernels read row-major blocks (mpk/SpMV.cpp:112).  A PETSc-side caller hands its Mat_SeqBAIJ arrays over as they are and
+// says so; the blocks are transposed on the way to the device (setup-time / value-refresh traffic, never per product).
+static void transpose_blocks_host(long long nb, const double* src, double* dst)
+{
+    for (long long k = 0; k < nb; k++)
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) dst[16 * k + 4 * r + c] = src[16 * k + 4 * c + r];
+}
+
+__global__ __launch_bounds__(256) void transpose_blocks_kernel(long long nb, const double* __restrict__ src, double* __restrict__ dst)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < 16 * nb; e += stride) {
+        const long long k = e >> 4;
+        const int r = (int)(e & 15) >> 2, c = (int)e & 3;
+        dst[e] = src[16 * k + 4 * c + r]; // coalesced stores; the 16 loads of a block hit one or two lines
+    }
+}
+
+extern "C" int mi_bcsr4_create_layout(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef, int layout,
+                                      mi_bcsr4_t* out)
+{
+    CHECK_ARG(layout == MI_BLOCK_ROWMAJOR || layout == MI_BLOCK_COLMAJOR, "unknown block layout");
+    if (layout == MI_BLOCK_ROWMAJOR) return mi_bcsr4_create(nbrows, nbcols, ptrow, indcol, coef, out);
+    CHECK_ARG(out, "out is null");
+    *out = nullptr;
+    CHECK_ARG(nbrows >= 0 && ptrow && ptrow[0] == 0 && ptrow[nbrows] >= 0, "bad argument");
+    const long long nb = ptrow[nbrows];
+    CHECK_ARG(nb == 0 || coef, "coef is null");
+    std::vector<double> t((size_t)nb * 16);
+    transpose_blocks_host(nb, coef, t.data());
+    return mi_bcsr4_create(nbrows, nbcols, ptrow, indcol, t.data(), out);
+}
+
+extern "C" int mi_bcsr4_update_values_layout(mi_bcsr4_t A, const double* coef, int layout)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(layout == MI_BLOCK_ROWMAJOR || layout == MI_BLOCK_COLMAJOR, "unknown block layout");
+    if (layout == MI_BLOCK_ROWMAJOR || A->nblocks == 0) return mi_bcsr4_update_values(A, coef);
+    CHECK_ARG(coef, "null coef");
+    std::vector<double> t((size_t)A->nblocks * 16);
+    transpose_blocks_host(A->nblocks, coef, t.data());
+    return mi_bcsr4_update_values(A, t.data());
+}
+
+extern "C" int mi_bcsr4_update_values_layout_dev(mi_bcsr4_t A, const double* d_coef, int layout, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(layout == MI_BLOCK_ROWMAJOR || layout == MI_BLOCK_COLMAJOR, "unknown block layout");
+    if (layout == MI_BLOCK_ROWMAJOR || A->nblocks == 0) return mi_bcsr4_update_values_dev(A, d_coef, s);
+    CHECK_ARG(d_coef && d_coef != A->d_coef, "null coef, or the handle's own array");
+    long long grid = (16 * A->nblocks + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(transpose_blocks_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, A->nblocks, d_coef, A->d_coef);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 extern "C" int mi_bcsr4_tile_info(mi_bcsr4_t A, int* built, int* in_use, double* us_plain, double* us_tile)
 {
     CHECK_ARG(A, "null handle");

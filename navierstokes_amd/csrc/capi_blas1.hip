@@ -114,6 +114,73 @@ extern "C" int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1
     return MI_OK;
 }
 
+// ---- product + dot in one pass (the f-4 pipeline SpMV -> dot + AXPY -> SpMV, mpk/SpMVmulti.cpp:563-569) -------------------
+// y = A x with the partial sums of b . y accumulated in the product's epilogue where the launch can carry it (the LEAN ring
+// kernel: ring_dot_eligible), else product and dot as separate launches — the same API either way.  *np = partials written to ws.
+static int spmv_with_dot_partials(mi_csr_t A, const double* d_x, double* d_y, const double* d_b, hipStream_t s, double* ws, int* np)
+{
+    int rc;
+    if (ring_dot_eligible(A)) {
+        RingDot dt{d_b, ws};
+        if ((rc = launch_spmv(A, d_x, d_y, s, true, nullptr, &dt))) return rc;
+        *np = A->ring.wgs;
+        return MI_OK;
+    }
+    if ((rc = launch_spmv(A, d_x, d_y, s))) return rc;
+    int seg;
+    red_geometry(A->n, np, &seg);
+    if (blas1_nt(A->n)) hipLaunchKernelGGL((reduce_stage1<0, true>), dim3(*np), dim3(kRedWG), 0, s, A->n, seg, d_b, d_y, ws, ws + kMaxPartials);
+    else hipLaunchKernelGGL((reduce_stage1<0, false>), dim3(*np), dim3(kRedWG), 0, s, A->n, seg, d_b, d_y, ws, ws + kMaxPartials);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_csr_dot_epilogue_info(mi_csr_t A, int* in_epilogue)
+{
+    CHECK_ARG(A && in_epilogue, "null argument");
+    *in_epilogue = ring_dot_eligible(A) ? 1 : 0;
+    return MI_OK;
+}
+
+extern "C" int mi_spmv_dot_dev(mi_csr_t A, const double* d_x, double* d_y, const double* d_b, double* d_beta_out, mi_stream_t s_)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(d_beta_out, "null beta");
+    CHECK_ARG(!A->mapped, "needs an unmapped matrix (b is indexed like y)");
+    hipStream_t s = (hipStream_t)s_;
+    if (A->n == 0) return reduce_dev<0, 0>(0, d_b, d_y, d_beta_out, s);
+    CHECK_ARG(d_x && d_y && d_b, "null vector");
+    double* ws = nullptr;
+    int rc = get_ws(s, &ws), np = 0;
+    if (rc) return rc;
+    if ((rc = spmv_with_dot_partials(A, d_x, d_y, d_b, s, ws, &np))) return rc;
+    hipLaunchKernelGGL((reduce_stage2<0>), dim3(1), dim3(kRedWG), 0, s, np, ws, ws + kMaxPartials, d_beta_out);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_spmv_orthogonalize_dev(mi_csr_t A, const double* d_x, double* d_x1, const double* d_b, double* d_x3, double alpha,
+                                         double* d_beta_out, mi_stream_t s_)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(d_beta_out, "null beta");
+    CHECK_ARG(!A->mapped, "needs an unmapped matrix (b is indexed like y)");
+    hipStream_t s = (hipStream_t)s_;
+    const int n = A->n;
+    if (n == 0) return reduce_dev<0, 0>(0, d_b, d_x1, d_beta_out, s);
+    CHECK_ARG(d_x && d_x1 && d_b && d_x3, "null vector");
+    double* ws = nullptr;
+    int rc = get_ws(s, &ws), np = 0;
+    if (rc) return rc;
+    if ((rc = spmv_with_dot_partials(A, d_x, d_x1, d_b, s, ws, &np))) return rc;
+    int grid = (n + kRedWG - 1) / kRedWG;
+    if (grid > 2048) grid = 2048;
+    if (blas1_nt(n)) hipLaunchKernelGGL(ortho_update_kernel<true>, dim3(grid), dim3(kRedWG), 0, s, n, alpha, np, ws, d_beta_out, d_b, d_x1, d_x3);
+    else hipLaunchKernelGGL(ortho_update_kernel<false>, dim3(grid), dim3(kRedWG), 0, s, n, alpha, np, ws, d_beta_out, d_b, d_x1, d_x3);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 extern "C" int mi_orthonormalize_against_basis_dev(int n, int m, const double* const* d_basis, double* d_y, double* d_dots,
                                                     mi_stream_t s_)
 {

@@ -170,6 +170,8 @@ static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const 
     RING_TRY(hipMemcpy(R.d_plan, best.plan.data(), sizeof(int) * best.plan.size(), hipMemcpyHostToDevice));
     RING_TRY(hipMalloc(&R.d_ok, sizeof(int) * best.run_ok.size()));
     RING_TRY(hipMemcpy(R.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
+    R.all_in_loop = true;
+    for (int g = 0; g < best.wgs; g++) R.all_in_loop = R.all_in_loop && best.run_ok[g] == 1;
     for (int g = 0; g < best.wgs; g++)
         R.uniform = R.uniform && best.run_rng[2 * g] == std::min(best.nblk, g * best.bpw) &&
                     best.run_rng[2 * g + 1] == std::min(best.nblk, (g + 1) * best.bpw);
@@ -645,6 +647,7 @@ static int maybe_reorder(mi_csr_t A, const int* ptrow, const int* indcol, const 
         A->d_xp = nullptr;
         return MI_OK;
     }
+    A->h_iperm = R.iperm; // host copy for mi_csr_perm (callers that keep their vectors in the library's numbering)
     release_natural_arrays(A);
     return MI_OK;
 }
@@ -690,6 +693,67 @@ extern "C" int mi_csr_reorder_info(mi_csr_t A, int* reordered, int* block, doubl
     if (spread_after) *spread_after = A->spread_after;
     if (us_natural) *us_natural = A->us_natural;
     if (us_reordered) *us_reordered = A->us_reordered;
+    return MI_OK;
+}
+
+// ---- the library's own numbering, for callers that own the loop (a Krylov solve: many products per matrix) ----------------
+extern "C" int mi_csr_perm(mi_csr_t A, int* reordered, int* perm)
+{
+    CHECK_ARG(A, "null handle");
+    if (reordered) *reordered = A->inner ? 1 : 0;
+    if (perm) {
+        if (A->inner) {
+            CHECK_ARG((int)A->h_iperm.size() == A->n, "permutation not kept on this handle");
+            for (int r = 0; r < A->n; r++) perm[A->h_iperm[r]] = r; // perm[old] = new
+        } else {
+            for (int i = 0; i < A->n; i++) perm[i] = i;
+        }
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_vec_to_internal_dev(mi_csr_t A, const double* d_x, double* d_x_int, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->n == 0) return MI_OK;
+    CHECK_ARG(d_x && d_x_int && d_x != d_x_int, "null vector, or in place");
+    if (A->inner) return gather_perm(A, d_x, d_x_int, (hipStream_t)s);
+    HIP_TRY(hipMemcpyAsync(d_x_int, d_x, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return MI_OK;
+}
+
+extern "C" int mi_vec_from_internal_dev(mi_csr_t A, const double* d_x_int, double* d_x, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->n == 0) return MI_OK;
+    CHECK_ARG(d_x && d_x_int && d_x != d_x_int, "null vector, or in place");
+    if (A->inner) return scatter_perm(A, d_x_int, d_x, (hipStream_t)s);
+    HIP_TRY(hipMemcpyAsync(d_x, d_x_int, sizeof(double) * (size_t)A->n, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return MI_OK;
+}
+
+extern "C" int mi_spmv_internal_dev(mi_csr_t A, const double* d_x_int, double* d_y_int, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    CHECK_ARG(A->n == A->ncols && !A->mapped, "the internal numbering is defined for square, unmapped matrices");
+    CHECK_ARG(A->n == 0 || (d_x_int && d_y_int), "null vector");
+    // a relabelled handle: the twin alone, reading and writing its own numbering — no gather, no row map, no per-handle
+    // scratch (so products on several streams may overlap); any other handle: its numbering IS the caller's
+    if (A->inner) return launch_spmv(A->inner, d_x_int, d_y_int, (hipStream_t)s, false);
+    return launch_spmv(A, d_x_int, d_y_int, (hipStream_t)s);
+}
+
+extern "C" int mi_spmk_internal_dev(mi_csr_t A, int k, const double* d_x_int, double* const* d_y_int_out, mi_stream_t s)
+{
+    CHECK_ARG(A, "null handle");
+    if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
+    CHECK_ARG(d_y_int_out, "null output array");
+    const double* src = d_x_int;
+    for (int p = 0; p < k; p++) {
+        int rc = mi_spmv_internal_dev(A, src, d_y_int_out[p], s);
+        if (rc) return rc;
+        src = d_y_int_out[p];
+    }
     return MI_OK;
 }
 

@@ -79,6 +79,7 @@ struct RingTable {
     std::vector<int> h_run_halo;
     bool uniform = true;       // runs are consecutive ranges of bpw blocks (the kernel then computes them)
     bool lean = false;         // the plan allows the LEAN instantiation (spmv_ring.hpp)
+    bool all_in_loop = false;  // every run is ring-served and holds no PLAIN block: every row is computed inside the counted loop
     unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block
     bool nt = false;                   // non-temporal loads of the values (chosen by measurement)
     bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
@@ -138,6 +139,7 @@ struct mi_csr_s {
     // map straight into the caller's numbering.  The natural-order device arrays are released then.
     mi_csr_t inner = nullptr;
     int* d_iperm = nullptr;     // [n] caller's index of new row / column
+    std::vector<int> h_iperm;   // the same on the host (mi_csr_perm)
     int* d_src_start = nullptr; // [n] offset of new row r' in the caller's coef (values refresh)
     double* d_xp = nullptr;     // x in the new numbering (one product at a time per handle)
     std::vector<double*> d_pp;  // powers in the new numbering
@@ -244,9 +246,11 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
 int resolve_kernel(const mi_csr_s* A);
 int get_table(mi_csr_t A, int nnzb, BlockTable** out);
 // launch_csr.hip
-int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr);
+int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr,
+                const RingDot* dot = nullptr);
+bool ring_dot_eligible(const mi_csr_s* A); // the next launch_spmv(A) can carry a dot epilogue (one partial per ring workgroup)
 // launch_ring.hip
-void launch_ring_cfg(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm);
+void launch_ring_cfg(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm, const RingDot* dot);
 // capi_blas1.hip
 int gather_perm(mi_csr_t A, const double* d_x, double* d_xp, hipStream_t s);
 int scatter_perm(mi_csr_t A, const double* d_src, double* d_dst, hipStream_t s);

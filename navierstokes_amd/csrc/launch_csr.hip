@@ -6,8 +6,20 @@
 #include "spmv_mring.hpp"
 
 // ---------------------------------------------------------------- SpMV launch
-int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm)
+bool ring_dot_eligible(const mi_csr_s* A)
 {
+    if (A->inner || A->n == 0 || A->d_rowmap || A->y_offset) return false;
+    if (resolve_kernel(A) != MI_KERNEL_RING) return false;
+    const RingTable& R = A->ring;
+    int depth = R.cfg.depth;
+    if (const char* e = getenv("MI355_RING_DEPTH")) depth = atoi(e);
+    return R.cfg.id == 4 && R.lean && depth != 3 && R.all_in_loop && R.wgs >= 1 && R.wgs <= 1024 /* kMaxPartials */ &&
+           !(getenv("MI355_SPMV_DOT_EPILOGUE") && !strcmp(getenv("MI355_SPMV_DOT_EPILOGUE"), "0"));
+}
+
+int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm, const RingDot* dot)
+{
+    if (dot && !ring_dot_eligible(A)) return fail(MI_ERR_STATE, "dot epilogue requested on a handle whose launch cannot carry it");
     if (A->n == 0) return MI_OK;
     // The fused multi-GPU step hands over a RingComm: its piece is numbered [ghosts | owned | ghosts], which only the ring
     // kernel's FUSED instantiation understands.  Any other launch would index x with that numbering — refuse, never drop it.
@@ -70,7 +82,7 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
         hipLaunchKernelGGL(spmv_csr_rowpar, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, V, d_x, d_y);
     } else if (kid == MI_KERNEL_RING) {
         V.nblk = A->ring.nblk;
-        launch_ring_cfg(A, V, d_x, d_y, s, comm); // launch_ring.hip
+        launch_ring_cfg(A, V, d_x, d_y, s, comm, dot); // launch_ring.hip
     } else {
         BlockTable* T = nullptr;
         int rc = get_table(A, 1024, &T);

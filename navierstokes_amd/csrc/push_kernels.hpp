@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void halo_push_kernel(const PushLink* __restri
 {
     const int2 w = work[blockIdx.x];
     const PushLink L = links[w.x];
-    double* dst = L.dst[step & 1u];
+    double* dst = (step & 1u) ? L.dst[1] : L.dst[0];
     const int i0 = w.y * kPushChunk, i1 = min(L.count, i0 + kPushChunk);
     if (L.count >= kPushBigLink && L.first >= 0 && ((L.first | i0) & 1) == 0 && (((uintptr_t)dst | (uintptr_t)x) & 15) == 0) {
         const double2* s2 = reinterpret_cast<const double2*>(x + L.first + i0);

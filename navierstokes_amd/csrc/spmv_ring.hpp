@@ -80,13 +80,25 @@ struct RingComm {
     unsigned spin_max; // polls before a wait gives up (2^kPushSpinLog2Default unless MI355_PUSH_SPIN_LOG2 says otherwise)
 };
 
+// The dot epilogue (DOT = true; mi_spmv_dot_dev / mi_spmv_orthogonalize_dev): while a row's value is still in its thread's
+// register it is also multiplied into that thread's running sum of b[row] * y[row]; at the end of the run the workgroup
+// reduces its threads' sums with a fixed tree and writes ONE partial — the finishing workgroup(s) of the consumer (the
+// orthogonalize update, blas1_kernels.hpp) add the <= 512 partials in a fixed order.  Deterministic, not the CPU's
+// left-to-right order (as every reduction of this library).  It replaces the separate dot pass between two products of a
+// Krylov step (mpk/SpMVmulti.cpp:563-569): b is read once per row here (8 B) instead of y and b being read again (16 B) by a
+// kernel of its own.  b's loads ride in the D-deep prefetch like every other load of the loop (unconditional, index clamped).
+struct RingDot {
+    const double* b;  // the dot's other vector, rows' numbering
+    double* partial;  // one double per workgroup of the launch
+};
+
 // one push link by the T threads of a workgroup (push_exchange.hpp: halo_push_kernel's body)
 template <int T>
 __device__ __forceinline__ void ring_push_link(const RingComm& C, const double* __restrict__ x, int l)
 {
     const int tid = threadIdx.x;
     const PushLink L = C.links[l];
-    double* dst = L.dst[C.step & 1u];
+    double* dst = (C.step & 1u) ? L.dst[1] : L.dst[0]; // (a select, not an indexed local array: that would live in scratch)
     if (L.first >= 0) {
         for (int i = tid; i < L.count; i += T) push_store(dst + i, x[L.first + i]);
     } else {
@@ -216,13 +228,14 @@ __device__ __forceinline__ double ring_row_chain(const double* s_c, const double
 // drained before block lb is reduced, so the "D blocks ahead" are never in flight together (ISA of the general form: vmcnt(0)
 // in front of the chains of every stage; of the LEAN form: vmcnt(33) with D = 4, one full drain per D blocks at the loop
 // header).  mi_csr_create launches the LEAN instantiation whenever the plan allows (all natural-order bands do).
-template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool NT, bool SKEW, bool FUSED = false, bool LEAN = false>
+template <int T, int NNZB, int RING, int D, int MAXB, bool MAPPED, bool NT, bool SKEW, bool FUSED = false, bool LEAN = false, bool DOT = false>
 __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __restrict__ plan,
                                                    const int* __restrict__ run_ok,
                                                    const unsigned short* __restrict__ slots,
                                                    const double* __restrict__ x, double* __restrict__ y,
-                                                   const int2* __restrict__ run_rng, int bpw, RingComm C)
+                                                   const int2* __restrict__ run_rng, int bpw, RingComm C, RingDot Dt = RingDot{nullptr, nullptr})
 {
+    static_assert(!DOT || (LEAN && !FUSED && !MAPPED), "the dot epilogue exists for the LEAN single-GPU instantiation (all rows inside the counted loop)");
     constexpr int PER = NNZB / T;
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
     static_assert(RING <= 65536, "ring slots are stored in 16 bits");
@@ -253,7 +266,10 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
         if (l0 >= 0)
             for (int l = l0; l < C.n_links; l += C.npush_runs) ring_push_link<T>(C, x, l);
     }
-    if (nb <= 0) return;
+    if (nb <= 0) {
+        if (DOT && tid == 0) Dt.partial[gw] = 0.0; // every workgroup of the launch owns one partial
+        return;
+    }
     const int clast = A.ncols - 1;
     // the plan is read back from LDS at a uniform address: tell the compiler so (SGPRs, scalar
     // address arithmetic for the stream loads instead of 64-bit vector adds per load)
@@ -293,6 +309,9 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     int2 pr[D];   // raw ptrow pair of this thread's row in the staged block
     double xr[D]; // the column this thread puts into the ring when the staged block becomes current
     int rm[D];    // rowmap[row] (MAPPED only)
+    double br[D]; // b[row] of this thread's row (DOT only)
+    double dacc = 0.0;
+    const int rlast = A.n - 1;
 
     auto issue = [&](int lb, int s) {
         const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
@@ -311,6 +330,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
         const int* rp = A.ptrow + uni(m0.x) + tid;
         pr[s] = make_int2(rp[0], rp[1]);
         if (MAPPED) rm[s] = (A.rowmap + uni(m0.x))[tid];
+        if (DOT) br[s] = Dt.b[min(uni(m0.x) + tid, rlast)];
         xr[s] = ring_ldx<FUSED>(x, C, min(uni(m1.x) + tid, clast));
     };
 
@@ -351,6 +371,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
             }
             const int2 prs = pr[s];
             const int rms = MAPPED ? rm[s] : 0;
+            const double brs = DOT ? br[s] : 0.0;
             // ---- refill this stage with block lb + D
             issue(lb + D, s);
             __syncthreads(); // staging complete; nobody gathers block lb from the ring any more
@@ -375,13 +396,33 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
                 }
             }
             // ---- row chains
-            if (tid < nrows) y[MAPPED ? rms : r0 + tid] = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
+            if (DOT) {
+                if (tid < nrows) {
+                    const double yv = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
+                    y[r0 + tid] = yv;
+                    dacc = fma(brs, yv, dacc);
+                }
+            } else if (tid < nrows) y[MAPPED ? rms : r0 + tid] = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
             if (!LEAN)
                 for (int r = r0 + tid + T; r < r0 + nrows; r += T) { // blocks of very short rows
                     const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
                     y[MAPPED ? A.rowmap[r] : r] = ring_row_chain<8, SKEW>(s_c, s_x, a, e);
                 }
         }
+    }
+    if (DOT) { // this workgroup's partial of b . y: wave shuffle tree, then the T / 64 waves through LDS, fixed order
+        __syncthreads(); // the staging arrays are free
+        double v = dacc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) s_c[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double t = s_c[0];
+            for (int w = 1; w < T / 64; w++) t += s_c[w];
+            Dt.partial[gw] = t;
+        }
+        return; // (the host launches this instantiation only for plans without PLAIN blocks or plain runs)
     }
     // PLAIN blocks of this run (ring_plan.hpp: a row the window cannot hold, at most kRingMaxPlain per run): the loop above
     // passed over them as over empty blocks; here, outside the counted pipeline, with direct gathers

@@ -90,6 +90,11 @@ def lib():
         "mi_krylov_basis_dev": [_vp, i, _vp, _vp, ll, i, _vp, _vp],
         "mi_csr_reorder_info": [_vp, P(i), P(i), P(d), P(d), P(d), P(d)],
         "mi_reorder_probe": [i, _vp, _vp, P(i), _vp, P(d), P(d)],
+        "mi_csr_perm": [_vp, P(i), _vp],
+        "mi_vec_to_internal_dev": [_vp, _vp, _vp, _vp],
+        "mi_vec_from_internal_dev": [_vp, _vp, _vp, _vp],
+        "mi_spmv_internal_dev": [_vp, _vp, _vp, _vp],
+        "mi_spmk_internal_dev": [_vp, i, _vp, _vp, _vp],
         "mi_csr_dims": [_vp, P(i), P(i), P(ll)],
         "mi_csr_set_kernel": [_vp, i],
         "mi_csr_get_kernel": [_vp, P(i)],
@@ -117,6 +122,9 @@ def lib():
         "mi_axpy_dev": [i, d, _vp, _vp, _vp],
         "mi_orthogonalize": [i, _vp, _vp, _vp, d, P(d)],
         "mi_orthogonalize_dev": [i, _vp, _vp, _vp, d, _vp, _vp],
+        "mi_spmv_dot_dev": [_vp, _vp, _vp, _vp, _vp, _vp],
+        "mi_csr_dot_epilogue_info": [_vp, P(i)],
+        "mi_spmv_orthogonalize_dev": [_vp, _vp, _vp, _vp, _vp, d, _vp, _vp],
         "mi_norm2": [i, _vp, P(d)],
         "mi_norm2_dev": [i, _vp, _vp, _vp],
         "mi_rel_error": [i, _vp, _vp, P(d)],
@@ -124,6 +132,9 @@ def lib():
         "mi_gather_dev": [i, _vp, _vp, _vp, _vp],
         "mi_bcsr4_create": [i, i, _vp, _vp, _vp, P(_vp)],
         "mi_bcsr4_destroy": [_vp],
+        "mi_bcsr4_create_layout": [i, i, _vp, _vp, _vp, i, P(_vp)],
+        "mi_bcsr4_update_values_layout": [_vp, _vp, i],
+        "mi_bcsr4_update_values_layout_dev": [_vp, _vp, i, _vp],
         "mi_bcsr4_spmv": [_vp, _vp, _vp],
         "mi_bcsr4_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_bcsr4_spmk": [_vp, i, _vp, _vp],
@@ -312,6 +323,32 @@ class csrmatrix:
         return dict(reordered=bool(r.value), block=b.value, spread_before=v[0].value, spread_after=v[1].value,
                     us_natural=v[2].value, us_reordered=v[3].value)
 
+    def dot_in_epilogue(self):
+        """True if SpMV_CSR_dot / SpMV_CSR_orthogonalize on this handle carry the dot inside the product's launch."""
+        r = _c.c_int()
+        check(lib().mi_csr_dot_epilogue_info(self.handle, _c.byref(r)))
+        return bool(r.value)
+
+    # -- the library's numbering (mi_csr_perm ...): permute once per solve, not once per product --------------------
+    def perm(self):
+        """(reordered, perm) with perm[old] = new — identity when the handle was not relabelled."""
+        r = _c.c_int()
+        p = np.empty(self.n, np.int32)
+        check(lib().mi_csr_perm(self.handle, _c.byref(r), p.ctypes.data))
+        return bool(r.value), p
+
+    def to_internal(self, x, out=None):
+        import torch
+        out = torch.empty_like(x) if out is None else out
+        check(lib().mi_vec_to_internal_dev(self.handle, _dev_ptr(x, self.n, "x"), _dev_ptr(out, self.n, "x_int"), _stream_ptr()))
+        return out
+
+    def from_internal(self, x_int, out=None):
+        import torch
+        out = torch.empty_like(x_int) if out is None else out
+        check(lib().mi_vec_from_internal_dev(self.handle, _dev_ptr(x_int, self.n, "x_int"), _dev_ptr(out, self.n, "x"), _stream_ptr()))
+        return out
+
     def update_values(self, coef):
         """New coefficients for the same pattern (mi_csr_update_values): numpy array (host) or CUDA tensor."""
         if _is_torch(coef):
@@ -342,7 +379,10 @@ class csrmatrix:
 class bcsr4x4_matrix:
     """struct bcsr4x4_matrix of mpk/SpMV.h:26-33 (row-major 4x4 blocks)."""
 
-    def __init__(self, nrows, ptrow, indcol, coef, nbcols=None):
+    def __init__(self, nrows, ptrow, indcol, coef, nbcols=None, layout="row"):
+        """layout: "row" — blocks row-major as mpk/ stores them; "col" — column-major as PETSc's MATSEQBAIJ stores them
+        (src/kernels/baij4_mad.c:73-76), transposed by the library on upload."""
+        self.layout = {"row": 0, "col": 1}[layout]
         self.nrows = int(nrows)
         self.ptrow = np.ascontiguousarray(ptrow, dtype=np.int32)
         self.indcol = np.ascontiguousarray(indcol, dtype=np.int32)
@@ -356,10 +396,19 @@ class bcsr4x4_matrix:
     def handle(self):
         if self._h is None:
             h = _vp()
-            check(lib().mi_bcsr4_create(self.nrows, self.nbcols, self.ptrow.ctypes.data, self.indcol.ctypes.data,
-                                        self.coef.ctypes.data, _c.byref(h)))
+            check(lib().mi_bcsr4_create_layout(self.nrows, self.nbcols, self.ptrow.ctypes.data, self.indcol.ctypes.data,
+                                               self.coef.ctypes.data, self.layout, _c.byref(h)))
             self._h = h
         return self._h
+
+    def update_values(self, coef):
+        """New block values (same pattern, same layout as at construction): numpy array or CUDA tensor."""
+        if _is_torch(coef):
+            check(lib().mi_bcsr4_update_values_layout_dev(self.handle, _dev_ptr(coef, 16 * self.nblocks, "coef"), self.layout, _stream_ptr()))
+        else:
+            self.coef = _host_f64(coef, 16 * self.nblocks, "coef")
+            check(lib().mi_bcsr4_update_values_layout(self.handle, self.coef.ctypes.data, self.layout))
+        return self
 
     def close(self):
         if self._h is not None:
@@ -406,6 +455,13 @@ def SpMV_CSR(y, x, A):
         yy = _host_f64(y, A.n, "y", writable=True)
         check(lib().mi_spmv(A.handle, xx.ctypes.data, yy.ctypes.data))
     return y
+
+
+def SpMV_CSR_internal(y_int, x_int, A):
+    """y_int = A x_int with both vectors in the library's numbering (csrmatrix.to_internal / from_internal): what a Krylov
+    loop calls between its one permutation in and its one permutation out.  Device tensors only."""
+    check(lib().mi_spmv_internal_dev(A.handle, _dev_ptr(x_int, A.n, "x_int"), _dev_ptr(y_int, A.n, "y_int"), _stream_ptr()))
+    return y_int
 
 
 # The reference's four CSR variants differ only in how the CPU is driven
@@ -590,6 +646,22 @@ def orthogonalize(nrow, b, x1, x3, alpha=1e-8):
     check(lib().mi_orthogonalize(nrow, _host_f64(b, nrow).ctypes.data, _host_f64(x1, nrow).ctypes.data,
                                  x3h.ctypes.data, float(alpha), _c.byref(out)))
     return out.value
+
+
+def SpMV_CSR_dot(y, x, A, b):
+    """y = A x and beta = b . y in one pass (mi_spmv_dot_dev): returns beta as a 1-element device tensor."""
+    beta = _scalar_dev()
+    check(lib().mi_spmv_dot_dev(A.handle, _dev_ptr(x, A.ncols, "x"), _dev_ptr(y, A.n, "y"), _dev_ptr(b, A.n, "b"), _dev_ptr(beta), _stream_ptr()))
+    return beta
+
+
+def SpMV_CSR_orthogonalize(x1, x, A, b, x3, alpha=1e-8):
+    """SpMV_CSR(x1, x, A); orthogonalize(n, b, x1, x3, alpha) — mpk/SpMVmulti.cpp:563-565 — as two launches: the dot rides in
+    the product's epilogue (mi_spmv_orthogonalize_dev).  Returns beta (1-element device tensor)."""
+    beta = _scalar_dev()
+    check(lib().mi_spmv_orthogonalize_dev(A.handle, _dev_ptr(x, A.ncols, "x"), _dev_ptr(x1, A.n, "x1"), _dev_ptr(b, A.n, "b"),
+                                          _dev_ptr(x3, A.n, "x3"), float(alpha), _dev_ptr(beta), _stream_ptr()))
+    return beta
 
 
 def orthonormalize_against_basis(basis, y):

@@ -635,3 +635,78 @@ def test_blocked_kernel_with_and_without_the_x_tile(force, monkeypatch):
     B2 = mpk.bcsr4x4_matrix(n // 4, bp2, bc2, bv2, nbcols=n // 4)
     mpk.SpMV_BCSR(y, x, B2)
     assert_bit_equal(y, O.spmv_bcsr4(bp2, bc2, bv2, x), f"empty block rows, tile={force}")
+
+
+@pytest.mark.parametrize("kind,n,kernel,expect_fused", [("s15", 300_000, "ring", True), ("svar", 200_000, "ring", True), ("s15", 300_000, "stream", False),
+                                                         ("s15", 3_000, "ring", True), ("sfe", 40_000, "auto", None)])
+def test_product_with_the_dot_in_its_epilogue(kind, n, kernel, expect_fused):
+    """mi_spmv_dot_dev / mi_spmv_orthogonalize_dev (the f-4 pipeline SpMV -> dot + AXPY -> SpMV of mpk/SpMVmulti.cpp:563-569 with
+    the dot folded into the product): every row of y is the oracle's fma chain whether or not the launch carried the dot; beta
+    is a fixed-tree reduction inside the bound all reductions of the library are held to; GIVEN beta the update is the
+    reference's fma bit for bit."""
+    p, c, v = synth.rows(kind, n)
+    x = synth.x_sin(0, n)
+    b = np.cos(0.002 * np.arange(n))
+    A = mpk.csrmatrix(n, p, c, v).set_kernel(kernel)
+    if expect_fused is not None:
+        assert A.dot_in_epilogue() == expect_fused, A.kernel_name()
+    yo = O.spmv(p, c, v, x)
+    bound = 1e-13 * float(np.abs(b * yo).sum())
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    beta = mpk.SpMV_CSR_dot(y, dev(x), A, dev(b))
+    assert_bit_equal(y.cpu().numpy(), yo, f"product with dot epilogue ({A.kernel_name()})")
+    assert abs(float(beta) - O.dot(b, yo)) <= bound, (float(beta), O.dot(b, yo), bound)
+    b2 = float(beta)
+    beta_again = mpk.SpMV_CSR_dot(y, dev(x), A, dev(b))
+    assert float(beta_again) == b2, "the reduction is deterministic run to run"
+    x1 = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    x3 = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    beta3 = mpk.SpMV_CSR_orthogonalize(x1, dev(x), A, dev(b), x3, 1e-8)
+    assert float(beta3) == b2
+    assert_bit_equal(x1.cpu().numpy(), yo, "x1 = A x")
+    assert_bit_equal(x3.cpu().numpy(), O.ortho_update(1e-8 * b2, b, yo), "x3 given the device's beta")
+    # the pipeline's second product on x3
+    x2 = torch.empty(n, dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(x2, x3, A)
+    assert_bit_equal(x2.cpu().numpy(), O.spmv(p, c, v, x3.cpu().numpy()), "x2 = A x3")
+
+
+def test_column_major_blocks_of_a_petsc_baij_matrix():
+    """The PETSc seam (integration/petsc_matmult_mi355.c): MATSEQBAIJ stores a 4x4 block column-major
+    (src/kernels/baij4_mad.c:73-76); mi_bcsr4_create_layout(MI_BLOCK_COLMAJOR) takes the array as it is.  The product must be
+    bit-equal to the row-major handle of the same matrix and to the oracle, also after a value refresh in either form."""
+    p, c, v = synth.fe_matrix(12)
+    n = len(p) - 1
+    bp, bc, bv = synth.csr_to_bcsr4(p, c, v)                       # row-major blocks (mpk layout)
+    bv_col = np.ascontiguousarray(bv.reshape(-1, 4, 4).transpose(0, 2, 1)).reshape(-1)  # what Mat_SeqBAIJ::a holds
+    x = synth.x_sin(0, n)
+    yo = O.spmv_bcsr4(bp, bc, bv, x)
+    A_row = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
+    A_col = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv_col, nbcols=n // 4, layout="col")
+    for A, what in ((A_row, "row-major"), (A_col, "column-major")):
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_BCSR(y, dev(x), A)
+        assert_bit_equal(y.cpu().numpy(), yo, f"{what} blocks")
+    yh = np.full(n, np.nan)
+    mpk.SpMV_BCSR(yh, x, A_col)  # the host-vector call the PETSc glue makes
+    assert_bit_equal(yh, yo, "column-major blocks, host vectors")
+    # a Newton step rewrites the values: refresh from a host array and from a device array, column-major both
+    bv2 = bv * np.cos(np.arange(len(bv)))
+    bv2_col = np.ascontiguousarray(bv2.reshape(-1, 4, 4).transpose(0, 2, 1)).reshape(-1)
+    yo2 = O.spmv_bcsr4(bp, bc, bv2, x)
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    A_col.update_values(bv2_col)
+    mpk.SpMV_BCSR(y, dev(x), A_col)
+    assert_bit_equal(y.cpu().numpy(), yo2, "after a host refresh, column-major")
+    A_col.update_values(dev(bv_col))
+    mpk.SpMV_BCSR(y, dev(x), A_col)
+    assert_bit_equal(y.cpu().numpy(), yo, "after a device refresh, column-major")
+    # the association the PETSc AVX2 kernel uses is NOT this chain: four per-column accumulators added at the end
+    # (src/kernels/baij4_avx2.c:42-66) — agreement to rounding only, documented as parity-unpinned (no PETSc here)
+    acc = np.zeros((4, n))
+    rows = np.repeat(np.arange(n // 4), np.diff(bp))
+    blk = bv.reshape(-1, 4, 4)
+    for j in range(4):
+        np.add.at(acc[j].reshape(-1, 4), rows, blk[:, :, j] * x.reshape(-1, 4)[bc][:, j:j + 1])
+    y_avx2_like = (acc[0] + acc[1]) + (acc[2] + acc[3])
+    assert O.rel_error(yo, y_avx2_like) < 1e-14

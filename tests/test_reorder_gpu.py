@@ -135,3 +135,54 @@ def test_auto_decision_is_measured_and_never_changes_bits():
     yd = torch.empty(400000, dtype=torch.float64, device="cuda")
     mpk.SpMV_CSR(yd, dev(x), A)
     assert_bit_equal(yd.cpu().numpy(), O.spmv(p, c, v, x), f"{A.kernel_name()} {info}")
+
+
+def _krylov_pass_in_internal_numbering(p, c, v, n, expect_reordered):
+    """SpMV -> orthogonalize -> SpMV (mpk/SpMVmulti.cpp:559-574) run ENTIRELY in the library's numbering: one permutation in,
+    one out.  Every row is the oracle's fma chain; beta is a reduction in another index order (inside the documented bound)
+    and, GIVEN the device's beta, the update and the second product are the oracle's bit for bit."""
+    A = mpk.csrmatrix(n, p, c, v)
+    reordered, perm = A.perm()
+    assert reordered == expect_reordered and sorted(perm.tolist()) == list(range(n))
+    x = synth.x_sin(0, n)
+    b = np.cos(0.002 * np.arange(n))
+    xi, bi = A.to_internal(dev(x)), A.to_internal(dev(b))
+    assert_bit_equal(xi.cpu().numpy()[perm], x, "to_internal: x_int[perm[i]] = x[i]")
+    assert_bit_equal(A.from_internal(xi).cpu().numpy(), x, "from_internal undoes to_internal")
+    y1 = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    x3 = torch.empty_like(y1)
+    y2 = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR_internal(y1, xi, A)
+    beta = mpk.orthogonalize(n, bi, y1, x3, 1e-8)
+    mpk.SpMV_CSR_internal(y2, x3, A)
+    torch.cuda.synchronize()
+    # back in the caller's numbering
+    y1o = O.spmv(p, c, v, x)
+    assert_bit_equal(A.from_internal(y1).cpu().numpy(), y1o, "internal product, un-permuted")
+    bdev = float(beta)
+    bound = 1e-13 * float(np.abs(b * y1o).sum())
+    assert abs(bdev - float(np.dot(b, y1o))) <= bound, (bdev, float(np.dot(b, y1o)), bound)
+    x3o = O.ortho_update(1e-8 * bdev, b, y1o)  # the reference's fused update, replayed on the host with the device's beta
+    assert_bit_equal(A.from_internal(x3).cpu().numpy(), x3o, "update, given the device's beta")
+    assert_bit_equal(A.from_internal(y2).cpu().numpy(), O.spmv(p, c, v, x3o), "second product")
+    # and the powers chain left in the internal numbering
+    outs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    ptrs = (mpk._vp * 3)(*[t.data_ptr() for t in outs])
+    mpk.check(mpk.lib().mi_spmk_internal_dev(A.handle, 3, mpk._vp(xi.data_ptr()), ptrs, mpk._stream_ptr()))
+    Y = O.spmk_chain(3, p, c, v, x)
+    for k in range(3):
+        assert_bit_equal(A.from_internal(outs[k]).cpu().numpy(), Y[k], f"internal power {k + 1}")
+
+
+def test_krylov_pass_in_the_internal_numbering(monkeypatch):
+    monkeypatch.setenv("MI355_REORDER", "1")
+    p0, c0, v0 = synth.pressure_matrix(24, 22, 20)
+    n = len(p0) - 1
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=1, seed=5)
+    _krylov_pass_in_internal_numbering(p, c, v, n, True)
+    p0, c0, v0 = synth.fe_matrix(10)
+    n = len(p0) - 1
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=4, seed=3)
+    _krylov_pass_in_internal_numbering(p, c, v, n, True)
+    monkeypatch.setenv("MI355_REORDER", "0")  # a handle that was not relabelled: the internal numbering is the caller's
+    _krylov_pass_in_internal_numbering(p, c, v, n, False)
