@@ -627,6 +627,8 @@ def main():
         roofline["csr_equivalent"] = dict(bytes_per_launch=B_csr, gbs=round(B_csr / launch_s / 1e9, 1),
                                           of_peak=round(B_csr / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                                           note="NOT a roofline fraction: CSR-model bytes over the time of a kernel that reads the blocked copy")
+    if k > 1 and world == 1 and not bcsr:
+        out_spmk = A.spmk_info(k)
     if k > 1 and world == 1:
         # matrix powers: `frac` above prices each of the k launches at the un-fused traffic k*B; a fused kernel that
         # read the matrix once would need B_fused = 12 nnz + 4 (n+1) + 8 n (1 + k) for the whole step
@@ -694,6 +696,10 @@ def main():
         ri = A.reorder_info()
         if ri["reordered"] or ri["block"]:
             out["reorder"] = {k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in ri.items()}
+    if k > 1 and world == 1 and not bcsr:
+        out["kernel_info"]["powers_step"] = dict(one_launch=out_spmk["one_launch"], eligible=out_spmk["eligible"],
+                                                 us_k_launches=round(out_spmk["us_k_launches"], 2), us_one_launch=round(out_spmk["us_one_launch"], 2),
+                                                 note="first k-step of the handle times both forms (same bits) and keeps the faster; MI355_SPMK_FUSED=0|1 forces")
     if parity is not None:
         out["parity"] = parity
     if halo_info is not None:

@@ -223,6 +223,18 @@ int mi_spmv_dev(mi_csr_t A, const double* d_x, double* d_y, mi_stream_t s);    /
 int mi_spmk(mi_csr_t A, int k, const double* x, double* const* y_out);                      /* host */
 int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s); /* device; d_y_out is a HOST array of k device pointers */
 
+/* The powers step runs as ONE launch where that is possible and faster (spmk_ring.hpp: every persistent workgroup keeps its run
+ * of row blocks for all k powers; a run's power p is published write-through + flag, power p + 1 waits for the flags of the runs
+ * its columns name) — k <= 8, ring-served square matrices whose whole grid is resident at once; the first k-step of a handle at a
+ * given k times both forms (same bits) and keeps the faster.  MI355_SPMK_FUSED=0 never, =1 always where eligible.  The handle
+ * carries the step's flags: one k-step at a time per handle.  Reports what the handle does at this k (after its first k-step). */
+int mi_csr_spmk_info(mi_csr_t A, int k, int* eligible, int* one_launch, double* us_k_launches, double* us_one_launch);
+
+/* host-only: derive the one-launch step's run dependencies as mi_csr_create would and CHECK them against the matrix (every column
+ * a run names or loads belongs to a run on its list; MI_ERR_STATE names the first violation).  *eligible = 0 when the plan cannot
+ * carry the step (rows outside the ring loop, or a band so wide that a run would wait for more than 64 others). */
+int mi_spmk_plan_probe(int n, const int* ptrow, const int* indcol, int* eligible, int* runs, int* max_deps);
+
 /* ---- BLAS-1 between SpMVs ---------------------------------------------- */
 /* out = sum x_i y_i  (std::inner_product, mpk/SpMVmulti.cpp:147).  Fixed
  * two-stage reduction tree: deterministic run to run, not the CPU's order. */

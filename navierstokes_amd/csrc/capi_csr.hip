@@ -141,7 +141,8 @@ static void free_ring_table(RingTable& R)
 }
 
 // device copy of a ring plan (plan records, run tables, 16-bit column stream) and what the launch needs to know about it
-static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const int* ptrow, const int* indcol, long long nnz, bool ghosts)
+static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const int* ptrow, const int* indcol, long long nnz, bool ghosts,
+                           const int* row_min = nullptr, const int* row_max = nullptr, bool square = false)
 {
     R.cfg = best.cfg;
     // Blocks of prefetch: with long runs (C4: 72 blocks per workgroup) four blocks in flight instead of two hide more of
@@ -172,6 +173,9 @@ static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const 
     RING_TRY(hipMemcpy(R.d_ok, best.run_ok.data(), sizeof(int) * best.run_ok.size(), hipMemcpyHostToDevice));
     R.all_in_loop = true;
     for (int g = 0; g < best.wgs; g++) R.all_in_loop = R.all_in_loop && best.run_ok[g] == 1;
+    R.h_dep_ptr.clear();
+    R.h_dep_run.clear();
+    if (square && row_min && R.all_in_loop && R.lean && best.cfg.id == 4 && !ghosts) build_run_deps(best, n, R.h_dep_ptr, R.h_dep_run);
     for (int g = 0; g < best.wgs; g++)
         R.uniform = R.uniform && best.run_rng[2 * g] == std::min(best.nblk, g * best.bpw) &&
                     best.run_rng[2 * g + 1] == std::min(best.nblk, (g + 1) * best.bpw);
@@ -293,7 +297,7 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
             if (forced) break;
         }
         {
-            const int rcr = fill_ring_table(A->ring, best, n, ptrow, indcol, nnz, ghost_lo < ghost_hi);
+            const int rcr = fill_ring_table(A->ring, best, n, ptrow, indcol, nnz, ghost_lo < ghost_hi, row_min.data(), row_max.data(), n == ncols);
             if (rcr != MI_OK) {
                 mi_csr_destroy(A);
                 return rcr;
@@ -490,7 +494,7 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
             build_ring_plan(kRingConfigs[3], n, ptrow, row_min.data(), row_max.data(), alt, ghost_lo, ghost_hi, 1);
             RingTable T2;
             if (nnz > 0 && 1.0 - (double)alt.bad_nnz / (double)nnz >= 0.90 &&
-                fill_ring_table(T2, alt, n, ptrow, indcol, nnz, ghost_lo < ghost_hi) == MI_OK) {
+                fill_ring_table(T2, alt, n, ptrow, indcol, nnz, ghost_lo < ghost_hi, row_min.data(), row_max.data(), n == ncols) == MI_OK) {
                 T2.nt = A->ring.nt;
                 double us64 = 0.0, us1 = 0.0;
                 A->kernel = MI_KERNEL_RING;
@@ -748,13 +752,11 @@ extern "C" int mi_spmk_internal_dev(mi_csr_t A, int k, const double* d_x_int, do
     CHECK_ARG(A, "null handle");
     if (k < 1 || k > MI_MAX_POWERS) return fail(MI_ERR_UNSUPPORTED, "k must be in 1..MI_MAX_POWERS");
     CHECK_ARG(d_y_int_out, "null output array");
-    const double* src = d_x_int;
-    for (int p = 0; p < k; p++) {
-        int rc = mi_spmv_internal_dev(A, src, d_y_int_out[p], s);
-        if (rc) return rc;
-        src = d_y_int_out[p];
-    }
-    return MI_OK;
+    CHECK_ARG(A->n == A->ncols && !A->mapped, "the internal numbering is defined for square, unmapped matrices");
+    if (A->n == 0) return MI_OK;
+    CHECK_ARG(d_x_int, "null vector");
+    for (int p = 0; p < k; p++) CHECK_ARG(d_y_int_out[p], "null output vector");
+    return spmk_unmapped(A->inner ? A->inner : A, k, d_x_int, d_y_int_out, (hipStream_t)s);
 }
 
 extern "C" int mi_csr_create_mapped(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
@@ -790,6 +792,7 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->d_xp);
     dfree(A->d_vtmp);
     for (double* p : A->d_pp) dfree(p);
+    spmk_release(A);
     delete A;
     return MI_OK;
 }
@@ -1022,6 +1025,65 @@ extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, in
     return MI_OK;
 }
 
+// host-only: the run dependencies of the one-launch powers step exactly as mi_csr_create derives them (ring configuration 4),
+// checked against the matrix: every column a run's rows NAME, and every column its lanes LOAD when the plan is replayed (window
+// fills, the T lanes behind a block's new columns, the empty blocks behind the run), lies in the rows of a run on its list.
+extern "C" int mi_spmk_plan_probe(int n, const int* ptrow, const int* indcol, int* eligible, int* runs, int* max_deps)
+{
+    CHECK_ARG(n >= 0 && ptrow && ptrow[0] == 0 && eligible, "bad argument");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    *eligible = 0;
+    if (runs) *runs = 0;
+    if (max_deps) *max_deps = 0;
+    if (n == 0 || ptrow[n] == 0) return MI_OK;
+    std::vector<int> row_min((size_t)n), row_max((size_t)n);
+    for (int i = 0; i < n; i++) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = ptrow[i]; k < ptrow[i + 1]; k++) {
+            CHECK_ARG(indcol[k] >= 0 && indcol[k] < n, "column index outside [0, n)");
+            lo = std::min(lo, indcol[k]);
+            hi = std::max(hi, indcol[k]);
+        }
+        row_min[i] = lo;
+        row_max[i] = hi;
+    }
+    RingPlanHost P;
+    build_ring_plan(kRingConfigs[3], n, ptrow, row_min.data(), row_max.data(), P);
+    bool all_in_loop = P.lean && P.nblk > 0;
+    for (int g = 0; g < P.wgs; g++) all_in_loop = all_in_loop && P.run_ok[g] == 1;
+    if (!all_in_loop) return MI_OK; // such a handle runs k launches
+    std::vector<int> dp, dr;
+    build_run_deps(P, n, dp, dr);
+    const int W = P.wgs, T = P.cfg.threads;
+    std::vector<int> owner((size_t)n, -1);
+    for (int g = 0; g < W; g++)
+        for (int b = P.run_rng[2 * g]; b < P.run_rng[2 * g + 1]; b++)
+            for (int r = P.plan[(size_t)8 * b]; r < P.plan[(size_t)8 * b] + P.plan[(size_t)8 * b + 2]; r++) owner[r] = g;
+    for (int i = 0; i < n; i++)
+        if (owner[i] < 0) return fail(MI_ERR_STATE, "a row belongs to no run");
+    int md = 0;
+    std::vector<char> on_list((size_t)W);
+    for (int g = 0; g < W; g++) {
+        md = std::max(md, dp[g + 1] - dp[g]);
+        std::fill(on_list.begin(), on_list.end(), 0);
+        for (int j = dp[g]; j < dp[g + 1]; j++) on_list[dr[j]] = 1;
+        const int b0 = P.run_rng[2 * g], b1 = P.run_rng[2 * g + 1];
+        if (b0 >= b1) continue;
+        for (int b = b0; b < b1; b++) {
+            const int* Q = &P.plan[(size_t)8 * b];
+            for (int k = Q[1]; k < Q[1] + Q[3]; k++)
+                if (!on_list[owner[indcol[k]]]) return fail(MI_ERR_STATE, "a run names a column of a run that is not on its list");
+            const int load_hi = std::min(n - 1, Q[4] + std::max(Q[5], T) - 1);
+            for (int col = Q[4]; col <= load_hi; col++)
+                if (!on_list[owner[col]]) return fail(MI_ERR_STATE, "a run loads a column of a run that is not on its list");
+        }
+    }
+    *eligible = md <= 64 ? 1 : 0;
+    if (runs) *runs = W;
+    if (max_deps) *max_deps = md;
+    return MI_OK;
+}
+
 extern "C" int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_blocked, long long* nblocks)
 {
     CHECK_ARG(n >= 0 && ptrow && is_blocked, "bad argument");
@@ -1238,9 +1300,11 @@ extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* 
     CHECK_ARG(A->n == A->ncols, "matrix powers need a square matrix");
     CHECK_ARG(!A->mapped, "matrix powers need an unmapped matrix");
     CHECK_ARG(d_y_out, "null output array");
-    if (A->inner && A->n > 0) {
-        // the whole chain in the new numbering (each power feeds the next without leaving it), every power scattered
-        // to the caller's numbering as it completes
+    if (A->n == 0) return MI_OK;
+    for (int p = 0; p < k; p++) CHECK_ARG(d_y_out[p], "null output vector");
+    if (A->inner) {
+        // the whole chain in the new numbering (each power feeds the next without leaving it), then every power scattered to
+        // the caller's numbering
         while ((int)A->d_pp.size() < k) {
             double* p = nullptr;
             HIP_TRY(hipMalloc(&p, sizeof(double) * (size_t)A->n));
@@ -1248,24 +1312,12 @@ extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* 
         }
         int rc = gather_perm(A, d_x, A->d_xp, (hipStream_t)s);
         if (rc) return rc;
-        const double* src = A->d_xp;
-        for (int p = 0; p < k; p++) {
-            CHECK_ARG(d_y_out[p], "null output vector");
-            if ((rc = launch_spmv(A->inner, src, A->d_pp[p], (hipStream_t)s, false))) return rc;
+        if ((rc = spmk_unmapped(A->inner, k, A->d_xp, A->d_pp.data(), (hipStream_t)s))) return rc;
+        for (int p = 0; p < k; p++)
             if ((rc = scatter_perm(A, A->d_pp[p], d_y_out[p], (hipStream_t)s))) return rc;
-            src = A->d_pp[p];
-        }
-        HIP_TRY(hipGetLastError());
         return MI_OK;
     }
-    const double* src = d_x;
-    for (int p = 0; p < k; p++) {
-        CHECK_ARG(A->n == 0 || d_y_out[p], "null output vector");
-        int rc = launch_spmv(A, src, d_y_out[p], (hipStream_t)s);
-        if (rc) return rc;
-        src = d_y_out[p];
-    }
-    return MI_OK;
+    return spmk_unmapped(A, k, d_x, d_y_out, (hipStream_t)s);
 }
 
 extern "C" int mi_spmk(mi_csr_t A, int k, const double* x, double* const* y_out)

@@ -80,6 +80,7 @@ struct RingTable {
     bool uniform = true;       // runs are consecutive ranges of bpw blocks (the kernel then computes them)
     bool lean = false;         // the plan allows the LEAN instantiation (spmv_ring.hpp)
     bool all_in_loop = false;  // every run is ring-served and holds no PLAIN block: every row is computed inside the counted loop
+    std::vector<int> h_dep_ptr, h_dep_run; // one-launch powers step: per run the runs its columns name (ring_plan.hpp: build_run_deps); empty if not built
     unsigned short* d_slots = nullptr; // 16-bit column stream (ring slots), nnzb per block
     bool nt = false;                   // non-temporal loads of the values (chosen by measurement)
     bool skew = false;                 // padded staging layout (many rows with a length that is a multiple of 8)
@@ -150,6 +151,17 @@ struct mi_csr_s {
     double* d_x = nullptr;
     double* d_y = nullptr;
     std::vector<double*> d_pow;
+    // the one-launch matrix-powers step (spmk_ring.hpp, launch_spmk.hip): run flags, dependency lists, the launch counter the
+    // flags count from, give-ups (host-visible, sticky), and per k the measured choice between one launch and k launches
+    unsigned* d_kflags = nullptr;
+    int* d_kdep_ptr = nullptr;
+    int* d_kdep_run = nullptr;
+    unsigned kstep_epoch = 0;
+    unsigned* h_ktimeouts = nullptr;
+    unsigned* d_ktimeouts = nullptr;
+    int kstep_setup = 0;                 // 0 not tried, 1 ready, -1 not eligible
+    int kstep_choice[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // per k <= 8: 0 not measured, 1 one launch, -1 k launches
+    double kstep_us[9][2] = {};          // measured microseconds per step: [k][0] k launches, [k][1] one launch
 };
 
 struct mi_bcsr4_s {
@@ -251,6 +263,10 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
 bool ring_dot_eligible(const mi_csr_s* A); // the next launch_spmv(A) can carry a dot epilogue (one partial per ring workgroup)
 // launch_ring.hip
 void launch_ring_cfg(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm, const RingDot* dot);
+// launch_spmk.hip: the k powers on an unmapped view of H (its row map, if any, is not applied): one launch where that is
+// eligible and measured faster, else k chained launches
+int spmk_unmapped(mi_csr_t H, int k, const double* d_x, double* const* d_y, hipStream_t s);
+void spmk_release(mi_csr_t H);
 // capi_blas1.hip
 int gather_perm(mi_csr_t A, const double* d_x, double* d_xp, hipStream_t s);
 int scatter_perm(mi_csr_t A, const double* d_src, double* d_dst, hipStream_t s);

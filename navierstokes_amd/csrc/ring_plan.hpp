@@ -271,7 +271,9 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
             const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b];
             int* P = &out.plan[(size_t)8 * b];
             P[0] = rows[b]; P[1] = ptrs[b]; P[2] = nrows; P[3] = nn;
-            P[4] = 0; P[5] = 0; P[6] = base; P[7] = 0;
+            // (a block without nonzeros brings no column; its lanes' loads — values never used — go where the last served block's
+            // went, so that every load of a run stays inside the column range build_run_deps derives from these records)
+            P[4] = live ? std::max(0, whi - 1) : 0; P[5] = 0; P[6] = base; P[7] = 0;
             run_nnz += nn;
             if (nrows > cfg.threads) out.lean = false; // (empty rows included: their zeros are stored by the loop's second pass)
             if (nn == 0) continue;
@@ -326,6 +328,47 @@ inline void build_ring_plan(const RingConfig& cfg, int n, const int* ptrow, cons
             if (nplain > 0) out.run_ok[g] = 3; // tells the kernel to look for PLAIN blocks behind its loop
         }
     }
+}
+
+// The one-launch matrix-powers step (spmk_ring.hpp): run g's power p + 1 reads power p of other runs' rows.  For a SQUARE
+// matrix: dep_run[dep_ptr[g] .. dep_ptr[g + 1]) = the runs (itself included) whose row range meets the range of columns run g
+// LOADS — not only the columns its rows name: the window's first fill may start below the first block's smallest column, and
+// lanes past a block's new columns load up to T - 1 entries beyond them (values never used).  With every load inside the
+// published range no cache of the consumer's XCD can ever hold a line of y_p from before its publication, which is what lets
+// the kernel do without an acquire between powers.  Taken from the plan records ({new_lo, new_cnt} per block) exactly as the
+// kernel replays them.  Runs are contiguous block ranges but need not be in row order; runs without rows depend on nothing and
+// nobody depends on them.  Only for plans whose every row is computed inside the ring loop (no PLAIN block, no plain run).
+inline void build_run_deps(const RingPlanHost& P, int n, std::vector<int>& dep_ptr, std::vector<int>& dep_run)
+{
+    const int W = P.wgs, T = P.cfg.threads;
+    std::vector<int> r0((size_t)W, 0), r1((size_t)W, 0), order;
+    for (int g = 0; g < W; g++) {
+        const int b0 = P.run_rng[2 * g], b1 = P.run_rng[2 * g + 1];
+        if (b0 >= b1) continue;
+        r0[g] = P.plan[(size_t)8 * b0];
+        r1[g] = P.plan[(size_t)8 * (b1 - 1)] + P.plan[(size_t)8 * (b1 - 1) + 2];
+        if (r1[g] > r0[g]) order.push_back(g);
+    }
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return r0[a] < r0[b]; });
+    dep_ptr.assign((size_t)W + 1, 0);
+    dep_run.clear();
+    for (int g = 0; g < W; g++) {
+        dep_ptr[g] = (int)dep_run.size();
+        if (r1[g] <= r0[g]) continue;
+        int cmin = 0x7fffffff, cmax = -1;
+        for (int b = P.run_rng[2 * g]; b < P.run_rng[2 * g + 1]; b++) {
+            const int* Q = &P.plan[(size_t)8 * b];
+            cmin = std::min(cmin, Q[4]);
+            cmax = std::max(cmax, std::min(n - 1, Q[4] + std::max(Q[5], T) - 1)); // new columns, or the T lanes' over-read
+        }
+        size_t lo = 0, hi = order.size();
+        while (lo < hi) { // first run (in row order) whose rows end beyond cmin
+            const size_t mid = (lo + hi) / 2;
+            if (r1[order[mid]] > cmin) hi = mid; else lo = mid + 1;
+        }
+        for (size_t i = lo; i < order.size() && r0[order[i]] <= cmax; i++) dep_run.push_back(order[i]);
+    }
+    dep_ptr[W] = (int)dep_run.size();
 }
 
 // The 16-bit column stream of the ring kernel: for block b, thread t, i < PER the

@@ -116,6 +116,8 @@ def lib():
         "mi_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_spmk": [_vp, i, _vp, _vp],
         "mi_spmk_dev": [_vp, i, _vp, _vp, _vp],
+        "mi_csr_spmk_info": [_vp, i, P(i), P(i), P(d), P(d)],
+        "mi_spmk_plan_probe": [i, _vp, _vp, P(i), P(i), P(i)],
         "mi_dot": [i, _vp, _vp, P(d)],
         "mi_dot_dev": [i, _vp, _vp, _vp, _vp],
         "mi_axpy": [i, d, _vp, _vp],
@@ -322,6 +324,13 @@ class csrmatrix:
         check(lib().mi_csr_reorder_info(self.handle, _c.byref(r), _c.byref(b), *[_c.byref(t) for t in v]))
         return dict(reordered=bool(r.value), block=b.value, spread_before=v[0].value, spread_after=v[1].value,
                     us_natural=v[2].value, us_reordered=v[3].value)
+
+    def spmk_info(self, k):
+        """dict(eligible, one_launch, us_k_launches, us_one_launch): how this handle runs the k-step (mi_csr_spmk_info)."""
+        e, o = _c.c_int(), _c.c_int()
+        a, b = _c.c_double(), _c.c_double()
+        check(lib().mi_csr_spmk_info(self.handle, int(k), _c.byref(e), _c.byref(o), _c.byref(a), _c.byref(b)))
+        return dict(eligible=bool(e.value), one_launch=bool(o.value), us_k_launches=a.value, us_one_launch=b.value)
 
     def dot_in_epilogue(self):
         """True if SpMV_CSR_dot / SpMV_CSR_orthogonalize on this handle carry the dot inside the product's launch."""

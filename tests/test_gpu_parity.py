@@ -710,3 +710,56 @@ def test_column_major_blocks_of_a_petsc_baij_matrix():
         np.add.at(acc[j].reshape(-1, 4), rows, blk[:, :, j] * x.reshape(-1, 4)[bc][:, j:j + 1])
     y_avx2_like = (acc[0] + acc[1]) + (acc[2] + acc[3])
     assert O.rel_error(yo, y_avx2_like) < 1e-14
+
+
+@pytest.mark.parametrize("kind,n,w", [("s15", 300_000, 2000), ("svar", 250_000, 2000), ("s15", 1_000_000, 2000), ("s15", 40_000, 300)])
+def test_matrix_powers_in_one_launch(kind, n, w, monkeypatch):
+    """The one-launch k-step (spmk_ring.hpp; SpM2V_CSR mpk/SpM2V.cpp:79-112, SpM3V / SpM4V mpk/SpMVmulti0.cpp:132-221): every
+    workgroup keeps its run for all powers, power p + 1 waits for the flags of the runs its columns name.  Forced on
+    (MI355_SPMK_FUSED=1): every power bit-equal to the chained oracle, for k = 2..8, repeatedly on one handle (the flags count on
+    from launch to launch) with a different x each time, and equal to what k launches give (MI355_SPMK_FUSED=0)."""
+    p, c, v = synth.rows(kind, n, w=w)
+    A = mpk.csrmatrix(n, p, c, v).set_kernel("ring")
+    xs = [synth.x_sin(0, n), np.cos(0.002 * np.arange(n)), synth.x_sin(0, n) * 0.5 - 0.25]
+    monkeypatch.setenv("MI355_SPMK_FUSED", "1")
+    outs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(8)]
+    for rep, k in enumerate((4, 2, 3, 8, 4, 4, 2)):
+        x = xs[rep % 3]
+        for t in outs:
+            t.fill_(float("nan"))
+        mpk.SpMkV(outs[:k], dev(x), A)
+        info = A.spmk_info(k)
+        assert info["eligible"] and info["one_launch"], (info, A.kernel_name(), A.ring_shape_info())
+        Y = O.spmk_chain(k, p, c, v, x)
+        for q in range(k):
+            assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"one launch, rep {rep}, k={k}, power {q + 1}")
+    monkeypatch.setenv("MI355_SPMK_FUSED", "0")
+    mpk.SpMkV(outs[:4], dev(xs[0]), A)
+    Y = O.spmk_chain(4, p, c, v, xs[0])
+    for q in range(4):
+        assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"k launches, power {q + 1}")
+    # the measured choice (no override): whichever form wins, the bits are the same and the handle says what it does
+    monkeypatch.delenv("MI355_SPMK_FUSED")
+    mpk.SpMkV(outs[:4], dev(xs[1]), A)
+    info = A.spmk_info(4)
+    assert info["us_k_launches"] > 0 and info["us_one_launch"] > 0, info
+    Y = O.spmk_chain(4, p, c, v, xs[1])
+    for q in range(4):
+        assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"measured choice {info}, power {q + 1}")
+
+
+def test_matrix_powers_in_one_launch_is_refused_where_it_cannot_run(monkeypatch):
+    """Handles the one-launch form is not built for (stream kernel, FE matrices on the blocked kernel, a band much wider than a
+    run) take k launches even when it is forced on — same bits."""
+    monkeypatch.setenv("MI355_SPMK_FUSED", "1")
+    for kind, n, w, kernel in (("s15", 100_000, 2000, "stream"), ("sfe", 40_000, 1500, "auto"), ("s15", 200_000, 60_000, "auto"),
+                               ("s15", 120_000, 4500, "ring")):  # (the last: ring configuration 3, 512 threads — no one-launch instantiation)
+        p, c, v = synth.rows(kind, n, w=w)
+        A = mpk.csrmatrix(n, p, c, v).set_kernel(kernel)
+        x = synth.x_sin(0, n)
+        outs = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3)]
+        mpk.SpMkV(outs, dev(x), A)
+        assert not A.spmk_info(3)["one_launch"], (kind, A.kernel_name())
+        Y = O.spmk_chain(3, p, c, v, x)
+        for q in range(3):
+            assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"{kind} {kernel} power {q + 1}")

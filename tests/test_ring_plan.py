@@ -150,3 +150,41 @@ def test_lean_plans():
     p = np.arange(n + 1, dtype=np.int32) * 2                # two entries per row: blocks of 256 rows, not 1024
     c = np.stack([np.arange(n), np.minimum(np.arange(n) + 3, n - 1)], 1).astype(np.int32).ravel()
     assert is_lean(p, c) and probe(p, c, 4)[2:4] == (0, 1.0)
+
+
+def test_one_launch_powers_step_dependencies_cover_every_load():
+    """spmk_ring.hpp's hand-off is safe without an acquire only if no load of a run ever touches a column whose owner is not on
+    the run's dependency list (ring_plan.hpp: build_run_deps).  mi_spmk_plan_probe derives the lists as mi_csr_create does and
+    replays every named and every loaded column against them — bands narrower and wider than a run, variable row lengths, empty
+    rows and whole empty blocks, a relabelled band."""
+    import ctypes
+    L = mpk.lib()
+
+    def probe(p, c, n):
+        p = np.ascontiguousarray(p, np.int32)
+        c = np.ascontiguousarray(c, np.int32)
+        e, r, m = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        mpk.check(L.mi_spmk_plan_probe(n, p.ctypes.data, c.ctypes.data, ctypes.byref(e), ctypes.byref(r), ctypes.byref(m)))
+        return e.value, r.value, m.value
+
+    for kind, n, w in (("s15", 300_000, 2000), ("svar", 200_000, 2000), ("s15", 1_000_000, 2000), ("s15", 60_000, 300), ("s15", 400_000, 2400)):
+        p, c, v = synth.rows(kind, n, w=w)
+        e, runs, md = probe(p, c, n)
+        assert e == 1 and runs >= 8 and 1 <= md <= 64, (kind, n, w, e, runs, md)
+    p, c, v = synth.rows("s15", 400_000, w=4000)  # rows span more columns than configuration 4's window holds: k launches
+    assert probe(p, c, 400_000)[0] == 0
+    # rows without nonzeros, and a stretch of 3000 empty rows (whole empty blocks inside a run)
+    p, c, v = synth.rows("s15", 200_000)
+    lens = np.diff(p).astype(np.int64)
+    keep = np.ones(len(c), bool)
+    rows = np.repeat(np.arange(200_000), lens)
+    keep[(rows % 7 == 3) | ((rows >= 50_000) & (rows < 53_000))] = False
+    cnt = np.zeros(200_000, np.int64)
+    np.add.at(cnt, rows[keep], 1)
+    p2 = np.concatenate([[0], np.cumsum(cnt)])
+    e, runs, md = probe(p2, c[keep], 200_000)
+    assert e == 1 and md <= 64, (e, runs, md)
+    # a band much wider than a run: still checked, not eligible
+    p, c, v = synth.rows("s15", 200_000, w=60_000)
+    e, runs, md = probe(p, c, 200_000)
+    assert e == 0
