@@ -278,6 +278,14 @@ def main():
 
             def step():
                 mpk.MatMatMult_SeqBAIJ_4(A, Xd, Yd, "chain")
+            step()  # the first product of the handle at this column count times the gather and the tile form and keeps the faster
+            torch.cuda.synchronize()
+            si = [_ct.c_int(), _ct.c_int(), _ct.c_int(), _ct.c_double(), _ct.c_double()]
+            mpk.check(mpk.lib().mi_bcsr4_spmm_info(A.handle, nvec, *[_ct.byref(t) for t in si]))
+            spmm_info = dict(tile_built=bool(si[0].value), tile_in_use=bool(si[1].value), longest_list=si[2].value,
+                             us_gather_form=round(si[3].value, 2), us_tile_form=round(si[4].value, 2))
+            if spmm_info["tile_in_use"]:
+                kernel_name = f"spmm_bcsr4_tile<{nvec}, 0, 3>"
         else:
             def step():
                 mpk.SpMV_BCSR(ys[0], x, A)
@@ -700,6 +708,8 @@ def main():
         out["kernel_info"]["powers_step"] = dict(one_launch=out_spmk["one_launch"], eligible=out_spmk["eligible"],
                                                  us_k_launches=round(out_spmk["us_k_launches"], 2), us_one_launch=round(out_spmk["us_one_launch"], 2),
                                                  note="first k-step of the handle times both forms (same bits) and keeps the faster; MI355_SPMK_FUSED=0|1 forces")
+    if world == 1 and bcsr and W.get("spmm"):
+        out["kernel_info"] = dict(kernel=kernel_name, **spmm_info)
     if parity is not None:
         out["parity"] = parity
     if halo_info is not None:

@@ -324,6 +324,11 @@ enum { MI_ARITH_CHAIN = 0, MI_ARITH_BLOCKACC = 1 };
 int mi_bcsr4_spmm(mi_bcsr4_t A, int s, const double* X, long long ldx, double* Y, long long ldy, int arith);          /* host */
 int mi_bcsr4_spmm_dev(mi_bcsr4_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, int arith,
                       mi_stream_t st);
+/* The product exists in two forms with the same bits: x blocks gathered through L1/L2 per block (spmm_bcsr4 / spmm_bcsr4_quad), or
+ * each group of 128 block rows gathering the S columns of its distinct block columns ONCE into an LDS tile (spmm_tile.hpp; lists
+ * built at the first product).  The first product of a handle at a column count times both and keeps the faster
+ * (MI355_SPMM_TILE=0 never builds the tile, =1 takes it unmeasured).  us_* = microseconds per launch measured then (0: not yet). */
+int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* tile_in_use, int* longest_list, double* us_gather, double* us_tile);
 /* the same for a CSR handle (MI_ARITH_CHAIN bits = SpMV_CSR_FMA per column): one launch over the blocked copy when the
  * matrix has exact 4x4 node-block structure, else s single-vector launches */
 int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, mi_stream_t st);

@@ -198,6 +198,9 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     dfree(A->d_tl_ptr);
     dfree(A->d_tl_nodes);
     dfree(A->d_tl_slots);
+    dfree(A->st.d_ptr);
+    dfree(A->st.d_nodes);
+    dfree(A->st.d_slots);
     dfree(A->d_x);
     dfree(A->d_y);
     for (double* p : A->d_pow) dfree(p);
@@ -332,6 +335,95 @@ static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long l
     }
 }
 
+// ---- the tile form (spmm_tile.hpp) ------------------------------------------------------------------------------------------
+
+// lists of distinct block columns per group of `per` block rows, and every block's position in its group's list
+static int build_spmm_tile_plan(mi_bcsr4_t A, int per, const std::vector<int>& ptrow, const std::vector<int>& indcol, SpmmTilePlan& T)
+{
+    const int nwg = (A->nbrows + per - 1) / per;
+    std::vector<int> wg_ptr((size_t)nwg + 1, 0);
+    std::vector<unsigned> nodes, u;
+    std::vector<unsigned short> slots((size_t)A->nblocks + 1, 0);
+    int umax = 0;
+    for (int w = 0; w < nwg; w++) {
+        const int b0 = ptrow[(size_t)w * per], b1 = ptrow[std::min<long long>((long long)(w + 1) * per, A->nbrows)];
+        u.assign(indcol.begin() + b0, indcol.begin() + b1);
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        if (u.size() > 65535) return -1;
+        umax = std::max(umax, (int)u.size());
+        for (int k = b0; k < b1; k++) slots[k] = (unsigned short)(std::lower_bound(u.begin(), u.end(), (unsigned)indcol[k]) - u.begin());
+        nodes.insert(nodes.end(), u.begin(), u.end());
+        wg_ptr[w + 1] = (int)nodes.size();
+    }
+    if (umax < 1) return -1;
+    nodes.push_back(0);
+    hipError_t er;
+    if ((er = hipMalloc(&T.d_ptr, sizeof(int) * wg_ptr.size())) != hipSuccess ||
+        (er = hipMalloc(&T.d_nodes, sizeof(unsigned) * nodes.size())) != hipSuccess ||
+        (er = hipMalloc(&T.d_slots, sizeof(unsigned short) * slots.size())) != hipSuccess ||
+        (er = hipMemcpy(T.d_ptr, wg_ptr.data(), sizeof(int) * wg_ptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (er = hipMemcpy(T.d_nodes, nodes.data(), sizeof(unsigned) * nodes.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (er = hipMemcpy(T.d_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        (void)hipGetLastError();
+        dfree(T.d_ptr);
+        dfree(T.d_nodes);
+        dfree(T.d_slots);
+        T = SpmmTilePlan();
+        return -1;
+    }
+    T.rows = per;
+    T.umax = umax;
+    return 1;
+}
+
+static int build_spmm_tile(mi_bcsr4_t A)
+{
+    if (A->st_state) return A->st_state;
+    A->st_state = -1;
+    const char* e = getenv("MI355_SPMM_TILE");
+    if ((e && !strcmp(e, "0")) || A->nblocks < 4096) return -1;
+    std::vector<int> ptrow((size_t)A->nbrows + 1), indcol((size_t)A->nblocks);
+    if (hipMemcpy(ptrow.data(), A->d_ptrow, sizeof(int) * ptrow.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(indcol.data(), A->d_indcol, sizeof(int) * indcol.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    A->st_state = build_spmm_tile_plan(A, 128, ptrow, indcol, A->st);
+    return A->st_state;
+}
+
+static const SpmmTilePlan* spmm_plan_of(const mi_bcsr4_s* A, int s)
+{
+    if (s < 1 || s > 4) return nullptr;
+    const SpmmTilePlan* Pl = A->st.d_ptr ? &A->st : nullptr;
+    if (!Pl || spmm_tile_lds(Pl, s) > kLdsBytesPerCU) return nullptr;
+    return Pl;
+}
+
+static bool spmm_tile_possible(const mi_bcsr4_s* A, int s) { return spmm_plan_of(A, s) != nullptr; }
+
+static hipError_t launch_spmm_tile(const mi_bcsr4_s* A, const Bcsr4View& V, int m, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t st)
+{
+    const SpmmTilePlan* Pl = spmm_plan_of(A, m);
+    if (!Pl) return hipErrorInvalidValue;
+    return spmm_tile_launch(A, Pl, V, m, arith, X, ldx, Y, ldy, st);
+}
+
+static void launch_spmm_gather(const Bcsr4View& V, int m, int arith, const double* Xj, long long ldx, double* Yj, long long ldy, hipStream_t st)
+{
+    switch (m) {
+    case 1: launch_spmm_s<1>(V, arith, Xj, ldx, Yj, ldy, st); break;
+    case 2: launch_spmm_s<2>(V, arith, Xj, ldx, Yj, ldy, st); break;
+    case 3: launch_spmm_s<3>(V, arith, Xj, ldx, Yj, ldy, st); break;
+    case 4: launch_spmm_s<4>(V, arith, Xj, ldx, Yj, ldy, st); break;
+    case 5: launch_spmm_s<5>(V, arith, Xj, ldx, Yj, ldy, st); break;
+    case 6: launch_spmm_s<6>(V, arith, Xj, ldx, Yj, ldy, st); break;
+    case 7: launch_spmm_s<7>(V, arith, Xj, ldx, Yj, ldy, st); break;
+    default: launch_spmm_s<8>(V, arith, Xj, ldx, Yj, ldy, st); break;
+    }
+}
+
 static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t st,
                        bool use_map)
 {
@@ -340,20 +432,70 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
         const int m = std::min(8, s - j0);
         const double* Xj = X + (size_t)j0 * ldx;
         double* Yj = Y + (size_t)j0 * ldy;
-        switch (m) {
-        case 1: launch_spmm_s<1>(V, arith, Xj, ldx, Yj, ldy, st); break;
-        case 2: launch_spmm_s<2>(V, arith, Xj, ldx, Yj, ldy, st); break;
-        case 3: launch_spmm_s<3>(V, arith, Xj, ldx, Yj, ldy, st); break;
-        case 4: launch_spmm_s<4>(V, arith, Xj, ldx, Yj, ldy, st); break;
-        case 5: launch_spmm_s<5>(V, arith, Xj, ldx, Yj, ldy, st); break;
-        case 6: launch_spmm_s<6>(V, arith, Xj, ldx, Yj, ldy, st); break;
-        case 7: launch_spmm_s<7>(V, arith, Xj, ldx, Yj, ldy, st); break;
-        default: launch_spmm_s<8>(V, arith, Xj, ldx, Yj, ldy, st); break;
+        // tile form or gather form: same bits; the first product of a handle at a column count times both and keeps the faster
+        // (MI355_SPMM_TILE=0 never builds the tile, =1 takes it unmeasured)
+        bool tile = false;
+        if (build_spmm_tile(A) == 1 && spmm_tile_possible(A, m)) {
+            const char* e = getenv("MI355_SPMM_TILE");
+            if (e && !strcmp(e, "1")) tile = true;
+            else {
+                if (A->spmm_choice[m] == 0) {
+                    hipEvent_t e0 = nullptr, e1 = nullptr;
+                    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                        double us[2] = {0, 0};
+                        for (int round = 0; round < 2; round++)
+                            for (int form = 0; form < 2; form++) {
+                                for (int i = 0; i < 2; i++) {
+                                    if (form) (void)launch_spmm_tile(A, V, m, arith, Xj, ldx, Yj, ldy, st);
+                                    else launch_spmm_gather(V, m, arith, Xj, ldx, Yj, ldy, st);
+                                }
+                                (void)hipEventRecord(e0, st);
+                                for (int i = 0; i < 5; i++) {
+                                    if (form) (void)launch_spmm_tile(A, V, m, arith, Xj, ldx, Yj, ldy, st);
+                                    else launch_spmm_gather(V, m, arith, Xj, ldx, Yj, ldy, st);
+                                }
+                                (void)hipEventRecord(e1, st);
+                                (void)hipEventSynchronize(e1);
+                                float ms = 0.f;
+                                (void)hipEventElapsedTime(&ms, e0, e1);
+                                const double t = ms * 1e3 / 5;
+                                us[form] = us[form] > 0 ? std::min(us[form], t) : t;
+                            }
+                        A->spmm_us[m][0] = us[0];
+                        A->spmm_us[m][1] = us[1];
+                        A->spmm_choice[m] = (hipGetLastError() == hipSuccess && us[1] > 0 && us[1] < us[0]) ? 1 : -1;
+                    } else {
+                        A->spmm_choice[m] = -1;
+                    }
+                    if (e0) (void)hipEventDestroy(e0);
+                    if (e1) (void)hipEventDestroy(e1);
+                }
+                tile = A->spmm_choice[m] == 1;
+            }
+        }
+        if (tile) {
+            hipError_t er = launch_spmm_tile(A, V, m, arith, Xj, ldx, Yj, ldy, st);
+            if (er != hipSuccess) return fail(MI_ERR_HIP, std::string("spmm tile kernel: ") + hipGetErrorString(er));
+        } else {
+            launch_spmm_gather(V, m, arith, Xj, ldx, Yj, ldy, st);
         }
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
+
+extern "C" int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* tile_in_use, int* longest_list, double* us_gather, double* us_tile)
+{
+    CHECK_ARG(A && s >= 1 && s <= 8, "bad argument");
+    if (tile_built) *tile_built = A->st_state == 1;
+    const char* e = getenv("MI355_SPMM_TILE");
+    if (tile_in_use) *tile_in_use = A->st_state == 1 && spmm_tile_possible(A, s) && ((e && !strcmp(e, "1")) || A->spmm_choice[s] == 1);
+    if (longest_list) { const SpmmTilePlan* Pl = spmm_plan_of(A, s); *longest_list = Pl ? Pl->umax : 0; }
+    if (us_gather) *us_gather = A->spmm_us[s][0];
+    if (us_tile) *us_tile = A->spmm_us[s][1];
+    return MI_OK;
+}
+
 
 extern "C" int mi_bcsr4_spmm_dev(mi_bcsr4_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, int arith,
                                  mi_stream_t st)

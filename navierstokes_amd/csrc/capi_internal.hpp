@@ -164,6 +164,13 @@ struct mi_csr_s {
     double kstep_us[9][2] = {};          // measured microseconds per step: [k][0] k launches, [k][1] one launch
 };
 
+struct SpmmTilePlan {
+    int rows = 0, umax = 0; // block rows per group; longest list
+    int* d_ptr = nullptr;
+    unsigned* d_nodes = nullptr;
+    unsigned short* d_slots = nullptr;
+};
+
 struct mi_bcsr4_s {
     int device = 0;
     int nbrows = 0, nbcols = 0;
@@ -178,6 +185,11 @@ struct mi_bcsr4_s {
     unsigned short* d_tl_slots = nullptr;
     bool use_tile = false;    // the measured choice between the two kernels (MI355_BCSR_TILE=0|1 forces)
     double tune_us_plain = 0.0, tune_us_tile = 0.0;
+    // x tile of the multi-vector product (spmm_tile.hpp): lists per group of 128 block rows, built at the first product
+    SpmmTilePlan st;
+    int st_state = 0;         // 0 not tried, 1 built, -1 not possible
+    int spmm_choice[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // per column count <= 8: 0 not measured, 1 tile kernel, -1 gather kernels
+    double spmm_us[9][2] = {};                         // [s][0] gather kernel, [s][1] tile kernel (microseconds per launch)
     double* d_x = nullptr;
     double* d_y = nullptr;
     std::vector<double*> d_pow;
@@ -270,5 +282,10 @@ void spmk_release(mi_csr_t H);
 // capi_blas1.hip
 int gather_perm(mi_csr_t A, const double* d_x, double* d_xp, hipStream_t s);
 int scatter_perm(mi_csr_t A, const double* d_src, double* d_dst, hipStream_t s);
+// launch_spmm_tile.hip: the multi-vector product's tile form (spmm_tile.hpp), up to four columns
+constexpr size_t kLdsBytesPerCU = 160 * 1024;
+static inline size_t spmm_tile_lds(const SpmmTilePlan* T, int s) { return T ? (size_t)T->umax * (4 * s + 2) * sizeof(double) : (size_t)-1; }
+hipError_t spmm_tile_launch(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const Bcsr4View& V, int s, int arith, const double* X, long long ldx,
+                            double* Y, long long ldy, hipStream_t st);
 // capi_bcsr.hip
 int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);
