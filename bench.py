@@ -89,8 +89,10 @@ def load_traffic(workload, kernel_name):
                     continue
                 # the temporal / non-temporal instantiations of one kernel move the same bytes (measured:
                 # 408.9 vs 410.4 thousand KB fetched), so a profile of either describes both
-                same = lambda a, b: a == b or (a.startswith("spmv_csr_ring<") and a.split(",")[:5] == b.split(",")[:5]
-                                               and a.split(",")[7:] == b.split(",")[7:])
+                # (round 3 added an eleventh template argument — the dot epilogue, false in a plain product — to the ring kernel)
+                norm = lambda a: a.replace(", false>", ">") if a.startswith("spmv_csr_ring<") and a.count(",") == 10 else a
+                same = lambda a, b: norm(a) == norm(b) or (a.startswith("spmv_csr_ring<") and norm(a).split(",")[:5] == norm(b).split(",")[:5]
+                                                           and norm(a).split(",")[7:] == norm(b).split(",")[7:])
                 if d.get("workload") == workload and same(d.get("kernel", ""), kernel_name):
                     best = (d.get("hbm_bytes_per_launch"), "profiles/" + f)
     return best if best else (None, None)
@@ -624,6 +626,9 @@ def main():
                     frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=load_traffic(args.workload, kernel_name)[0] if world == 1 else None,
                     traffic_source=load_traffic(args.workload, kernel_name)[1] if world == 1 else None,
+                    traffic_note="PROFILED value, not measured in this run: HBM-side bytes per launch of this kernel on this workload from the rocprofv3 "
+                                 "--pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ (file named in traffic_source, with its round, command "
+                                 "and the gfx950 x2 read correction); counters cannot be read inside the timed run",
                     kernel=kernel_name, algorithmic_bytes_per_launch=B_exec, launch_us=round(launch_s * 1e6, 2),
                     bytes_model=("BCSR 4x4: 132 B per block + 4 B per block row + 16 B per row (the format the kernel reads)" if runs_blocked
                                  else "CSR: 12 B per nonzero + 4 B per row pointer + 16 B per row (SURVEY.md §8d)"),

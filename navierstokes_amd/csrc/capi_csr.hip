@@ -1247,9 +1247,9 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     switch (resolve_kernel(A)) {
     case MI_KERNEL_STREAM: return A->stream_nt ? "spmv_csr_stream<1024, true>" : "spmv_csr_stream<1024, false>";
     case MI_KERNEL_RING: { // the name rocprofv3 prints for the instantiation launch_ring picks
-        static thread_local char nm[112];
+        static thread_local char nm[128];
         const RingConfig& c = A->ring.cfg;
-        snprintf(nm, sizeof nm, "spmv_csr_ring<%d, %d, %d, %d, %d, %s, %s, %s, false, %s>", c.threads, c.nnzb, c.ring, c.depth, kRingMaxB,
+        snprintf(nm, sizeof nm, "spmv_csr_ring<%d, %d, %d, %d, %d, %s, %s, %s, false, %s, false>", c.threads, c.nnzb, c.ring, c.depth, kRingMaxB,
                  A->d_rowmap ? "true" : "false", A->ring.nt ? "true" : "false", A->ring.skew ? "true" : "false",
                  A->ring.lean && c.threads == 256 && c.depth != 3 ? "true" : "false");
         return nm;
