@@ -165,9 +165,22 @@ def self_launch(ngpus):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL, the push windows)
     limit = int(os.environ.get("MI355_BENCH_LAUNCH_TIMEOUT", "1500"))
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    # the child's stdout is filtered: the ONE JSON line goes to our stdout, anything else a rank or a backend prints there
+    # (gloo's connection banner, for one) goes to stderr — the contract is one JSON line on stdout
+    import threading
+    child = subprocess.Popen(cmd, env=env, start_new_session=True, stdout=subprocess.PIPE, text=True, bufsize=1)
+
+    def relay():
+        for ln in child.stdout:
+            looks_json = ln.lstrip().startswith("{") and '"metric"' in ln
+            (sys.stdout if looks_json else sys.stderr).write(ln)
+            (sys.stdout if looks_json else sys.stderr).flush()
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
     try:
-        return child.wait(timeout=limit)
+        rc = child.wait(timeout=limit)
+        pump.join(timeout=10)
+        return rc
     except subprocess.TimeoutExpired:
         print(f"bench.py: the {ngpus}-rank child did not finish within {limit} s; stopping its process group", file=sys.stderr, flush=True)
         for sig in (signal.SIGTERM, signal.SIGKILL):
