@@ -16,7 +16,8 @@ static hipError_t launch_t(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const Bc
     }
     const int nwg = (A->nbrows + Pl->rows - 1) / Pl->rows;
     Bcsr4Tile Tl{Pl->d_ptr, Pl->d_nodes, Pl->d_slots};
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSpmmTileThreads), spmm_tile_lds(Pl, S), st, V, Tl, X, ldx, Y, ldy, nwg);
+    static const int chunk = getenv("MI355_SPMM_TILE_XCD_CHUNK") ? atoi(getenv("MI355_SPMM_TILE_XCD_CHUNK")) : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSpmmTileThreads), spmm_tile_lds(Pl, S), st, V, Tl, X, ldx, Y, ldy, nwg, chunk);
     return hipGetLastError();
 }
 

@@ -35,12 +35,14 @@ constexpr int kSpmmTileRows = kSpmmTileThreads / 4;
 
 template <int S, int ARITH, int P>
 __global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_tile(Bcsr4View A, Bcsr4Tile Tl, const double* __restrict__ X, long long ldx,
-                                                                     double* __restrict__ Y, long long ldy, int nwg)
+                                                                     double* __restrict__ Y, long long ldy, int nwg, int xcd_chunk)
 {
     extern __shared__ __attribute__((aligned(16))) double s_xt[];
     constexpr int REC = 4 * S + 2; // doubles per node record (16-byte aligned; the pad spreads records over the LDS banks)
     constexpr int T = kSpmmTileThreads;
-    const int wg = (int)blockIdx.x;
+    // xcd_chunk > 0: tiles in XCD-chunked order (spmv_kernels.hpp: xcd_remap_chunked) — neighbouring tiles, which share most of
+    // their nodes, then run on ONE XCD and find each other's x blocks in its L2
+    const int wg = xcd_chunk > 0 ? xcd_remap_chunked((int)blockIdx.x, nwg, xcd_chunk) : (int)blockIdx.x;
     if (wg >= nwg) return;
     const int tid = threadIdx.x;
     const int g = wg * T + tid;
