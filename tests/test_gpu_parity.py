@@ -763,3 +763,35 @@ def test_matrix_powers_in_one_launch_is_refused_where_it_cannot_run(monkeypatch)
         Y = O.spmk_chain(3, p, c, v, x)
         for q in range(3):
             assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"{kind} {kernel} power {q + 1}")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_patterns_round3_paths(seed, monkeypatch):
+    """The planner fuzz's random patterns (rows of wildly different lengths, wandering / jumping column clusters, duplicates,
+    unsorted rows) through round 3's entry points: the one-launch powers step forced on (it runs where the plan allows and the
+    handle takes k launches elsewhere), the product with the dot in its epilogue, and the internal-numbering calls — bitwise
+    against the oracle (beta inside its bound)."""
+    from test_planner_fuzz import random_pattern
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([5000, 20000, 60000, 150000]))
+    p, c = random_pattern(rng, n)
+    v = rng.uniform(-1, 1, len(c)) / max(1.0, float(np.diff(p).max()))  # keep A^k x finite for long rows
+    x = rng.uniform(-1, 1, n)
+    b = rng.uniform(-1, 1, n)
+    monkeypatch.setenv("MI355_SPMK_FUSED", "1")
+    for kernel in ("auto", "ring"):
+        A = mpk.csrmatrix(n, p, c, v).set_kernel(kernel)
+        Y = O.spmk_chain(3, p, c, v, x)
+        for rep in range(2):  # twice: the flags count on
+            outs = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3)]
+            mpk.SpMkV(outs, dev(x), A)
+            for q in range(3):
+                assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"seed {seed} {kernel} -> {A.kernel_name()} {A.spmk_info(3)} rep {rep} power {q + 1}")
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        beta = mpk.SpMV_CSR_dot(y, dev(x), A, dev(b))
+        assert_bit_equal(y.cpu().numpy(), Y[0], f"seed {seed} {kernel}: product with dot (epilogue={A.dot_in_epilogue()})")
+        assert abs(float(beta) - O.dot(b, Y[0])) <= 1e-13 * float(np.abs(b * Y[0]).sum()) + 1e-300
+        xi = A.to_internal(dev(x))
+        yi = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR_internal(yi, xi, A)
+        assert_bit_equal(A.from_internal(yi).cpu().numpy(), Y[0], f"seed {seed} {kernel}: internal numbering")

@@ -50,3 +50,19 @@ def test_plans_replay_on_random_patterns(seed):
     assert 0.0 <= frac <= 1.0 and (runs >= 1 or nblk == 0)
     nblk, tot, mx, listed = tile_probe(p, c, threads=int(rng.integers(1, 4)))
     assert listed <= p[-1] and mx <= 2048
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_powers_step_dependencies_on_random_patterns(seed):
+    """mi_spmk_plan_probe on the same random patterns: wherever the one-launch powers step is eligible, every column a run names
+    or loads belongs to a run on its dependency list (the probe raises on the first violation)."""
+    import ctypes
+    from navierstokes_amd import mpk
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([7, 300, 5000, 20000, 60000, 200000]))
+    p, c = random_pattern(rng, n)
+    p = np.ascontiguousarray(p, np.int32)
+    c = np.ascontiguousarray(c, np.int32)
+    e, r, m = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    mpk.check(mpk.lib().mi_spmk_plan_probe(n, p.ctypes.data, c.ctypes.data, ctypes.byref(e), ctypes.byref(r), ctypes.byref(m)))
+    assert e.value in (0, 1) and (e.value == 0 or (r.value >= 8 and 1 <= m.value <= 64))

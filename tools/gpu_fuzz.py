@@ -25,6 +25,24 @@ for seed in range(first, last):
         names.append(A.kernel_name().split("<")[0][9:] + ("" if ok else "!!"))
         bad += not ok
         del A
+    if os.environ.get("FUZZ_ROUND3", "1") != "0":  # round 3's paths on the same pattern: one-launch powers step, dot epilogue
+        os.environ["MI355_SPMK_FUSED"] = "1"
+        vs = v / max(1.0, float(np.diff(p).max()))
+        A = mpk.csrmatrix(n, p, c, vs).set_kernel("ring")
+        Y = O.spmk_chain(3, p, c, vs, x)
+        for rep in range(2):
+            outs = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3)]
+            mpk.SpMkV(outs, xd, A)
+            ok = all(np.array_equal(outs[q].cpu().numpy().view(np.uint64), Y[q].view(np.uint64)) for q in range(3))
+            bad += not ok
+        names.append(("spmk1" if A.spmk_info(3)["one_launch"] else "spmk3") + ("" if ok else "!!"))
+        bv = rng.uniform(-1, 1, n)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        beta = float(mpk.SpMV_CSR_dot(y, xd, A, torch.from_numpy(bv).cuda()))
+        ok = np.array_equal(y.cpu().numpy().view(np.uint64), Y[0].view(np.uint64)) and abs(beta - O.dot(bv, Y[0])) <= 1e-13 * float(np.abs(bv * Y[0]).sum()) + 1e-300
+        names.append(("dotE" if A.dot_in_epilogue() else "dot2") + ("" if ok else "!!"))
+        bad += not ok
+        del A
     print(f"seed {seed} n {n} nnz {len(c)}: {' '.join(names)}", flush=True)
 print("MISMATCHES", bad)
 sys.exit(1 if bad else 0)
