@@ -201,6 +201,11 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     dfree(A->st.d_ptr);
     dfree(A->st.d_nodes);
     dfree(A->st.d_slots);
+    dfree(A->st.d_rows);
+    dfree(A->st64.d_ptr);
+    dfree(A->st64.d_nodes);
+    dfree(A->st64.d_slots);
+    dfree(A->st64.d_rows);
     dfree(A->d_x);
     dfree(A->d_y);
     for (double* p : A->d_pow) dfree(p);
@@ -337,43 +342,105 @@ static void launch_spmm_s(const Bcsr4View& V, int arith, const double* X, long l
 
 // ---- the tile form (spmm_tile.hpp) ------------------------------------------------------------------------------------------
 
-// lists of distinct block columns per group of `per` block rows, and every block's position in its group's list
-static int build_spmm_tile_plan(mi_bcsr4_t A, int per, const std::vector<int>& ptrow, const std::vector<int>& indcol, SpmmTilePlan& T)
+// Tiles of the multi-vector product: groups of at most `per` block rows, the list of distinct block columns each group touches, and
+// every block's position in its group's list.  The groups are CLUSTERS of the block graph, not runs of consecutive rows: grown
+// breadth-first from the lowest unassigned row over unassigned rows (a "ball" of the mesh), because the tile's cost — its gather, its
+// LDS — is the number of distinct columns per row, and a ball of 128 nodes of a 3-D mesh touches ~2.5 per row where 128
+// consecutive nodes (1.9 mesh lines) touch 5.1 (FE matrix, 68^3 cells: lists of 321 against 654 entries on average).  A cluster
+// whose list would exceed `ucap` entries is cut in halves (in growth order) until it fits: the LDS footprint, hence the
+// workgroups per CU, is set by the LONGEST list.  rows[t * per + i] = block row of lane group i of tile t, or -1 - (a valid row of
+// the tile) for unused places (those lanes shadow that row and store nothing).
+static int build_spmm_tile_plan(mi_bcsr4_t A, int per, int ucap, const std::vector<int>& ptrow, const std::vector<int>& indcol, SpmmTilePlan& T)
 {
-    const int nwg = (A->nbrows + per - 1) / per;
-    std::vector<int> wg_ptr((size_t)nwg + 1, 0);
+    const int nbr = A->nbrows;
+    std::vector<int> order;           // block rows in cluster growth order
+    std::vector<int> cuts;            // first position of every cluster, then cut further below
+    order.reserve((size_t)nbr);
+    {
+        std::vector<char> assigned((size_t)nbr, 0);
+        std::vector<int> stamp((size_t)nbr, 0), queue;
+        int seed = 0, tid = 0, in_cur = 0;
+        while (true) {
+            while (seed < nbr && assigned[seed]) seed++;
+            if (seed >= nbr) break;
+            if (in_cur == 0) {
+                tid++;
+                cuts.push_back((int)order.size());
+            }
+            queue.clear();
+            queue.push_back(seed);
+            stamp[seed] = tid;
+            for (size_t qh = 0; qh < queue.size() && in_cur < per; qh++) {
+                const int r = queue[qh];
+                order.push_back(r);
+                assigned[r] = 1;
+                in_cur++;
+                for (int k = ptrow[r]; k < ptrow[r + 1]; k++) {
+                    const int nb = indcol[k];
+                    if (nb < nbr && !assigned[nb] && stamp[nb] != tid) { // (columns beyond the rows: a rectangular matrix has no such node)
+                        stamp[nb] = tid;
+                        queue.push_back(nb);
+                    }
+                }
+            }
+            if (in_cur == per) in_cur = 0; // full; else the component ran dry: the next seed continues this cluster
+        }
+        cuts.push_back((int)order.size());
+    }
+    // lists; clusters over the cap are halved
+    std::vector<int> wg_ptr(1, 0), rows;
     std::vector<unsigned> nodes, u;
     std::vector<unsigned short> slots((size_t)A->nblocks + 1, 0);
     int umax = 0;
-    for (int w = 0; w < nwg; w++) {
-        const int b0 = ptrow[(size_t)w * per], b1 = ptrow[std::min<long long>((long long)(w + 1) * per, A->nbrows)];
-        u.assign(indcol.begin() + b0, indcol.begin() + b1);
+    std::vector<std::pair<int, int>> work; // [first, end) positions in `order`, processed in order (a stack keeps the order)
+    for (size_t t = cuts.size() - 1; t-- > 0;) work.push_back({cuts[t], cuts[t + 1]});
+    while (!work.empty()) {
+        const std::pair<int, int> w = work.back();
+        work.pop_back();
+        if (w.first >= w.second) continue;
+        u.clear();
+        for (int i = w.first; i < w.second; i++) u.insert(u.end(), indcol.begin() + ptrow[order[i]], indcol.begin() + ptrow[order[i] + 1]);
         std::sort(u.begin(), u.end());
         u.erase(std::unique(u.begin(), u.end()), u.end());
+        if ((int)u.size() > ucap && w.second - w.first > 1) {
+            const int mid = (w.first + w.second) / 2;
+            work.push_back({mid, w.second});
+            work.push_back({w.first, mid});
+            continue;
+        }
         if (u.size() > 65535) return -1;
         umax = std::max(umax, (int)u.size());
-        for (int k = b0; k < b1; k++) slots[k] = (unsigned short)(std::lower_bound(u.begin(), u.end(), (unsigned)indcol[k]) - u.begin());
+        for (int i = w.first; i < w.second; i++)
+            for (int k = ptrow[order[i]]; k < ptrow[order[i] + 1]; k++)
+                slots[k] = (unsigned short)(std::lower_bound(u.begin(), u.end(), (unsigned)indcol[k]) - u.begin());
         nodes.insert(nodes.end(), u.begin(), u.end());
-        wg_ptr[w + 1] = (int)nodes.size();
+        wg_ptr.push_back((int)nodes.size());
+        for (int i = 0; i < per; i++) rows.push_back(w.first + i < w.second ? order[w.first + i] : -1 - order[w.first]);
     }
-    if (umax < 1) return -1;
+    const int ntiles = (int)wg_ptr.size() - 1;
+    if (umax < 1 || ntiles < 1) return -1;
     nodes.push_back(0);
     hipError_t er;
     if ((er = hipMalloc(&T.d_ptr, sizeof(int) * wg_ptr.size())) != hipSuccess ||
         (er = hipMalloc(&T.d_nodes, sizeof(unsigned) * nodes.size())) != hipSuccess ||
         (er = hipMalloc(&T.d_slots, sizeof(unsigned short) * slots.size())) != hipSuccess ||
+        (er = hipMalloc(&T.d_rows, sizeof(int) * rows.size())) != hipSuccess ||
         (er = hipMemcpy(T.d_ptr, wg_ptr.data(), sizeof(int) * wg_ptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
         (er = hipMemcpy(T.d_nodes, nodes.data(), sizeof(unsigned) * nodes.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-        (er = hipMemcpy(T.d_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        (er = hipMemcpy(T.d_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (er = hipMemcpy(T.d_rows, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice)) != hipSuccess) {
         (void)hipGetLastError();
         dfree(T.d_ptr);
         dfree(T.d_nodes);
         dfree(T.d_slots);
+        dfree(T.d_rows);
         T = SpmmTilePlan();
         return -1;
     }
     T.rows = per;
     T.umax = umax;
+    T.ntiles = ntiles;
+    T.mean_list = (double)(nodes.size() - 1) / ntiles;
     return 1;
 }
 
@@ -389,7 +456,12 @@ static int build_spmm_tile(mi_bcsr4_t A)
         (void)hipGetLastError();
         return -1;
     }
-    A->st_state = build_spmm_tile_plan(A, 128, ptrow, indcol, A->st);
+    // list caps: what lets two workgroups share a CU at four columns (128-row tiles: 368 x 144 B = 53 KB) and at eight (64-row tiles,
+    // two quads per block row: 256 x 272 B = 70 KB); MI355_SPMM_TILE_UCAP=<128-row cap>,<64-row cap> for A/B
+    int cap128 = 368, cap64 = 256;
+    if (const char* ce = getenv("MI355_SPMM_TILE_UCAP")) (void)sscanf(ce, "%d,%d", &cap128, &cap64);
+    A->st_state = build_spmm_tile_plan(A, 128, cap128, ptrow, indcol, A->st);
+    (void)build_spmm_tile_plan(A, 64, cap64, ptrow, indcol, A->st64);
     return A->st_state;
 }
 
@@ -401,13 +473,13 @@ static const SpmmTilePlan* spmm_plan_of(const mi_bcsr4_s* A, int s)
     return Pl;
 }
 
-static bool spmm_tile_possible(const mi_bcsr4_s* A, int s) { return spmm_plan_of(A, s) != nullptr; }
+enum { kSpmmGather = 0, kSpmmTile = 1, kSpmmOct = 2, kSpmmOctNt = 3, kSpmmForms = 4 };
 
-static hipError_t launch_spmm_tile(const mi_bcsr4_s* A, const Bcsr4View& V, int m, int arith, const double* X, long long ldx, double* Y, long long ldy, hipStream_t st)
+static bool spmm_form_possible(const mi_bcsr4_s* A, int s, int form)
 {
-    const SpmmTilePlan* Pl = spmm_plan_of(A, m);
-    if (!Pl) return hipErrorInvalidValue;
-    return spmm_tile_launch(A, Pl, V, m, arith, X, ldx, Y, ldy, st);
+    if (form == kSpmmGather) return true;
+    if (form == kSpmmTile) return spmm_plan_of(A, s) != nullptr;
+    return s % 2 == 0 && A->st64.d_ptr && spmm_tile_lds(&A->st64, s) <= kLdsBytesPerCU;
 }
 
 static void launch_spmm_gather(const Bcsr4View& V, int m, int arith, const double* Xj, long long ldx, double* Yj, long long ldy, hipStream_t st)
@@ -432,67 +504,80 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
         const int m = std::min(8, s - j0);
         const double* Xj = X + (size_t)j0 * ldx;
         double* Yj = Y + (size_t)j0 * ldy;
-        // tile form or gather form: same bits; the first product of a handle at a column count times both and keeps the faster
-        // (MI355_SPMM_TILE=0 never builds the tile, =1 takes it unmeasured)
-        bool tile = false;
-        if (build_spmm_tile(A) == 1 && spmm_tile_possible(A, m)) {
+        // four forms, same bits: gather kernels; LDS tile with four lanes per block row (up to four columns); LDS tile with eight
+        // lanes per block row (even column counts), coefficients loaded temporally or non-temporally.  The first product of a handle
+        // at a column count times the possible ones and keeps the fastest (MI355_SPMM_TILE=0..3 forces a form)
+        auto run = [&](int form) -> hipError_t {
+            if (form == kSpmmTile) return spmm_tile_launch(A, spmm_plan_of(A, m), V, m, arith, Xj, ldx, Yj, ldy, st);
+            if (form == kSpmmOct || form == kSpmmOctNt) return spmm_otile_launch(A, &A->st64, V, m, arith, form == kSpmmOctNt, Xj, ldx, Yj, ldy, st);
+            launch_spmm_gather(V, m, arith, Xj, ldx, Yj, ldy, st);
+            return hipGetLastError();
+        };
+        int form = kSpmmGather;
+        if (build_spmm_tile(A) == 1) {
             const char* e = getenv("MI355_SPMM_TILE");
-            if (e && !strcmp(e, "1")) tile = true;
+            const int forced = e ? atoi(e) : -1;
+            if (forced >= 0 && forced < kSpmmForms) form = spmm_form_possible(A, m, forced) ? forced : kSpmmGather;
             else {
                 if (A->spmm_choice[m] == 0) {
                     hipEvent_t e0 = nullptr, e1 = nullptr;
+                    int best = kSpmmGather;
                     if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-                        double us[2] = {0, 0};
-                        for (int round = 0; round < 2; round++)
-                            for (int form = 0; form < 2; form++) {
-                                for (int i = 0; i < 2; i++) {
-                                    if (form) (void)launch_spmm_tile(A, V, m, arith, Xj, ldx, Yj, ldy, st);
-                                    else launch_spmm_gather(V, m, arith, Xj, ldx, Yj, ldy, st);
-                                }
+                        double us[kSpmmForms] = {0, 0, 0, 0};
+                        bool ok = true;
+                        for (int round = 0; round < 2 && ok; round++)
+                            for (int f = 0; f < kSpmmForms && ok; f++) {
+                                if (!spmm_form_possible(A, m, f)) continue;
+                                for (int i = 0; i < 2 && ok; i++) ok = run(f) == hipSuccess;
                                 (void)hipEventRecord(e0, st);
-                                for (int i = 0; i < 5; i++) {
-                                    if (form) (void)launch_spmm_tile(A, V, m, arith, Xj, ldx, Yj, ldy, st);
-                                    else launch_spmm_gather(V, m, arith, Xj, ldx, Yj, ldy, st);
-                                }
+                                for (int i = 0; i < 5 && ok; i++) ok = run(f) == hipSuccess;
                                 (void)hipEventRecord(e1, st);
                                 (void)hipEventSynchronize(e1);
                                 float ms = 0.f;
                                 (void)hipEventElapsedTime(&ms, e0, e1);
                                 const double t = ms * 1e3 / 5;
-                                us[form] = us[form] > 0 ? std::min(us[form], t) : t;
+                                us[f] = us[f] > 0 ? std::min(us[f], t) : t;
                             }
-                        A->spmm_us[m][0] = us[0];
-                        A->spmm_us[m][1] = us[1];
-                        A->spmm_choice[m] = (hipGetLastError() == hipSuccess && us[1] > 0 && us[1] < us[0]) ? 1 : -1;
-                    } else {
-                        A->spmm_choice[m] = -1;
+                        for (int f = 0; f < kSpmmForms; f++) {
+                            A->spmm_us[m][f] = us[f];
+                            if (ok && us[f] > 0 && us[f] < us[best]) best = f;
+                        }
+                        if (!ok) { (void)hipGetLastError(); best = kSpmmGather; }
                     }
                     if (e0) (void)hipEventDestroy(e0);
                     if (e1) (void)hipEventDestroy(e1);
+                    A->spmm_choice[m] = 1 + best;
                 }
-                tile = A->spmm_choice[m] == 1;
+                form = A->spmm_choice[m] - 1;
             }
         }
-        if (tile) {
-            hipError_t er = launch_spmm_tile(A, V, m, arith, Xj, ldx, Yj, ldy, st);
-            if (er != hipSuccess) return fail(MI_ERR_HIP, std::string("spmm tile kernel: ") + hipGetErrorString(er));
-        } else {
-            launch_spmm_gather(V, m, arith, Xj, ldx, Yj, ldy, st);
-        }
+        hipError_t er = run(form);
+        if (er != hipSuccess) return fail(MI_ERR_HIP, std::string("multi-vector product: ") + hipGetErrorString(er));
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
-extern "C" int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* tile_in_use, int* longest_list, double* us_gather, double* us_tile)
+extern "C" int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* form_in_use, int* longest_list, double us[4])
 {
     CHECK_ARG(A && s >= 1 && s <= 8, "bad argument");
     if (tile_built) *tile_built = A->st_state == 1;
-    const char* e = getenv("MI355_SPMM_TILE");
-    if (tile_in_use) *tile_in_use = A->st_state == 1 && spmm_tile_possible(A, s) && ((e && !strcmp(e, "1")) || A->spmm_choice[s] == 1);
-    if (longest_list) { const SpmmTilePlan* Pl = spmm_plan_of(A, s); *longest_list = Pl ? Pl->umax : 0; }
-    if (us_gather) *us_gather = A->spmm_us[s][0];
-    if (us_tile) *us_tile = A->spmm_us[s][1];
+    if (form_in_use) {
+        const char* e = getenv("MI355_SPMM_TILE");
+        const int forced = e ? atoi(e) : -1;
+        int form = kSpmmGather;
+        if (A->st_state == 1) {
+            if (forced >= 0 && forced < kSpmmForms) form = spmm_form_possible(A, s, forced) ? forced : kSpmmGather;
+            else if (A->spmm_choice[s] > 0) form = A->spmm_choice[s] - 1;
+        }
+        *form_in_use = form;
+    }
+    if (longest_list) {
+        const SpmmTilePlan* Pl = spmm_plan_of(A, s) ? spmm_plan_of(A, s) : (A->st64.d_ptr ? &A->st64 : nullptr);
+        *longest_list = Pl ? Pl->umax : 0;
+    }
+    if (us)
+        for (int f = 0; f < kSpmmForms; f++) us[f] = A->spmm_us[s][f];
     return MI_OK;
 }
 

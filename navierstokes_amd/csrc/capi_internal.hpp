@@ -165,10 +165,12 @@ struct mi_csr_s {
 };
 
 struct SpmmTilePlan {
-    int rows = 0, umax = 0; // block rows per group; longest list
+    int rows = 0, umax = 0, ntiles = 0; // block rows per tile (at most); longest list; tiles
+    double mean_list = 0.0;
     int* d_ptr = nullptr;
     unsigned* d_nodes = nullptr;
     unsigned short* d_slots = nullptr;
+    int* d_rows = nullptr;              // [ntiles * rows]: block row per lane group, -1 - r for unused places
 };
 
 struct mi_bcsr4_s {
@@ -185,11 +187,13 @@ struct mi_bcsr4_s {
     unsigned short* d_tl_slots = nullptr;
     bool use_tile = false;    // the measured choice between the two kernels (MI355_BCSR_TILE=0|1 forces)
     double tune_us_plain = 0.0, tune_us_tile = 0.0;
-    // x tile of the multi-vector product (spmm_tile.hpp): lists per group of 128 block rows, built at the first product
-    SpmmTilePlan st;
+    // x tiles of the multi-vector product (spmm_tile.hpp): lists per group of 128 block rows (st) and of 64 (st64: the eight-column
+    // form with two quads per block row), built at the first product
+    SpmmTilePlan st, st64;
     int st_state = 0;         // 0 not tried, 1 built, -1 not possible
-    int spmm_choice[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // per column count <= 8: 0 not measured, 1 tile kernel, -1 gather kernels
-    double spmm_us[9][2] = {};                         // [s][0] gather kernel, [s][1] tile kernel (microseconds per launch)
+    int spmm_choice[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // per column count <= 8: 0 not measured, else 1 + the form that measured fastest
+    double spmm_us[9][4] = {};                         // [s][form] microseconds per launch: 0 gather kernels, 1 tile (four lanes per block row),
+                                                       // 2 / 3 tile with eight lanes per block row, temporal / non-temporal coefficient loads
     double* d_x = nullptr;
     double* d_y = nullptr;
     std::vector<double*> d_pow;
@@ -287,5 +291,7 @@ constexpr size_t kLdsBytesPerCU = 160 * 1024;
 static inline size_t spmm_tile_lds(const SpmmTilePlan* T, int s) { return T ? (size_t)T->umax * (4 * s + 2) * sizeof(double) : (size_t)-1; }
 hipError_t spmm_tile_launch(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const Bcsr4View& V, int s, int arith, const double* X, long long ldx,
                             double* Y, long long ldy, hipStream_t st);
+hipError_t spmm_otile_launch(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const Bcsr4View& V, int s, int arith, bool nt, const double* X, long long ldx,
+                             double* Y, long long ldy, hipStream_t st);
 // capi_bcsr.hip
 int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);

@@ -4,23 +4,21 @@
 // Why: in spmm_bcsr4 / spmm_bcsr4_quad (spmv_kernels.hpp) every block costs its lanes a dependent chain — block column from
 // memory, THEN the S x blocks through L1/L2 — and S x blocks of 32 bytes from S different arrays per block: 4.6 M blocks x S
 // scattered 32-byte reads.  The kernel sat at 45-54 % of its byte model and fetched 1.31x the model's bytes (x once per XCD).
-// Here a workgroup of 512 threads owns 128 block rows; the host lists the distinct block columns they touch (~660 for the
-// FE matrix: a 2.8x reuse) and gives every block the 16-bit position of its column in that list.  The workgroup gathers the S
+// Here a workgroup of 512 threads owns a tile of up to 128 block rows; the host lists the distinct block columns they touch (~320
+// for the FE matrix) and gives every block the 16-bit position of its column in that list.  The workgroup gathers the S
 // columns of those nodes into LDS once (node-major records of 4 S + 2 doubles: the two pad doubles spread neighbouring
 // records over the banks), and the inner loop waits for COEFFICIENTS only — a pure stream, P blocks deep in registers — while
 // x comes from LDS (2 S ds_read_b128 per block and lane, quads broadcast).
-// What it buys and what it does not (FE matrix, 1.31 M rows, bench.py fe_spmm4 / fe_spmm8; profiles/r03_spmm_tile_ablation.txt):
-// four columns 168-174 -> 152-156 us (this kernel, 128 block rows per workgroup).  The remaining gap to the coefficient
-// stream's own time (113 us for the single-vector kernel) is the GATHER at the top of each workgroup: two dependent round
-// trips (list entry, then the node's x block) during which the CU idles — the tile's LDS footprint (95 KB at four columns)
-// admits ONE workgroup per CU.  Compiled out, the kernel runs 130 us (162 -> 130 on the box of that run; at eight columns with
-// two quads per block row 263 -> 165); LDS bank conflicts cost nothing (every lane reading slot 0: 160 us).  Two remedies were
-// built and measured slower: smaller tiles for two workgroups per CU (64 rows: 164 us — more distinct columns per row, more
-// gather work) and persistent workgroups that fetch tile i + 1's x blocks into registers while tile i is multiplied (231 us /
-// 414 us: vmcnt counts loads in issue order, so the first coefficient wait of a tile also waits for every x block issued in
-// front of it — the latency is not hidden, and the staging costs registers and a second barrier).  At eight columns the
-// gather forms stay ahead (223-236 us against 263).  What would hide it is a second set of waves that only gathers, with a
-// second LDS tile — which 160 KB do not hold at these tile sizes.
+// The groups are CLUSTERS of the block graph (capi_bcsr.hip: build_spmm_tile_plan — breadth-first balls), not runs of consecutive
+// rows: a ball of 128 nodes of a 3-D mesh touches ~2.5 distinct columns per row where 128 consecutive nodes touch 5.1, which
+// halves the gather and the LDS footprint (three workgroups per CU at four columns).
+// Measured (FE matrix, 1.31 M rows; DESIGN.md §4.8, profiles/r03_spmm_tile_ablation.txt): four columns 168-179 -> 148-157 us in every
+// tile form built; eight columns 227-237 -> 180-192 us with eight lanes per block row and non-temporal coefficient loads
+// (spmm_bcsr4_otile below).  Compiling pieces out of this kernel shows where the rest goes: no gather 133 us, no Y stores 128-131,
+// neither 114 (= the single-vector kernel's coefficient stream) — about 20 us each, additive, neither explained by bytes (PMC: the
+// stores add no fetch traffic; the gathers 157 MB of 809): the stores are the memory-side read/write turnaround of DESIGN §4.4, the
+// gather two dependent round trips per workgroup.  Persistent workgroups with the next tile's x blocks staged in registers were
+// built twice and measured slower (231 / 164-170 us at four columns: vmcnt counts in issue order, and the staging costs registers).
 // Arithmetic: exactly spmm_bcsr4's (ARITH 0: one fma chain per row and column, bit-equal to SpMV_BCSR_FMA; ARITH 1: per-block
 // partial sums added to the row value) — same blocks in the same order.
 #pragma once
@@ -45,9 +43,10 @@ __global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_tile(Bcsr4View A,
     const int wg = xcd_chunk > 0 ? xcd_remap_chunked((int)blockIdx.x, nwg, xcd_chunk) : (int)blockIdx.x;
     if (wg >= nwg) return;
     const int tid = threadIdx.x;
-    const int g = wg * T + tid;
-    const int bi = min(g >> 2, A.nbrows - 1), q = g & 3; // (lanes past the last block row shadow it and store nothing)
-    const bool live = (g >> 2) < A.nbrows;
+    const int q = tid & 3;
+    const int rr = Tl.rows[wg * kSpmmTileRows + (tid >> 2)]; // the tile's rows are a cluster of the block graph, not a range
+    const bool live = rr >= 0;
+    const int bi = live ? rr : -1 - rr;                       // (unused places shadow a row of the tile and store nothing)
     const int u0 = Tl.wg_ptr[wg], U = Tl.wg_ptr[wg + 1] - u0;
     const int ia0 = A.ptrow[bi], ia1 = A.ptrow[bi + 1];
     const int last = max(ia1 - 1, ia0);
@@ -126,6 +125,118 @@ __global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_tile(Bcsr4View A,
         const size_t orow = 4 * (size_t)(A.browmap ? A.browmap[bi] : bi) + q;
 #pragma unroll
         for (int j = 0; j < S; j++) Y[(size_t)j * ldy + orow] = acc[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// EIGHT lanes per block row (S even): lane l of a row's octet loads doubles [2l, 2l + 1] of every block — ONE 16-byte load per lane
+// and block, the octet reading the block's 128 bytes as one contiguous line (the quad forms read it as two instructions of four
+// strided 16-byte pieces each).  Lanes 2q and 2q + 1 hold the two halves of row q and swap them through DPP (quad_perm [1,0,3,2]),
+// after which both hold the whole row; lane (q, h = l & 1) runs the fma chains of row q for the S / 2 columns of group h — so every
+// (row, column) chain is still ONE lane's sequential chain over the row's blocks, bit for bit spmm_bcsr4's.  Half the load
+// instructions per block, whole lines per instruction (which is what lets the coefficient stream be loaded non-temporally without
+// being fetched twice, NT), half the LDS reads and accumulators per lane, and twice the waves per block row: 64 block rows per
+// 512-thread tile.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int S, int ARITH, int P, bool NT>
+__global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_otile(Bcsr4View A, Bcsr4Tile Tl, const double* __restrict__ X, long long ldx,
+                                                                      double* __restrict__ Y, long long ldy, int nwg)
+{
+    static_assert(S % 2 == 0, "two column groups");
+    extern __shared__ __attribute__((aligned(16))) double s_xt[];
+    typedef double dvec2 __attribute__((ext_vector_type(2)));
+    constexpr int REC = 4 * S + 2, SL = S / 2, T = kSpmmTileThreads, ROWS = T / 8;
+    const int wg = (int)blockIdx.x;
+    if (wg >= nwg) return;
+    const int tid = threadIdx.x;
+    const int l = tid & 7, q = l >> 1, h = l & 1;
+    const int rr = Tl.rows[wg * ROWS + (tid >> 3)];
+    const bool live = rr >= 0;
+    const int bi = live ? rr : -1 - rr; // (unused places shadow a row of the tile and store nothing)
+    const int u0 = Tl.wg_ptr[wg], U = Tl.wg_ptr[wg + 1] - u0;
+    const int ia0 = A.ptrow[bi], ia1 = A.ptrow[bi + 1];
+    const int last = max(ia1 - 1, ia0);
+    const double* cl = A.coef + 2 * l;
+    dvec2 a[P];
+    unsigned sl[P];
+    auto ldc = [&](int blk) -> dvec2 {
+        const dvec2* p = reinterpret_cast<const dvec2*>(cl + 16 * (size_t)blk);
+        if (NT) return __builtin_nontemporal_load(p);
+        return *p;
+    };
+#pragma unroll
+    for (int t = 0; t < P; t++) {
+        const int blk = min(ia0 + t, last);
+        a[t] = ldc(blk);
+        sl[t] = Tl.slots[blk];
+    }
+    const int total = U * S;
+    for (int e0 = tid; e0 < total; e0 += 4 * T) {
+        double2 v0[4], v1[4];
+        int jj[4], uu[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int e = min(e0 + r * T, total - 1);
+            jj[r] = e / U;
+            uu[r] = e - jj[r] * U;
+            const unsigned node = Tl.nodes[u0 + uu[r]];
+            const double2* xb = reinterpret_cast<const double2*>(X + (size_t)jj[r] * ldx + 4 * (size_t)node);
+            v0[r] = xb[0];
+            v1[r] = xb[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (e0 + r * T < total) {
+                double2* d = reinterpret_cast<double2*>(s_xt + (size_t)uu[r] * REC + 4 * jj[r]);
+                d[0] = v0[r];
+                d[1] = v1[r];
+            }
+    }
+    __syncthreads();
+    double acc[SL];
+#pragma unroll
+    for (int j = 0; j < SL; j++) acc[j] = 0.0;
+    for (int ia = ia0; ia < ia1; ia += P) {
+#pragma unroll
+        for (int t = 0; t < P; t++) {
+            const dvec2 mine = a[t];
+            const double2* xs = reinterpret_cast<const double2*>(s_xt + (size_t)sl[t] * REC + 4 * SL * h);
+            const int nb = min(ia + t + P, last);
+            a[t] = ldc(nb);
+            sl[t] = Tl.slots[nb];
+            // the partner lane (l ^ 1) holds the other half of this row: swap neighbours inside the quad
+            constexpr int kSwap = 0xB1; // quad_perm [1, 0, 3, 2]
+            const double ox = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(mine.x), kSwap, 0xf, 0xf, true),
+                                               __builtin_amdgcn_mov_dpp(__double2loint(mine.x), kSwap, 0xf, 0xf, true));
+            const double oy = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(mine.y), kSwap, 0xf, 0xf, true),
+                                               __builtin_amdgcn_mov_dpp(__double2loint(mine.y), kSwap, 0xf, 0xf, true));
+            const double c0 = h ? ox : mine.x, c1 = h ? oy : mine.y, c2 = h ? mine.x : ox, c3 = h ? mine.y : oy;
+            if (ia + t < ia1) { // uniform within the octet
+#pragma unroll
+                for (int j = 0; j < SL; j++) {
+                    const double2 v01 = xs[2 * j], v23 = xs[2 * j + 1];
+                    if (ARITH == 0) {
+                        double sacc = acc[j];
+                        sacc = fma(c0, v01.x, sacc);
+                        sacc = fma(c1, v01.y, sacc);
+                        sacc = fma(c2, v23.x, sacc);
+                        sacc = fma(c3, v23.y, sacc);
+                        acc[j] = sacc;
+                    } else {
+                        double p = fma(c0, v01.x, 0.0);
+                        p = fma(c1, v01.y, p);
+                        p = fma(c2, v23.x, p);
+                        p = fma(c3, v23.y, p);
+                        acc[j] = __dadd_rn(acc[j], p);
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+        const size_t orow = 4 * (size_t)(A.browmap ? A.browmap[bi] : bi) + q;
+#pragma unroll
+        for (int j = 0; j < SL; j++) Y[(size_t)(SL * h + j) * ldy + orow] = acc[j];
     }
 }
 

@@ -291,6 +291,7 @@ struct Bcsr4Tile {
     const int* wg_ptr;            // [nwg + 1] first list entry of each workgroup
     const unsigned* nodes;        // distinct block columns per workgroup
     const unsigned short* slots;  // per block: position of its column in its workgroup's list
+    const int* rows = nullptr;    // multi-vector tiles only (spmm_tile.hpp): block row of every lane group, -1 - r for unused places
 };
 
 template <int P>

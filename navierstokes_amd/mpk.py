@@ -85,7 +85,7 @@ def lib():
         "mi_part_push_disable": [_vp],
         "mi_part_push_unfuse": [_vp],
         "mi_bcsr4_spmm": [_vp, i, _vp, ll, _vp, ll, i],
-        "mi_bcsr4_spmm_info": [_vp, i, P(i), P(i), P(i), P(d), P(d)],
+        "mi_bcsr4_spmm_info": [_vp, i, P(i), P(i), P(i), P(d)],
         "mi_bcsr4_spmm_dev": [_vp, i, _vp, ll, _vp, ll, i, _vp],
         "mi_spmm_dev": [_vp, i, _vp, ll, _vp, ll, _vp],
         "mi_krylov_basis_dev": [_vp, i, _vp, _vp, ll, i, _vp, _vp],

@@ -126,3 +126,38 @@ def test_krylov_basis_orthonormal():
         lhs = O.spmv(p, c, v, V[k])
         rhs = H[k, : k + 1] @ V[: k + 1] + H[k, k + 1] * V[k + 1]
         assert O.rel_error(lhs, rhs) <= 1e-12
+
+
+@pytest.mark.parametrize("form", ["1", "2", "3"])
+@pytest.mark.parametrize("s", [2, 4, 6, 8, 11])
+def test_spmm_every_tile_form_bitwise(form, s, monkeypatch):
+    """The multi-vector product's tile forms forced on (MI355_SPMM_TILE: 1 = four lanes per block row, 2 / 3 = eight lanes per block
+    row with temporal / non-temporal coefficient loads; a form that does not exist for a column count falls back to the gather
+    kernels): tiles are breadth-first clusters of the block graph, rows of a tile are not consecutive — every column bit-equal to
+    the oracle in both associations, on an FE matrix, on the same matrix under a random node numbering, and on a matrix with empty
+    block rows and a block-row count that is no multiple of the tile size."""
+    monkeypatch.setenv("MI355_SPMM_TILE", form)
+    mats = []
+    p, c, v = synth.fe_matrix(13, 11, 9)
+    mats.append(("fe", p, c, v))
+    p2, c2, v2, _ = synth.permute_nodes(p, c, v, block=4, seed=3)
+    mats.append(("fe scrambled", p2, c2, v2))
+    for name, p, c, v in mats:
+        n = len(p) - 1
+        bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+        if name == "fe":  # empty block rows
+            keep = np.ones(n // 4, bool)
+            keep[[5, 200, 201, n // 4 - 1]] = False
+            lens = np.diff(bp) * keep
+            sel = np.repeat(keep, np.diff(bp))
+            bp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+            bc, bv = bc[sel], bv.reshape(-1, 16)[sel].reshape(-1)
+        A = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
+        X = _vectors(n, s)
+        for arith, orc in (("chain", O.spmv_bcsr4), ("blockacc", O.spmv_bcsr4_blockacc)):
+            for rep in range(2):
+                Y = torch.full((s, n), float("nan"), dtype=torch.float64, device="cuda")
+                mpk.MatMatMult_SeqBAIJ_4(A, dev(X), Y, arith)
+                Yh = Y.cpu().numpy()
+                for j in range(s):
+                    assert_bit_equal(Yh[j], orc(bp, bc, bv, X[j]), f"{name} form {form} s={s} {arith} column {j} rep {rep}")
