@@ -119,7 +119,8 @@ int mi_csr_dims(mi_csr_t A, int* n, int* ncols, long long* nnz);
  * builds A' = P A P^T with every row's nonzeros in the caller's order, and keeps it if it measures faster.  The
  * permutation never shows: x is gathered into the new numbering before a product and y is written back through a
  * row map, and since a row's terms keep their order every bit of y equals the unreordered kernels' (and the
- * reference's SpMV_CSR_FMA).  A reordered handle owns one gather buffer: issue its products on one stream at a time.
+ * reference's SpMV_CSR_FMA).  A reordered handle keeps one gather buffer per stream it has multiplied on (products of one handle on
+ * different streams do not share scratch; mi_spmk_dev's power buffers are per handle: one k-step at a time).
  * MI355_REORDER=0 disables, =1 forces.  *reordered = 1 if the handle computes through the relabelled twin; block = 4
  * if nodes of four rows were moved, 1 if single rows; spread = mean |column - row| in nodes before / after;
  * us_* = measured launch time of the natural-order choice and of the twin incl. its gather (0 if not measured). */
@@ -227,7 +228,8 @@ int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* d_y_out, mi
  * of row blocks for all k powers; a run's power p is published write-through + flag, power p + 1 waits for the flags of the runs
  * its columns name) — k <= 8, ring-served square matrices whose whole grid is resident at once; the first k-step of a handle at a
  * given k times both forms (same bits) and keeps the faster.  MI355_SPMK_FUSED=0 never, =1 always where eligible.  The handle
- * carries the step's flags: one k-step at a time per handle.  Reports what the handle does at this k (after its first k-step). */
+ * carries the step's flags: one k-step at a time per handle.  Under HIP stream capture the step is recorded as k launches (the flags'
+ * epoch is a kernel argument; a replayed graph would present it again).  Reports what the handle does at this k (after its first k-step). */
 int mi_csr_spmk_info(mi_csr_t A, int k, int* eligible, int* one_launch, double* us_k_launches, double* us_one_launch);
 
 /* host-only: derive the one-launch step's run dependencies as mi_csr_create would and CHECK them against the matrix (every column
@@ -412,7 +414,8 @@ int mi_part_status(mi_part_t P);
  * cross-stream hand-off.  Set-up (collective, once): every rank calls mi_part_push_export, the 64-byte handles and the
  * (2*nranks+1)-entry layouts are all-gathered by any side channel, every rank calls mi_part_push_connect with all of
  * them.  One PROCESS per rank (ranks as threads of one process share hardware queues and can deadlock in the wait).
- * All ranks must then call mi_part_spmv_push_dev the same number of times (the flags carry the step number).
+ * All ranks must then call mi_part_spmv_push_dev the same number of times (the flags carry the step number; for the same reason the
+ * call refuses to be captured into a HIP graph: MI_ERR_UNSUPPORTED).
  * A wait on a stalled neighbour gives up after minutes; that is sticky and reported like a hand-off time-out. */
 #define MI_IPC_HANDLE_BYTES 64
 int mi_part_push_export(mi_part_t P, void* handle64, long long* layout /* [2*nranks + 1] */);

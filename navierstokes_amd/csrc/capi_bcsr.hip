@@ -514,7 +514,9 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
             return hipGetLastError();
         };
         int form = kSpmmGather;
-        if (build_spmm_tile(A) == 1) {
+        const bool capturing = stream_is_capturing(st); // no first-use measurement (it synchronises) and no plan upload under capture
+        if (capturing && A->st_state == 1 && A->spmm_choice[m] > 0) form = A->spmm_choice[m] - 1;
+        if (!capturing && build_spmm_tile(A) == 1) {
             const char* e = getenv("MI355_SPMM_TILE");
             const int forced = e ? atoi(e) : -1;
             if (forced >= 0 && forced < kSpmmForms) form = spmm_form_possible(A, m, forced) ? forced : kSpmmGather;

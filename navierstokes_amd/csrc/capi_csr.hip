@@ -652,6 +652,7 @@ static int maybe_reorder(mi_csr_t A, const int* ptrow, const int* indcol, const 
         return MI_OK;
     }
     A->h_iperm = R.iperm; // host copy for mi_csr_perm (callers that keep their vectors in the library's numbering)
+    A->xp_claimed = false; // (the measurement above ran on the default stream: the gather buffer goes to the caller's first stream)
     release_natural_arrays(A);
     return MI_OK;
 }
@@ -790,6 +791,7 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->d_iperm);
     dfree(A->d_src_start);
     dfree(A->d_xp);
+    for (auto& kv : A->xp_more) dfree(kv.second);
     dfree(A->d_vtmp);
     for (double* p : A->d_pp) dfree(p);
     spmk_release(A);
@@ -1310,9 +1312,11 @@ extern "C" int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* 
             HIP_TRY(hipMalloc(&p, sizeof(double) * (size_t)A->n));
             A->d_pp.push_back(p);
         }
-        int rc = gather_perm(A, d_x, A->d_xp, (hipStream_t)s);
+        double* xp = nullptr;
+        int rc = reorder_scratch(A, (hipStream_t)s, &xp);
         if (rc) return rc;
-        if ((rc = spmk_unmapped(A->inner, k, A->d_xp, A->d_pp.data(), (hipStream_t)s))) return rc;
+        if ((rc = gather_perm(A, d_x, xp, (hipStream_t)s))) return rc;
+        if ((rc = spmk_unmapped(A->inner, k, xp, A->d_pp.data(), (hipStream_t)s))) return rc;
         for (int p = 0; p < k; p++)
             if ((rc = scatter_perm(A, A->d_pp[p], d_y_out[p], (hipStream_t)s))) return rc;
         return MI_OK;

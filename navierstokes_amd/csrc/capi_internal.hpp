@@ -61,6 +61,19 @@ static inline int fail(int code, const std::string& msg)
 
 int need_device(); // capi_lib.hip
 
+// true while stream s is being captured into a HIP graph.  Entry points whose kernels take a per-call counter as an ARGUMENT (the
+// one-launch powers step's epoch, the push step's step number) or that measure on first use must not do either under capture:
+// a replayed graph would present the same counter again and every in-kernel wait would pass at once.
+static inline bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
 // ---------------------------------------------------------------- handles
 struct BlockTable {
     int nnzb = 0;
@@ -142,8 +155,11 @@ struct mi_csr_s {
     int* d_iperm = nullptr;     // [n] caller's index of new row / column
     std::vector<int> h_iperm;   // the same on the host (mi_csr_perm)
     int* d_src_start = nullptr; // [n] offset of new row r' in the caller's coef (values refresh)
-    double* d_xp = nullptr;     // x in the new numbering (one product at a time per handle)
-    std::vector<double*> d_pp;  // powers in the new numbering
+    double* d_xp = nullptr;     // x in the new numbering: the buffer of the FIRST stream that multiplies with this handle ...
+    hipStream_t xp_stream = nullptr;
+    bool xp_claimed = false;
+    std::map<hipStream_t, double*> xp_more; // ... products enqueued on other streams get a gather buffer of their own (reorder_scratch)
+    std::vector<double*> d_pp;  // powers in the new numbering (mi_spmk_dev: one k-step at a time per handle)
     double* d_vtmp = nullptr;   // staging for mi_csr_update_values (host values)
     double spread_before = 0.0, spread_after = 0.0, us_natural = 0.0, us_reordered = 0.0;
     int reorder_block = 0;      // 0: no reordering attempted
@@ -277,6 +293,9 @@ int get_table(mi_csr_t A, int nnzb, BlockTable** out);
 int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map = true, const RingComm* comm = nullptr,
                 const RingDot* dot = nullptr);
 bool ring_dot_eligible(const mi_csr_s* A); // the next launch_spmv(A) can carry a dot epilogue (one partial per ring workgroup)
+// launch_csr.hip: the x gather buffer of a relabelled handle for products enqueued on stream s (one per stream, so that products of
+// one handle on different streams do not share scratch; allocated on first use — not under stream capture)
+int reorder_scratch(mi_csr_t A, hipStream_t s, double** buf);
 // launch_ring.hip
 void launch_ring_cfg(const mi_csr_s* A, const CsrView& V, const double* d_x, double* d_y, hipStream_t s, const RingComm* comm, const RingDot* dot);
 // launch_spmk.hip: the k powers on an unmapped view of H (its row map, if any, is not applied): one launch where that is

@@ -638,6 +638,9 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
     }
     if (!P->push_ready) return fail(MI_ERR_STATE, "mi_part_push_connect was not called");
     if ((rc = part_handoff_status(P))) return rc;
+    if (stream_is_capturing(s))
+        return fail(MI_ERR_UNSUPPORTED, "the push step cannot be captured into a HIP graph: its step number is a kernel argument (a replay would "
+                                        "present an old step and every wait would pass at once); capture mi_part_spmv_dev (RCCL, events) instead");
     const unsigned step = ++P->push_step;
     static const unsigned spin_max = 1u << (getenv("MI355_PUSH_SPIN_LOG2") ? std::max(8, std::min(30, atoi(getenv("MI355_PUSH_SPIN_LOG2")))) : kPushSpinLog2Default);
     if (P->fused) { // ONE launch: push workgroups first, then the ring kernel over all rows, ghost readers waiting in-kernel

@@ -6,6 +6,24 @@
 #include "spmv_mring.hpp"
 
 // ---------------------------------------------------------------- SpMV launch
+int reorder_scratch(mi_csr_t A, hipStream_t s, double** buf)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!A->xp_claimed || A->xp_stream == s) {
+        A->xp_claimed = true;
+        A->xp_stream = s;
+        *buf = A->d_xp;
+        return MI_OK;
+    }
+    double*& b = A->xp_more[s];
+    if (!b) {
+        if (stream_is_capturing(s)) return fail(MI_ERR_STATE, "first product of a relabelled handle on this stream: run one outside stream capture first (it allocates a gather buffer)");
+        HIP_TRY(hipMalloc(&b, sizeof(double) * (size_t)A->n));
+    }
+    *buf = b;
+    return MI_OK;
+}
+
 bool ring_dot_eligible(const mi_csr_s* A)
 {
     if (A->inner || A->n == 0 || A->d_rowmap || A->y_offset) return false;
@@ -26,9 +44,11 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
     if (comm && (A->inner || A->d_rowmap || resolve_kernel(A) != MI_KERNEL_RING))
         return fail(MI_ERR_STATE, "fused multi-GPU step: the combined piece must be an unmapped, unreordered, ring-served handle");
     if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
-        int rc = gather_perm(A, d_x, A->d_xp, s);
+        double* xp = nullptr;
+        int rc = reorder_scratch(A, s, &xp);
         if (rc) return rc;
-        return launch_spmv(A->inner, A->d_xp, d_y, s, true);
+        if ((rc = gather_perm(A, d_x, xp, s))) return rc;
+        return launch_spmv(A->inner, xp, d_y, s, true);
     }
     const int kid = resolve_kernel(A);
     if (use_map) d_y += A->y_offset;

@@ -140,7 +140,8 @@ int spmk_unmapped(mi_csr_t H, int k, const double* d_x, double* const* d_y, hipS
     if (H->h_ktimeouts && __atomic_load_n(H->h_ktimeouts, __ATOMIC_ACQUIRE) != 0)
         return fail(MI_ERR_HIP, "mi_spmk: a hand-off wait of the one-launch powers step gave up (workgroups of the grid were not all resident); "
                                 "results since then are invalid — set MI355_SPMK_FUSED=0 when other kernels share the GPU");
-    if (k < 2 || k > kSpmkFusedMaxK || env_is("MI355_SPMK_FUSED", "0") || spmk_setup(H) != 1) return spmk_chain(H, k, d_x, d_y, s);
+    // (under stream capture: k launches — the one-launch step's flag epoch is a kernel argument, a replayed graph would reuse it)
+    if (k < 2 || k > kSpmkFusedMaxK || env_is("MI355_SPMK_FUSED", "0") || stream_is_capturing(s) || spmk_setup(H) != 1) return spmk_chain(H, k, d_x, d_y, s);
     if (env_is("MI355_SPMK_FUSED", "1")) return spmk_fused(H, k, d_x, d_y, s);
     if (H->kstep_choice[k] == 0) {
         // first k-step of this handle at this k: both forms are the same bits, so run each a few times on the caller's own

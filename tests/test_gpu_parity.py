@@ -795,3 +795,33 @@ def test_random_patterns_round3_paths(seed, monkeypatch):
         yi = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
         mpk.SpMV_CSR_internal(yi, xi, A)
         assert_bit_equal(A.from_internal(yi).cpu().numpy(), Y[0], f"seed {seed} {kernel}: internal numbering")
+
+
+def test_powers_step_under_hip_graph_capture_is_recorded_as_k_launches(monkeypatch):
+    """A captured k-step must not bake the one-launch step's flag epoch into a graph (a replay would present the same epoch and every
+    in-kernel wait would pass at once): under capture mi_spmk_dev records k plain launches.  Replayed five times with a different x
+    each time: every power bitwise."""
+    monkeypatch.setenv("MI355_SPMK_FUSED", "1")
+    n = 300_000
+    p, c, v = synth.rows("s15", n)
+    A = mpk.csrmatrix(n, p, c, v).set_kernel("ring")
+    xs = [synth.x_sin(0, n), np.cos(0.002 * np.arange(n)), synth.x_sin(0, n) * 0.5 - 0.25]
+    xd = dev(xs[0]).clone()
+    outs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    mpk.SpMkV(outs, xd, A)  # eager first: one launch, plans uploaded outside any capture
+    assert A.spmk_info(3)["one_launch"]
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            mpk.SpMkV(outs, xd, A)
+    for rep in range(5):
+        xd.copy_(dev(xs[rep % 3]))
+        for t in outs:
+            t.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        Y = O.spmk_chain(3, p, c, v, xs[rep % 3])
+        for q in range(3):
+            assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"graph replay {rep}, power {q + 1}")

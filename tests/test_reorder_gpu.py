@@ -186,3 +186,30 @@ def test_krylov_pass_in_the_internal_numbering(monkeypatch):
     _krylov_pass_in_internal_numbering(p, c, v, n, True)
     monkeypatch.setenv("MI355_REORDER", "0")  # a handle that was not relabelled: the internal numbering is the caller's
     _krylov_pass_in_internal_numbering(p, c, v, n, False)
+
+
+def test_products_of_one_relabelled_handle_on_two_streams(monkeypatch):
+    """A relabelled handle keeps one x gather buffer PER STREAM: products of the same handle enqueued on two streams with different
+    x, unsynchronised against each other, each give the oracle's bits (with one shared buffer the second gather would overwrite the
+    first product's x under its feet)."""
+    monkeypatch.setenv("MI355_REORDER", "1")
+    p0, c0, v0 = synth.rows("s15", 200_000)
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=1, seed=9)
+    n = 200_000
+    A = mpk.csrmatrix(n, p, c, v)
+    assert A.reorder_info()["reordered"]
+    xa, xb = synth.x_sin(0, n), np.cos(0.002 * np.arange(n))
+    ya_ref, yb_ref = O.spmv(p, c, v, xa), O.spmv(p, c, v, xb)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    da, db = dev(xa), dev(xb)
+    ya = torch.empty(n, dtype=torch.float64, device="cuda")
+    yb = torch.empty(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            mpk.SpMV_CSR(ya, da, A)
+        with torch.cuda.stream(s2):
+            mpk.SpMV_CSR(yb, db, A)
+    torch.cuda.synchronize()
+    assert_bit_equal(ya.cpu().numpy(), ya_ref, "stream 1")
+    assert_bit_equal(yb.cpu().numpy(), yb_ref, "stream 2")
