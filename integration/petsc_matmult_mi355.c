@@ -26,6 +26,7 @@
  */
 #include <petscmat.h>
 #include <../src/mat/impls/baij/seq/baij.h> /* Mat_SeqBAIJ: i, j, a, mbs, nbs, bs2 (as src/include/kernels.h:8) */
+#include <../src/mat/impls/aij/seq/aij.h>   /* Mat_SeqAIJ: i, j, a, nz (as src/include/kernels.h:9) */
 
 #include "mi355_spmv.h"
 
@@ -102,5 +103,80 @@ PetscErrorCode OverrideMatMultWithMI355(Mat mat)
     PetscCall(PetscObjectTypeCompare((PetscObject)mat, MATSEQBAIJ, &is_seqbaij));
     PetscCheck(is_seqbaij, PETSC_COMM_WORLD, PETSC_ERR_ARG_WRONG, "Matrix must be of type MATSEQBAIJ");
     PetscCall(MatSetOperation(mat, MATOP_MULT, (void (*)(void))MatMult_MI355));
+    PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* ---- MATSEQAIJ: the seam of src/kernels/aij_mad.c:8-32 / aij_fma.c (MatMult_SeqAIJ, MatMult_SeqAIJ_FMA; variants 0 and 1 of
+ * src/main.c:113-123 and src/kernels/variant_selector.c:3-15).  The CSR arrays go to mi_csr_create as they are; each row of y is
+ * the sequential fma chain in storage order — bit-equal to MatMult_SeqAIJ_FMA's `sum = fma(aa[j], x[aj[j]], sum)` loop wherever
+ * that kernel really emits fma (its mpk twin SpMV_CSR_FMA is what the oracle is pinned to), within 1e-15 of the mul-then-add of
+ * aij_mad.c. */
+typedef struct {
+    mi_csr_t          h;
+    PetscObjectState  state;
+} MI355AijCtx;
+
+static PetscErrorCode MI355AijCtxDestroy(void *p)
+{
+    MI355AijCtx *ctx = (MI355AijCtx *)p;
+    PetscFunctionBegin;
+    if (ctx) {
+        (void)mi_csr_destroy(ctx->h);
+        PetscCall(PetscFree(ctx));
+    }
+    PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+PetscErrorCode MatMult_MI355_AIJ(Mat A, Vec xx, Vec zz)
+{
+    Mat_SeqAIJ        *a = (Mat_SeqAIJ *)A->data;
+    PetscContainer     box = NULL;
+    MI355AijCtx       *ctx = NULL;
+    PetscObjectState   st;
+    const PetscScalar *x;
+    PetscScalar       *z;
+
+    PetscFunctionBegin;
+    PetscCheck(sizeof(PetscInt) == sizeof(int) && sizeof(PetscScalar) == sizeof(double), PETSC_COMM_SELF, PETSC_ERR_SUP,
+               "libmi355spmv takes int32 indices and real double values");
+    PetscCall(PetscObjectStateGet((PetscObject)A, &st));
+    PetscCall(PetscObjectQuery((PetscObject)A, "mi355_matmult_aij_ctx", (PetscObject *)&box));
+    if (!box) {
+        PetscCall(PetscNew(&ctx));
+        MI_CALL(mi_csr_create((int)A->rmap->n, (int)A->cmap->n, (const int *)a->i, (const int *)a->j, (const double *)a->a, &ctx->h));
+        ctx->state = st;
+        PetscCall(PetscContainerCreate(PETSC_COMM_SELF, &box));
+        PetscCall(PetscContainerSetPointer(box, ctx));
+        PetscCall(PetscContainerSetUserDestroy(box, MI355AijCtxDestroy));
+        PetscCall(PetscObjectCompose((PetscObject)A, "mi355_matmult_aij_ctx", (PetscObject)box));
+        PetscCall(PetscContainerDestroy(&box));
+    } else {
+        PetscCall(PetscContainerGetPointer(box, (void **)&ctx));
+        if (ctx->state != st) {
+            MI_CALL(mi_csr_update_values(ctx->h, (const double *)a->a));
+            ctx->state = st;
+        }
+    }
+    PetscCall(VecGetArrayRead(xx, &x));
+    PetscCall(VecGetArrayWrite(zz, &z));
+    MI_CALL(mi_spmv(ctx->h, (const double *)x, (double *)z));
+    PetscCall(VecRestoreArrayRead(xx, &x));
+    PetscCall(VecRestoreArrayWrite(zz, &z));
+    PetscCall(PetscLogFlops(2.0 * a->nz)); /* as src/kernels/aij_mad.c:30 */
+    PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* One selector for both matrix types, in the place of MatMult_SeqBAIJ_4_VariantSelector (src/kernels/variant_selector.c:3-15): the
+ * CPU variants 0..5 differ in how the CPU is driven; on the GPU they are one kernel per storage format. */
+PetscErrorCode MatMult_MI355_Selector(Mat A, Vec xx, Vec zz)
+{
+    PetscBool is_baij, is_aij;
+
+    PetscFunctionBegin;
+    PetscCall(PetscObjectTypeCompare((PetscObject)A, MATSEQBAIJ, &is_baij));
+    PetscCall(PetscObjectTypeCompare((PetscObject)A, MATSEQAIJ, &is_aij));
+    if (is_baij && ((Mat_SeqBAIJ *)A->data)->bs2 == 16) PetscCall(MatMult_MI355(A, xx, zz));
+    else if (is_aij) PetscCall(MatMult_MI355_AIJ(A, xx, zz));
+    else SETERRQ(PETSC_COMM_SELF, PETSC_ERR_SUP, "MatMult_MI355_Selector: MATSEQAIJ or MATSEQBAIJ with block size 4 (convert an 8x8 BAIJ matrix with MatConvert(A, MATSEQAIJ, ...), as src/benchmark_spmv.c:185 does)");
     PetscFunctionReturn(PETSC_SUCCESS);
 }
