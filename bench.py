@@ -719,6 +719,11 @@ def main():
             if "mring<" in kernel_name:
                 rs = A.ring_shape_info()
                 out["kernel_info"]["mring_plan"].update(us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
+        pl = A.placement_info()
+        if pl["values"]:
+            out["kernel_info"]["placement_draws_us"] = dict(pl, note="mi_csr_create timed the chosen kernel on fresh device copies of the value array, then of the 16-bit column "
+                                                                  "stream, and kept the fastest of each (first entry: as first allocated); where the arrays — the caller's x and y "
+                                                                  "included — lie in device memory moves a WARM launch by up to 15 %, a cold one not at all (DESIGN 4.12)")
         ti = A.tile_info()
         if ti["built"]:
             out["kernel_info"]["tile_plan"] = dict(row_blocks=ti["nblk"], distinct_columns_per_nnz=round(ti["unique_per_nnz"], 4))

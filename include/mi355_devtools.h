@@ -15,6 +15,14 @@ int mi_debug_xcc_map(int wgs, int* host_out);
  * buffers, e.g. x and y), then a synchronise.  Behind mi_flush_cache() this brings the address translations back without
  * bringing the data back (one line per stride): it separates "cold caches" from "cold TLB" in a cold-start measurement. */
 int mi_debug_touch_pages(mi_csr_t A, int stride_bytes, const void* d_extra0, long long bytes0, const void* d_extra1, long long bytes1);
+/* timeline of ONE launch of the multi-window ring kernel on the handle's plan (its relabelled twin's, if it has one; depth 4,
+ * non-temporal, unmapped instantiation): host_out[4 * i] = {start, end (100 MHz ticks), XCD, blocks of the run (< 0: plain path, 0: no
+ * run)} of workgroup i; *wgs_out = the grid.  d_x / d_y: device vectors in the numbering of the matrix that runs (tools/mring_timeline.py). */
+int mi_debug_mring_trace(mi_csr_t A, const double* d_x, double* d_y, int max_wgs, long long* host_out, int* wgs_out);
+/* placement experiments (tools/placement_lottery.py): move one device array of the handle's ring path (0 coefficients, 1 ring slots,
+ * 2 row pointers, 3 ring plan records) to a fresh allocation (how: 0 hipMalloc, 2 / 3 hipExtMallocWithFlags uncached / fine-grained; 1 =
+ * hipDeviceMallocContiguous is refused: it ended in a GPU memory fault here); the old one is freed after the new one exists. */
+int mi_debug_move_array(mi_csr_t A, int which, int how, unsigned long long* old_ptr, unsigned long long* new_ptr);
 /* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
 int mi_part_push_debug_preset(mi_part_t P, unsigned value);
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 300 /* 0.3.0 */
+#define MI355_SPMV_VERSION 301 /* 0.3.1 */
 
 enum {
     MI_OK = 0,
@@ -186,6 +186,12 @@ int mi_csr_tile_info(mi_csr_t A, int* built, int* nblk, double* unique_per_nnz, 
  * aligned slot segments, over-long rows unlisted) and report its size.  threads = 0: as many as the library would use. */
 int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, int* nblk, long long* distinct_total,
                        int* max_distinct, long long* nnz_listed);
+/* Placement draws: for matrices beyond the caches (>= 20 M nonzeros, a CSR kernel chosen) mi_csr_create times the
+ * chosen kernel on a few fresh device copies of the value array, then of the 16-bit column stream, and keeps the fastest copy of
+ * each — where these arrays lie in device memory moves a warm launch by up to 15 %.  us[0 .. *n_values) = microseconds per launch
+ * with the value array as first allocated ([0]) and after each draw; us[*n_values .. *n_total) the same for the column stream
+ * (cap = length of us; both counts 0: no draws were made).  MI355_PLACEMENT_DRAWS=0 turns the draws off, =N sets their number. */
+int mi_csr_placement_info(mi_csr_t A, int* n_values, int* n_total, double* us, int cap);
 /* Multi-window ring kernel (MI_KERNEL_MRING, mring_plan.hpp): mi_csr_create plans it for matrices the single ring does not serve
  * and keeps the plan when it serves >= 90 % of the nonzeros (MI355_MRING=0 never, =1 always keep); mi_csr_set_kernel builds it
  * on request.  us[0..1] = measured microseconds per launch, temporal / non-temporal value loads (MI355_MRING_NT=0|1 forces). */
@@ -194,6 +200,10 @@ int mi_csr_mring_info(mi_csr_t A, int* built, int* runs, int* runs_not_served, d
  * nonzero's 16-bit slot must hold its column when its block runs, runs cover every block once, records are consistent). */
 int mi_mring_plan_probe(int n, const int* ptrow, const int* indcol, int* nblk, int* runs, int* runs_not_served,
                         double* nnz_fraction_served, long long* window_restarts);
+/* host-only: the DISPATCH ORDER of that plan's runs (mring_plan.hpp: workgroup i of the grid goes to XCD i % 8, an XCD takes its
+ * workgroups in order, 64 resident at a time): *table_len = the kernel's grid = 8 * per_xcd; run_blocks[x * per_xcd + j] = blocks of
+ * the run the j-th workgroup of XCD x executes (0: none).  Long runs come first in every XCD's share, the short ones behind them. */
+int mi_mring_plan_deal_probe(int n, const int* ptrow, const int* indcol, int* table_len, int* run_blocks, int cap);
 /* host-only: would the ring plan of this pattern (configuration config_id) run the LEAN instantiation of the kernel — no block
  * inside a run bringing more than T new columns, none holding more than T rows (spmv_ring.hpp)?  The planner cuts its runs
  * at window restarts to make it so; only configuration 4 has the instantiation. */

@@ -79,3 +79,63 @@ extern "C" int mi_part_push_debug_preset(mi_part_t P, unsigned value)
     HIP_TRY(hipMemcpy(P->win_flags, f.data(), sizeof(unsigned) * f.size(), hipMemcpyHostToDevice));
     return MI_OK;
 }
+
+// the multi-window ring kernel's timeline: one launch of the TRACE instantiation (depth 4, non-temporal, unmapped) on the handle's
+// own tables (the relabelled twin's, if there is one); out[4 * i] = {start, end (100 MHz ticks), XCD, blocks (< 0: plain path)} of
+// workgroup i.  x and y are device vectors in the numbering of the matrix that runs.
+#include "spmv_mring.hpp"
+extern "C" int mi_debug_mring_trace(mi_csr_t A, const double* d_x, double* d_y, int max_wgs, long long* host_out, int* wgs_out)
+{
+    CHECK_ARG(A && d_x && d_y && host_out && wgs_out, "null argument");
+    if (A->inner) A = A->inner;
+    const MringTable& M = A->mring;
+    if (!M.d_plan) return fail(MI_ERR_STATE, "no multi-window ring plan on this handle");
+    CHECK_ARG(M.wgs <= max_wgs, "output array too small");
+    CsrView V{};
+    V.n = A->n;
+    V.ncols = A->ncols;
+    V.ptrow = A->d_ptrow;
+    V.indcol = A->d_indcol;
+    V.coef = A->d_coef;
+    V.rowmap = nullptr;
+    V.nblk = M.nblk;
+    long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(long long) * 4 * (size_t)M.wgs));
+    HIP_TRY(hipMemset(d, 0, sizeof(long long) * 4 * (size_t)M.wgs));
+    hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, 4, kMringMaxB, false, true, false, true>), dim3(M.wgs), dim3(kMringThreads), 0, nullptr,
+                       V, reinterpret_cast<const int4*>(M.d_plan), reinterpret_cast<const int4*>(M.d_first), M.d_ok, M.d_slots, d_x, d_y,
+                       reinterpret_cast<const int2*>(M.d_rng), M.wgs, d);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, d, sizeof(long long) * 4 * (size_t)M.wgs, hipMemcpyDeviceToHost));
+    dfree(d);
+    *wgs_out = M.wgs;
+    return MI_OK;
+}
+
+// placement experiments (tools/placement_lottery.py): move ONE device array of the handle's ring path to a fresh allocation (the old one
+// is freed only after the new one exists, so the new one is different memory).  which: 0 coefficients, 1 ring slots, 2 row pointers,
+// 3 ring plan records; how: 0 hipMalloc, 2 / 3 hipExtMallocWithFlags uncached / fine-grained (1 = contiguous is refused).  *old_ptr / *new_ptr: the
+// addresses, for the record.
+extern "C" int mi_debug_move_array(mi_csr_t A, int which, int how, unsigned long long* old_ptr, unsigned long long* new_ptr)
+{
+    CHECK_ARG(A && which >= 0 && which <= 3 && (how == 0 || how == 2 || how == 3), "bad argument (how = 1, hipDeviceMallocContiguous, is refused: a copy into such a buffer ended in a GPU memory fault on this pool, twice)");
+    if (A->inner) A = A->inner;
+    void** slot = nullptr;
+    size_t bytes = 0;
+    if (which == 0) { slot = (void**)&A->d_coef; bytes = sizeof(double) * (size_t)A->nnz; }
+    if (which == 1) { slot = (void**)&A->ring.d_slots; bytes = sizeof(unsigned short) * (size_t)A->ring.nblk * A->ring.cfg.nnzb; }
+    if (which == 2) { slot = (void**)&A->d_ptrow; bytes = sizeof(int) * ((size_t)A->n + 1); }
+    if (which == 3) { slot = (void**)&A->ring.d_plan; bytes = sizeof(int) * 8 * (size_t)A->ring.nblk; }
+    if (!*slot || bytes == 0) return fail(MI_ERR_STATE, "the handle has no such array");
+    void* fresh = nullptr;
+    if (how == 0) HIP_TRY(hipMalloc(&fresh, bytes));
+    else HIP_TRY(hipExtMallocWithFlags(&fresh, bytes, how == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    if (old_ptr) *old_ptr = (unsigned long long)(uintptr_t)*slot;
+    if (new_ptr) *new_ptr = (unsigned long long)(uintptr_t)fresh;
+    void* old = *slot;
+    *slot = fresh;
+    HIP_TRY(hipFree(old));
+    return MI_OK;
+}

@@ -52,7 +52,7 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
     }
     const int kid = resolve_kernel(A);
     if (use_map) d_y += A->y_offset;
-    CsrView V;
+    CsrView V{};
     V.n = A->n;
     V.ncols = A->ncols;
     V.ptrow = A->d_ptrow;
@@ -79,7 +79,7 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
         V.nblk = M.nblk;
         const int4* plan = reinterpret_cast<const int4*>(M.d_plan);
         const int2* rng = reinterpret_cast<const int2*>(M.d_rng);
-#define MRING_L(D_, MP_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, D_, kMringMaxB, MP_, NT_, SK_>), dim3(kNXCD * ((M.nruns + kNXCD - 1) / kNXCD)), dim3(kMringThreads), 0, s, V, plan, reinterpret_cast<const int4*>(M.d_first), M.d_ok, M.d_slots, d_x, d_y, rng, M.nruns)
+#define MRING_L(D_, MP_, NT_, SK_) hipLaunchKernelGGL((spmv_csr_mring<kMringThreads, kMringNnzb, D_, kMringMaxB, MP_, NT_, SK_>), dim3(M.wgs), dim3(kMringThreads), 0, s, V, plan, reinterpret_cast<const int4*>(M.d_first), M.d_ok, M.d_slots, d_x, d_y, rng, M.wgs)
 #define MRING_L3(D_, MP_) do { if (M.nt) { if (M.skew) MRING_L(D_, MP_, true, true); else MRING_L(D_, MP_, true, false); } \
                                else { if (M.skew) MRING_L(D_, MP_, false, true); else MRING_L(D_, MP_, false, false); } } while (0)
 #define MRING_L2(D_) do { if (V.rowmap) MRING_L3(D_, true); else MRING_L3(D_, false); } while (0)

@@ -44,7 +44,7 @@ void spmk_release(mi_csr_t H)
 
 static CsrView unmapped_view(const mi_csr_s* H)
 {
-    CsrView V;
+    CsrView V{};
     V.n = H->n;
     V.ncols = H->ncols;
     V.ptrow = H->d_ptrow;

@@ -43,15 +43,17 @@ constexpr int kMringW = 960;        // entries per window (a multiple of 64)
 constexpr int kMringRing = kMringK * kMringW; // doubles of LDS for all windows together: with staging and the plan records
                                               // two workgroups fit a CU's LDS, like the single ring's
 constexpr int kMringGap = 256;      // neighbouring distinct columns this far apart belong to different clusters
+constexpr int kMringLead = 4;       // groups a window runs ahead of what its cluster needs, where spare groups allow
 constexpr int kMringGroups = 8;     // groups of 64 new columns a block inside a run may bring (2 per wave of the kernel)
 constexpr int kMringNnzb = 2048, kMringThreads = 256, kMringWgUnit = 512;
+constexpr int kMringXcds = 8;       // workgroup i of a grid goes to XCD i % 8 (= kNXCD of the kernels; this header has no HIP in it)
 constexpr int kMringMaxB = 96;      // blocks per run (the LDS copy of a run's records)
 constexpr int kMringRec = 20;       // ints per block record: {r0, p0, rows, nnz} {flags, groups, plain rows, 0} {gcol[8]} {gslot[8] as 16-bit pairs}
 constexpr int kMringFirst = 16;     // ints per run: first block's windows {lo[5]} {count[5]} {offset in its ring [5]} {0}
 static_assert(kMringW % 64 == 0, "windows are refilled in groups of 64 columns");
 
 struct MringPlanHost {
-    int nblk = 0, wgs = 0, nruns = 0, bpw = 0, bad_runs = 0; // wgs: array lengths (>= nruns); the kernel's grid is 8 * ceil(nruns / 8)
+    int nblk = 0, wgs = 0, nruns = 0, bpw = 0, bad_runs = 0; // wgs: length of the per-run tables = the kernel's grid (8 XCD shares, the shorter ones padded with empty entries); nruns of them hold a run
     long long bad_nnz = 0;
     std::vector<int> plan;   // kMringRec ints per block; flags 1 = window-served, 2 = PLAIN {r0, p0, 0, nnz} {2, 0, rows, 0}, 0 = empty
     std::vector<int> first;  // kMringFirst ints per run
@@ -104,9 +106,6 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
     }
     long long weight = 0;
     for (int b = 0; b < nblk; b++) weight += wide[b] ? kRingPlainWeight : 1;
-    const long long per_unit = (long long)(kMringMaxB - kRingPlainWeight) * kMringWgUnit;
-    int wgs = kMringWgUnit * (int)((weight + per_unit - 1) / per_unit);
-    if (wgs < kMringWgUnit) wgs = kMringWgUnit;
     out.plan.assign((size_t)kMringRec * nblk, 0);
     out.slots.assign((size_t)nblk * nnzb, 0);
 
@@ -177,7 +176,7 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
                 const int l = S.hi[w] - (C[j].hi + 1);
                 if (l < lead) { lead = l; pick = w; }
             }
-            if (pick < 0 || lead >= 4 * 64) break; // far enough ahead everywhere
+            if (pick < 0 || lead >= kMringLead * 64) break; // far enough ahead everywhere
             R.groups[pick]++;
             S.hi[pick] += 64;
             S.lo[pick] = std::max(S.lo[pick], S.hi[pick] - W);
@@ -187,21 +186,22 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
             while (S.live[w] && S.lo[w] - S.base[w] >= W) S.base[w] += W;
     };
 
-    std::vector<int> cuts, first;
+    std::vector<int> cuts, first, forced_at;
     int forced = 0;
-    // One pass over the blocks with a given weight per run; returns the number of runs.  Cuts forced by blocks that need more
-    // groups than the loop refills come on top of the weight cuts, so the pass is repeated with heavier runs until everything
-    // fits ONE round of workgroups: a second round starts when the first workgroups finish, and a long run dealt to it is the
-    // launch's tail (measured on a relabelled 100^3-cell mesh: 626 runs in two rounds 51 us).
-    auto pass = [&](long long target) {
+    // One pass over the blocks: runs are cut where their weight would pass `target` — or, when `planned` is given, exactly at the
+    // listed blocks — and, on top, wherever a block needs more groups than the loop refills (a forced cut; where these fall depends
+    // a little on where the run began, since that decides what the windows hold).  emit = false: cuts only.
+    auto pass = [&](long long target, const std::vector<int>* planned, bool emit) {
         cuts.assign(1, 0);
         first.assign(kMringFirst, 0);
+        forced_at.clear();
         forced = 0;
-        std::fill(out.plan.begin(), out.plan.end(), 0);
+        if (emit) std::fill(out.plan.begin(), out.plan.end(), 0);
     Win S;
     reset(S);
     long long cum = 0;
     int count = 0;
+    size_t pi = 0;
     for (int b = 0; b < nblk; b++) {
         const int nn = ptrs[b + 1] - ptrs[b], nrows = rows[b + 1] - rows[b], wb = wide[b] ? kRingPlainWeight : 1;
         auto fresh = [&]() {
@@ -209,7 +209,21 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
             cum = 0; count = 0;
             reset(S);
         };
-        if (count > 0 && (count >= kMringMaxB || cum + wb > target)) fresh();
+        while (planned && pi < planned->size() && (*planned)[pi] < b) pi++;
+        const bool cut_here = planned ? (pi < planned->size() && (*planned)[pi] == b) : cum + wb > target;
+        if (count > 0 && (count >= kMringMaxB || cut_here)) fresh();
+        if (!emit) { // cuts only: the windows' state decides where a block forces a new run, nothing is written
+            if (nn > 0 && wide[b]) reset(S);
+            else if (nn > 0) {
+                Step R;
+                need(b, S, R);
+                if (count > 0 && R.total > G) { fresh(); forced++; forced_at.push_back(b); need(b, S, R); }
+                commit(b, S, R, count == 0 ? kMringLead * K : G - R.total);
+            }
+            cum += wb;
+            count++;
+            continue;
+        }
         int* P = &out.plan[(size_t)kMringRec * b];
         P[0] = rows[b]; P[1] = ptrs[b]; P[2] = nrows; P[3] = nn;
         for (int g = 0; g < G; g++) P[8 + g] = std::min(std::max(0, n - 64), rows[b]); // unused groups: a harmless load near the rows
@@ -220,9 +234,9 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
         } else if (nn > 0) {
             Step R;
             need(b, S, R);
-            if (count > 0 && R.total > G) { fresh(); forced++; need(b, S, R); } // this block starts a run: its windows are filled whole
+            if (count > 0 && R.total > G) { fresh(); forced++; forced_at.push_back(b); need(b, S, R); } // this block starts a run: its windows are filled whole
             const bool first_now = count == 0;
-            commit(b, S, R, first_now ? 0 : G - R.total);
+            commit(b, S, R, first_now ? kMringLead * K : G - R.total); // a run's first windows come in with the lead the loop keeps (the prologue loads whole windows anyway)
             P[4] = 1;
             if (first_now) {
                 int* F = &first[first.size() - kMringFirst];
@@ -263,29 +277,104 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
     }
         return (int)cuts.size();
     };
-    long long target = (weight + wgs - 1) / wgs;
-    int nr = pass(target);
-    for (int it = 0; it < 4 && nr > wgs; it++) {
-        const long long spare = (long long)wgs - forced;
-        if (spare < wgs / 4) break; // mostly forced cuts: more rounds it is
-        target = (weight + spare - 1) / spare + it;
-        nr = pass(target);
+    // Where to cut, and who runs what.  How a grid of these workgroups is dispatched (tools/mring_timeline.py, the kernel's TRACE
+    // instantiation): workgroup i goes to XCD i % 8; an XCD takes its workgroups strictly in order, each bound to one of its four
+    // shader engines in turn, two per CU (LDS) — so a workgroup beyond the 64 resident ones starts only when a slot of ITS engine
+    // frees, and everything behind it waits with it: short runs among the first 64 free their slots for nobody until the long
+    // runs end (seen: late-comers starting at 145 us of 165, whatever had finished at 5).  The two workgroups of a CU do not share it
+    // evenly either: one finishes after ~90 % of the launch, and the late-comers then run beside the other.  Hence:
+    //   * a run is LONG or SHORT (at most kMringShort blocks' weight); at most 64 long runs per XCD, all in its first round, in
+    //     matrix order (neighbouring runs share the XCD's L2); the short ones behind them — what is left of the first round, then
+    //     the second, where a short run ends before the launch's last long run does;
+    //   * forced cuts (a block that needs more groups than the loop refills: ~90 on a relabelled 5 M-row mesh) split the matrix into
+    //     segments; a segment is cut into equal pieces of at most `target`, so that no remainder falls between short and long, and
+    //     `target` is the smallest for which the long runs fit the first round (91-block runs beside stubs -> 78-block runs).
+    const int slots_per_xcd = kMringWgUnit / kMringXcds;
+    const long long ideal = std::max<long long>(1, (weight + kMringWgUnit - 1) / kMringWgUnit);
+    const long long kMringShort = std::min<long long>(5, ideal / 8); // (a second-round run has the launch's last tenth to itself)
+    std::vector<long long> cumw((size_t)nblk + 1, 0);
+    for (int b = 0; b < nblk; b++) cumw[b + 1] = cumw[b] + (wide[b] ? kRingPlainWeight : 1);
+    auto run_weight = [&](int r) { return cumw[r + 1 < (int)cuts.size() ? cuts[r + 1] : nblk] - cumw[cuts[r]]; };
+    auto count_long = [&]() {
+        int nl = 0;
+        for (int r = 0; r < (int)cuts.size(); r++) nl += run_weight(r) > kMringShort;
+        return nl;
+    };
+    const char* e1 = getenv("MI355_MRING_DEAL"); // A/B: 0 = runs by weight only, no more runs than resident workgroups (the round-2 rule)
+    const bool by_weight = e1 && atoi(e1) == 0;
+    std::vector<int> planned;
+    if (by_weight || ideal >= kMringMaxB) {
+        long long target = ideal;
+        pass(target, nullptr, false);
+        while (by_weight && (int)cuts.size() > kMringWgUnit && target < kMringMaxB) pass(++target, nullptr, false);
+        pass(target, nullptr, true);
+    } else {
+        pass(ideal, nullptr, false);
+        std::vector<int> seg(forced_at); // segment boundaries: where blocks force a cut whatever the weight
+        seg.insert(seg.begin(), 0);
+        seg.push_back(nblk);
+        for (long long target = ideal;; target++) {
+            planned.clear();
+            for (size_t i = 0; i + 1 < seg.size(); i++) {
+                const int b0 = seg[i], b1 = seg[i + 1];
+                const long long w = cumw[b1] - cumw[b0];
+                if (i > 0) planned.push_back(b0);
+                if (w <= kMringShort) continue;
+                const long long pieces = (w + target - 1) / target;
+                int b = b0;
+                for (long long q = 1; q < pieces; q++) { // piece q ends where the segment's weight passes q / pieces of the whole
+                    while (b < b1 && (cumw[b] - cumw[b0]) * pieces < w * q) b++;
+                    if (b > b0 && b < b1 && (planned.empty() || planned.back() < b)) planned.push_back(b);
+                }
+            }
+            pass(0, &planned, false);
+            if (count_long() <= kMringWgUnit || target >= kMringMaxB) break;
+        }
+        pass(0, &planned, true);
     }
-    while ((int)cuts.size() > wgs) wgs += kMringWgUnit;
     const int nruns = (int)cuts.size();
-    out.wgs = wgs;
+    // dispatch order: per XCD its long runs, then its short ones
+    std::vector<std::vector<int>> share(kMringXcds);
+    {
+        const int nl = count_long();
+        std::vector<std::vector<int>> shorts(kMringXcds);
+        int il = 0, x = 0;
+        for (int r = 0; r < nruns; r++) {
+            if (run_weight(r) > kMringShort || by_weight) {
+                x = nl <= kMringWgUnit && !by_weight ? (int)((long long)il * kMringXcds / std::max(nl, 1)) : (int)((long long)r * kMringXcds / nruns);
+                share[x].push_back(r);
+                il++;
+            } else shorts[x].push_back(r);
+        }
+        for (int q = 0; q < kMringXcds; q++) {
+            // workgroups j and j + 32 of an XCD share a CU, which is done when both are: its longest run beside its shortest, and so on
+            std::vector<int>& L = share[q];
+            const int m = (int)L.size(), half = slots_per_xcd / 2;
+            if (!by_weight && m > half && m <= slots_per_xcd) {
+                std::vector<int> byw(L);
+                std::stable_sort(byw.begin(), byw.end(), [&](int a, int b) { return run_weight(a) > run_weight(b); });
+                for (int r = 0; r < m; r++) L[r < half ? r : half + (m - 1 - r)] = byw[r];
+            }
+            L.insert(L.end(), shorts[q].begin(), shorts[q].end());
+        }
+    }
+    int per_xcd = 1;
+    for (int q = 0; q < kMringXcds; q++) per_xcd = std::max(per_xcd, (int)share[q].size());
+    const int ntab = kMringXcds * per_xcd;
+    out.wgs = ntab;
     out.nruns = nruns;
     out.bpw = (nblk + nruns - 1) / nruns;
     out.restarts = forced;
-    out.run_ok.assign(wgs, 1);
-    out.run_rng.assign((size_t)2 * wgs, 0);
-    out.first.assign((size_t)kMringFirst * wgs, 0);
-    std::copy(first.begin(), first.end(), out.first.begin());
-    for (int g = 0; g < wgs; g++) {
-        out.run_rng[2 * g] = g < nruns ? cuts[g] : nblk;
-        out.run_rng[2 * g + 1] = g + 1 < nruns ? cuts[g + 1] : nblk;
+    out.run_ok.assign(ntab, 1);
+    out.run_rng.assign((size_t)2 * ntab, 0);
+    out.first.assign((size_t)kMringFirst * ntab, 0);
+    for (int g = 0; g < ntab; g++) { // table entry g = what workgroup g % per_xcd of XCD g / per_xcd runs (nothing: an empty range)
+        const int q = g / per_xcd, j = g % per_xcd, r = j < (int)share[q].size() ? share[q][j] : -1;
+        out.run_rng[2 * g] = r >= 0 ? cuts[r] : nblk;
+        out.run_rng[2 * g + 1] = r >= 0 ? (r + 1 < nruns ? cuts[r + 1] : nblk) : nblk;
+        if (r >= 0) std::copy(first.begin() + (size_t)kMringFirst * r, first.begin() + (size_t)kMringFirst * (r + 1), out.first.begin() + (size_t)kMringFirst * g);
     }
-    for (int g = 0; g < nruns; g++) { // runs with too many PLAIN blocks go down the plain path as a whole
+    for (int g = 0; g < ntab; g++) { // runs with too many PLAIN blocks go down the plain path as a whole
         int nplain = 0;
         long long run_nnz = 0, plain_nnz = 0;
         for (int b = out.run_rng[2 * g]; b < out.run_rng[2 * g + 1]; b++) {

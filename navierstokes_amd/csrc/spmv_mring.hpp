@@ -20,12 +20,24 @@
 
 namespace mi355 {
 
-template <int T, int NNZB, int D, int MAXB, bool MAPPED, bool NT, bool SKEW>
+// TRACE (devtools build only, mi_debug_mring_trace): every workgroup leaves {start, end} of its run in 100 MHz ticks, its XCD and its
+// number of blocks — the launch's timeline, for judging how the planner dealt the runs out.
+template <int T, int NNZB, int D, int MAXB, bool MAPPED, bool NT, bool SKEW, bool TRACE = false>
 __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __restrict__ plan, const int4* __restrict__ first,
                                                     const int* __restrict__ run_ok, const unsigned short* __restrict__ slots,
                                                     const double* __restrict__ x, double* __restrict__ y,
-                                                    const int2* __restrict__ run_rng, int nruns)
+                                                    const int2* __restrict__ run_rng, int nruns, long long* __restrict__ trace = nullptr)
 {
+    const long long t_start = TRACE ? (long long)wall_clock64() : 0;
+    auto leave = [&](int nblocks) {
+        if (TRACE && threadIdx.x == 0) {
+            long long* o = trace + 4 * (size_t)blockIdx.x;
+            o[0] = t_start;
+            o[1] = (long long)wall_clock64();
+            o[2] = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) | ((long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 8); // HW_REG_XCC_ID | HW_REG_HW_ID[15:0] << 8 (cu_id [11:8], sh_id [12], se_id [15:13])
+            o[3] = nblocks;
+        }
+    };
     constexpr int K = kMringK, W = kMringW, RING = K * W, PER = NNZB / T, R4 = kMringRec / 4;
     static_assert(T == 256 && kMringGroups == 8 && kMringRec == 20 && kMringFirst == 16, "two groups per wave; record layout");
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
@@ -36,14 +48,15 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
     __shared__ int4 s_plan[R4 * (MAXB + 2 * D + 2)];
     const int* s_rec = reinterpret_cast<const int*>(s_plan);
     const int tid = threadIdx.x;
-    // neighbouring runs share an XCD's L2; the runs that exist (forced cuts make their number irregular) are dealt out evenly
-    // over the eight XCDs — dealing out grid slots instead left whole XCDs idle when the grid was rounded up
+    // The per-run tables are in DISPATCH order (mring_plan.hpp): entry x * per_xcd + j is what the j-th workgroup of XCD x runs — a
+    // contiguous share of the matrix per XCD (neighbouring runs share its L2), its longest runs first, so that when there are more
+    // runs than resident workgroups the late-comers are the short ones; nruns = 8 * per_xcd table entries, some of them empty.
     const int bid = (int)blockIdx.x, per_xcd = (nruns + kNXCD - 1) / kNXCD;
     const int gw = (bid & (kNXCD - 1)) * per_xcd + (bid >> 3);
-    if ((bid >> 3) >= per_xcd || gw >= nruns) return;
+    if ((bid >> 3) >= per_xcd || gw >= nruns) return leave(0);
     const int2 rng = run_rng[gw];
     const int b_begin = rng.x, nb = rng.y - rng.x; // <= MAXB by construction of the plan
-    if (nb <= 0) return;
+    if (nb <= 0) return leave(0);
     const int clast = A.ncols - 1;
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     const RingComm nocomm{};
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
             const int4 m0 = s_plan[R4 * lb];
             ring_simple_block<T, NNZB, MAPPED, false>(A, x, y, m0.x, m0.y, m0.z, m0.w, s_c, s_x, nocomm);
         }
-        return;
+        return leave(-nb);
     }
 
     double c[D][PER];
@@ -154,12 +167,13 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
         }
     }
     // PLAIN blocks of this run, behind the loop (spmv_ring.hpp)
-    if (!(run_kind & 2)) return;
+    if (!(run_kind & 2)) return leave(nb);
     for (int lb = 0; lb < nb; lb++) {
         if (uni(s_rec[kMringRec * lb + 4]) != 2) continue;
         const int4 m0 = s_plan[R4 * lb];
         ring_simple_block<T, NNZB, MAPPED, false>(A, x, y, uni(m0.x), uni(m0.y), uni(s_rec[kMringRec * lb + 6]), uni(m0.w), s_c, s_x, nocomm);
     }
+    leave(nb);
 }
 
 } // namespace mi355

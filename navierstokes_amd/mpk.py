@@ -110,6 +110,8 @@ def lib():
         "mi_csr_tile_info": [_vp, P(i), P(i), P(d), P(d), P(i)],
         "mi_bcsr4_tile_info": [_vp, P(i), P(i), P(d), P(d)],
         "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
+        "mi_csr_placement_info": [_vp, P(i), P(i), P(d), i],
+        "mi_mring_plan_deal_probe": [i, _vp, _vp, P(i), _vp, i],
         "mi_mring_plan_probe": [i, _vp, _vp, P(i), P(i), P(i), P(d), P(ll)],
         "mi_tile_plan_probe": [i, _vp, _vp, i, P(i), P(ll), P(i), P(ll)],
         "mi_stream_read_probe": [ll, i, P(d)],
@@ -300,6 +302,13 @@ class csrmatrix:
             if "tile" in self.kernel_name():
                 nt = t["nt"]
         return out, bool(nt)
+
+    def placement_info(self):
+        """dict(values=[us as first allocated, us after each draw ...], column_stream=[...]) — mi_csr_placement_info (create-time placement draws)."""
+        nv, nt = _c.c_int(), _c.c_int()
+        us = (_c.c_double * 32)()
+        check(lib().mi_csr_placement_info(self.handle, _c.byref(nv), _c.byref(nt), us, 32))
+        return dict(values=[round(us[k], 2) for k in range(nv.value)], column_stream=[round(us[k], 2) for k in range(nv.value, nt.value)])
 
     def mring_info(self):
         """dict(built, runs, runs_not_served, nnz_fraction, us, us_nt, nt) — mi_csr_mring_info (multi-window ring plan)."""

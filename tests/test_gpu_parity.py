@@ -333,8 +333,16 @@ def test_full_size_c4_and_c3():
     y12 = torch.empty_like(y)
     mpk.SpMV_CSR(y12, 0.5 * d1 + ones, A)
     assert O.rel_error((0.5 * y + y1).cpu().numpy(), y12.cpu().numpy()) <= 1e-14
+    # the create-time placement draws (value array and column stream re-copied, fastest copy kept): recorded, and the copies that
+    # are kept are the ones later value updates write into
+    pi = A.placement_info()
+    assert len(pi["values"]) >= 2 and len(pi["column_stream"]) >= 2 and all(t > 0 for t in pi["values"] + pi["column_stream"]), pi
+    v2 = v * np.cos(np.arange(len(v)))
+    A.update_values(v2)
+    mpk.SpMV_CSR(y, d1, A)
+    assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v2, x1), "C4 after the placement draws and a value update")
     A.close()
-    del p, c, v
+    del p, c, v, v2
     n = 1_000_000
     p, c, v = synth.rows("s15", n)
     A = mpk.csrmatrix(n, p, c, v)

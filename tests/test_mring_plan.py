@@ -66,3 +66,38 @@ def test_windows_restart_and_swap_roles():
     six = (np.arange(per)[None, :] % 6) * 40_000 + (rows[:, None] % 500)
     nblk, runs, bad, frac, _ = probe(p, six.astype(np.int32).ravel())
     assert frac == 0.0
+
+
+def deal(p, c):
+    L = mpk.lib()
+    p = np.ascontiguousarray(p, np.int32)
+    c = np.ascontiguousarray(c, np.int32)
+    tl = ctypes.c_int()
+    blocks = np.zeros(8192, np.int32)
+    mpk.check(L.mi_mring_plan_deal_probe(len(p) - 1, p.ctypes.data, c.ctypes.data, ctypes.byref(tl), blocks.ctypes.data, len(blocks)))
+    assert tl.value % 8 == 0 and tl.value <= len(blocks)
+    return blocks[: tl.value].reshape(8, -1)
+
+
+def test_runs_are_dealt_for_the_dispatch_order_measured_on_the_hardware():
+    """mring_plan.hpp: an XCD takes its workgroups in order, 64 resident at a time, and a late-comer waits for a slot of its own
+    shader engine — so every XCD's LONG runs must be among its first 64 workgroups (the short ones behind them), the long runs
+    must be few enough for that, and nearly equal (a forced cut leaves no stub beside a full-length run).  Relabelled mesh: the
+    prologue's lead keeps the forced cuts to a handful."""
+    p, c, v = synth.pressure_matrix(100, 96, 92)
+    ps, cs, _ = synth.permute_nodes(p, c, v, block=1)[:3]
+    p2, c2 = relabelled(np.ascontiguousarray(ps, np.int32), np.ascontiguousarray(cs, np.int32))
+    for pp, cc, tag in ((p, c, "natural"), (p2, c2, "relabelled")):
+        nblk, runs, bad, frac, restarts = probe(pp, cc)
+        T = deal(pp, cc)
+        assert int(T.sum()) == nblk and int((T > 0).sum()) == runs, tag
+        long_ = T > min(5, -(-nblk // 512) // 8)
+        assert long_.sum() <= 512 and (long_[:, 64:].sum() == 0), (tag, long_.sum(axis=1))      # all long runs in the first round
+        assert T.max() <= 96, tag
+        assert restarts <= max(4, nblk // 400), (tag, restarts, nblk)
+        lens = T[long_]
+        assert lens.max() <= 1.25 * np.median(lens) + 2, (tag, int(lens.max()), float(np.median(lens)))
+        # workgroups j and j + 32 of an XCD share a CU: the sums are balanced (longest beside shortest)
+        if T.shape[1] >= 64:
+            pair = T[:, :32] + T[:, 32:64]
+            assert pair.max() <= 1.2 * np.median(pair) + 4, (tag, pair.max(axis=1))
