@@ -833,3 +833,35 @@ def test_powers_step_under_hip_graph_capture_is_recorded_as_k_launches(monkeypat
         Y = O.spmk_chain(3, p, c, v, xs[rep % 3])
         for q in range(3):
             assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"graph replay {rep}, power {q + 1}")
+
+
+def test_mring_with_second_round_workgroups_is_bitwise(monkeypatch):
+    """A relabelled 0.75 M-row mesh operator through the multi-window ring kernel: its plan holds more runs than the 512 workgroups the
+    GPU keeps resident (forced cuts leave short runs, dealt out behind the long ones: mring_plan.hpp), so the launch has workgroups
+    that start late.  Natural order beside it (one round).  Both bitwise against the oracle, twice (the second launch warm)."""
+    import ctypes
+    from test_ring_plan import relabelled
+    from test_mring_plan import deal
+    monkeypatch.setenv("MI355_REORDER", "0")
+    monkeypatch.setenv("MI355_SPMV_KERNEL", "mring")
+    p, c, v = synth.pressure_matrix(120, 100, 60)
+    ps, cs, vs = synth.permute_nodes(p, c, v, block=1)[:3]
+    p2, c2 = relabelled(np.ascontiguousarray(ps, np.int32), np.ascontiguousarray(cs, np.int32))
+    v2 = np.cos(np.arange(len(c2)) * 0.37) + 1.5
+    late = 0
+    for pp, cc, vv, tag in ((p, c, v, "natural"), (p2, c2, v2, "relabelled")):
+        n = len(pp) - 1
+        T = deal(pp, cc)
+        late += int((T[:, 64:] > 0).sum())
+        A = mpk.csrmatrix(n, pp, cc, vv)
+        assert "mring" in A.kernel_name(), A.kernel_name()
+        x = synth.x_sin(0, n)
+        d = dev(x)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        yo = O.spmv(pp, cc, vv, x)
+        for rep in range(2):
+            mpk.SpMV_CSR(y, d, A)
+            assert_bit_equal(y.cpu().numpy(), yo, f"mring {tag} launch {rep}")
+            y.fill_(float("nan"))
+        A.close()
+    assert late > 0, "the test matrix no longer produces second-round workgroups: pick another"
