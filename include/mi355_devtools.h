@@ -23,6 +23,9 @@ int mi_debug_mring_trace(mi_csr_t A, const double* d_x, double* d_y, int max_wgs
  * 2 row pointers, 3 ring plan records) to a fresh allocation (how: 0 hipMalloc, 2 / 3 hipExtMallocWithFlags uncached / fine-grained; 1 =
  * hipDeviceMallocContiguous is refused: it ended in a GPU memory fault here); the old one is freed after the new one exists. */
 int mi_debug_move_array(mi_csr_t A, int which, int how, unsigned long long* old_ptr, unsigned long long* new_ptr);
+/* run-length experiments on one placement (tools/mring_skew_ab.py): re-plan the handle's multi-window ring kernel with runs alternately
+ * skew_pct per cent longer / shorter (the longer dispatched to the older workgroup of every CU) INTO the device arrays it already has */
+int mi_debug_mring_replan(mi_csr_t A, int skew_pct, int* table_len, int* longest_run);
 /* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
 int mi_part_push_debug_preset(mi_part_t P, unsigned value);
 

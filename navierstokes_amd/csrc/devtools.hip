@@ -139,3 +139,42 @@ extern "C" int mi_debug_move_array(mi_csr_t A, int which, int how, unsigned long
     HIP_TRY(hipFree(old));
     return MI_OK;
 }
+
+// run-length experiments on ONE placement (tools/mring_skew_ab.py): rebuild the handle's multi-window ring plan with the given skew and
+// write it into the device arrays the handle already has (plan records and slots keep their size: the row blocks do not change; the small
+// per-run tables are re-allocated).  Needs the handle's column indices on the device.
+#include "mring_plan.hpp"
+extern "C" int mi_debug_mring_replan(mi_csr_t A, int skew_pct, int* table_len, int* longest_run)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    MringTable& M = A->mring;
+    if (!M.d_plan || !A->d_indcol) return fail(MI_ERR_STATE, "no multi-window ring plan (or no column indices) on this handle");
+    std::vector<int> ind((size_t)A->nnz);
+    HIP_TRY(hipMemcpy(ind.data(), A->d_indcol, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+    MringPlanHost P;
+    build_mring_plan(A->n, A->h_ptrow.data(), ind.data(), P, 0, skew_pct);
+    if (P.nblk != M.nblk) return fail(MI_ERR_STATE, "the new plan has other row blocks");
+    if (const char* bad = check_mring_plan(P, A->n, A->h_ptrow.data(), ind.data())) return fail(MI_ERR_STATE, std::string("mring plan: ") + bad);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(M.d_plan, P.plan.data(), sizeof(int) * P.plan.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(M.d_slots, P.slots.data(), sizeof(unsigned short) * P.slots.size(), hipMemcpyHostToDevice));
+    dfree(M.d_first); dfree(M.d_ok); dfree(M.d_rng);
+    M.d_first = M.d_ok = M.d_rng = nullptr;
+    HIP_TRY(hipMalloc(&M.d_first, sizeof(int) * P.first.size()));
+    HIP_TRY(hipMalloc(&M.d_ok, sizeof(int) * P.run_ok.size()));
+    HIP_TRY(hipMalloc(&M.d_rng, sizeof(int) * P.run_rng.size()));
+    HIP_TRY(hipMemcpy(M.d_first, P.first.data(), sizeof(int) * P.first.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(M.d_ok, P.run_ok.data(), sizeof(int) * P.run_ok.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(M.d_rng, P.run_rng.data(), sizeof(int) * P.run_rng.size(), hipMemcpyHostToDevice));
+    M.wgs = P.wgs;
+    M.nruns = P.nruns;
+    M.bpw = P.bpw;
+    M.bad_runs = P.bad_runs;
+    if (table_len) *table_len = P.wgs;
+    if (longest_run) {
+        *longest_run = 0;
+        for (int g = 0; g < P.wgs; g++) *longest_run = std::max(*longest_run, P.run_rng[2 * g + 1] - P.run_rng[2 * g]);
+    }
+    return MI_OK;
+}

@@ -63,7 +63,7 @@ struct MringPlanHost {
     long long restarts = 0;            // runs started because a block needed more groups than the loop refills (diagnostic)
 };
 
-inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPlanHost& out, int row_align_arg = 0)
+inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPlanHost& out, int row_align_arg = 0, int skew_pct = 0)
 {
     out = MringPlanHost();
     const int K = kMringK, W = kMringW, T = kMringThreads, nnzb = kMringNnzb, per = nnzb / T, G = kMringGroups;
@@ -323,7 +323,9 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
                 const long long pieces = (w + target - 1) / target;
                 int b = b0;
                 for (long long q = 1; q < pieces; q++) { // piece q ends where the segment's weight passes q / pieces of the whole
-                    while (b < b1 && (cumw[b] - cumw[b0]) * pieces < w * q) b++;
+                    // (skew_pct: pieces alternately that many per cent longer and shorter; the longer go to the older workgroup of a CU)
+                    const long long num = 100 * q + ((q & 1) ? skew_pct : 0);
+                    while (b < b1 && (cumw[b] - cumw[b0]) * pieces * 100 < w * num) b++;
                     if (b > b0 && b < b1 && (planned.empty() || planned.back() < b)) planned.push_back(b);
                 }
             }
