@@ -711,14 +711,18 @@ def main():
                                   autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
         if "spmv_csr_ring<" in kernel_name:
             rs = A.ring_shape_info()
-            out["kernel_info"]["ring_plan"] = dict(row_blocks=rs["blocks"], lean=rs["lean"], prefetch_depth=rs["depth"],
-                                                   us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
+            out["kernel_info"]["ring_plan"] = dict(row_blocks=rs["blocks"], lean=rs["lean"], prefetch_depth=rs["depth"], value_loads="16 B per lane (nonzero pairs)",
+                                                   block_shape="cut at the nonzero count (>= 20 M nnz: insensitive to where x and y lie)" if nnz_global >= 20_000_000
+                                                   else "whole waves of rows")
+            if rs["us_aligned"] > 0:  # MI355_RING_SHAPE_COMPARE=1
+                out["kernel_info"]["ring_plan"].update(us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
         mi = A.mring_info()
         if mi["built"]:
             out["kernel_info"]["mring_plan"] = dict(runs=mi["runs"], runs_on_plain_path=mi["runs_not_served"], nnz_fraction_served=round(mi["nnz_fraction"], 4))
             if "mring<" in kernel_name:
                 rs = A.ring_shape_info()
-                out["kernel_info"]["mring_plan"].update(us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
+                if rs["us_aligned"] > 0:  # MI355_RING_SHAPE_COMPARE=1
+                    out["kernel_info"]["mring_plan"].update(us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
         pl = A.placement_info()
         if pl["values"]:
             out["kernel_info"]["placement_draws_us"] = dict(pl, note="mi_csr_create timed the chosen kernel on fresh device copies of the value array, then of the 16-bit column "

@@ -47,6 +47,17 @@ static void free_mring(mi_csr_t A)
 }
 
 // Plan of the multi-window ring kernel (host arrays of the caller, or nullptr: the handle's device copy is read back)
+// Block shape of the ring / multi-window ring plans by matrix size (row_align argument of the planners; 0 = their default of 64).
+// Whole waves of rows per block pay below ~20 M nonzeros (2-5 % on every box tried).  Beyond, their rate turned out to depend on
+// WHERE THE CALLER'S x AND y lie in device memory — 133 / 144 / 153 us for three x / y pairs on one and the same C4 handle, and
+// 149-154 us for sixteen pairs in another process — while blocks cut at the nonzero count alone run 138-146 us whatever the
+// vectors (tools/state_probe.py, state_probe2.py; profiles/r03_state_probe.txt): their 1088-byte steps through y, x and the
+// row pointers keep the 512 workgroups' streams out of phase with each other, the whole-wave plan's 1 KiB steps do not.  The
+// create-time comparison of the two (rounds 2-3) timed them on the library's own scratch vectors and so could not tell what the
+// caller would see; large matrices now take the unaligned blocks outright.
+constexpr long long kLargeNnz = 20000000;
+static int large_row_align(long long nnz) { return nnz >= kLargeNnz ? 1 : 0; }
+
 static int build_mring(mi_csr_t A, const int* indcol, int row_align = 0)
 {
     if (A->mring.d_plan || A->n == 0 || A->nnz == 0) return MI_OK;
@@ -286,7 +297,7 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         for (int t = 0; t < kNumRingConfigs && !have; t++) {
             const int id = forced >= 1 && forced <= kNumRingConfigs ? forced : order[t];
             RingPlanHost P;
-            build_ring_plan(kRingConfigs[id - 1], n, ptrow, row_min.data(), row_max.data(), P, ghost_lo, ghost_hi);
+            build_ring_plan(kRingConfigs[id - 1], n, ptrow, row_min.data(), row_max.data(), P, ghost_lo, ghost_hi, large_row_align(nnz));
             const double okf = 1.0 - (double)P.bad_nnz / (double)nnz;
             if (forced || okf >= 0.90) {
                 best = std::move(P);
@@ -326,7 +337,7 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         const char* ke = getenv("MI355_SPMV_KERNEL");
         const bool asked = (me && !strcmp(me, "1")) || (ke && !strcmp(ke, "mring"));
         if (n > 0 && nnz > 0 && !(me && !strcmp(me, "0")) && (asked || (A->auto_kernel != MI_KERNEL_RING && nnz >= 200000))) {
-            const int rcm = build_mring(A, indcol);
+            const int rcm = build_mring(A, indcol, large_row_align(nnz));
             if (rcm != MI_OK) {
                 mi_csr_destroy(A);
                 return rcm;
@@ -499,42 +510,44 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
             *us_out = ms * 1e3 / timed;
             return MI_OK;
         };
-        // Large ring-served matrices: blocks ending on multiples of 64 rows (the default plan) against unaligned blocks — which
-        // is faster depends on the box (ring_plan.hpp), so both are built and timed; the loser is released.
+        // Large ring-served matrices take UNALIGNED blocks (large_row_align()).  MI355_RING_SHAPE_COMPARE=1 also builds the plan of
+        // whole-wave blocks and times both on the create-time scratch vectors (mi_csr_ring_shape_info; the shape in use stays unless
+        // the other is 2 % faster) — a comparison that says little about the caller's vectors, which is why it is no longer the rule.
         // (a rank's combined piece of the fused multi-GPU step included: timed here without the exchange, as a plain product)
-        if (A->auto_kernel == MI_KERNEL_RING && A->ring.cfg.id == 4 && nnz >= 20000000 && !getenv("MI355_RING_ROW_ALIGN")) {
+        const bool shape_compare = getenv("MI355_RING_SHAPE_COMPARE") && !strcmp(getenv("MI355_RING_SHAPE_COMPARE"), "1") && !getenv("MI355_RING_ROW_ALIGN");
+        if (shape_compare && A->auto_kernel == MI_KERNEL_RING && A->ring.cfg.id == 4 && nnz >= kLargeNnz) {
             RingPlanHost alt;
-            build_ring_plan(kRingConfigs[3], n, ptrow, row_min.data(), row_max.data(), alt, ghost_lo, ghost_hi, 1);
+            build_ring_plan(kRingConfigs[3], n, ptrow, row_min.data(), row_max.data(), alt, ghost_lo, ghost_hi, 64);
             RingTable T2;
             if (nnz > 0 && 1.0 - (double)alt.bad_nnz / (double)nnz >= 0.90 &&
                 fill_ring_table(T2, alt, n, ptrow, indcol, nnz, ghost_lo < ghost_hi, row_min.data(), row_max.data(), n == ncols) == MI_OK) {
                 T2.nt = A->ring.nt;
                 double us64 = 0.0, us1 = 0.0;
                 A->kernel = MI_KERNEL_RING;
-                int rct = time_now(3, 8, &us64);
-                std::swap(A->ring, T2);
-                if (rct == MI_OK) rct = time_now(3, 8, &us1);
-                A->kernel = MI_KERNEL_AUTO;
-                A->tune_us_ring_aligned = us64;
-                A->tune_us_ring_unaligned = us1;
-                if (rct != MI_OK || !(us1 < 0.98 * us64)) std::swap(A->ring, T2); // keep the default unless the other is clearly faster
-                free_ring_table(T2);
-            }
-        }
-        if (A->auto_kernel == MI_KERNEL_MRING && nnz >= 20000000 && !getenv("MI355_RING_ROW_ALIGN")) { // the same for the multi-window ring
-            MringTable keep = A->mring;
-            A->mring = MringTable();
-            if (build_mring(A, indcol, 1) == MI_OK && A->mring.d_plan && A->mring.ok_fraction >= 0.90) {
-                A->mring.nt = keep.nt;
-                double us64 = 0.0, us1 = 0.0;
-                A->kernel = MI_KERNEL_MRING;
                 int rct = time_now(3, 8, &us1);
-                std::swap(A->mring, keep);
+                std::swap(A->ring, T2);
                 if (rct == MI_OK) rct = time_now(3, 8, &us64);
                 A->kernel = MI_KERNEL_AUTO;
                 A->tune_us_ring_aligned = us64;
                 A->tune_us_ring_unaligned = us1;
-                if (rct == MI_OK && us1 < 0.98 * us64) std::swap(A->mring, keep); // the unaligned plan is clearly faster here
+                if (rct != MI_OK || !(us64 < 0.98 * us1)) std::swap(A->ring, T2); // keep the default unless the other is clearly faster
+                free_ring_table(T2);
+            }
+        }
+        if (shape_compare && A->auto_kernel == MI_KERNEL_MRING && nnz >= kLargeNnz) { // the same for the multi-window ring
+            MringTable keep = A->mring;
+            A->mring = MringTable();
+            if (build_mring(A, indcol, 64) == MI_OK && A->mring.d_plan && A->mring.ok_fraction >= 0.90) {
+                A->mring.nt = keep.nt;
+                double us64 = 0.0, us1 = 0.0;
+                A->kernel = MI_KERNEL_MRING;
+                int rct = time_now(3, 8, &us64);
+                std::swap(A->mring, keep);
+                if (rct == MI_OK) rct = time_now(3, 8, &us1);
+                A->kernel = MI_KERNEL_AUTO;
+                A->tune_us_ring_aligned = us64;
+                A->tune_us_ring_unaligned = us1;
+                if (rct == MI_OK && us64 < 0.98 * us1) std::swap(A->mring, keep); // the whole-wave plan is clearly faster here
             } else {
                 std::swap(A->mring, keep);
             }
@@ -1061,7 +1074,7 @@ extern "C" int mi_ring_plan_probe(int n, const int* ptrow, const int* indcol, in
             if (content[(indcol[Q[1] + k] - Q[6]) >= c.ring ? indcol[Q[1] + k] - Q[6] - c.ring : indcol[Q[1] + k] - Q[6]] != indcol[Q[1] + k])
                 return fail(MI_ERR_STATE, "a nonzero's column is not in the window when its block runs");
         for (int k = 0; k < Q[3]; k++) { // slot of nonzero k as the kernel's thread (k % T), element k / T reads it
-            const int slot = slots[(size_t)b * c.nnzb + (size_t)(k % T) * per + k / T];
+            const int slot = slots[(size_t)b * c.nnzb + (size_t)ring_slot_pos(T, per, k)];
             int want = indcol[Q[1] + k] - Q[6];
             if (want >= c.ring) want -= c.ring;
             if (slot != want || slot < 0 || slot >= c.ring) return fail(MI_ERR_STATE, "16-bit slot disagrees with the column");
@@ -1299,7 +1312,7 @@ extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
     if (kernel_id == MI_KERNEL_MRING) {
         int rc = need_device();
         if (rc) return rc;
-        if ((rc = build_mring(A, nullptr))) return rc;
+        if ((rc = build_mring(A, nullptr, large_row_align(A->nnz)))) return rc;
     }
     A->kernel = kernel_id;
     return MI_OK;

@@ -263,9 +263,10 @@ inline void build_mring_plan(int n, const int* ptrow, const int* indcol, MringPl
             const Cl* C = &cls[cl_ptr[b]];
             const int nc = cl_ptr[b + 1] - cl_ptr[b], p0 = ptrs[b];
             unsigned short* o = &out.slots[(size_t)b * nnzb];
+            const bool pair = ring_pairs(T); // (ring_pair.hpp: the thread owns nonzero pairs, 16-byte value loads)
             for (int t = 0; t < T; t++)
                 for (int i = 0; i < per; i++) {
-                    const int k = std::min(t + i * T, nn - 1);
+                    const int k = std::min(pair ? 2 * (t + (i >> 1) * T) + (i & 1) : t + i * T, nn - 1);
                     const int c = indcol[p0 + k];
                     int j = 0;
                     while (j + 1 < nc && c > C[j].hi) j++;
@@ -462,7 +463,7 @@ inline const char* check_mring_plan(const MringPlanHost& P, int n, const int* pt
             for (int i = 0; i < 64; i++) content[sl + i] = Q[8 + g] + i;
         }
         for (int k = 0; k < Q[3]; k++) {
-            const int slot = P.slots[(size_t)b * nnzb + (size_t)(k % T) * per + k / T];
+            const int slot = P.slots[(size_t)b * nnzb + (size_t)ring_slot_pos(T, per, k)];
             if (slot < 0 || slot >= K * W) return "slot outside the LDS array";
             if (content[slot] != indcol[Q[1] + k]) return "a nonzero's slot does not hold its column when its block runs";
         }

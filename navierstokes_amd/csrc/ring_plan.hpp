@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "partition.hpp"
+#include "ring_pair.hpp"
 
 namespace mi355 {
 
@@ -49,6 +50,14 @@ static const RingConfig kRingConfigs[kNumRingConfigs] = {
     {4, 256, 2048, 5120, 2, 512},
 };
 static const int kRingConfigOrder[kNumRingConfigs] = {4, 1, 2, 3};
+
+// position, inside a block's nnzb entries of the column stream, of the block's k-th nonzero (thread-major: PER entries per thread)
+inline int ring_slot_pos(int T, int per, int k)
+{
+    if (!ring_pairs(T)) return (k % T) * per + k / T;
+    const int m = k >> 1; // pair index t + i*T
+    return (m % T) * per + 2 * (m / T) + (k & 1);
+}
 
 struct RingPlanHost {
     RingConfig cfg{};
@@ -373,8 +382,8 @@ inline void build_run_deps(const RingPlanHost& P, int n, std::vector<int>& dep_p
 
 // The 16-bit column stream of the ring kernel: for block b, thread t, i < PER the
 // ring slot of nonzero k = t + i*T of the block (the last nonzero again for k >= nnz of the
-// block) at out[(b*T + t)*PER + i].  Blocks the ring does not serve get zeros (their runs take
-// the plain path, which reads indcol).
+// block) at out[(b*T + t)*PER + i] — configuration 4: of nonzero k = 2(t + (i/2)T) + (i & 1), see ring_pairs().  Blocks the
+// ring does not serve get zeros (their runs take the plain path, which reads indcol).
 inline void build_ring_slots(const RingPlanHost& P, const int* indcol, std::vector<unsigned short>& out)
 {
     const int T = P.cfg.threads, per = P.cfg.nnzb / T, ring = P.cfg.ring;
@@ -384,9 +393,10 @@ inline void build_ring_slots(const RingPlanHost& P, const int* indcol, std::vect
         const int p0 = Q[1], nn = Q[3], base = Q[6];
         if (Q[7] != 1 || nn <= 0 || nn > P.cfg.nnzb) continue;
         unsigned short* o = &out[(size_t)b * P.cfg.nnzb];
+        const bool pair = ring_pairs(T);
         for (int t = 0; t < T; t++)
             for (int i = 0; i < per; i++) {
-                const int k = std::min(t + i * T, nn - 1);
+                const int k = std::min(pair ? 2 * (t + (i >> 1) * T) + (i & 1) : t + i * T, nn - 1);
                 int p = indcol[p0 + k] - base;
                 if (p >= ring) p -= ring;
                 o[t * per + i] = (unsigned short)p;

@@ -63,10 +63,11 @@ __global__ __launch_bounds__(T) void spmk_csr_ring(CsrView A, const int4* __rest
                                                    const int2* __restrict__ run_rng, int bpw, SpmkArgs K)
 {
     constexpr int PER = NNZB / T;
+    constexpr bool PAIR = ring_pairs(T); // (ring_pair.hpp: the order of the 16-bit column stream this kernel shares with spmv_csr_ring)
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
-    constexpr int LDSN = NNZB + NNZB / 32 + 1;
-    __shared__ double s_c[LDSN];
-    __shared__ double s_x[LDSN];
+    constexpr int LDSN = NNZB + NNZB / 32 + 2;
+    __shared__ __attribute__((aligned(16))) double s_c[LDSN];
+    __shared__ __attribute__((aligned(16))) double s_x[LDSN];
     __shared__ double s_ring[RING];
     __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
     const int tid = threadIdx.x;
@@ -134,12 +135,7 @@ __global__ __launch_bounds__(T) void spmk_csr_ring(CsrView A, const int4* __rest
 
         auto issue = [&](int lb, int s) {
             const int4 m0 = s_plan[2 * lb], m1 = s_plan[2 * lb + 1];
-            const double* cb = A.coef + uni(m0.y) + (tid & ((uni(m1.w) & 1) ? -1 : 0));
-#pragma unroll
-            for (int i = 0; i < PER; i++) {
-                if (NT) c[s][i] = __builtin_nontemporal_load(&cb[i * T]);
-                else c[s][i] = cb[i * T];
-            }
+            ring_load_coefs<T, PER, NT, PAIR>(c[s], A.coef + uni(m0.y), tid & ((uni(m1.w) & 1) ? -1 : 0));
             sl[s] = (slotv + (size_t)min(b_begin + lb, bslot_last) * T)[tid];
             const int* rp = A.ptrow + uni(m0.x) + tid;
             pr[s] = make_int2(rp[0], rp[1]);
@@ -170,12 +166,7 @@ __global__ __launch_bounds__(T) void spmk_csr_ring(CsrView A, const int4* __rest
                 double xv[PER];
 #pragma unroll
                 for (int i = 0; i < PER; i++) xv[i] = s_ring[min((unsigned)sl[s][i], (unsigned)(RING - 1))];
-#pragma unroll
-                for (int i = 0; i < PER; i++) {
-                    const int kk = SKEW ? sk(tid + i * T) : tid + i * T;
-                    s_c[kk] = c[s][i];
-                    s_x[kk] = xv[i];
-                }
+                ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
                 const int2 prs = pr[s];
                 issue(lb + D, s);
                 __syncthreads();

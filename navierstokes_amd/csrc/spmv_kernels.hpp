@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ring_pair.hpp"
+
 namespace mi355 {
 
 constexpr int kWG = 256;        // threads per workgroup (4 waves of 64)
@@ -97,6 +99,66 @@ __device__ __forceinline__ double row_chain(const double* s_c, const double* s_x
             if (k0 + u < re) s = fma(cc[u], xx[u], s);
     }
     return s;
+}
+
+// The value stream of one block into a thread's registers, and from there (with the x values gathered from the ring) into the
+// staging arrays.  PAIR (ring_pair.hpp, configuration 4): the thread owns nonzero pairs and loads them 16 bytes at a time — a
+// block starts at any nonzero, so the pairs are only 8-byte aligned in memory (global loads need dword alignment only); staged,
+// a pair is 16-byte aligned in the plain layout (one ds_write_b128) and two 8-byte writes in the skewed one.
+// `lane` = tid, or 0 for a sentinel block behind the run (one address per load instead of 16 KB of values nobody uses).
+typedef double RingCoef2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef double RingLds2 __attribute__((ext_vector_type(2)));
+
+template <int T, int PER, bool NT, bool PAIR>
+__device__ __forceinline__ void ring_load_coefs(double (&c)[PER], const double* __restrict__ block_base, int lane)
+{
+    if (PAIR) {
+        static_assert(!PAIR || PER % 2 == 0, "pairs");
+        const RingCoef2* cb = reinterpret_cast<const RingCoef2*>(block_base) + lane;
+#pragma unroll
+        for (int i = 0; i < PER / 2; i++) {
+            RingCoef2 v;
+            if (NT) v = __builtin_nontemporal_load(&cb[i * T]);
+            else v = cb[i * T];
+            c[2 * i] = v.x;
+            c[2 * i + 1] = v.y;
+        }
+    } else {
+        const double* cb = block_base + lane;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (NT) c[i] = __builtin_nontemporal_load(&cb[i * T]);
+            else c[i] = cb[i * T];
+        }
+    }
+}
+
+template <int T, int PER, bool SKEW, bool PAIR>
+__device__ __forceinline__ void ring_stage(double* s_c, double* s_x, const double (&c)[PER], const double (&xv)[PER], int tid)
+{
+    if (PAIR) {
+#pragma unroll
+        for (int i = 0; i < PER / 2; i++) {
+            const int k0 = 2 * (tid + i * T);
+            if (SKEW) { // k0 is even: k0 and k0 + 1 share their group of 32, so their padded slots are neighbours
+                const int k = sk(k0);
+                s_c[k] = c[2 * i];
+                s_c[k + 1] = c[2 * i + 1];
+                s_x[k] = xv[2 * i];
+                s_x[k + 1] = xv[2 * i + 1];
+            } else {
+                *reinterpret_cast<RingLds2*>(s_c + k0) = RingLds2{c[2 * i], c[2 * i + 1]};
+                *reinterpret_cast<RingLds2*>(s_x + k0) = RingLds2{xv[2 * i], xv[2 * i + 1]};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = SKEW ? sk(tid + i * T) : tid + i * T;
+            s_c[k] = c[i];
+            s_x[k] = xv[i];
+        }
+    }
 }
 
 // NT: matrix stream loaded non-temporally (see spmv_ring.hpp; chosen per matrix by mi_csr_create)

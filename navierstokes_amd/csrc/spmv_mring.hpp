@@ -41,9 +41,10 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
     constexpr int K = kMringK, W = kMringW, RING = K * W, PER = NNZB / T, R4 = kMringRec / 4;
     static_assert(T == 256 && kMringGroups == 8 && kMringRec == 20 && kMringFirst == 16, "two groups per wave; record layout");
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
-    constexpr int LDSN = NNZB + NNZB / 32 + 1;
-    __shared__ double s_c[LDSN];
-    __shared__ double s_x[LDSN];
+    constexpr bool PAIR = ring_pairs(T); // (ring_pair.hpp)
+    constexpr int LDSN = NNZB + NNZB / 32 + 2;
+    __shared__ __attribute__((aligned(16))) double s_c[LDSN];
+    __shared__ __attribute__((aligned(16))) double s_x[LDSN];
     __shared__ double s_ring[RING];
     __shared__ int4 s_plan[R4 * (MAXB + 2 * D + 2)];
     const int* s_rec = reinterpret_cast<const int*>(s_plan);
@@ -97,12 +98,7 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
     auto issue = [&](int lb, int s) {
         const int4 m0 = s_plan[R4 * lb];
         const int flags = uni(s_rec[kMringRec * lb + 4]);
-        const double* cb = A.coef + uni(m0.y) + (tid & ((flags & 1) ? -1 : 0));
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            if (NT) c[s][i] = __builtin_nontemporal_load(&cb[i * T]);
-            else c[s][i] = cb[i * T];
-        }
+        ring_load_coefs<T, PER, NT, PAIR>(c[s], A.coef + uni(m0.y), tid & ((flags & 1) ? -1 : 0));
         sl[s] = (slotv + (size_t)min(b_begin + lb, bslot_last) * T)[tid];
         const int* rp = A.ptrow + uni(m0.x) + tid;
         pr[s] = make_int2(rp[0], rp[1]);
@@ -146,12 +142,7 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
             double xv[PER];
 #pragma unroll
             for (int i = 0; i < PER; i++) xv[i] = s_ring[min((unsigned)sl[s][i], (unsigned)(RING - 1))];
-#pragma unroll
-            for (int i = 0; i < PER; i++) {
-                const int k = SKEW ? sk(tid + i * T) : tid + i * T;
-                s_c[k] = c[s][i];
-                s_x[k] = xv[i];
-            }
+            ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
             const int2 prs = pr[s];
             const int rms = MAPPED ? rm[s] : 0;
             issue(lb + D, s); // refill this stage with block lb + D

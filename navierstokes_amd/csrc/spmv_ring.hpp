@@ -205,6 +205,8 @@ __device__ __forceinline__ double ring_row_chain(const double* s_c, const double
     return s;
 }
 
+// (ring_load_coefs / ring_stage — the value stream into registers and on into the staging arrays, 16 bytes per lane where the
+// thread owns nonzero pairs — live in spmv_kernels.hpp beside the row chains; spmk_ring.hpp and spmv_mring.hpp use them too.)
 // T threads, NNZB nonzeros per row block (PER = NNZB/T per thread), RING doubles of
 // x window, D blocks of prefetch, runs of at most MAXB blocks per workgroup.
 // LDS = 16 B * (NNZB + NNZB/32) staging + 8 B * RING + 32 B * (MAXB + 2D + 2) plan.
@@ -237,11 +239,12 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
 {
     static_assert(!DOT || (LEAN && !FUSED && !MAPPED), "the dot epilogue exists for the LEAN single-GPU instantiation (all rows inside the counted loop)");
     constexpr int PER = NNZB / T;
+    constexpr bool PAIR = ring_pairs(T);
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
     static_assert(RING <= 65536, "ring slots are stored in 16 bits");
-    constexpr int LDSN = NNZB + NNZB / 32 + 1;
-    __shared__ double s_c[LDSN];
-    __shared__ double s_x[LDSN];
+    constexpr int LDSN = NNZB + NNZB / 32 + 2;
+    __shared__ __attribute__((aligned(16))) double s_c[LDSN];
+    __shared__ __attribute__((aligned(16))) double s_x[LDSN];
     __shared__ double s_ring[RING];
     __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
     const int tid = threadIdx.x;
@@ -320,12 +323,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
         // kRingPadNnz / kRingPadRows) and their values are never used
         // (a sentinel block behind the run — flags 0 — collapses to one address per load instead of
         // streaming 16 KB of the next run's values nobody uses: 2 % of the kernel's HBM traffic)
-        const double* cb = A.coef + uni(m0.y) + (tid & ((uni(m1.w) & 1) ? -1 : 0));
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            if (NT) c[s][i] = __builtin_nontemporal_load(&cb[i * T]);
-            else c[s][i] = cb[i * T];
-        }
+        ring_load_coefs<T, PER, NT, PAIR>(c[s], A.coef + uni(m0.y), tid & ((uni(m1.w) & 1) ? -1 : 0));
         sl[s] = (slotv + (size_t)min(b_begin + lb, bslot_last) * T)[tid];
         const int* rp = A.ptrow + uni(m0.x) + tid;
         pr[s] = make_int2(rp[0], rp[1]);
@@ -363,12 +361,7 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
             double xv[PER];
 #pragma unroll
             for (int i = 0; i < PER; i++) xv[i] = s_ring[min((unsigned)sl[s][i], (unsigned)(RING - 1))]; // slots are < RING by construction
-#pragma unroll
-            for (int i = 0; i < PER; i++) {
-                const int k = SKEW ? sk(tid + i * T) : tid + i * T;
-                s_c[k] = c[s][i];
-                s_x[k] = xv[i];
-            }
+            ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
             const int2 prs = pr[s];
             const int rms = MAPPED ? rm[s] : 0;
             const double brs = DOT ? br[s] : 0.0;
