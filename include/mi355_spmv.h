@@ -151,9 +151,11 @@ int mi_reorder_probe(int n, const int* ptrow, const int* indcol, int* block, int
  * per-block path); mi_csr_ring_info reports how much of the matrix the ring serves. */
 int mi_csr_set_kernel(mi_csr_t A, int kernel_id);
 int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable);
-/* Shape of the ring plan in use: row blocks, whether the LEAN instantiation runs, blocks of prefetch; and, for matrices of
- * >= 20 M nonzeros, the create-time measurement that chose between row blocks ending on multiples of 64 rows and unaligned
- * ones (microseconds per launch; 0 = not compared; which is faster depends on the box). */
+/* Shape of the ring plan in use: row blocks, whether the LEAN instantiation runs, blocks of prefetch.  Matrices of >= 20 M
+ * nonzeros take row blocks cut at the nonzero count, smaller ones blocks ending on multiples of 64 rows (the first shape's
+ * rate does not depend on where the caller's x and y lie in device memory, the second's does: DESIGN.md 4.1).  With
+ * MI355_RING_SHAPE_COMPARE=1 in the environment mi_csr_create also times the other shape on its scratch vectors
+ * (microseconds per launch; 0 = not compared). */
 int mi_csr_ring_shape_info(mi_csr_t A, int* blocks, int* lean, int* depth, double* us_aligned, double* us_unaligned);
 /* MI_KERNEL_AUTO is decided by measurement: mi_csr_create times the candidate kernels (ring if
  * >= 90 % of the nonzeros are ring-served, stream, tile if a plan was kept, BCSR 4x4 if a blocked copy exists) on the new
