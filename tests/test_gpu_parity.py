@@ -312,6 +312,44 @@ def test_rccl_plumbing_selftest():
     assert err.value == 0.0
 
 
+def test_block_shape_of_large_and_small_matrices(monkeypatch):
+    """Round 3: matrices of >= 20 M nonzeros take row blocks cut at the nonzero count (their rate does not depend on where the
+    caller's vectors lie), smaller ones blocks of whole waves of rows; MI355_RING_SHAPE_COMPARE=1 times both shapes at create.
+    Either way every row is the reference's fma chain (mpk/SpMV.cpp:23-56), bit for bit."""
+    n = 1_400_000  # 21 M nonzeros
+    p, c, v = synth.rows("s15", n)
+    x = synth.x_sin(0, n)
+    yo = O.spmv(p, c, v, x)
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    A = mpk.csrmatrix(n, p, c, v)
+    _ = A.handle
+    rs = A.ring_shape_info()
+    assert "spmv_csr_ring<" in A.kernel_name() and rs["us_aligned"] == 0.0 and rs["us_unaligned"] == 0.0, (A.kernel_name(), rs)
+    assert rs["blocks"] == -(-n // 136), rs  # 136 rows of 15 nonzeros fill a 2048-nonzero block; 128-row blocks would be more
+    mpk.SpMV_CSR(y, dev(x), A)
+    assert_bit_equal(y.cpu().numpy(), yo, "large matrix, blocks cut at the nonzero count")
+    A.close()
+    monkeypatch.setenv("MI355_RING_SHAPE_COMPARE", "1")
+    B = mpk.csrmatrix(n, p, c, v)
+    _ = B.handle
+    rs = B.ring_shape_info()
+    assert rs["us_aligned"] > 0.0 and rs["us_unaligned"] > 0.0 and rs["blocks"] in (-(-n // 136), -(-n // 128)), rs
+    y.zero_()
+    mpk.SpMV_CSR(y, dev(x), B)
+    assert_bit_equal(y.cpu().numpy(), yo, "large matrix after the create-time shape comparison")
+    B.close()
+    monkeypatch.delenv("MI355_RING_SHAPE_COMPARE")
+    m = 200_000  # 3 M nonzeros: whole waves of rows
+    p, c, v = synth.rows("s15", m)
+    S = mpk.csrmatrix(m, p, c, v)
+    S.set_kernel("ring")
+    assert S.ring_shape_info()["blocks"] == -(-m // 128), S.ring_shape_info()
+    ys = torch.empty(m, dtype=torch.float64, device="cuda")
+    xs = synth.x_sin(0, m)
+    mpk.SpMV_CSR(ys, dev(xs), S)
+    assert_bit_equal(ys.cpu().numpy(), O.spmv(p, c, v, xs), "small matrix, whole-wave blocks")
+
+
 def test_full_size_c4_and_c3():
     """BASELINE configs at full size.  C4: 5 M rows / 75 M nnz single SpMV; C3: k = 4 matrix powers on the
     1 M-row matrix.  Both bitwise against the oracle's fma chain, plus the size-independent
