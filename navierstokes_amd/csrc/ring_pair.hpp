@@ -15,6 +15,11 @@ namespace mi355 {
 #endif
 constexpr bool kRingPair4 = MI355_RING_PAIR != 0;
 constexpr bool ring_pairs(int threads) { return kRingPair4 && threads == 256; }
+// the ring family stages {coef, x} pairs and reads a row chain's terms with ds_read_b128 (spmv_kernels.hpp: ring_stage_cx)
+#ifndef MI355_RING_MERGED
+#define MI355_RING_MERGED 1
+#endif
+constexpr bool kRingMergedStage = MI355_RING_MERGED != 0;
 // (Measured on the stream and tile kernels too — the thread owning nonzero pairs, 16 + 8 bytes of values and columns per load: the
 // 5 M-row mesh 184-186 -> 181-183 us through the stream kernel and no difference through the tile kernel; the 1 M-row mesh, which
 // lives in the Infinity Cache, 28.75 -> 29.5 us — a wave's gather then spans 128 nonzeros instead of 64.  Not kept there.)

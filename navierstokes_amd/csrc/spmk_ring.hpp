@@ -66,8 +66,10 @@ __global__ __launch_bounds__(T) void spmk_csr_ring(CsrView A, const int4* __rest
     constexpr bool PAIR = ring_pairs(T); // (ring_pair.hpp: the order of the 16-bit column stream this kernel shares with spmv_csr_ring)
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
     constexpr int LDSN = NNZB + NNZB / 32 + 2;
-    __shared__ __attribute__((aligned(16))) double s_c[LDSN];
-    __shared__ __attribute__((aligned(16))) double s_x[LDSN];
+    __shared__ __attribute__((aligned(16))) double s_cx_raw[2 * LDSN]; // two arrays of doubles (plain path), or LDSN {coef, x} pairs
+    double* const s_c = s_cx_raw;
+    double* const s_x = s_cx_raw + LDSN;
+    RingCx* const s_cx = reinterpret_cast<RingCx*>(s_cx_raw);
     __shared__ double s_ring[RING];
     __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
     const int tid = threadIdx.x;
@@ -166,7 +168,8 @@ __global__ __launch_bounds__(T) void spmk_csr_ring(CsrView A, const int4* __rest
                 double xv[PER];
 #pragma unroll
                 for (int i = 0; i < PER; i++) xv[i] = s_ring[min((unsigned)sl[s][i], (unsigned)(RING - 1))];
-                ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
+                if (kRingMergedStage) ring_stage_cx<T, PER, SKEW, PAIR>(s_cx, c[s], xv, tid);
+                else ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
                 const int2 prs = pr[s];
                 issue(lb + D, s);
                 __syncthreads();
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(T) void spmk_csr_ring(CsrView A, const int4* __rest
                     const double xn = xr[(s + 1) % D];
                     if (tid < qy) s_ring[ring_slot<RING>(qx + tid, qz)] = xn;
                 }
-                if (tid < nrows) st_coherent(y + r0 + tid, ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0));
+                if (tid < nrows) st_coherent(y + r0 + tid, kRingMergedStage ? ring_row_chain_cx<8, SKEW>(s_cx, prs.x - p0, prs.y - p0) : ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0));
             }
         }
         if (pw + 1 < K.k) { // publish: every storing wave's stores have left, then the flag

@@ -161,6 +161,62 @@ __device__ __forceinline__ void ring_stage(double* s_c, double* s_x, const doubl
     }
 }
 
+// MERGED staging (ring_pair.hpp: kRingMergedStage): the staging area holds {coef, x} PAIRS, 16 bytes per nonzero, instead of two arrays
+// of doubles — a term of a row chain is then ONE 16-byte-aligned ds_read_b128 where the two-array form reads its operands as
+// ds_read2_b64 pairs at 8-byte alignment (a row starts at any nonzero), which cost four times the LDS cycles per byte
+// (MI355X_MICROARCH.md, LDS).  With rows of odd length the lanes' 16-byte slots fall on distinct banks (stride 16 L mod 256).
+typedef double RingCx __attribute__((ext_vector_type(2)));
+
+template <int T, int PER, bool SKEW, bool PAIR>
+__device__ __forceinline__ void ring_stage_cx(RingCx* s_cx, const double (&c)[PER], const double (&xv)[PER], int tid)
+{
+    if (PAIR) {
+#pragma unroll
+        for (int i = 0; i < PER / 2; i++) {
+            const int k0 = 2 * (tid + i * T), k = SKEW ? sk(k0) : k0; // (k0 even: its neighbour shares the group of 32)
+            s_cx[k] = RingCx{c[2 * i], xv[2 * i]};
+            s_cx[k + 1] = RingCx{c[2 * i + 1], xv[2 * i + 1]};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; i++) s_cx[SKEW ? sk(tid + i * T) : tid + i * T] = RingCx{c[i], xv[i]};
+    }
+}
+
+template <int U, bool SKEW>
+__device__ __forceinline__ double ring_row_chain_cx(const RingCx* s_cx, int ra, int re)
+{
+    double s = 0.0;
+    if (SKEW) {
+        for (int k0 = ra; k0 < re; k0 += U) {
+            RingCx v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = s_cx[sk(min(k0 + u, re - 1))];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (k0 + u < re) s = fma(v[u].x, v[u].y, s);
+        }
+        return s;
+    }
+    int k = ra;
+    for (; k + U <= re; k += U) {
+        RingCx v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = s_cx[k + u];
+#pragma unroll
+        for (int u = 0; u < U; u++) s = fma(v[u].x, v[u].y, s);
+    }
+    if (k < re) {
+        RingCx v[U];
+#pragma unroll
+        for (int u = 0; u < U - 1; u++) v[u] = s_cx[k + u];
+#pragma unroll
+        for (int u = 0; u < U - 1; u++)
+            if (k + u < re) s = fma(v[u].x, v[u].y, s);
+    }
+    return s;
+}
+
 // NT: matrix stream loaded non-temporally (see spmv_ring.hpp; chosen per matrix by mi_csr_create)
 template <int NNZB, bool NT = false>
 __global__ __launch_bounds__(kWG) void spmv_csr_stream(CsrView A, const double* __restrict__ x,

@@ -43,8 +43,10 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
     constexpr bool PAIR = ring_pairs(T); // (ring_pair.hpp)
     constexpr int LDSN = NNZB + NNZB / 32 + 2;
-    __shared__ __attribute__((aligned(16))) double s_c[LDSN];
-    __shared__ __attribute__((aligned(16))) double s_x[LDSN];
+    __shared__ __attribute__((aligned(16))) double s_cx_raw[2 * LDSN]; // two arrays of doubles (plain path), or LDSN {coef, x} pairs
+    double* const s_c = s_cx_raw;
+    double* const s_x = s_cx_raw + LDSN;
+    RingCx* const s_cx = reinterpret_cast<RingCx*>(s_cx_raw);
     __shared__ double s_ring[RING];
     __shared__ int4 s_plan[R4 * (MAXB + 2 * D + 2)];
     const int* s_rec = reinterpret_cast<const int*>(s_plan);
@@ -142,7 +144,8 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
             double xv[PER];
 #pragma unroll
             for (int i = 0; i < PER; i++) xv[i] = s_ring[min((unsigned)sl[s][i], (unsigned)(RING - 1))];
-            ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
+            if (kRingMergedStage) ring_stage_cx<T, PER, SKEW, PAIR>(s_cx, c[s], xv, tid);
+            else ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
             const int2 prs = pr[s];
             const int rms = MAPPED ? rm[s] : 0;
             issue(lb + D, s); // refill this stage with block lb + D
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(T) void spmv_csr_mring(CsrView A, const int4* __res
                 if (s0 != 0xffffu) s_ring[s0 + lane] = xr[(s + 1) % D][0];
                 if (s1 != 0xffffu) s_ring[s1 + lane] = xr[(s + 1) % D][1];
             }
-            if (tid < nrows) y[MAPPED ? rms : r0 + tid] = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
+            if (tid < nrows) y[MAPPED ? rms : r0 + tid] = kRingMergedStage ? ring_row_chain_cx<8, SKEW>(s_cx, prs.x - p0, prs.y - p0) : ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
         }
     }
     // PLAIN blocks of this run, behind the loop (spmv_ring.hpp)

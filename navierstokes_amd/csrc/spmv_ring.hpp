@@ -243,8 +243,10 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     typedef unsigned short SlotVec __attribute__((ext_vector_type(PER)));
     static_assert(RING <= 65536, "ring slots are stored in 16 bits");
     constexpr int LDSN = NNZB + NNZB / 32 + 2;
-    __shared__ __attribute__((aligned(16))) double s_c[LDSN];
-    __shared__ __attribute__((aligned(16))) double s_x[LDSN];
+    __shared__ __attribute__((aligned(16))) double s_cx_raw[2 * LDSN]; // two arrays of doubles (plain path), or LDSN {coef, x} pairs
+    double* const s_c = s_cx_raw;
+    double* const s_x = s_cx_raw + LDSN;
+    RingCx* const s_cx = reinterpret_cast<RingCx*>(s_cx_raw);
     __shared__ double s_ring[RING];
     __shared__ int4 s_plan[2 * (MAXB + 2 * D + 2)];
     const int tid = threadIdx.x;
@@ -361,7 +363,8 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
             double xv[PER];
 #pragma unroll
             for (int i = 0; i < PER; i++) xv[i] = s_ring[min((unsigned)sl[s][i], (unsigned)(RING - 1))]; // slots are < RING by construction
-            ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
+            if (kRingMergedStage) ring_stage_cx<T, PER, SKEW, PAIR>(s_cx, c[s], xv, tid);
+            else ring_stage<T, PER, SKEW, PAIR>(s_c, s_x, c[s], xv, tid);
             const int2 prs = pr[s];
             const int rms = MAPPED ? rm[s] : 0;
             const double brs = DOT ? br[s] : 0.0;
@@ -391,15 +394,15 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
             // ---- row chains
             if (DOT) {
                 if (tid < nrows) {
-                    const double yv = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
+                    const double yv = kRingMergedStage ? ring_row_chain_cx<8, SKEW>(s_cx, prs.x - p0, prs.y - p0) : ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
                     y[r0 + tid] = yv;
                     dacc = fma(brs, yv, dacc);
                 }
-            } else if (tid < nrows) y[MAPPED ? rms : r0 + tid] = ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
+            } else if (tid < nrows) y[MAPPED ? rms : r0 + tid] = kRingMergedStage ? ring_row_chain_cx<8, SKEW>(s_cx, prs.x - p0, prs.y - p0) : ring_row_chain<8, SKEW>(s_c, s_x, prs.x - p0, prs.y - p0);
             if (!LEAN)
                 for (int r = r0 + tid + T; r < r0 + nrows; r += T) { // blocks of very short rows
                     const int a = A.ptrow[r] - p0, e = A.ptrow[r + 1] - p0;
-                    y[MAPPED ? A.rowmap[r] : r] = ring_row_chain<8, SKEW>(s_c, s_x, a, e);
+                    y[MAPPED ? A.rowmap[r] : r] = kRingMergedStage ? ring_row_chain_cx<8, SKEW>(s_cx, a, e) : ring_row_chain<8, SKEW>(s_c, s_x, a, e);
                 }
         }
     }
