@@ -55,6 +55,25 @@ static void free_mring(mi_csr_t A)
 // row pointers keep the 512 workgroups' streams out of phase with each other, the whole-wave plan's 1 KiB steps do not.  The
 // create-time comparison of the two (rounds 2-3) timed them on the library's own scratch vectors and so could not tell what the
 // caller would see; large matrices now take the unaligned blocks outright.
+// Staging layout of the ring kernels' row chains (SKEW template argument): one pad slot per 32 staged nonzeros, or none.  A row
+// chain reads its terms as 16-byte {coef, x} pairs (ring_stage_cx), lane l starting 16 * (length of the rows in front) bytes into the
+// staging area: rows whose length is a multiple of 16 put every lane of a wave on the same four banks (16-way conflicts: uniform
+// rows of 16 run 134-139 us plain and 92-102 us padded, rows of 32 132-136 against 107.5, rows of 8 89 against 79-85), and the pad
+// slot breaks that up — at the price of index arithmetic per term, which is why every other shape is faster WITHOUT it: S15 140.5
+// against 147.5 us, SVAR (lengths 8..22 mixed) 147 against 159-163, rows of 24 96.7 against 103.5, the FE shape (rows of 56) 162.6
+// against 201.  (Measured with the merged staging of round 3's second session, tools/skew_ab.py; the two-array staging of
+// rounds 1-2 wanted the pad for every multiple of 8.)  Mixed lengths do not line up whatever their share, so the rule asks for a
+// MAJORITY of such rows.
+static bool ring_wants_skew(int n, const int* ptrow)
+{
+    long long bad = 0;
+    for (int i = 0; i < n; i++) {
+        const int len = ptrow[i + 1] - ptrow[i];
+        bad += len > 0 && (len % 16 == 0 || len == 8);
+    }
+    return 2 * bad > n;
+}
+
 constexpr long long kLargeNnz = 20000000;
 static int large_row_align(long long nnz) { return nnz >= kLargeNnz ? 1 : 0; }
 
@@ -93,12 +112,7 @@ static int build_mring(mi_csr_t A, const int* indcol, int row_align = 0)
     M.restarts = P.restarts;
     M.ok_fraction = 1.0 - (double)P.bad_nnz / (double)A->nnz;
     M.depth = P.bpw >= 40 ? 4 : 2; // as for the single ring (tools/depth_ab.py)
-    long long mult8 = 0;
-    for (int i = 0; i < A->n; i++) {
-        const int len = A->h_ptrow[i + 1] - A->h_ptrow[i];
-        mult8 += len > 0 && len % 8 == 0;
-    }
-    M.skew = 10 * mult8 > A->n;
+    M.skew = ring_wants_skew(A->n, A->h_ptrow.data());
     M.nt = 10.0 * (double)A->nnz + 16.0 * (double)A->n > 0.75 * 256e6;
     return MI_OK;
 }
@@ -204,14 +218,7 @@ static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const 
         RING_TRY(hipMemcpy(R.d_slots, slots.data(), sizeof(unsigned short) * slots.size(), hipMemcpyHostToDevice));
     }
 #undef RING_TRY
-    // staging layout of the row chains: plain unless more than a tenth of the rows have a length
-    // that is a multiple of 8 (their LDS segments would start on the same two banks)
-    long long mult8 = 0;
-    for (int i = 0; i < n; i++) {
-        const int len = ptrow[i + 1] - ptrow[i];
-        mult8 += len > 0 && len % 8 == 0;
-    }
-    R.skew = 10 * mult8 > n;
+    R.skew = ring_wants_skew(n, ptrow);
     if (const char* e2 = getenv("MI355_RING_SKEW")) R.skew = atoi(e2) != 0;
     return MI_OK;
 }
