@@ -24,6 +24,6 @@ def cold(reps=8):
     return t
 print(n, A.kernel_name(), flush=True)
 for rnd in range(3):
-    for d in ("2", "3", "4"):
+    for d in (os.environ.get("MI355_DEPTHS", "2,3,4").split(",")):
         os.environ["MI355_RING_DEPTH"] = d
         print(f"  round {rnd} depth {d}: back-to-back {pipelined():7.2f} us   cold caches (busy GPU) {cold():7.2f} us", flush=True)
