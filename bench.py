@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--exchange", default=None, choices=["auto", "native", "push", "torch"], help="N > 1: which halo exchange drives the step")
     ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold single-shot and in-pipeline measurements")
+    ap.add_argument("--plain-vectors", action="store_true", help="N = 1, y = A x on a matrix of >= 20 M nonzeros: allocate x and y with torch instead of "
+                    "letting the library place them (mi_vec_alloc_placed: candidate pairs timed, fastest kept — DESIGN 4.12)")
     ap.add_argument("--internal", action="store_true", help="N = 1, y = A x CSR workloads: x and y stay in the library's numbering "
                     "(mi_spmv_internal_dev: a relabelled matrix pays no gather and no mapped store per product; what a Krylov loop does)")
     args = ap.parse_args()
@@ -272,6 +274,7 @@ def main():
             sys.exit("the permuted workloads are 1-GPU configurations")
         p, c, v, _ = synth.permute_nodes(p, c, v, block=W["perm_block"], seed=synth.DEFAULT_SEED)
     x_host = synth.x_sin(lo, hi)
+    vector_info = None
     bcsr = bool(W.get("bcsr"))
     if world == 1 and bcsr:
         bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
@@ -317,6 +320,27 @@ def main():
         ring_cfg, ring_runs, ring_bad, ring_frac = A.ring_info()
         x = torch.from_numpy(x_host).cuda()
         ys = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(k)]
+        if k == 1 and not args.internal and not args.plain_vectors and nnz_global >= 20_000_000 and len(p) - 1 == n:
+            # What a solver that keeps its vectors would do once per solve: let the library place x and y (a product's rate depends on
+            # which physical memory its vectors were handed, on some boxes by 12 %).  The torch-allocated pair is timed first, for the record.
+            def quick(xv, yv, reps=60):
+                for _ in range(10):
+                    mpk.SpMV_CSR(yv, xv, A)
+                q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                q0.record()
+                for _ in range(reps):
+                    mpk.SpMV_CSR(yv, xv, A)
+                q1.record()
+                q1.synchronize()
+                return q0.elapsed_time(q1) / reps * 1e3
+            us_torch = quick(x, ys[0])
+            (xp_, yp_), cand_us = A.alloc_vectors(2, draws=8)
+            xp_.copy_(x)
+            us_placed = quick(xp_, yp_)
+            vector_info = dict(placed=True, torch_allocated_us=round(us_torch, 2), placed_us=round(us_placed, 2), candidate_pairs_us=cand_us,
+                               note="x and y of the timed region were allocated by mi_vec_alloc_placed (eight candidate pairs allocated one after the other, y = A x "
+                                    "timed on each, fastest kept); torch_allocated_us = the same product on plain torch allocations, 60 launches (--plain-vectors runs on those)")
+            x, ys = xp_, [yp_]
         if k == 1 and args.internal:
             x_caller = x
             x = A.to_internal(x_caller)  # once per solve, not once per product
@@ -723,6 +747,8 @@ def main():
                 rs = A.ring_shape_info()
                 if rs["us_aligned"] > 0:  # MI355_RING_SHAPE_COMPARE=1
                     out["kernel_info"]["mring_plan"].update(us_blocks_of_whole_waves=round(rs["us_aligned"], 1), us_unaligned_blocks=round(rs["us_unaligned"], 1))
+        if vector_info:
+            out["kernel_info"]["vectors"] = vector_info
         pl = A.placement_info()
         if pl["values"]:
             out["kernel_info"]["placement_draws_us"] = dict(pl, note="mi_csr_create timed the chosen kernel on fresh device copies of the value array, then of the 16-bit column "

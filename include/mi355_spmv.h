@@ -194,6 +194,17 @@ int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, 
  * with the value array as first allocated ([0]) and after each draw; us[*n_values .. *n_total) the same for the column stream
  * (cap = length of us; both counts 0: no draws were made).  MI355_PLACEMENT_DRAWS=0 turns the draws off, =N sets their number. */
 int mi_csr_placement_info(mi_csr_t A, int* n_values, int* n_total, double* us, int cap);
+/* The same for the CALLER's vectors (round 3): on some MI355X boxes a product with A runs 126 or 141-143 us by which
+ * physical memory its x and y were handed — in windows that follow the order of allocation — whatever the kernel does.  A solver that
+ * keeps its vectors for many products (src/solve_newton.c:1265: one KSPSolve, hundreds of MatMults) can let the library place them:
+ * mi_vec_alloc_placed allocates nvec device vectors of max(rows, columns) doubles each (zero-filled, 256-byte aligned) for use with A,
+ * by allocating `draws` candidate PAIRS one after the other, timing y = A x on each pair (a few launches on stream 0, synchronous),
+ * keeping the nvec vectors of the fastest pairs and freeing the others.  draws <= 1 (or a matrix of < 20 M nonzeros, whose products
+ * live in the caches): plain allocations, nothing timed.  us[0 .. *n_us) = microseconds per launch of each candidate pair in the
+ * order drawn (cap = length of us).  Vectors are released with mi_vec_free_placed (any order, any time after the handle's last use).
+ * Results do not depend on where a vector lies: placement is a matter of speed only. */
+int mi_vec_alloc_placed(mi_csr_t A, int nvec, int draws, double** d_vecs, double* us, int cap, int* n_us);
+int mi_vec_free_placed(double* d_vec);
 /* Multi-window ring kernel (MI_KERNEL_MRING, mring_plan.hpp): mi_csr_create plans it for matrices the single ring does not serve
  * and keeps the plan when it serves >= 90 % of the nonzeros (MI355_MRING=0 never, =1 always keep); mi_csr_set_kernel builds it
  * on request.  us[0..1] = measured microseconds per launch, temporal / non-temporal value loads (MI355_MRING_NT=0|1 forces). */

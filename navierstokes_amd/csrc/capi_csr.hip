@@ -1215,6 +1215,76 @@ extern "C" int mi_csr_placement_info(mi_csr_t A, int* n_values, int* n_total, do
     return MI_OK;
 }
 
+// Placement draws for the caller's vectors (include/mi355_spmv.h)
+extern "C" int mi_vec_alloc_placed(mi_csr_t A, int nvec, int draws, double** d_vecs, double* us, int cap, int* n_us)
+{
+    CHECK_ARG(A && nvec >= 1 && d_vecs && cap >= 0 && (cap == 0 || us), "bad argument");
+    int rc = need_device();
+    if (rc) return rc;
+    if (n_us) *n_us = 0;
+    const size_t len = (size_t)std::max(A->n, A->ncols) + 64; // (64 doubles of slack: the kernels' clamped loads stay inside)
+    const size_t bytes = sizeof(double) * len;
+    const int npairs = (nvec + 1) / 2;
+    if (draws > 64) draws = 64;
+    const bool timed = draws > npairs && A->nnz >= kLargeNnz && A->n == A->ncols;
+    const int cand = timed ? draws : npairs;
+    std::vector<double*> xs((size_t)cand, nullptr), ys((size_t)cand, nullptr);
+    auto release = [&]() {
+        for (double* q : xs) dfree(q);
+        for (double* q : ys) dfree(q);
+    };
+    for (int c = 0; c < cand; c++) { // pairs one after the other: the levels come in windows of consecutive allocations
+        hipError_t e = hipMalloc(&xs[c], bytes);
+        if (e == hipSuccess) e = hipMalloc(&ys[c], bytes);
+        if (e == hipSuccess) e = hipMemset(xs[c], 0, bytes);
+        if (e == hipSuccess) e = hipMemset(ys[c], 0, bytes);
+        if (e != hipSuccess) {
+            release();
+            return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("mi_vec_alloc_placed: ") + hipGetErrorString(e));
+        }
+    }
+    std::vector<int> order((size_t)cand);
+    for (int c = 0; c < cand; c++) order[c] = c;
+    if (timed) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        std::vector<double> t((size_t)cand, 0.0);
+        bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        for (int c = 0; c < cand && ok; c++) {
+            for (int w = 0; w < 4 && ok; w++) ok = mi_spmv_dev(A, xs[c], ys[c], nullptr) == MI_OK;
+            ok = ok && hipEventRecord(e0, nullptr) == hipSuccess;
+            for (int w = 0; w < 10 && ok; w++) ok = mi_spmv_dev(A, xs[c], ys[c], nullptr) == MI_OK;
+            float ms = 0.f;
+            ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            t[c] = ms * 1e3 / 10;
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (!ok) {
+            release();
+            return fail(MI_ERR_HIP, "mi_vec_alloc_placed: timing a candidate pair failed");
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t[a] < t[b]; });
+        for (int c = 0; c < cand && c < cap; c++) us[c] = t[c];
+        if (n_us) *n_us = std::min(cand, cap);
+        // y = A * 0 left zeros in the y candidates (or NaN-free garbage if A holds infinities): hand out zero-filled vectors
+        for (int c = 0; c < cand; c++) (void)hipMemset(ys[c], 0, bytes);
+        (void)hipDeviceSynchronize();
+    }
+    for (int v = 0; v < nvec; v++) { // vector 2k and 2k + 1 = the x and the y of the k-th fastest pair
+        double*& slot = (v & 1) ? ys[order[v >> 1]] : xs[order[v >> 1]];
+        d_vecs[v] = slot;
+        slot = nullptr;
+    }
+    release(); // everything not handed out
+    return MI_OK;
+}
+
+extern "C" int mi_vec_free_placed(double* d_vec)
+{
+    if (d_vec) HIP_TRY(hipFree(d_vec));
+    return MI_OK;
+}
+
 extern "C" int mi_csr_mring_info(mi_csr_t A, int* built, int* runs, int* runs_not_served, double* nnz_fraction_served, double us[2], int* nt)
 {
     CHECK_ARG(A, "null handle");

@@ -111,6 +111,8 @@ def lib():
         "mi_bcsr4_tile_info": [_vp, P(i), P(i), P(d), P(d)],
         "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
         "mi_csr_placement_info": [_vp, P(i), P(i), P(d), i],
+        "mi_vec_alloc_placed": [_vp, i, i, P(_vp), P(d), i, P(i)],
+        "mi_vec_free_placed": [_vp],
         "mi_mring_plan_deal_probe": [i, _vp, _vp, P(i), _vp, i],
         "mi_mring_plan_probe": [i, _vp, _vp, P(i), P(i), P(i), P(d), P(ll)],
         "mi_tile_plan_probe": [i, _vp, _vp, i, P(i), P(ll), P(i), P(ll)],
@@ -310,6 +312,25 @@ class csrmatrix:
         check(lib().mi_csr_placement_info(self.handle, _c.byref(nv), _c.byref(nt), us, 32))
         return dict(values=[round(us[k], 2) for k in range(nv.value)], column_stream=[round(us[k], 2) for k in range(nv.value, nt.value)])
 
+    def alloc_vectors(self, nvec=2, draws=8):
+        """nvec device vectors (torch float64 tensors of length n, zero-filled) placed for products with this matrix —
+        mi_vec_alloc_placed: the library allocates `draws` candidate x / y pairs, times y = A x on each and keeps the fastest
+        (where a vector lies in device memory moves a product by up to 12 % on some boxes).
+        Returns (tensors, us_per_candidate_pair).  The memory belongs to the returned tensors' `_placed` owner: it is released
+        when the last of them is garbage-collected."""
+        import torch
+        ptrs = (_vp * nvec)()
+        us = (_c.c_double * 64)()
+        nus = _c.c_int()
+        check(lib().mi_vec_alloc_placed(self.handle, nvec, draws, ptrs, us, 64, _c.byref(nus)))
+        out = []
+        for k in range(nvec):
+            buf = _PlacedBuffer(int(ptrs[k]), max(self.n, self.ncols))
+            t = torch.as_tensor(buf, device="cuda")[: self.n]
+            t._placed = buf  # keeps the allocation alive as long as the tensor object lives
+            out.append(t)
+        return out, [round(us[k], 2) for k in range(nus.value)]
+
     def mring_info(self):
         """dict(built, runs, runs_not_served, nnz_fraction, us, us_nt, nt) — mi_csr_mring_info (multi-window ring plan)."""
         b, r, bad, nt = _c.c_int(), _c.c_int(), _c.c_int(), _c.c_int()
@@ -458,6 +479,22 @@ def COO2CSR(nrow, irow, jcol, val):
     np.add.at(ptrow, r + 1, 1)
     ptrow = np.cumsum(ptrow)
     return csrmatrix(nrow, ptrow.astype(np.int32), c.astype(np.int32), v)
+
+
+class _PlacedBuffer:
+    """A device vector allocated by mi_vec_alloc_placed, visible to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.ptr = ptr
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().mi_vec_free_placed(self.ptr)
+                self.ptr = 0
+        except Exception:
+            pass
 
 
 # --------------------------------------------------------------------- SpMV

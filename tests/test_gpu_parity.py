@@ -350,6 +350,39 @@ def test_block_shape_of_large_and_small_matrices(monkeypatch):
     assert_bit_equal(ys.cpu().numpy(), O.spmv(p, c, v, xs), "small matrix, whole-wave blocks")
 
 
+def test_vectors_placed_by_the_library():
+    """mi_vec_alloc_placed (round 3): x and y allocated by the library after timing candidate pairs.  Placement is a matter
+    of speed only — the product on placed vectors is the reference's fma chain bit for bit (mpk/SpMV.cpp:23-56) — candidates are timed
+    only for matrices beyond the caches, and the vectors come zero-filled and are released with their tensors."""
+    n = 1_400_000  # 21 M nonzeros: candidates are timed
+    p, c, v = synth.rows("s15", n)
+    x = synth.x_sin(0, n)
+    A = mpk.csrmatrix(n, p, c, v)
+    (xp, yp, zp), us = A.alloc_vectors(3, draws=4)
+    assert len(us) == 4 and all(t > 0 for t in us), us
+    for t in (xp, yp, zp):
+        assert t.shape == (n,) and t.dtype == torch.float64 and t.is_cuda and float(t.abs().max()) == 0.0
+        assert t.data_ptr() % 256 == 0
+    assert len({xp.data_ptr(), yp.data_ptr(), zp.data_ptr()}) == 3
+    xp.copy_(dev(x))
+    mpk.SpMV_CSR(yp, xp, A)
+    yo = O.spmv(p, c, v, x)
+    assert_bit_equal(yp.cpu().numpy(), yo, "product on placed vectors")
+    mpk.SpMV_CSR(zp, yp, A)  # and chained: a placed vector as the next product's input
+    assert_bit_equal(zp.cpu().numpy(), O.spmv(p, c, v, yo), "second product on placed vectors")
+    del xp, yp, zp
+    A.close()
+    m = 50_000  # small: plain allocations, nothing timed
+    p, c, v = synth.rows("s15", m)
+    S = mpk.csrmatrix(m, p, c, v)
+    (a, b), us = S.alloc_vectors(2, draws=8)
+    assert us == [] and float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0
+    xs = synth.x_sin(0, m)
+    a.copy_(dev(xs))
+    mpk.SpMV_CSR(b, a, S)
+    assert_bit_equal(b.cpu().numpy(), O.spmv(p, c, v, xs), "small matrix, placed (plainly allocated) vectors")
+
+
 def test_full_size_c4_and_c3():
     """BASELINE configs at full size.  C4: 5 M rows / 75 M nnz single SpMV; C3: k = 4 matrix powers on the
     1 M-row matrix.  Both bitwise against the oracle's fma chain, plus the size-independent
