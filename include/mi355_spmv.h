@@ -198,7 +198,8 @@ int mi_csr_placement_info(mi_csr_t A, int* n_values, int* n_total, double* us, i
  * physical memory its x and y were handed — in windows that follow the order of allocation — whatever the kernel does.  A solver that
  * keeps its vectors for many products (src/solve_newton.c:1265: one KSPSolve, hundreds of MatMults) can let the library place them:
  * mi_vec_alloc_placed allocates nvec device vectors of max(rows, columns) doubles each (zero-filled, 256-byte aligned) for use with A,
- * by allocating `draws` candidate PAIRS one after the other, timing y = A x on each pair (a few launches on stream 0, synchronous),
+ * by allocating `draws` candidate PAIRS one after the other (the first: the scratch pair mi_csr_create's own placement draws were timed
+ * on, kept by the handle for this call), timing y = A x on each pair (a few launches on stream 0, synchronous),
  * keeping the nvec vectors of the fastest pairs and freeing the others.  draws <= 1 (or a matrix of < 20 M nonzeros, whose products
  * live in the caches): plain allocations, nothing timed.  us[0 .. *n_us) = microseconds per launch of each candidate pair in the
  * order drawn (cap = length of us).  Vectors are released with mi_vec_free_placed (any order, any time after the handle's last use).

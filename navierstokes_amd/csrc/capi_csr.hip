@@ -75,6 +75,8 @@ static bool ring_wants_skew(int n, const int* ptrow)
 }
 
 constexpr long long kLargeNnz = 20000000;
+// doubles in a vector handed out by mi_vec_alloc_placed (64 of slack: the kernels' clamped loads stay inside)
+static size_t placed_vector_len(int n, int ncols) { return (size_t)std::max(n, ncols) + 64; }
 static int large_row_align(long long nnz) { return nnz >= kLargeNnz ? 1 : 0; }
 
 static int build_mring(mi_csr_t A, const int* indcol, int row_align = 0)
@@ -405,8 +407,14 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         struct TuneScratch { // released on every exit path, the early error returns of TRY_OR_CLEAN included
             double *tx = nullptr, *ty = nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr;
+            mi_csr_s* keep_into = nullptr; // set once the placement draws are through: the handle keeps the pair they were timed on
             ~TuneScratch()
             {
+                if (keep_into) {
+                    keep_into->kept_x = tx;
+                    keep_into->kept_y = ty;
+                    tx = ty = nullptr;
+                }
                 dfree(tx);
                 dfree(ty);
                 if (e0) (void)hipEventDestroy(e0);
@@ -415,9 +423,11 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         } ts;
         double *&tx = ts.tx, *&ty = ts.ty;
         hipEvent_t &e0 = ts.e0, &e1 = ts.e1;
-        TRY_OR_CLEAN(hipMalloc(&tx, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
-        TRY_OR_CLEAN(hipMalloc(&ty, sizeof(double) * (size_t)(A->n_out > 0 ? A->n_out : 1)));
-        TRY_OR_CLEAN(hipMemset(tx, 0, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1)));
+        // (sized like the vectors mi_vec_alloc_placed hands out: for a large square matrix this very pair becomes its first candidate)
+        const size_t scratch_len = placed_vector_len(n, ncols);
+        TRY_OR_CLEAN(hipMalloc(&tx, sizeof(double) * std::max(scratch_len, (size_t)(ncols > 0 ? ncols : 1))));
+        TRY_OR_CLEAN(hipMalloc(&ty, sizeof(double) * std::max(scratch_len, (size_t)(A->n_out > 0 ? A->n_out : 1))));
+        TRY_OR_CLEAN(hipMemset(tx, 0, sizeof(double) * std::max(scratch_len, (size_t)(ncols > 0 ? ncols : 1))));
         TRY_OR_CLEAN(hipEventCreate(&e0));
         TRY_OR_CLEAN(hipEventCreate(&e1));
         const bool ring_ok = A->auto_kernel == MI_KERNEL_RING;
@@ -599,6 +609,9 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
                 A->place_draws_coef = (int)A->place_us.size();
                 if (A->auto_kernel == MI_KERNEL_RING) redraw((void**)&A->ring.d_slots, sizeof(unsigned short) * (size_t)A->ring.nblk * A->ring.cfg.nnzb, (draws + 1) / 2);
                 else if (A->auto_kernel == MI_KERNEL_MRING) redraw((void**)&A->mring.d_slots, sizeof(unsigned short) * (size_t)A->mring.nblk * kMringNnzb, (draws + 1) / 2);
+                // The draws chose copies that are fast WITH THIS x / y pair; a caller that asks the library for its vectors gets the pair
+                // itself as the first candidate (user-facing square handles only: a partition's pieces and mapped views are not handed vectors)
+                if (!rowmap && n == ncols && n == A->n_out && !(ghost_lo < ghost_hi)) ts.keep_into = A;
             }
         }
     }
@@ -845,6 +858,8 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->d_rowmap);
     dfree(A->d_x);
     dfree(A->d_y);
+    dfree(A->kept_x);
+    dfree(A->kept_y);
     for (double* p : A->d_pow) dfree(p);
     for (auto& kv : A->tables) {
         dfree(kv.second.d_blk);
@@ -1222,8 +1237,7 @@ extern "C" int mi_vec_alloc_placed(mi_csr_t A, int nvec, int draws, double** d_v
     int rc = need_device();
     if (rc) return rc;
     if (n_us) *n_us = 0;
-    const size_t len = (size_t)std::max(A->n, A->ncols) + 64; // (64 doubles of slack: the kernels' clamped loads stay inside)
-    const size_t bytes = sizeof(double) * len;
+    const size_t bytes = sizeof(double) * placed_vector_len(A->n, A->ncols);
     const int npairs = (nvec + 1) / 2;
     if (draws > 64) draws = 64;
     const bool timed = draws > npairs && A->nnz >= kLargeNnz && A->n == A->ncols;
@@ -1234,8 +1248,16 @@ extern "C" int mi_vec_alloc_placed(mi_csr_t A, int nvec, int draws, double** d_v
         for (double* q : ys) dfree(q);
     };
     for (int c = 0; c < cand; c++) { // pairs one after the other: the levels come in windows of consecutive allocations
-        hipError_t e = hipMalloc(&xs[c], bytes);
-        if (e == hipSuccess) e = hipMalloc(&ys[c], bytes);
+        hipError_t e = hipSuccess;
+        if (c == 0 && A->kept_x && A->kept_y) { // the pair the create-time placement draws were timed on (ownership leaves the handle)
+            xs[0] = A->kept_x;
+            ys[0] = A->kept_y;
+            A->kept_x = A->kept_y = nullptr;
+        } else {
+            e = hipMalloc(&xs[c], bytes);
+            if (e == hipSuccess) e = hipMalloc(&ys[c], bytes);
+        }
+        // (the kept pair too: its y holds what the draws' products left there)
         if (e == hipSuccess) e = hipMemset(xs[c], 0, bytes);
         if (e == hipSuccess) e = hipMemset(ys[c], 0, bytes);
         if (e != hipSuccess) {

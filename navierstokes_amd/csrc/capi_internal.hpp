@@ -144,6 +144,7 @@ struct mi_csr_s {
     int auto_kernel = MI_KERNEL_STREAM;
     std::vector<double> place_us; // placement draws at create (capi_csr.hip): microseconds per launch, value array first ([0] = as first allocated) ...
     int place_draws_coef = 0;     // ... place_us[0 .. place_draws_coef) belong to the value array, the rest to the 16-bit column stream
+    double *kept_x = nullptr, *kept_y = nullptr; // the scratch pair the placement draws were timed on, kept for mi_vec_alloc_placed (its first candidate)
     double tune_us_ring = 0.0, tune_us_ring_nt = 0.0, tune_us_stream = 0.0, tune_us_stream_nt = 0.0;
     double tune_us_ring_aligned = 0.0, tune_us_ring_unaligned = 0.0; // large matrices: the two block shapes (0 = not compared)
     bool stream_nt = false; // non-temporal matrix loads in the stream kernel
