@@ -192,7 +192,8 @@ int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, 
  * chosen kernel on a few fresh device copies of the value array, then of the 16-bit column stream, and keeps the fastest copy of
  * each — where these arrays lie in device memory moves a warm launch by up to 15 %.  us[0 .. *n_values) = microseconds per launch
  * with the value array as first allocated ([0]) and after each draw; us[*n_values .. *n_total) the same for the column stream
- * (cap = length of us; both counts 0: no draws were made).  MI355_PLACEMENT_DRAWS=0 turns the draws off, =N sets their number. */
+ * (cap = length of us; both counts 0: no draws were made).  MI355_PLACEMENT_DRAWS=0 turns the draws off, =N sets their number
+ * (default 12 for the value array, capped so that the copies fit an eighth of the free device memory; half as many for the stream). */
 int mi_csr_placement_info(mi_csr_t A, int* n_values, int* n_total, double* us, int cap);
 /* The same for the CALLER's vectors (round 3): on some MI355X boxes a product with A runs 126 or 141-143 us by which
  * physical memory its x and y were handed — in windows that follow the order of allocation — whatever the kernel does.  A solver that

@@ -580,10 +580,19 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         // records nothing; no allocation flag or address property found that predicts it).  So for matrices beyond the caches the
         // chosen kernel is timed on a few fresh copies of those two arrays and the fastest copy is the one kept; every candidate
         // stays allocated until the draws are over (a freed block would just be handed out again).  MI355_PLACEMENT_DRAWS=0 turns
-        // it off, =N sets the number of draws (default 4 for the values, 2 for the column stream).
+        // it off, =N sets the number of draws (default 12 for the values — as many as fit an eighth of the free device memory —, half as
+        // many for the column stream).  Twelve since the round's second session: on one box the draws of three processes read
+        // [143 143 148 148 148 148 148 136 135 135 122.7 122.7 122.5] us, the same in each — the fast stretch of device memory began
+        // 6 GB into the process's allocations, out of reach of four draws (25 ms and 7 GB, both transient, for a 600 MB value array).
         {
             const char* pe = getenv("MI355_PLACEMENT_DRAWS");
-            const int draws = pe ? std::max(0, std::min(16, atoi(pe))) : 4;
+            int draws = pe ? std::max(0, std::min(16, atoi(pe))) : 12;
+            if (!pe) {
+                size_t mem_free = 0, mem_total = 0;
+                if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && nnz > 0)
+                    draws = (int)std::min<size_t>((size_t)draws, mem_free / 8 / (sizeof(double) * (size_t)nnz));
+                else (void)hipGetLastError();
+            }
             const bool streams_coef = A->auto_kernel == MI_KERNEL_RING || A->auto_kernel == MI_KERNEL_MRING || A->auto_kernel == MI_KERNEL_STREAM || A->auto_kernel == MI_KERNEL_TILE;
             if (draws > 0 && streams_coef && nnz >= 20000000) {
                 auto redraw = [&](void** slot, size_t bytes, int ndraws) {
