@@ -593,7 +593,8 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
                     draws = (int)std::min<size_t>((size_t)draws, mem_free / 8 / (sizeof(double) * (size_t)nnz));
                 else (void)hipGetLastError();
             }
-            const bool streams_coef = A->auto_kernel == MI_KERNEL_RING || A->auto_kernel == MI_KERNEL_MRING || A->auto_kernel == MI_KERNEL_STREAM || A->auto_kernel == MI_KERNEL_TILE;
+            const bool blocked_choice = A->auto_kernel == MI_KERNEL_BCSR4 && A->blocked && A->blocked->d_coef;
+            const bool streams_coef = A->auto_kernel == MI_KERNEL_RING || A->auto_kernel == MI_KERNEL_MRING || A->auto_kernel == MI_KERNEL_STREAM || A->auto_kernel == MI_KERNEL_TILE || blocked_choice;
             if (draws > 0 && streams_coef && nnz >= 20000000) {
                 auto redraw = [&](void** slot, size_t bytes, int ndraws) {
                     double best = 0.0;
@@ -614,7 +615,9 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
                     }
                     for (void* l : losers) dfree(l);
                 };
-                redraw((void**)&A->d_coef, sizeof(double) * (size_t)nnz, draws);
+                // (a matrix that runs the blocked kernel streams the BLOCKED copy's values: 16 doubles per block, zero fill included)
+                if (blocked_choice) redraw((void**)&A->blocked->d_coef, sizeof(double) * 16 * (size_t)A->blocked->nblocks, draws);
+                else redraw((void**)&A->d_coef, sizeof(double) * (size_t)nnz, draws);
                 A->place_draws_coef = (int)A->place_us.size();
                 if (A->auto_kernel == MI_KERNEL_RING) redraw((void**)&A->ring.d_slots, sizeof(unsigned short) * (size_t)A->ring.nblk * A->ring.cfg.nnzb, (draws + 1) / 2);
                 else if (A->auto_kernel == MI_KERNEL_MRING) redraw((void**)&A->mring.d_slots, sizeof(unsigned short) * (size_t)A->mring.nblk * kMringNnzb, (draws + 1) / 2);
