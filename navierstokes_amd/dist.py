@@ -440,6 +440,25 @@ class DistCSR:
                 dist.all_reduce(part, group=self.group)
         return part
 
+    def orthogonalize(self, b_local, x1_local, x3_local, alpha=1e-8):
+        """x3 = x1 - alpha (b . x1) b across ranks — orthogonalize(n, b, x1, x3, alpha), mpk/SpMVmulti.cpp:146-151, with the dot made
+        global: every rank's fixed-tree partial, one all_reduce of a double, then the reference's fused update on the owned slice,
+        x3_i = fma(-(alpha * beta), b_i, x1_i) — bit-equal to the single-GPU update GIVEN beta (an axpy with a = -(alpha * beta) is that
+        very fma).  Returns beta as a 1-element tensor.  x3 may be x1 (in place, the form of mpk/2SpMV.cpp:3-11)."""
+        beta = self.dot(b_local, x1_local)
+        a = -(float(alpha) * float(beta))  # (one host read of the reduced scalar: the all_reduce has synchronised the ranks anyway)
+        if x3_local.data_ptr() != x1_local.data_ptr():
+            x3_local.copy_(x1_local)
+        if self.compute is None:
+            mpk.axpy(a, b_local, x3_local)
+        else:  # CPU ranks (gloo tests): the same fma, element by element
+            from fractions import Fraction  # exact product and sum, one rounding: int / int division rounds correctly
+            bb, xx = b_local.numpy(), x3_local.numpy()
+            fa = Fraction(a)
+            for i in range(len(xx)):
+                xx[i] = float(fa * Fraction(float(bb[i])) + Fraction(float(xx[i])))
+        return beta
+
     def close(self):
         if self._h is not None:
             mpk.lib().mi_part_destroy(self._h)

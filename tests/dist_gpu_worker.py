@@ -106,6 +106,15 @@ def main():
         g = float(dc.dot(ys[0], ys[0]))
         ref = float(np.dot(Y[0], Y[0]))
         ok = ok and abs(g - ref) <= 1e-12 * ref
+        # distributed orthogonalize (mpk/SpMVmulti.cpp:146-151): global beta inside the reduction bound, and GIVEN that beta the owned
+        # slice of x3 is the reference's fused update fma(-(alpha beta), b, x1) bit for bit (oracle: orc_ortho_update)
+        x3 = torch.empty_like(ys[1])
+        beta = float(dc.orthogonalize(ys[0], ys[1], x3, 1e-8))
+        torch.cuda.synchronize()
+        ref_beta, bound = float(np.dot(Y[0], Y[1])), float(np.dot(np.abs(Y[0]), np.abs(Y[1])))
+        ok = ok and abs(beta - ref_beta) <= 1e-13 * bound
+        ok = ok and np.array_equal(x3.cpu().numpy().view(np.uint64), O.ortho_update(1e-8 * beta, Y[0][lo:hi], Y[1][lo:hi]).view(np.uint64))
+        mark("distributed orthogonalize done")
         dc.close()
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -52,7 +52,19 @@ def main():
     ok = all(np.array_equal(ys[k].numpy().view(np.uint64), Y[k][lo:hi].view(np.uint64)) for k in range(3))
     g = dc.dot(ys[0], ys[0])
     ok_dot = abs(float(g) - float(np.dot(Y[0], Y[0]))) <= 1e-12 * float(np.dot(Y[0], Y[0]))
-    flag = torch.tensor([1 if (ok and ok_dot) else 0])
+    # distributed orthogonalize (mpk/SpMVmulti.cpp:146-151): beta within the reduction bound, the update the reference's fma GIVEN beta
+    b_loc, x1_loc = ys[0][: min(len(ys[0]), 2000)].clone(), ys[1][: min(len(ys[1]), 2000)].clone()
+    x3_loc = torch.empty_like(x1_loc)
+    beta = float(dc.orthogonalize(b_loc, x1_loc, x3_loc, 1e-8))
+    from fractions import Fraction
+    a = -(1e-8 * beta)
+    want = np.array([float(Fraction(a) * Fraction(float(b_loc[i])) + Fraction(float(x1_loc[i]))) for i in range(len(x1_loc))])
+    parts = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    mine = torch.tensor([float(torch.dot(b_loc, x1_loc)), float(torch.dot(b_loc.abs(), x1_loc.abs()))], dtype=torch.float64)
+    dist.all_gather(parts, mine)
+    ref_beta, bound = sum(float(t[0]) for t in parts), sum(float(t[1]) for t in parts)
+    ok_ortho = np.array_equal(x3_loc.numpy().view(np.uint64), want.view(np.uint64)) and abs(beta - ref_beta) <= 1e-13 * bound
+    flag = torch.tensor([1 if (ok and ok_dot and ok_ortho) else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(f"DIST_RESULT ok={int(flag)} world={world} halo={dc.n_halo} boundary={dc.n_boundary} interior={dc.n_interior}")
