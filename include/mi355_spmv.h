@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 301 /* 0.3.1 */
+#define MI355_SPMV_VERSION 400 /* 0.4.0 */
 
 enum {
     MI_OK = 0,
@@ -460,6 +460,67 @@ int mi_part_push_disable(mi_part_t P);
  * `count` doubles to itself through the same send/recv/stream/event code path
  * (the per-step cost measurements of this path live in tools/comm_timing.hip) */
 int mi_comm_selftest(int count, double* max_abs_err);
+
+/* ---- ONE process, N GPUs: the row-range partition behind a single handle -------------------------------------------
+ * "mi_dist_create(ndev, ...)"; "Threading: one host thread drives all GPUs (or one per GPU internally), hidden
+ * behind the ABI".  The reference's callers are single-process C++ programs that call SpMV_CSR(y, x, A) from one thread
+ * (mpk/2SpMV.cpp:128-141, mpk/SpM2V.cpp:885-889, mpk/SpMVmulti0.cpp:369-411 behind the seam mpk/SpMV.h:52-66): this is the form
+ * of the multi-GPU path they can reach (the mpk/SpMV.h shim routes to it with MI355_NGPUS=N).  The
+ * mi_part_* entry points above are its per-rank building blocks and stay what a process-per-GPU host (bench.py, torch.distributed)
+ * drives itself.
+ *
+ * mi_dist_create cuts the n rows into ndev contiguous ranges of (nearly) equal nonzero count — at node boundaries for a matrix
+ * with exact 4x4 node-block structure —, plans every rank's share (partition.hpp: columns relabelled to owned | ghosts, each
+ * row's nonzeros kept in the caller's order, so every row of y is the CSR-ordered fma chain of SpMV_CSR_FMA for every ndev),
+ * uploads rank r's pieces to device r mod (devices present) — MI355_DIST_DEVICES="0,2,..." overrides the map — and starts one
+ * worker thread per rank, which enqueues that rank's launches from then on.  Host pointers; the caller's arrays are not retained.
+ * The halo exchange of a step is chosen at create (mi_dist_exchange_name / _note say which and why):
+ *   "push"   ranks on distinct devices with peer access: the peer-push step of mi_part_spmv_push_dev (one launch per rank in its
+ *            fused form) with the neighbours' windows reached through peer pointers;
+ *   "rccl"   mi_part_spmv_dev per rank (grouped ncclSend / ncclRecv on the rank's comm stream);
+ *   "event"  any rank-to-device map, N ranks on ONE device included: halo entries copied straight into the peers' vectors with
+ *            hipMemcpyPeerAsync on the sender's stream, ordered by HIP events.
+ * A candidate is used only after one product through it equalled one through the event exchange bit for bit on every rank.
+ * MI355_DIST_EXCHANGE=event|push|rccl forces one (create fails if it is not usable). */
+typedef struct mi_dist_s* mi_dist_t;
+typedef struct mi_dist_vec_s* mi_dist_vec_t; /* a vector distributed like the rows: per rank [owned | halo] on the rank's device */
+int mi_dist_create(int ndev, int n, const int* ptrow, const int* indcol, const double* coef, mi_dist_t* out);
+int mi_dist_destroy(mi_dist_t D);
+/* *exchange: 0 event, 1 push, 2 rccl; *fused = 1: the push step is one launch per rank; halo_*: ghost entries over all ranks / of the largest */
+int mi_dist_info(mi_dist_t D, int* nranks, int* distinct_devices, int* exchange, int* fused, long long* halo_total, long long* halo_max);
+const char* mi_dist_exchange_name(mi_dist_t D);
+const char* mi_dist_exchange_note(mi_dist_t D); /* what was tried at create, in order, and why a candidate was dropped */
+int mi_dist_rank_info(mi_dist_t D, int rank, int* device, long long* row_start, int* n_local, int* n_halo, long long* nnz_local,
+                      mi_stream_t* stream /* the stream the rank's work is enqueued on */);
+/* new coefficients for an unchanged pattern, in the order of the arrays given to mi_dist_create (see mi_csr_update_values) */
+int mi_dist_update_values(mi_dist_t D, const double* coef);
+/* Host vectors of length n — the reference's calling convention: scatter, compute, gather, synchronise.
+ *   mi_dist_spmv          y = A x                                  SpMV_CSR{,_OPT,_FMA,_AVX2}, mpk/SpMV.cpp:6-85
+ *   mi_dist_spmk          y_out[p] = A^(p+1) x, one exchange per power   SpM2V_CSR mpk/SpM2V.cpp:79-112, SpM3V / SpM4V mpk/SpMVmulti0.cpp:132-221
+ *   mi_dist_dot           every rank's fixed-tree partial (mi_dot_dev), summed on the host in rank order: deterministic for a given
+ *                         ndev, inside the bound documented at mi_dot
+ *   mi_dist_orthogonalize x3 = fma(-(alpha * beta), b, x1) with beta = that dot   orthogonalize, mpk/SpMVmulti.cpp:146-151
+ *                         (x3 == x1 allowed: the in-place form of mpk/2SpMV.cpp:3-11); given beta the update is the reference's bits */
+int mi_dist_spmv(mi_dist_t D, const double* x, double* y);
+int mi_dist_spmk(mi_dist_t D, int k, const double* x, double* const* y_out);
+int mi_dist_dot(mi_dist_t D, const double* x, const double* y, double* out);
+int mi_dist_orthogonalize(mi_dist_t D, const double* b, const double* x1, double* x3, double alpha, double* beta_out);
+/* Device-resident vectors (a solver that keeps its vectors on the GPUs between products).  mi_dist_vec_set / _get move a full
+ * host vector in / out (synchronous); mi_dist_vec_ptr gives rank r's buffer (n_local + n_halo doubles on the rank's device; the
+ * owned entries first) for the caller's own kernels, to be enqueued on the rank's stream (mi_dist_rank_info). */
+int mi_dist_vec_create(mi_dist_t D, mi_dist_vec_t* out);
+int mi_dist_vec_destroy(mi_dist_vec_t v);
+int mi_dist_vec_set(mi_dist_vec_t v, const double* host /* [n] */);
+int mi_dist_vec_get(mi_dist_vec_t v, double* host /* [n] */);
+int mi_dist_vec_ptr(mi_dist_vec_t v, int rank, double** d_ptr);
+/* Asynchronous: the step is enqueued on every rank's stream when the call returns; mi_dist_synchronize waits for all ranks and
+ * reports an in-kernel wait that gave up (push) or a hand-off time-out (rccl).  x and y (and the k outputs) must be distinct vectors. */
+int mi_dist_spmv_dev(mi_dist_t D, mi_dist_vec_t x, mi_dist_vec_t y);
+int mi_dist_spmk_dev(mi_dist_t D, int k, mi_dist_vec_t x, const mi_dist_vec_t* y_out /* host array of k vectors */);
+int mi_dist_synchronize(mi_dist_t D);
+/* the reductions return their scalar on the host and therefore synchronise */
+int mi_dist_dot_dev(mi_dist_t D, mi_dist_vec_t a, mi_dist_vec_t b, double* out);
+int mi_dist_orthogonalize_dev(mi_dist_t D, mi_dist_vec_t b, mi_dist_vec_t x1, mi_dist_vec_t x3, double alpha, double* beta_out);
 
 #ifdef __cplusplus
 }

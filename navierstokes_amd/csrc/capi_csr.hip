@@ -227,8 +227,108 @@ static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const 
 
 static int time_handle(mi_csr_t A, int warm, int timed, double* us);
 
+// Placement draws (round 3; FROZEN in round 4: no further work goes into it).  WHERE the value array lies in device
+// memory moves a warm launch of the streaming kernels by up to 15 % on some boxes (tools/placement_lottery.py: 137-139 us against 158-166
+// for handles of one and the same matrix and plan in one process; the coefficient array decides, the 16-bit column stream adds a few us,
+// row pointers and plan records nothing; no allocation flag or address property found that predicts it).  So for matrices beyond the
+// caches the chosen kernel is timed on a few fresh copies of those two arrays and the fastest copy is the one kept; every candidate
+// stays allocated until the draws are over (a freed block would just be handed out again).
+// Default since round 4: at most 4 draws of the value array (2 of the column stream), and none after the first when the first copy
+// times within 2 % of the original (a box where placements are alike: nothing to find).  MI355_PLACEMENT_DRAWS=N (0..16) sets the
+// number and disables the early stop — the 12-draw / 7 GB form of round 3 is MI355_PLACEMENT_DRAWS=12; =0 turns the draws off.
+// tx / ty: the x / y pair to time on (null: a fresh pair is allocated; kept as A->kept_x/y when keep_pair and draws were made).
+static int placement_draws(mi_csr_t A, double* tx, double* ty, bool keep_pair)
+{
+    const long long nnz = A->nnz;
+    const char* pe = getenv("MI355_PLACEMENT_DRAWS");
+    int draws = pe ? std::max(0, std::min(16, atoi(pe))) : 4;
+    const bool early_stop = pe == nullptr;
+    if (!pe) {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && nnz > 0)
+            draws = (int)std::min<size_t>((size_t)draws, mem_free / 8 / (sizeof(double) * (size_t)nnz));
+        else (void)hipGetLastError();
+    }
+    const bool blocked_choice = A->auto_kernel == MI_KERNEL_BCSR4 && A->blocked && A->blocked->d_coef;
+    const bool streams_coef = A->auto_kernel == MI_KERNEL_RING || A->auto_kernel == MI_KERNEL_MRING || A->auto_kernel == MI_KERNEL_STREAM || A->auto_kernel == MI_KERNEL_TILE || blocked_choice;
+    if (!(draws > 0 && streams_coef && nnz >= kLargeNnz)) return MI_OK;
+    struct Own {
+        double *x = nullptr, *y = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Own()
+        {
+            dfree(x);
+            dfree(y);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } own;
+    if (!tx || !ty) {
+        const size_t len = std::max(placed_vector_len(A->n, A->ncols), (size_t)(A->n_out > 0 ? A->n_out : 1));
+        HIP_TRY(hipMalloc(&own.x, sizeof(double) * len));
+        HIP_TRY(hipMalloc(&own.y, sizeof(double) * len));
+        HIP_TRY(hipMemset(own.x, 0, sizeof(double) * len));
+        tx = own.x;
+        ty = own.y;
+    }
+    HIP_TRY(hipEventCreate(&own.e0));
+    HIP_TRY(hipEventCreate(&own.e1));
+    auto time_now = [&](int warm, int timed, double* us_out) -> int {
+        int rc2;
+        for (int w = 0; w < warm; w++)
+            if ((rc2 = launch_spmv(A, tx, ty, nullptr))) return rc2;
+        if (hipEventRecord(own.e0, nullptr) != hipSuccess) return MI_ERR_HIP;
+        for (int w = 0; w < timed; w++)
+            if ((rc2 = launch_spmv(A, tx, ty, nullptr))) return rc2;
+        float ms = 0.f;
+        if (hipEventRecord(own.e1, nullptr) != hipSuccess || hipEventSynchronize(own.e1) != hipSuccess || hipEventElapsedTime(&ms, own.e0, own.e1) != hipSuccess) return MI_ERR_HIP;
+        *us_out = ms * 1e3 / timed;
+        return MI_OK;
+    };
+    // pad_bytes: the zeroed tail the array was ALLOCATED with behind its payload — the ring family's unclamped loads read up to
+    // kRingPadNnz values past the last nonzero, the blocked kernel one block past the last block; a copy must carry it too
+    // (round 3's draws copied the payload into an exactly-sized buffer: every product on a redrawn array then read past its end)
+    auto redraw = [&](void** slot, size_t bytes, size_t pad_bytes, int ndraws) {
+        double best = 0.0;
+        if (!*slot || bytes == 0 || time_now(3, 8, &best) != MI_OK) return;
+        const double first = best;
+        A->place_us.push_back(best);
+        std::vector<void*> losers;
+        for (int d = 0; d < ndraws; d++) {
+            void* fresh = nullptr;
+            if (hipMalloc(&fresh, bytes + pad_bytes) != hipSuccess) { (void)hipGetLastError(); break; } // no room for a copy: keep what there is
+            if ((pad_bytes && hipMemset((char*)fresh + bytes, 0, pad_bytes) != hipSuccess) ||
+                hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipGetLastError(); dfree(fresh); break; }
+            std::swap(*slot, fresh); // fresh = the previous holder from here
+            double t = 0.0;
+            const int rct = time_now(3, 8, &t);
+            A->place_us.push_back(rct == MI_OK ? t : -1.0);
+            if (rct == MI_OK && t < 0.96 * best) best = t; // the copy is clearly faster (two timings of ONE placement differ by 2-3 %): it holds the data from now on
+            else std::swap(*slot, fresh);
+            losers.push_back(fresh);
+            if (early_stop && d == 0 && rct == MI_OK && std::fabs(t - first) <= 0.02 * first) break; // placements are alike on this box
+        }
+        for (void* l : losers) dfree(l);
+    };
+    // (a matrix that runs the blocked kernel streams the BLOCKED copy's values: 16 doubles per block, zero fill included)
+    if (blocked_choice) redraw((void**)&A->blocked->d_coef, sizeof(double) * 16 * (size_t)A->blocked->nblocks, sizeof(double) * 16, draws); // capi_bcsr.hip: 16 * (nb + 1)
+    else redraw((void**)&A->d_coef, sizeof(double) * (size_t)nnz, sizeof(double) * (size_t)kRingPadNnz, draws);
+    A->place_draws_coef = (int)A->place_us.size();
+    // (the slot streams are allocated at exactly nblk * nnzb entries: no tail to carry)
+    if (A->auto_kernel == MI_KERNEL_RING) redraw((void**)&A->ring.d_slots, sizeof(unsigned short) * (size_t)A->ring.nblk * A->ring.cfg.nnzb, 0, (draws + 1) / 2);
+    else if (A->auto_kernel == MI_KERNEL_MRING) redraw((void**)&A->mring.d_slots, sizeof(unsigned short) * (size_t)A->mring.nblk * kMringNnzb, 0, (draws + 1) / 2);
+    // The draws chose copies that are fast WITH THIS x / y pair; a caller that asks the library for its vectors gets the pair
+    // itself as the first candidate (user-facing square handles only: a partition's pieces and mapped views are not handed vectors)
+    if (keep_pair && !A->kept_x) {
+        A->kept_x = tx;
+        A->kept_y = ty;
+        if (tx == own.x) own.x = own.y = nullptr;
+    }
+    return MI_OK;
+}
+
 int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef,
-                    const int* rowmap, mi_csr_t* out, int ghost_lo, int ghost_hi)
+                    const int* rowmap, mi_csr_t* out, int ghost_lo, int ghost_hi, bool defer_placement)
 {
     CHECK_ARG(out, "out is null");
     *out = nullptr;
@@ -407,14 +507,8 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         struct TuneScratch { // released on every exit path, the early error returns of TRY_OR_CLEAN included
             double *tx = nullptr, *ty = nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            mi_csr_s* keep_into = nullptr; // set once the placement draws are through: the handle keeps the pair they were timed on
             ~TuneScratch()
             {
-                if (keep_into) {
-                    keep_into->kept_x = tx;
-                    keep_into->kept_y = ty;
-                    tx = ty = nullptr;
-                }
                 dfree(tx);
                 dfree(ty);
                 if (e0) (void)hipEventDestroy(e0);
@@ -574,57 +668,11 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
             free_mring(A);
             A->mring = keep;
         }
-        // Placement draws (round 3).  WHERE the value array lies in device memory moves a warm launch of the streaming
-        // kernels by up to 15 % (tools/placement_lottery.py: 137-139 us against 158-166 for handles of one and the same matrix and
-        // plan in one process; the coefficient array decides, the 16-bit column stream adds a few us, row pointers and plan
-        // records nothing; no allocation flag or address property found that predicts it).  So for matrices beyond the caches the
-        // chosen kernel is timed on a few fresh copies of those two arrays and the fastest copy is the one kept; every candidate
-        // stays allocated until the draws are over (a freed block would just be handed out again).  MI355_PLACEMENT_DRAWS=0 turns
-        // it off, =N sets the number of draws (default 12 for the values — as many as fit an eighth of the free device memory —, half as
-        // many for the column stream).  Twelve since the round's second session: on one box the draws of three processes read
-        // [143 143 148 148 148 148 148 136 135 135 122.7 122.7 122.5] us, the same in each — the fast stretch of device memory began
-        // 6 GB into the process's allocations, out of reach of four draws (25 ms and 7 GB, both transient, for a 600 MB value array).
-        {
-            const char* pe = getenv("MI355_PLACEMENT_DRAWS");
-            int draws = pe ? std::max(0, std::min(16, atoi(pe))) : 12;
-            if (!pe) {
-                size_t mem_free = 0, mem_total = 0;
-                if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && nnz > 0)
-                    draws = (int)std::min<size_t>((size_t)draws, mem_free / 8 / (sizeof(double) * (size_t)nnz));
-                else (void)hipGetLastError();
-            }
-            const bool blocked_choice = A->auto_kernel == MI_KERNEL_BCSR4 && A->blocked && A->blocked->d_coef;
-            const bool streams_coef = A->auto_kernel == MI_KERNEL_RING || A->auto_kernel == MI_KERNEL_MRING || A->auto_kernel == MI_KERNEL_STREAM || A->auto_kernel == MI_KERNEL_TILE || blocked_choice;
-            if (draws > 0 && streams_coef && nnz >= 20000000) {
-                auto redraw = [&](void** slot, size_t bytes, int ndraws) {
-                    double best = 0.0;
-                    if (!*slot || bytes == 0 || time_now(3, 8, &best) != MI_OK) return;
-                    A->place_us.push_back(best);
-                    std::vector<void*> losers;
-                    for (int d = 0; d < ndraws; d++) {
-                        void* fresh = nullptr;
-                        if (hipMalloc(&fresh, bytes) != hipSuccess) { (void)hipGetLastError(); break; } // no room for a copy: keep what there is
-                        if (hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipGetLastError(); dfree(fresh); break; }
-                        std::swap(*slot, fresh); // fresh = the previous holder from here
-                        double t = 0.0;
-                        const int rct = time_now(3, 8, &t);
-                        A->place_us.push_back(rct == MI_OK ? t : -1.0);
-                        if (rct == MI_OK && t < 0.96 * best) best = t; // the copy is clearly faster (two timings of ONE placement differ by 2-3 %): it holds the data from now on
-                        else std::swap(*slot, fresh);
-                        losers.push_back(fresh);
-                    }
-                    for (void* l : losers) dfree(l);
-                };
-                // (a matrix that runs the blocked kernel streams the BLOCKED copy's values: 16 doubles per block, zero fill included)
-                if (blocked_choice) redraw((void**)&A->blocked->d_coef, sizeof(double) * 16 * (size_t)A->blocked->nblocks, draws);
-                else redraw((void**)&A->d_coef, sizeof(double) * (size_t)nnz, draws);
-                A->place_draws_coef = (int)A->place_us.size();
-                if (A->auto_kernel == MI_KERNEL_RING) redraw((void**)&A->ring.d_slots, sizeof(unsigned short) * (size_t)A->ring.nblk * A->ring.cfg.nnzb, (draws + 1) / 2);
-                else if (A->auto_kernel == MI_KERNEL_MRING) redraw((void**)&A->mring.d_slots, sizeof(unsigned short) * (size_t)A->mring.nblk * kMringNnzb, (draws + 1) / 2);
-                // The draws chose copies that are fast WITH THIS x / y pair; a caller that asks the library for its vectors gets the pair
-                // itself as the first candidate (user-facing square handles only: a partition's pieces and mapped views are not handed vectors)
-                if (!rowmap && n == ncols && n == A->n_out && !(ghost_lo < ghost_hi)) ts.keep_into = A;
-            }
+        // placement draws (placement_draws() below): on the scratch pair the comparisons above ran on; deferred when the caller
+        // (mi_csr_create) may still replace this handle's arrays by a relabelled twin
+        if (!defer_placement) {
+            const int rcp = placement_draws(A, tx, ty, !rowmap && n == ncols && n == A->n_out && !(ghost_lo < ghost_hi));
+            if (rcp == MI_OK && A->kept_x == tx) tx = ty = nullptr; // the handle keeps the pair (mi_vec_alloc_placed's first candidate)
         }
     }
 #undef TRY_OR_CLEAN
@@ -754,9 +802,10 @@ static int maybe_reorder(mi_csr_t A, const int* ptrow, const int* indcol, const 
 
 extern "C" int mi_csr_create(int n, int ncols, const int* ptrow, const int* indcol, const double* coef, mi_csr_t* out)
 {
-    int rc = csr_create_impl(n, ncols, ptrow, indcol, coef, nullptr, out);
+    // (placement draws deferred: a handle that maybe_reorder replaces by its relabelled twin would draw for arrays it is about to release)
+    int rc = csr_create_impl(n, ncols, ptrow, indcol, coef, nullptr, out, 0, 0, true);
     if (rc) return rc;
-    if ((rc = maybe_reorder(*out, ptrow, indcol, coef))) {
+    if ((rc = maybe_reorder(*out, ptrow, indcol, coef)) || (!(*out)->inner && (rc = placement_draws(*out, nullptr, nullptr, n == ncols)))) {
         mi_csr_destroy(*out);
         *out = nullptr;
     }

@@ -289,7 +289,7 @@ struct Scratch {
 
 // capi_csr.hip
 int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const double* coef, const int* rowmap, mi_csr_t* out,
-                    int ghost_lo = 0, int ghost_hi = 0);
+                    int ghost_lo = 0, int ghost_hi = 0, bool defer_placement = false);
 int resolve_kernel(const mi_csr_s* A);
 int get_table(mi_csr_t A, int nnzb, BlockTable** out);
 // launch_csr.hip
@@ -315,5 +315,9 @@ hipError_t spmm_tile_launch(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const B
                             double* Y, long long ldy, hipStream_t st);
 hipError_t spmm_otile_launch(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const Bcsr4View& V, int s, int arith, bool nt, const double* X, long long ldx,
                              double* Y, long long ldy, hipStream_t st);
+// capi_part.hip: pieces of the peer-push set-up that capi_dist.hip (ranks of one process on different devices) uses directly
+int part_push_window(mi_part_s* P);
+void part_push_layout(const mi_part_s* P, long long* layout /* [2*nranks + 1] */);
+int part_push_connect_bases(mi_part_s* P, void* const* bases /* [nranks] */, const long long* layouts);
 // capi_bcsr.hip
 int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);

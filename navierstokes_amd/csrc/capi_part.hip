@@ -8,6 +8,7 @@
 // windows of ranks living in THIS process
 static std::map<std::string, void*> g_win_registry;
 static void part_comm_release(mi_part_s* P);
+static int part_need_timeouts(mi_part_s* P);
 
 // ---------------------------------------------------------------- RCCL, resolved at run time (rccl_loader.hpp)
 static Rccl& g_rccl = rccl_state();
@@ -384,11 +385,10 @@ static int part_need_timeouts(mi_part_s* P)
     return MI_OK;
 }
 
-extern "C" int mi_part_push_export(mi_part_t P, void* handle64, long long* layout)
+// my receive window (allocated once): uncached device memory, nranks flag slots + two parities of n_halo doubles
+int part_push_window(mi_part_s* P)
 {
-    CHECK_ARG(P && handle64 && layout, "null argument");
     if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
-    static_assert(sizeof(hipIpcMemHandle_t) == MI_IPC_HANDLE_BYTES, "IPC handle size");
     const PartPlan& pl = P->plan;
     if (!P->win) {
         const size_t bytes = win_data_offset(pl.nranks) + sizeof(double) * 2 * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1);
@@ -408,6 +408,25 @@ extern "C" int mi_part_push_export(mi_part_t P, void* handle64, long long* layou
         P->win_flags = (unsigned*)P->win;
         P->win_data = (double*)((char*)P->win + win_data_offset(pl.nranks));
     }
+    return MI_OK;
+}
+
+void part_push_layout(const mi_part_s* P, long long* layout)
+{
+    const PartPlan& pl = P->plan;
+    layout[0] = pl.n_halo;
+    for (int p = 0; p < pl.nranks; p++) {
+        layout[1 + p] = pl.recv_offsets[p];
+        layout[1 + pl.nranks + p] = pl.recv_counts[p];
+    }
+}
+
+extern "C" int mi_part_push_export(mi_part_t P, void* handle64, long long* layout)
+{
+    CHECK_ARG(P && handle64 && layout, "null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == MI_IPC_HANDLE_BYTES, "IPC handle size");
+    int rc = part_push_window(P);
+    if (rc) return rc;
     hipIpcMemHandle_t h;
     HIP_TRY(hipIpcGetMemHandle(&h, P->win));
     memcpy(handle64, &h, sizeof h);
@@ -417,11 +436,7 @@ extern "C" int mi_part_push_export(mi_part_t P, void* handle64, long long* layou
         g_win_registry[P->win_key] = P->win;
         P->win_registered = true;
     }
-    layout[0] = pl.n_halo;
-    for (int p = 0; p < pl.nranks; p++) {
-        layout[1 + p] = pl.recv_offsets[p];
-        layout[1 + pl.nranks + p] = pl.recv_counts[p];
-    }
+    part_push_layout(P, layout);
     return MI_OK;
 }
 
@@ -431,21 +446,13 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
     if (!P->win) return fail(MI_ERR_STATE, "mi_part_push_export was not called");
     if (P->push_ready) return MI_OK;
     const PartPlan& pl = P->plan;
-    const int R = pl.nranks, me = pl.rank, LW = 2 * R + 1;
-    int rc = part_need_timeouts(P);
-    if (rc) return rc;
-    std::vector<PushLink> links;
-    std::vector<int> nb;
+    const int R = pl.nranks, me = pl.rank;
     // MI355_PUSH_LOOPBACK=1 (tools/sim_rank.py only): a handle may map windows of its own process — one rank's step timed on
     // one GPU with its pushes looped back and every flag preset, so that nothing ever waits
     const bool loopback = getenv("MI355_PUSH_LOOPBACK") && !strcmp(getenv("MI355_PUSH_LOOPBACK"), "1");
+    std::vector<void*> bases((size_t)R, nullptr);
     for (int p = 0; p < R; p++) {
-        if (p == me) continue;
-        const long long* Lp = layouts + (size_t)p * LW;
-        const long long peer_nhalo = Lp[0], peer_off = Lp[1 + me], peer_cnt = Lp[1 + R + me];
-        if (peer_cnt != pl.send_counts[p]) return fail(MI_ERR_STATE, "peer expects a different number of entries than this rank sends");
-        if (pl.send_counts[p] == 0 && pl.recv_counts[p] == 0) continue; // not a neighbour
-        nb.push_back(p);
+        if (p == me || (pl.send_counts[p] == 0 && pl.recv_counts[p] == 0)) continue; // not a neighbour
         void* base = nullptr;
         const std::string key((const char*)handles + (size_t)p * MI_IPC_HANDLE_BYTES, MI_IPC_HANDLE_BYTES);
         {
@@ -454,10 +461,12 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
             if (it != g_win_registry.end()) base = it->second; // a window of this very process
         }
         if (base && !loopback)
-            // Ranks as threads of one process cannot use this exchange: their streams share the process's few hardware queues
-            // (GPU_MAX_HW_QUEUES, 4 by default), a queue runs its kernels in order, and a kernel that spins on a peer's flag can
+            // Ranks as threads of one process ON ONE DEVICE cannot use this exchange: their streams share the process's few hardware
+            // queues (GPU_MAX_HW_QUEUES, 4 by default), a queue runs its kernels in order, and a kernel that spins on a peer's flag can
             // sit in the queue in front of the very kernel that would raise it — seen as a hang of four rank threads
             // (gpurun_out/t_dist.log, round 2).  Nothing the library does can order another rank's launches, so it refuses.
+            // (mi_dist_*, capi_dist.hip, connects windows of one process that live on DIFFERENT devices — separate queues — through
+            // part_push_connect_bases directly.)
             return fail(MI_ERR_UNSUPPORTED, "peer push needs one PROCESS per rank: a peer's window belongs to this process "
                                             "(rank threads share hardware queues and can deadlock in the wait); use the RCCL or torch exchange");
         if (!base) {
@@ -466,6 +475,32 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
             HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
             P->ipc_opened.push_back(base);
         }
+        bases[p] = base;
+    }
+    return part_push_connect_bases(P, bases.data(), layouts);
+}
+
+// bases[p] = the address at which THIS rank's device reaches peer p's receive window (IPC mapping, or — ranks of one process on
+// different devices with peer access enabled — the peer's own pointer); null for ranks that are not neighbours
+int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* layouts)
+{
+    if (!P->win) return fail(MI_ERR_STATE, "no receive window");
+    if (P->push_ready) return MI_OK;
+    const PartPlan& pl = P->plan;
+    const int R = pl.nranks, me = pl.rank, LW = 2 * R + 1;
+    int rc = part_need_timeouts(P);
+    if (rc) return rc;
+    std::vector<PushLink> links;
+    std::vector<int> nb;
+    for (int p = 0; p < R; p++) {
+        if (p == me) continue;
+        const long long* Lp = layouts + (size_t)p * LW;
+        const long long peer_nhalo = Lp[0], peer_off = Lp[1 + me], peer_cnt = Lp[1 + R + me];
+        if (peer_cnt != pl.send_counts[p]) return fail(MI_ERR_STATE, "peer expects a different number of entries than this rank sends");
+        if (pl.send_counts[p] == 0 && pl.recv_counts[p] == 0) continue; // not a neighbour
+        nb.push_back(p);
+        void* base = bases[p];
+        if (!base) return fail(MI_ERR_ARG, "no window address for a neighbour");
         double* pdata = (double*)((char*)base + win_data_offset(R));
         PushLink L;
         L.dst[0] = pdata + peer_off;

@@ -118,18 +118,26 @@ extern "C" int mi_debug_mring_trace(mi_csr_t A, const double* d_x, double* d_y, 
 // addresses, for the record.
 extern "C" int mi_debug_move_array(mi_csr_t A, int which, int how, unsigned long long* old_ptr, unsigned long long* new_ptr)
 {
-    CHECK_ARG(A && which >= 0 && which <= 3 && (how == 0 || how == 2 || how == 3), "bad argument (how = 1, hipDeviceMallocContiguous, is refused: a copy into such a buffer ended in a GPU memory fault on this pool, twice)");
+    // how = 1 (hipDeviceMallocContiguous) stays refused.  Round 3 moved the value array into such a buffer twice and both runs ended in
+    // a GPU memory fault; the flag was blamed and refused, the logs were not kept (profiles/r03_contiguous_fault.txt).  What is known
+    // from the code of that session: this function then copied exactly sizeof(double) * nnz bytes into an exactly-sized buffer, while the
+    // ring kernels read up to kRingPadNnz values past the last nonzero (launch_ring_impl.hpp: "device arrays are padded for the kernel's
+    // unclamped loads").  Behind a hipMalloc block the allocator's granule usually maps that tail; behind a physically contiguous
+    // exactly-sized buffer it need not.  The missing pad explains the fault at least as well as the flag does; the move now carries
+    // the pad (below), the flag has not been tried again.
+    CHECK_ARG(A && which >= 0 && which <= 3 && (how == 0 || how == 2 || how == 3), "bad argument (how = 1, hipDeviceMallocContiguous, is refused: see the comment in devtools.hip)");
     if (A->inner) A = A->inner;
     void** slot = nullptr;
-    size_t bytes = 0;
-    if (which == 0) { slot = (void**)&A->d_coef; bytes = sizeof(double) * (size_t)A->nnz; }
+    size_t bytes = 0, pad_bytes = 0;
+    if (which == 0) { slot = (void**)&A->d_coef; bytes = sizeof(double) * (size_t)A->nnz; pad_bytes = sizeof(double) * (size_t)kRingPadNnz; }
     if (which == 1) { slot = (void**)&A->ring.d_slots; bytes = sizeof(unsigned short) * (size_t)A->ring.nblk * A->ring.cfg.nnzb; }
-    if (which == 2) { slot = (void**)&A->d_ptrow; bytes = sizeof(int) * ((size_t)A->n + 1); }
+    if (which == 2) { slot = (void**)&A->d_ptrow; bytes = sizeof(int) * ((size_t)A->n + 1); pad_bytes = sizeof(int) * (size_t)kRingPadRows; }
     if (which == 3) { slot = (void**)&A->ring.d_plan; bytes = sizeof(int) * 8 * (size_t)A->ring.nblk; }
     if (!*slot || bytes == 0) return fail(MI_ERR_STATE, "the handle has no such array");
     void* fresh = nullptr;
-    if (how == 0) HIP_TRY(hipMalloc(&fresh, bytes));
-    else HIP_TRY(hipExtMallocWithFlags(&fresh, bytes, how == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+    if (how == 0) HIP_TRY(hipMalloc(&fresh, bytes + pad_bytes));
+    else HIP_TRY(hipExtMallocWithFlags(&fresh, bytes + pad_bytes, how == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+    if (pad_bytes) HIP_TRY(hipMemset((char*)fresh + bytes, 0, pad_bytes)); // the zeroed tail the original allocation has (capi_csr.hip)
     HIP_TRY(hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice));
     HIP_TRY(hipDeviceSynchronize());
     if (old_ptr) *old_ptr = (unsigned long long)(uintptr_t)*slot;

@@ -107,6 +107,22 @@ struct Slot {
 
 std::map<Key, Slot<mi_csr_t>> g_csr;
 std::map<Key, Slot<mi_bcsr4_t>> g_bcsr;
+std::map<Key, Slot<mi_dist_t>> g_dist;
+
+// MI355_NGPUS=N (N >= 2): the CSR entry points of this header — SpMV_CSR*, SpM2V_CSR*, SpM3V, SpM4V*, orthogonalize — run on
+// a mi_dist handle (include/mi355_spmv.h: the matrix row-partitioned over N GPUs of this ONE process) instead of a one-GPU
+// handle; same bits.  Unset / 1: one GPU.  (The blocked entry points stay on one GPU.)
+int ngpus()
+{
+    static const int n = [] {
+        const char* e = std::getenv("MI355_NGPUS");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 2 && v <= 64 ? v : 0;
+    }();
+    return n;
+}
+mi_dist_t g_last_dist = nullptr; // the handle orthogonalize(nrow, ...) distributes its vectors like (it takes no matrix)
+int g_last_dist_n = -1;
 
 // the device copy of A, brought up to date with the caller's arrays
 template <class H, class Create, class Update, class Destroy>
@@ -153,6 +169,26 @@ mi_csr_t device_csr(csrmatrix& A)
         [&](mi_csr_t h) { MI_CALL(mi_csr_update_values(h, A.coef.data())); }, [](mi_csr_t h) { mi_csr_destroy(h); });
 }
 
+mi_dist_t device_dist(csrmatrix& A)
+{
+    const Key k{A.ptrow.data(), A.indcol.data(), A.coef.data()};
+    mi_dist_t h = device_copy<mi_dist_t>(
+        g_dist, k, A.n, A.ptrow.data(), A.indcol.data(), A.coef.data(), 1,
+        [&]() {
+            mi_dist_t d = nullptr;
+            MI_CALL(mi_dist_create(ngpus(), A.n, A.ptrow.data(), A.indcol.data(), A.coef.data(), &d));
+            return d;
+        },
+        [&](mi_dist_t d) { MI_CALL(mi_dist_update_values(d, A.coef.data())); },
+        [](mi_dist_t d) {
+            if (d == g_last_dist) g_last_dist = nullptr;
+            mi_dist_destroy(d);
+        });
+    g_last_dist = h;
+    g_last_dist_n = A.n;
+    return h;
+}
+
 mi_bcsr4_t device_bcsr(const bcsr4x4_matrix& A)
 {
     const Key k{A.ptrow.data(), A.indcol.data(), A.coef.data()};
@@ -175,7 +211,8 @@ mi_bcsr4_t device_bcsr(const bcsr4x4_matrix& A)
 
 void powers(int k, double* const* outs, double* x, csrmatrix& A)
 {
-    MI_CALL(mi_spmk(device_csr(A), k, x, outs));
+    if (ngpus()) MI_CALL(mi_dist_spmk(device_dist(A), k, x, outs));
+    else MI_CALL(mi_spmk(device_csr(A), k, x, outs));
 }
 
 } // namespace
@@ -191,6 +228,12 @@ void mi355_invalidate(csrmatrix& A)
         mi_csr_destroy(it->second.handle);
         g_csr.erase(it);
     }
+    std::map<Key, Slot<mi_dist_t> >::iterator jt = g_dist.find(Key{A.ptrow.data(), A.indcol.data(), A.coef.data()});
+    if (jt != g_dist.end()) {
+        if (jt->second.handle == g_last_dist) g_last_dist = nullptr;
+        mi_dist_destroy(jt->second.handle);
+        g_dist.erase(jt);
+    }
 }
 
 void mi355_invalidate(const bcsr4x4_matrix& A)
@@ -204,7 +247,11 @@ void mi355_invalidate(const bcsr4x4_matrix& A)
 
 // ---- y = A x ------------------------------------------------------------------
 
-void SpMV_CSR(double* y, double* x, csrmatrix& A) { MI_CALL(mi_spmv(device_csr(A), x, y)); }
+void SpMV_CSR(double* y, double* x, csrmatrix& A)
+{
+    if (ngpus()) MI_CALL(mi_dist_spmv(device_dist(A), x, y));
+    else MI_CALL(mi_spmv(device_csr(A), x, y));
+}
 void SpMV_CSR_OPT(double* y, double* x, csrmatrix& A) { SpMV_CSR(y, x, A); }
 void SpMV_CSR_FMA(double* y, double* x, csrmatrix& A) { SpMV_CSR(y, x, A); }
 void SpMV_CSR_AVX2(double* y, double* x, csrmatrix& A) { SpMV_CSR(y, x, A); }
@@ -340,13 +387,16 @@ void orthogonalize(int nrow, const std::vector<double>& b, const std::vector<dou
                    std::vector<double>& x3, double alpha)
 {
     double beta = 0.0;
-    MI_CALL(mi_orthogonalize(nrow, b.data(), x1.data(), x3.data(), alpha, &beta));
+    // N GPUs: the vectors are distributed like the rows of the matrix last multiplied with (the call names no matrix)
+    if (ngpus() && g_last_dist && g_last_dist_n == nrow) MI_CALL(mi_dist_orthogonalize(g_last_dist, b.data(), x1.data(), x3.data(), alpha, &beta));
+    else MI_CALL(mi_orthogonalize(nrow, b.data(), x1.data(), x3.data(), alpha, &beta));
 }
 
 void orthogonalize(int nrow, const std::vector<double>& x, std::vector<double>& y, double alpha)
 {
     double beta = 0.0;
-    MI_CALL(mi_orthogonalize(nrow, x.data(), y.data(), y.data(), alpha, &beta)); // in place: x3 == x1
+    if (ngpus() && g_last_dist && g_last_dist_n == nrow) MI_CALL(mi_dist_orthogonalize(g_last_dist, x.data(), y.data(), y.data(), alpha, &beta));
+    else MI_CALL(mi_orthogonalize(nrow, x.data(), y.data(), y.data(), alpha, &beta)); // in place: x3 == x1
 }
 
 void orthonormalize_against_basis(int nrow, std::vector<std::vector<double> >& basis, std::vector<double>& y)

@@ -150,9 +150,13 @@ __global__ __launch_bounds__(T) void spmk_csr_ring(CsrView A, const int4* __rest
             constexpr int FILL = (RING + T - 1) / T;
             const int4 q = s_plan[1];
             const int c0 = uni(q.x) + tid, cend = uni(q.x) + uni(q.y), qz = uni(q.z);
+            // Loads stay inside what build_run_deps accounts for this run — the first block's new columns, or T entries from q.x —
+            // so that no line of y_p is touched before the runs that own it have published it (narrow bands: a run's rows plus
+            // band can span fewer than RING columns, and an unclamped fill would reach into rows of runs not on the dependency list)
+            const int chi = min(max(cend, uni(q.x) + T) - 1, clast);
             double v[FILL];
 #pragma unroll
-            for (int u = 0; u < FILL; u++) v[u] = ld_coherent(x + min(c0 + u * T, clast));
+            for (int u = 0; u < FILL; u++) v[u] = ld_coherent(x + min(c0 + u * T, chi));
 #pragma unroll
             for (int u = 0; u < FILL; u++)
                 if (c0 + u * T < cend) s_ring[ring_slot<RING>(c0 + u * T, qz)] = v[u];

@@ -167,11 +167,33 @@ def lib():
         "mi_part_comm_info": [_vp, P(i), P(i)],
         "mi_part_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_comm_selftest": [i, P(d)],
+        "mi_dist_create": [i, i, _vp, _vp, _vp, P(_vp)],
+        "mi_dist_destroy": [_vp],
+        "mi_dist_info": [_vp, P(i), P(i), P(i), P(i), P(ll), P(ll)],
+        "mi_dist_rank_info": [_vp, i, P(i), P(ll), P(i), P(i), P(ll), P(_vp)],
+        "mi_dist_update_values": [_vp, _vp],
+        "mi_dist_spmv": [_vp, _vp, _vp],
+        "mi_dist_spmk": [_vp, i, _vp, _vp],
+        "mi_dist_dot": [_vp, _vp, _vp, P(d)],
+        "mi_dist_orthogonalize": [_vp, _vp, _vp, _vp, d, P(d)],
+        "mi_dist_vec_create": [_vp, P(_vp)],
+        "mi_dist_vec_destroy": [_vp],
+        "mi_dist_vec_set": [_vp, _vp],
+        "mi_dist_vec_get": [_vp, _vp],
+        "mi_dist_vec_ptr": [_vp, i, P(_vp)],
+        "mi_dist_spmv_dev": [_vp, _vp, _vp],
+        "mi_dist_spmk_dev": [_vp, i, _vp, _vp],
+        "mi_dist_synchronize": [_vp],
+        "mi_dist_dot_dev": [_vp, _vp, _vp, P(d)],
+        "mi_dist_orthogonalize_dev": [_vp, _vp, _vp, _vp, d, P(d)],
     }
     for name, argt in sigs.items():
         fn = getattr(L, name)
         fn.argtypes = argt
         fn.restype = _c.c_int
+    for name in ("mi_dist_exchange_name", "mi_dist_exchange_note"):
+        getattr(L, name).argtypes = [_vp]
+        getattr(L, name).restype = _c.c_char_p
     # diagnostics of include/mi355_devtools.h: present only in libmi355spmv_dev.so (`make devtools`; tools/ load it through
     # MI355_SPMV_LIBRARY), never in the product library
     for name, argt in {"mi_debug_xcc_map": [i, _vp], "mi_debug_touch_pages": [_vp, i, _vp, ll, _vp, ll],
@@ -453,6 +475,138 @@ class bcsr4x4_matrix:
     def close(self):
         if self._h is not None:
             lib().mi_bcsr4_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DistVector:
+    """mi_dist_vec_t: a vector distributed like the rows of a DistMatrix (per rank [owned | halo] on the rank's device)."""
+
+    def __init__(self, D, host=None):
+        self.D = D
+        h = _vp()
+        check(lib().mi_dist_vec_create(D.handle, _c.byref(h)))
+        self._h = h
+        if host is not None:
+            self.set(host)
+
+    def set(self, host):
+        host = _host_f64(host, self.D.n, "x")
+        check(lib().mi_dist_vec_set(self._h, host.ctypes.data))
+        return self
+
+    def get(self, out=None):
+        out = np.empty(self.D.n, np.float64) if out is None else _host_f64(out, self.D.n, "out", writable=True)
+        check(lib().mi_dist_vec_get(self._h, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._h is not None and self.D._h is not None:
+            lib().mi_dist_vec_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DistMatrix:
+    """mi_dist_t (include/mi355_spmv.h): one csrmatrix row-partitioned over `ndev` GPUs behind ONE handle of ONE process — the
+    form of the multi-GPU path the reference's single-process harnesses reach (SpMV_CSR / SpM4V / orthogonalize of mpk/SpMV.h
+    through the shim with MI355_NGPUS).  Host vectors: spmv / spmk / dot / orthogonalize mirror the reference's calls;
+    device-resident vectors: vector(), spmv_dev / spmk_dev / synchronize."""
+
+    def __init__(self, ndev, n, ptrow, indcol, coef):
+        self.ndev, self.n = int(ndev), int(n)
+        ptrow = np.ascontiguousarray(ptrow, dtype=np.int32)
+        indcol = np.ascontiguousarray(indcol, dtype=np.int32)
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        self.nnz = int(ptrow[-1]) if self.n > 0 else 0
+        h = _vp()
+        self._h = None
+        check(lib().mi_dist_create(self.ndev, self.n, ptrow.ctypes.data, indcol.ctypes.data, coef.ctypes.data, _c.byref(h)))
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        L = lib()
+        nr, dd, ex, fu, ht, hm = _c.c_int(), _c.c_int(), _c.c_int(), _c.c_int(), _c.c_longlong(), _c.c_longlong()
+        check(L.mi_dist_info(self._h, _c.byref(nr), _c.byref(dd), _c.byref(ex), _c.byref(fu), _c.byref(ht), _c.byref(hm)))
+        ranks = []
+        for r in range(nr.value):
+            dev, r0, nl, nh, nz, st = _c.c_int(), _c.c_longlong(), _c.c_int(), _c.c_int(), _c.c_longlong(), _vp()
+            check(L.mi_dist_rank_info(self._h, r, _c.byref(dev), _c.byref(r0), _c.byref(nl), _c.byref(nh), _c.byref(nz), _c.byref(st)))
+            ranks.append(dict(device=dev.value, row_start=r0.value, n_local=nl.value, n_halo=nh.value, nnz_local=nz.value))
+        return dict(nranks=nr.value, distinct_devices=dd.value, exchange=L.mi_dist_exchange_name(self._h).decode(),
+                    fused=bool(fu.value), halo_total=ht.value, halo_max=hm.value, note=L.mi_dist_exchange_note(self._h).decode(),
+                    ranks=ranks)
+
+    def update_values(self, coef):
+        coef = _host_f64(coef, self.nnz, "coef")
+        check(lib().mi_dist_update_values(self._h, coef.ctypes.data))
+
+    # -- host vectors: the reference's calling convention
+    def spmv(self, y, x):
+        x, y = _host_f64(x, self.n, "x"), _host_f64(y, self.n, "y", writable=True)
+        check(lib().mi_dist_spmv(self._h, x.ctypes.data, y.ctypes.data))
+        return y
+
+    def spmk(self, ys, x):
+        x = _host_f64(x, self.n, "x")
+        ys = [_host_f64(t, self.n, "y_out", writable=True) for t in ys]
+        arr = (_vp * len(ys))(*[t.ctypes.data for t in ys])
+        check(lib().mi_dist_spmk(self._h, len(ys), x.ctypes.data, arr))
+        return ys
+
+    def dot(self, x, y):
+        out = _c.c_double()
+        check(lib().mi_dist_dot(self._h, _host_f64(x, self.n).ctypes.data, _host_f64(y, self.n).ctypes.data, _c.byref(out)))
+        return out.value
+
+    def orthogonalize(self, b, x1, x3, alpha=1e-8):
+        beta = _c.c_double()
+        x3 = _host_f64(x3, self.n, "x3", writable=True)
+        check(lib().mi_dist_orthogonalize(self._h, _host_f64(b, self.n).ctypes.data, _host_f64(x1, self.n).ctypes.data, x3.ctypes.data,
+                                          float(alpha), _c.byref(beta)))
+        return beta.value
+
+    # -- device-resident vectors
+    def vector(self, host=None):
+        return DistVector(self, host)
+
+    def spmv_dev(self, y, x):
+        check(lib().mi_dist_spmv_dev(self._h, x._h, y._h))
+
+    def spmk_dev(self, ys, x):
+        arr = (_vp * len(ys))(*[t._h for t in ys])
+        check(lib().mi_dist_spmk_dev(self._h, len(ys), x._h, arr))
+
+    def dot_dev(self, a, b):
+        out = _c.c_double()
+        check(lib().mi_dist_dot_dev(self._h, a._h, b._h, _c.byref(out)))
+        return out.value
+
+    def orthogonalize_dev(self, b, x1, x3, alpha=1e-8):
+        beta = _c.c_double()
+        check(lib().mi_dist_orthogonalize_dev(self._h, b._h, x1._h, x3._h, float(alpha), _c.byref(beta)))
+        return beta.value
+
+    def synchronize(self):
+        check(lib().mi_dist_synchronize(self._h))
+
+    def close(self):
+        if self._h is not None:
+            lib().mi_dist_destroy(self._h)
             self._h = None
 
     def __del__(self):

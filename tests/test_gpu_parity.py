@@ -827,6 +827,34 @@ def test_matrix_powers_in_one_launch(kind, n, w, monkeypatch):
         assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"measured choice {info}, power {q + 1}")
 
 
+@pytest.mark.parametrize("n,hb", [(1_000_000, 1), (300_000, 3)])
+def test_matrix_powers_in_one_launch_on_a_narrow_band(n, hb, monkeypatch):
+    """with a narrow band (tridiagonal at 1 M rows) a run's rows plus band span fewer columns than the window's first
+    fill, which used to load all 5120 entries from its first column unconditionally — lines of y_p owned by runs that are NOT on
+    the dependency list, possibly before their publication.  The fill is now clamped to the first block's new columns; every
+    power of the one-launch k = 4 step must equal the chained oracle, launch after launch on one handle."""
+    i = np.arange(n, dtype=np.int64)
+    cols = np.stack([i + d for d in range(-hb, hb + 1)], axis=1)
+    ok = (cols >= 0) & (cols < n)
+    p = np.concatenate([[0], np.cumsum(ok.sum(axis=1))]).astype(np.int32)
+    c = cols[ok].astype(np.int32)
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-0.4, 0.4, len(c))
+    A = mpk.csrmatrix(n, p, c, v).set_kernel("ring")
+    monkeypatch.setenv("MI355_SPMK_FUSED", "1")
+    outs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(4)]
+    for rep in range(6):
+        x = np.cos(0.001 * (rep + 1) * np.arange(n))
+        for t in outs:
+            t.fill_(float("nan"))
+        mpk.SpMkV(outs, dev(x), A)
+        info = A.spmk_info(4)
+        assert info["eligible"] and info["one_launch"], info
+        Y = O.spmk_chain(4, p, c, v, x)
+        for q in range(4):
+            assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"narrow band hb={hb}, rep {rep}, power {q + 1}")
+
+
 def test_matrix_powers_in_one_launch_is_refused_where_it_cannot_run(monkeypatch):
     """Handles the one-launch form is not built for (stream kernel, FE matrices on the blocked kernel, a band much wider than a
     run) take k launches even when it is forced on — same bits."""

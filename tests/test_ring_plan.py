@@ -188,3 +188,12 @@ def test_one_launch_powers_step_dependencies_cover_every_load():
     p, c, v = synth.rows("s15", 200_000, w=60_000)
     e, runs, md = probe(p, c, 200_000)
     assert e == 0
+    # narrow bands: a run's rows plus band span fewer columns than the window's first fill (5120) — the kernel clamps
+    # that fill to the first block's new columns (spmk_ring.hpp), which is what the probe's replay of the loads assumes
+    for n, hb in ((1_000_000, 1), (300_000, 3), (120_000, 40)):
+        i = np.arange(n, dtype=np.int64)
+        cols = np.stack([i + d for d in range(-hb, hb + 1)], axis=1)
+        ok = (cols >= 0) & (cols < n)
+        p = np.concatenate([[0], np.cumsum(ok.sum(axis=1))])
+        e, runs, md = probe(p, cols[ok], n)
+        assert e == 1 and md <= 8, (n, hb, e, runs, md)
