@@ -199,6 +199,100 @@ def self_launch(ngpus):
         return 130
 
 
+def single_process_main(args):
+    """--single-process: ONE process drives the N GPUs through a mi_dist handle (include/mi355_spmv.h; what the reference's
+    single-process harnesses reach through the mpk/SpMV.h shim with MI355_NGPUS=N).  Same workload, same metric, same JSON line;
+    the timed region is K steps enqueued back to back on device-resident distributed vectors between two mi_dist_synchronize()."""
+    import torch  # (device count only: this process never makes torch's context current on the GPUs the library drives)
+    from navierstokes_amd import mpk, synth
+
+    W = WORKLOADS[args.workload]
+    n, k, kind = W["n"], W["k"], W["kind"]
+    if kind not in ("s15", "fe") or W.get("bcsr") or W.get("perm_block"):
+        sys.exit("--single-process runs the c2 / c3 / c4 / tiny / fe workloads")
+    N = args.gpus
+    t_setup = time.perf_counter()
+    p, c, v = synth.fe_matrix(W["cells"]) if kind == "fe" else synth.rows(kind, n)
+    nnz = len(c)
+    x_host = synth.x_sin(0, n)
+    D = mpk.DistMatrix(N, n, p, c, v)
+    info = D.info()
+    vx = D.vector(x_host)
+    outs = [D.vector() for _ in range(k)]
+    if k == 1:
+        def step():
+            D.spmv_dev(outs[0], vx)
+    else:
+        def step():
+            D.spmk_dev(outs, vx)
+    D.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    for _ in range(args.warmup):
+        step()
+    D.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    D.synchronize()
+    wall = time.perf_counter() - t0
+    parity = None
+    if not args.no_parity:
+        from oracle import oracle as O  # checker only
+        Y = O.spmk_chain(k, p, c, v, x_host)
+        got = [t.get() for t in outs]
+        parity = dict(rel_error=max(O.rel_error(Y[i], got[i]) for i in range(k)),
+                      bitwise=all(np.array_equal(Y[i].view(np.uint64), got[i].view(np.uint64)) for i in range(k)),
+                      against="oracle/cpu_ref.c fma chain (= reference SpMV_CSR_OPT/_FMA), full vectors gathered from the ranks")
+    value = 2.0 * nnz * k * args.steps / wall / 1e9
+    B_rank = max(algorithmic_bytes(r["n_local"], r["nnz_local"]) for r in info["ranks"])
+    launch_s = wall / (args.steps * k)
+    achieved = B_rank / launch_s / 1e9
+    out = dict(metric="fp64 CSR SpMV GFLOP/s & % HBM roofline @ nnz; 1/2/4/8 GPU", value=round(value, 2), unit="GFLOP/s", n_gpus=N, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(wall * 1e3 / args.steps, 5), higher_is_better=True, scaling="strong", vs_baseline=None,
+               dtype="f64", data="synthetic",
+               config=dict(workload=W["desc"], name=args.workload, n=n, nnz=nnz, k=k, seed="0x5EED", half_bandwidth=synth.DEFAULT_W,
+                           partition=f"row-range x{N}, ONE process (mi_dist: a worker thread per rank)", cold=False, numbering="caller's"),
+               roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                             algorithmic_bytes_per_launch=B_rank, launch_us=round(launch_s * 1e6, 2),
+                             bytes_model="CSR: 12 B per nonzero + 4 B per row pointer + 16 B per row (SURVEY.md §8d), the largest rank's share",
+                             timing="host clock between two mi_dist_synchronize() around the K steps / launches (the ranks' streams live on different devices)"),
+               pct_hbm_roofline=round(100 * achieved / HBM_PEAK_GBS, 2),
+               halo=dict(driver="mi_dist (one process, N devices)", exchange=info["exchange"], fused_one_launch_per_rank=info["fused"], exchange_note=info["note"],
+                         distinct_devices=info["distinct_devices"], devices_visible=torch.cuda.device_count(), halo_total=info["halo_total"], halo_max=info["halo_max"],
+                         ranks=[dict(device=r["device"], rows=r["n_local"], halo=r["n_halo"]) for r in info["ranks"]]),
+               setup_s=round(t_setup, 2))
+    if parity is not None:
+        out["parity"] = parity
+    print(json.dumps(out), flush=True)
+    for t in [vx] + outs:
+        t.close()
+    D.close()
+
+
+def run_single_process_child(args, timeout_s=240):
+    """N > 1, rank 0, after the timed region of the process-per-GPU path: the same workload through ONE process (a child of its own,
+    so that a failure or a hang there costs this line nothing but the field).  Returns the child's JSON line as a dict, or a note."""
+    import subprocess
+    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                  "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--single-process", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--workload", args.workload]
+    if "MI355_FORCE_DEVICE" in os.environ:  # development: every rank on one card
+        env["MI355_DIST_DEVICES"] = os.environ["MI355_FORCE_DEVICE"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, start_new_session=True)
+    except subprocess.TimeoutExpired:
+        return dict(ok=False, note=f"child did not finish in {timeout_s} s")
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith("{"):
+            try:
+                d = json.loads(line)
+                return dict(ok=True, value=d["value"], ms_per_step=d["ms_per_step"], frac=d["roofline"]["frac"], halo=d["halo"], parity=d.get("parity"), setup_s=d.get("setup_s"))
+            except Exception:  # noqa: BLE001
+                break
+    return dict(ok=False, note=f"child exited {r.returncode}: {(r.stderr or r.stdout)[-300:]}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,7 +311,13 @@ def main():
                     "the timed region, `value` and `roofline` stay on the plain allocations")
     ap.add_argument("--internal", action="store_true", help="N = 1, y = A x CSR workloads: x and y stay in the library's numbering "
                     "(mi_spmv_internal_dev: a relabelled matrix pays no gather and no mapped store per product; what a Krylov loop does)")
+    ap.add_argument("--single-process", action="store_true", help="drive the N GPUs from ONE process through a mi_dist handle (what the reference's "
+                    "single-process harnesses reach through the shim with MI355_NGPUS=N) instead of one process per GPU")
+    ap.add_argument("--no-single-process-extra", action="store_true", help="N > 1: do not also time the one-process form (a child process of rank 0, "
+                    "after the timed region; reported as `single_process`, never as `value`)")
     args = ap.parse_args()
+    if args.single_process:
+        return single_process_main(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
@@ -775,6 +875,18 @@ def main():
     if halo_info is not None:
         out["halo"] = halo_info
     out["setup_s"] = round(t_setup, 2)
+    if world > 1 and not args.no_single_process_extra and kind in ("s15", "fe") and not args.cold:
+        # the same workload through ONE process (mi_dist_*): the other ranks wait on the HOST (a gloo group — an RCCL barrier would
+        # keep a kernel spinning on their GPUs while the child measures)
+        import datetime
+        side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+        torch.cuda.synchronize()
+        dist.barrier(group=side)
+        if rank == 0:
+            out["single_process"] = run_single_process_child(args)
+            out["single_process"]["note"] = ("the same workload driven by ONE process over the N devices (python bench.py --gpus N --single-process: mi_dist_create, a worker "
+                                             "thread per rank), run as a child of rank 0 after the timed region while the other ranks wait on the host; never `value`")
+        dist.barrier(group=side)
     if rank == 0 and world == 1 and not bcsr and k == 1 and not args.no_cpu_baseline:
         # the reference's calling convention (host pointers): x H2D + kernel + y D2H per call; never `value`
         xh, yh = x_host, np.empty(n)

@@ -40,3 +40,22 @@ def test_bench_gpus_2_on_one_card_prints_one_json_line():
     assert h["exchanges"]["push"]["ok"], h["exchanges"]["push"]           # separate processes: the IPC windows must come up
     assert h["exchange_bytes_per_step"]["sent_all_ranks"] > 0 and h["overlap"]["compute_only_us"] > 0
     assert h["torch_world"] == 2 and "rccl_ranks" in h
+    # the one-process form of the same workload (mi_dist_*), timed by a child of rank 0 behind the timed region
+    sp = d["single_process"]
+    assert sp["ok"], sp
+    assert sp["parity"]["bitwise"] is True and sp["halo"]["exchange"] == "event" and sp["value"] > 0, sp
+
+
+@pytest.mark.gpu
+def test_bench_single_process_prints_one_json_line():
+    """`python3 bench.py --gpus 3 --single-process`: one process, three ranks behind a mi_dist handle (all on cuda:0 here), k = 4 powers."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--single-process", "--workload", "c3", "--steps", "5", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["parity"]["bitwise"] is True and d["config"]["k"] == 4
+    assert d["halo"]["exchange"] in ("event", "push", "rccl") and len(d["halo"]["ranks"]) == 3
