@@ -19,6 +19,14 @@
  *     ... link the solver with -L<repo>/navierstokes_amd/csrc -lmi355spmv
  * In src/solve_newton.c replace OverrideMatMultWithAVX2(J) by OverrideMatMultWithMI355(J) (same signature).
  *
+ * Vectors.  Two branches per product (round 4):
+ *   - DEVICE vectors (VECSEQHIP / VECHIP, a PETSc configured --with-hip; run the solver with -vec_type hip): VecHIPGetArrayRead /
+ *     VecHIPGetArrayWrite hand out the HBM pointers and the product is mi_bcsr4_spmv_dev / mi_spmv_dev on them — no PCIe traffic per
+ *     GMRES iteration: the kernel's own rate (bench.py: 112-120 us per product of the 1.3 M-row FE matrix, 137-150 us at C4);
+ *   - HOST vectors (VECSEQ, the reference's default: VecCreateSeq, src/solve_newton.c:972): x goes in and y comes out over PCIe on
+ *     every product — bench.py's `pcie_inclusive`: 1.64 ms per call at 5 M rows = 92 GFLOP/s, 11x the kernel.  Correct, and still
+ *     4-5x the reference's CPU kernel, but the seam to use for speed is the device branch.
+ *
  * Arithmetic: each row of y is ONE fma chain over the row's blocks in storage order, columns 0..3 inside a block —
  * the bits of mpk's SpMV_BCSR_FMA (mpk/SpMV.cpp:150-178).  MatMult_SeqBAIJ_4_AVX2 keeps four per-column accumulators
  * and adds them at the end (src/kernels/baij4_avx2.c:42-66): the two agree to rounding (rel. 1e-16 per row), not bit
@@ -46,6 +54,17 @@ static PetscErrorCode MI355MatCtxDestroy(void *p)
     PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* is this Vec a HIP device vector?  (type names as of PETSc 3.18+: VECSEQHIP, VECMPIHIP, VECHIP) */
+static PetscErrorCode MI355VecOnDevice(Vec v, PetscBool *on)
+{
+    PetscFunctionBegin;
+    *on = PETSC_FALSE;
+#if defined(PETSC_HAVE_HIP) /* a PETSc built without HIP vectors has neither the types nor VecHIPGetArray* */
+    PetscCall(PetscObjectTypeCompareAny((PetscObject)v, on, VECSEQHIP, VECMPIHIP, VECHIP, ""));
+#endif
+    PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 #define MI_CALL(expr)                                                                                          \
     do {                                                                                                       \
         int mi_rc_ = (expr);                                                                                   \
@@ -60,6 +79,7 @@ PetscErrorCode MatMult_MI355(Mat A, Vec xx, Vec zz)
     PetscObjectState   st;
     const PetscScalar *x;
     PetscScalar       *z;
+    PetscBool          xdev, zdev;
 
     PetscFunctionBegin;
     PetscCheck(a->bs2 == 16, PETSC_COMM_SELF, PETSC_ERR_ARG_WRONG, "MatMult_MI355 needs block size 4");
@@ -85,11 +105,28 @@ PetscErrorCode MatMult_MI355(Mat A, Vec xx, Vec zz)
             ctx->state = st;
         }
     }
-    PetscCall(VecGetArrayRead(xx, &x));
-    PetscCall(VecGetArrayWrite(zz, &z));
-    MI_CALL(mi_bcsr4_spmv(ctx->h, (const double *)x, (double *)z)); /* host vectors in, host vector out (VECSEQ) */
-    PetscCall(VecRestoreArrayRead(xx, &x));
-    PetscCall(VecRestoreArrayWrite(zz, &z));
+    PetscCall(MI355VecOnDevice(xx, &xdev));
+    PetscCall(MI355VecOnDevice(zz, &zdev));
+    if (xdev && zdev) {
+#if defined(PETSC_HAVE_HIP)
+        /* device-resident vectors: the product runs where they live.  The launch goes to the null stream between two device
+         * synchronisations (a few microseconds each; PETSc's own work runs on its PetscDeviceContext's stream — a caller that wants the
+         * product ON that stream passes the hipStream_t of PetscDeviceContextGetStreamHandle as the last argument and drops both) */
+        PetscCall(VecHIPGetArrayRead(xx, &x));
+        PetscCall(VecHIPGetArrayWrite(zz, &z));
+        MI_CALL(mi_device_synchronize());
+        MI_CALL(mi_bcsr4_spmv_dev(ctx->h, (const double *)x, (double *)z, NULL));
+        MI_CALL(mi_device_synchronize());
+        PetscCall(VecHIPRestoreArrayRead(xx, &x));
+        PetscCall(VecHIPRestoreArrayWrite(zz, &z));
+#endif
+    } else {
+        PetscCall(VecGetArrayRead(xx, &x));
+        PetscCall(VecGetArrayWrite(zz, &z));
+        MI_CALL(mi_bcsr4_spmv(ctx->h, (const double *)x, (double *)z)); /* host vectors (VECSEQ): x in, y out over PCIe */
+        PetscCall(VecRestoreArrayRead(xx, &x));
+        PetscCall(VecRestoreArrayWrite(zz, &z));
+    }
     PetscCall(PetscLogFlops(2.0 * a->nz * a->bs2 - 4.0 * a->nonzerorowcnt)); /* as src/kernels/baij4_avx2.c:82 */
     PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -135,6 +172,7 @@ PetscErrorCode MatMult_MI355_AIJ(Mat A, Vec xx, Vec zz)
     PetscObjectState   st;
     const PetscScalar *x;
     PetscScalar       *z;
+    PetscBool          xdev, zdev;
 
     PetscFunctionBegin;
     PetscCheck(sizeof(PetscInt) == sizeof(int) && sizeof(PetscScalar) == sizeof(double), PETSC_COMM_SELF, PETSC_ERR_SUP,
@@ -157,11 +195,25 @@ PetscErrorCode MatMult_MI355_AIJ(Mat A, Vec xx, Vec zz)
             ctx->state = st;
         }
     }
-    PetscCall(VecGetArrayRead(xx, &x));
-    PetscCall(VecGetArrayWrite(zz, &z));
-    MI_CALL(mi_spmv(ctx->h, (const double *)x, (double *)z));
-    PetscCall(VecRestoreArrayRead(xx, &x));
-    PetscCall(VecRestoreArrayWrite(zz, &z));
+    PetscCall(MI355VecOnDevice(xx, &xdev));
+    PetscCall(MI355VecOnDevice(zz, &zdev));
+    if (xdev && zdev) {
+#if defined(PETSC_HAVE_HIP)
+        PetscCall(VecHIPGetArrayRead(xx, &x));
+        PetscCall(VecHIPGetArrayWrite(zz, &z));
+        MI_CALL(mi_device_synchronize());
+        MI_CALL(mi_spmv_dev(ctx->h, (const double *)x, (double *)z, NULL)); /* see MatMult_MI355 for the stream */
+        MI_CALL(mi_device_synchronize());
+        PetscCall(VecHIPRestoreArrayRead(xx, &x));
+        PetscCall(VecHIPRestoreArrayWrite(zz, &z));
+#endif
+    } else {
+        PetscCall(VecGetArrayRead(xx, &x));
+        PetscCall(VecGetArrayWrite(zz, &z));
+        MI_CALL(mi_spmv(ctx->h, (const double *)x, (double *)z));
+        PetscCall(VecRestoreArrayRead(xx, &x));
+        PetscCall(VecRestoreArrayWrite(zz, &z));
+    }
     PetscCall(PetscLogFlops(2.0 * a->nz)); /* as src/kernels/aij_mad.c:30 */
     PetscFunctionReturn(PETSC_SUCCESS);
 }
