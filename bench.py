@@ -385,6 +385,14 @@ def main():
         bt = [_ct.c_int(), _ct.c_int(), _ct.c_double(), _ct.c_double()]
         mpk.check(mpk.lib().mi_bcsr4_tile_info(A.handle, _ct.byref(bt[0]), _ct.byref(bt[1]), _ct.byref(bt[2]), _ct.byref(bt[3])))
         kernel_name = "spmv_bcsr4_tile<2>" if bt[1].value else "spmv_bcsr4<2>"
+        sb, sf, ss, spad = _ct.c_int(), _ct.c_int(), _ct.c_longlong(), _ct.c_double()
+        sus = (_ct.c_double * 4)()
+        mpk.check(mpk.lib().mi_bcsr4_sell_info(A.handle, _ct.byref(sb), _ct.byref(sf), _ct.byref(ss), _ct.byref(spad), sus))
+        bcsr_forms = dict(us_row_per_quad=round(bt[2].value, 2), us_row_per_quad_x_tile=round(bt[3].value, 2), sliced_copy_built=bool(sb.value),
+                          sliced_form_in_use=sf.value, sliced_steps=ss.value, sliced_padding=round(spad.value, 5),
+                          us_sliced=dict(d4_nt=round(sus[0], 2), d4_temporal=round(sus[1], 2), d6_nt=round(sus[2], 2), d4_nt_4waves=round(sus[3], 2)))
+        if sf.value >= 0:
+            kernel_name = ["spmv_bcsr4_sell<4, true>", "spmv_bcsr4_sell<4, false>", "spmv_bcsr4_sell<6, true>", "spmv_bcsr4_sell<4, true>"][sf.value]
         ring_cfg, ring_runs, ring_bad, ring_frac = 0, 0, 0, 0.0
         x = torch.from_numpy(x_host).cuda()
         ys = [torch.empty(n, dtype=torch.float64, device="cuda")]
@@ -870,6 +878,8 @@ def main():
                                                  note="first k-step of the handle times both forms (same bits) and keeps the faster; MI355_SPMK_FUSED=0|1 forces")
     if world == 1 and bcsr and W.get("spmm"):
         out["kernel_info"] = dict(kernel=kernel_name, **spmm_info)
+    elif world == 1 and bcsr:
+        out["kernel_info"] = dict(kernel=kernel_name, forms=bcsr_forms)
     if parity is not None:
         out["parity"] = parity
     if halo_info is not None:

@@ -1,6 +1,7 @@
 // capi_bcsr.hip: BCSR 4x4 handles and products, multi-vector products, Krylov basis — part of libmi355spmv.so (see capi_internal.hpp for the layout of the library).
 // Built for gfx950 only; no CPU fallback anywhere: every compute entry point needs a HIP device.
 #include "capi_internal.hpp"
+#include "spmv_bcsr_sell.hpp"
 
 // ---------------------------------------------------------------- BCSR 4x4
 extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
@@ -96,7 +97,94 @@ extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const i
             }
         }
     }
+    // The sliced copy (spmv_bcsr_sell.hpp): built for matrices large enough to stream (MI355_BCSR_SELL=0 never, =1 always and
+    // unmeasured with D = 4, non-temporal); its four variants are timed against the row-per-quad kernels above and the fastest of
+    // all is what mi_bcsr4_spmv* launches.  Costs a second copy of the block values on the device (+0.9 % padding on the FE matrix).
+    {
+        const char* se = getenv("MI355_BCSR_SELL");
+        const char* at = getenv("MI355_SPMV_AUTOTUNE");
+        const bool forced = se && !strcmp(se, "1");
+        if (!(se && !strcmp(se, "0")) && (forced || nb >= 100000) && nbcols < (1 << 30)) {
+            SellPlanHost P, P2;
+            build_sell_plan(nbrows, ptrow, indcol, 2048, P);
+            build_sell_wave_ranges(P, 4096, P2.wrng, P2.nwaves);
+            const size_t vbytes = sizeof(double) * (size_t)(P.nsteps + kSellPadSteps) * kSellStepDoubles;
+            if ((e = hipMalloc(&A->d_sell_val, vbytes)) != hipSuccess || (e = hipMalloc(&A->d_sell_col, sizeof(unsigned) * P.col.size())) != hipSuccess ||
+                (e = hipMalloc(&A->d_sell_sptr, sizeof(int) * P.sptr.size())) != hipSuccess || (e = hipMalloc(&A->d_sell_wrng, sizeof(int) * P.wrng.size())) != hipSuccess ||
+                (e = hipMalloc(&A->d_sell_wrng2, sizeof(int) * P2.wrng.size())) != hipSuccess ||
+                (e = hipMemcpy(A->d_sell_wrng2, P2.wrng.data(), sizeof(int) * P2.wrng.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemset(A->d_sell_val + (size_t)P.nsteps * kSellStepDoubles, 0, sizeof(double) * (size_t)kSellPadSteps * kSellStepDoubles)) != hipSuccess ||
+                (e = hipMemcpy(A->d_sell_col, P.col.data(), sizeof(unsigned) * P.col.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->d_sell_sptr, P.sptr.data(), sizeof(int) * P.sptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(A->d_sell_wrng, P.wrng.data(), sizeof(int) * P.wrng.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+                mi_bcsr4_destroy(A);
+                return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 sliced copy: ") + hipGetErrorString(e));
+            }
+            A->sell_nslices = P.nslices;
+            A->sell_nwaves = P.nwaves;
+            A->sell_nwaves2 = P2.nwaves;
+            A->sell_nsteps = P.nsteps;
+            A->sell_stale = true; // filled on the first product's stream
+            if (const char* fe = getenv("MI355_BCSR_SELL_FORM")) A->sell_form = std::max(0, std::min(3, atoi(fe))); // tests: one variant, unmeasured
+            else if (forced) A->sell_form = 0;
+            else if (!(at && !strcmp(at, "0"))) {
+                double *tx = nullptr, *ty = nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                const size_t nx = 4 * (size_t)std::max(nbcols, 1), ny = 4 * (size_t)std::max(nbrows, 1);
+                if (hipMalloc(&tx, sizeof(double) * nx) == hipSuccess && hipMalloc(&ty, sizeof(double) * ny) == hipSuccess &&
+                    hipMemset(tx, 0, sizeof(double) * nx) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                    double us[5] = {0, 0, 0, 0, 0}; // [0] the row-per-quad choice made above, [1..4] the sliced variants
+                    for (int round = 0; round < 2; round++)
+                        for (int c = 0; c < 5; c++) {
+                            A->sell_form = c - 1;
+                            for (int w = 0; w < 3; w++) (void)launch_bcsr4(A, tx, ty, nullptr, false);
+                            (void)hipEventRecord(e0, nullptr);
+                            for (int w = 0; w < 8; w++) (void)launch_bcsr4(A, tx, ty, nullptr, false);
+                            (void)hipEventRecord(e1, nullptr);
+                            (void)hipEventSynchronize(e1);
+                            float ms = 0.f;
+                            (void)hipEventElapsedTime(&ms, e0, e1);
+                            const double t = ms * 1e3 / 8;
+                            us[c] = us[c] > 0 ? std::min(us[c], t) : t;
+                        }
+                    int best = 0;
+                    for (int c = 1; c < 5; c++) {
+                        A->tune_us_sell[c - 1] = us[c];
+                        if (us[c] > 0 && us[c] < us[best]) best = c;
+                    }
+                    if (A->tune_us_plain <= 0 && A->tune_us_tile <= 0) A->tune_us_plain = us[0];
+                    A->sell_form = best - 1;
+                }
+                dfree(tx);
+                dfree(ty);
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+            } else A->sell_form = 0; // no measurement: the sliced, non-temporal form for matrices of this size
+        }
+    }
     *out = A;
+    return MI_OK;
+}
+
+// (re)fill the sliced copy from the row-major blocks, on stream s
+static int sell_fill(mi_bcsr4_t A, hipStream_t s)
+{
+    const int grid = std::max(1, std::min(A->sell_nslices, 8192));
+    hipLaunchKernelGGL(bcsr4_to_sell_kernel, dim3((unsigned)grid), dim3(64), 0, s, A->sell_nslices, A->nbrows, A->d_ptrow, A->d_coef, A->d_sell_sptr, A->d_sell_val);
+    HIP_TRY(hipGetLastError());
+    A->sell_stale = false;
+    return MI_OK;
+}
+
+extern "C" int mi_bcsr4_sell_info(mi_bcsr4_t A, int* built, int* form_in_use, long long* steps, double* padding, double us[4])
+{
+    CHECK_ARG(A, "null handle");
+    if (built) *built = A->d_sell_val != nullptr;
+    if (form_in_use) *form_in_use = A->d_sell_val ? A->sell_form : -1;
+    if (steps) *steps = A->sell_nsteps;
+    if (padding) *padding = A->nblocks > 0 && A->d_sell_val ? (double)A->sell_nsteps * kSellRows / (double)A->nblocks - 1.0 : 0.0;
+    if (us)
+        for (int i = 0; i < 4; i++) us[i] = A->tune_us_sell[i];
     return MI_OK;
 }
 
@@ -156,6 +244,7 @@ extern "C" int mi_bcsr4_update_values_layout_dev(mi_bcsr4_t A, const double* d_c
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(transpose_blocks_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, A->nblocks, d_coef, A->d_coef);
     HIP_TRY(hipGetLastError());
+    bcsr4_values_changed(A);
     return MI_OK;
 }
 
@@ -176,6 +265,7 @@ extern "C" int mi_bcsr4_update_values(mi_bcsr4_t A, const double* coef)
     if (A->nblocks == 0) return MI_OK;
     CHECK_ARG(coef, "null coef");
     HIP_TRY(hipMemcpy(A->d_coef, coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyHostToDevice));
+    bcsr4_values_changed(A);
     return MI_OK;
 }
 
@@ -185,6 +275,7 @@ extern "C" int mi_bcsr4_update_values_dev(mi_bcsr4_t A, const double* d_coef, mi
     if (A->nblocks == 0) return MI_OK;
     CHECK_ARG(d_coef, "null coef");
     HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    bcsr4_values_changed(A);
     return MI_OK;
 }
 
@@ -198,6 +289,11 @@ extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
     dfree(A->d_tl_ptr);
     dfree(A->d_tl_nodes);
     dfree(A->d_tl_slots);
+    dfree(A->d_sell_val);
+    dfree(A->d_sell_col);
+    dfree(A->d_sell_sptr);
+    dfree(A->d_sell_wrng);
+    dfree(A->d_sell_wrng2);
     dfree(A->st.d_ptr);
     dfree(A->st.d_nodes);
     dfree(A->st.d_slots);
@@ -224,6 +320,24 @@ int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bo
     const int nwg = (int)((threads + kWG - 1) / kWG);
     static const int chunk = getenv("MI355_BCSR_XCD_CHUNK") ? atoi(getenv("MI355_BCSR_XCD_CHUNK")) : 0;
     const int grid = nwg;
+    // the sliced form: unmapped products only (a relabelled matrix's block-row map scatters y; its twin keeps the row-per-quad kernels)
+    if (A->sell_form >= 0 && A->d_sell_val && !V.browmap && !(A->sell_stale && stream_is_capturing((hipStream_t)s))) {
+        if (A->sell_stale) {
+            int rc = sell_fill(A, (hipStream_t)s);
+            if (rc) return rc;
+        }
+        const bool four = A->sell_form == 3;
+        SellView S{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, four ? A->d_sell_wrng2 : A->d_sell_wrng, A->sell_nslices, A->nbrows};
+        const int swg = (four ? A->sell_nwaves2 : A->sell_nwaves) / 4;
+        switch (A->sell_form) {
+        case 0: hipLaunchKernelGGL((spmv_bcsr4_sell<4, true>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
+        case 1: hipLaunchKernelGGL((spmv_bcsr4_sell<4, false>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
+        case 2: hipLaunchKernelGGL((spmv_bcsr4_sell<6, true>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
+        default: hipLaunchKernelGGL((spmv_bcsr4_sell<4, true>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
     if (A->use_tile && A->d_tl_ptr) {
         Bcsr4Tile Tl{A->d_tl_ptr, A->d_tl_nodes, A->d_tl_slots};
         hipLaunchKernelGGL(spmv_bcsr4_tile<kBcsrDepth>, dim3((unsigned)grid), dim3(kWG), 0, (hipStream_t)s, V, Tl, d_x, d_y, nwg);

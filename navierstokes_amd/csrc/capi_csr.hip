@@ -970,6 +970,7 @@ static int refresh_blocked_values(mi_csr_t A, hipStream_t s)
     hipLaunchKernelGGL(bcsr4_values_from_csr_kernel, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, s,
                        A->blocked->nbrows, A->d_ptrow, A->d_coef, A->blocked->d_ptrow, A->blocked->d_coef);
     HIP_TRY(hipGetLastError());
+    bcsr4_values_changed(A->blocked);
     return MI_OK;
 }
 
@@ -1501,7 +1502,12 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
         return nm;
     }
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
-    case MI_KERNEL_BCSR4: return A->blocked && A->blocked->use_tile && A->blocked->d_tl_ptr ? "spmv_bcsr4_tile<2>" : "spmv_bcsr4<2>";
+    case MI_KERNEL_BCSR4: {
+        const mi_bcsr4_s* B = A->blocked;
+        static const char* const sell_names[4] = {"spmv_bcsr4_sell<4, true>", "spmv_bcsr4_sell<4, false>", "spmv_bcsr4_sell<6, true>", "spmv_bcsr4_sell<4, true>"};
+        if (B && B->sell_form >= 0 && B->d_sell_val && !B->d_browmap) return sell_names[B->sell_form & 3];
+        return B && B->use_tile && B->d_tl_ptr ? "spmv_bcsr4_tile<2>" : "spmv_bcsr4<2>";
+    }
     case MI_KERNEL_MRING: {
         static thread_local char nm[96];
         snprintf(nm, sizeof nm, "spmv_csr_mring<%d, %d, %d, %d, %s, %s, %s>", kMringThreads, kMringNnzb, A->mring.depth, kMringMaxB,

@@ -206,6 +206,18 @@ struct mi_bcsr4_s {
     unsigned short* d_tl_slots = nullptr;
     bool use_tile = false;    // the measured choice between the two kernels (MI355_BCSR_TILE=0|1 forces)
     double tune_us_plain = 0.0, tune_us_tile = 0.0;
+    // the sliced copy (spmv_bcsr_sell.hpp): 16 block rows per slice, one contiguous stream per persistent wave; null if not built
+    double* d_sell_val = nullptr;
+    unsigned* d_sell_col = nullptr;
+    int* d_sell_sptr = nullptr;
+    int* d_sell_wrng = nullptr;  // slice ranges of the waves: [sell_nwaves + 1] for 2 waves per SIMD ...
+    int* d_sell_wrng2 = nullptr; // ... and [sell_nwaves2 + 1] for 4
+    int sell_nslices = 0, sell_nwaves = 0, sell_nwaves2 = 0;
+    long long sell_nsteps = 0;
+    bool sell_stale = false;  // d_coef changed since the sliced copy was filled: refilled on the next product's stream
+    int sell_form = -1;       // -1: not in use; else the variant the create-time measurement kept: 0 D=4 nt, 1 D=4 temporal, 2 D=6 nt (two waves per
+                              // SIMD each), 3 D=4 nt with four waves per SIMD
+    double tune_us_sell[4] = {0, 0, 0, 0};
     // x tiles of the multi-vector product (spmm_tile.hpp): lists per group of 128 block rows (st) and of 64 (st64: the eight-column
     // form with two quads per block row), built at the first product
     SpmmTilePlan st, st64;
@@ -320,4 +332,6 @@ int part_push_window(mi_part_s* P);
 void part_push_layout(const mi_part_s* P, long long* layout /* [2*nranks + 1] */);
 int part_push_connect_bases(mi_part_s* P, void* const* bases /* [nranks] */, const long long* layouts);
 // capi_bcsr.hip
+// the blocked copy's values were rewritten (by whoever holds d_coef): the sliced copy follows on the next product
+static inline void bcsr4_values_changed(mi_bcsr4_s* A) { if (A && A->d_sell_val) A->sell_stale = true; }
 int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);

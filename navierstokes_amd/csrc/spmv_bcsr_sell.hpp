@@ -1,0 +1,212 @@
+// spmv_bcsr_sell.hpp — the blocked product as ONE contiguous stream per wave (round 4).
+//
+// SpMV_BCSR{,_OPT,_FMA,_AVX2}(y, x, A), mpk/SpMV.cpp:90-219 — and, through the blocked copy mi_csr_create makes of an FE matrix,
+// SpMV_CSR of the reference's own matrix family (mpk/log/log_SPMV.txt:1-90: 44-58 nonzeros per row in 4x4 node blocks).
+// Arithmetic unchanged: lane (r, q) owns row 4*bi + q of block row bi and runs ONE fma chain over the row's blocks in storage
+// order, columns 0..3 inside a block — the bits of SpMV_BCSR_FMA (mpk/SpMV.cpp:150-178).
+//
+// What changed is where the bytes lie and how they are asked for.  spmv_bcsr4 (spmv_kernels.hpp) gives every block row to a quad
+// that walks its ~15 blocks with a two-deep pipeline of its own: each load instruction of a wave touches sixteen 128-byte lines
+// at 64 bytes each (the second instruction touches the same sixteen again, which is why non-temporal loads lose 30 % there), a
+// wave lives for ~8 round trips of which two are its start (row pointers, then the first blocks) and one its drain, and the
+// launch is 5 133 workgroups coming and going.  It streams its 660 MB at 5.85 TB/s whatever the order of its rows or the
+// source of x — the rate of TEMPORAL loads on this part (profiles/NOTES.md) — where a non-temporal sweep reads 6.4-7.0.
+//
+// Here the library keeps a SLICED copy of the block values (mi_bcsr4_create; a format of its own making, like the CSR ring's
+// 16-bit column stream): a slice is 16 consecutive block rows — one wave: 16 quads — padded to the slice's longest row (0.9 % on
+// the 68^3 FE matrix), and step j of a slice holds the j-th block of each of its rows as TWO contiguous kilobytes:
+//     val[step][0][lane] = {a(q,0), a(q,1)}      val[step][1][lane] = {a(q,2), a(q,3)}      lane = 4*r + q
+// so that each of the wave's two 16-byte loads per step reads one contiguous KiB — whole lines, once — and may be non-temporal.
+// A wave is PERSISTENT and owns a contiguous range of slices: its whole input is one contiguous stream (values) beside a second
+// (block columns, 64 B per step), prefetched D steps ahead with unconditional, counted loads that never look at a row or slice
+// boundary; the boundary (every ~15 steps, wave-uniform since slices are padded) only decides when the accumulators are stored.
+// x is gathered through L1 / L2 as in spmv_bcsr4 (columns one round ahead of x): measured there, its source does not matter.
+// Padding steps are never multiplied (a lane past its row's end keeps its sum: fma(0, x, s) could flip a -0).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace mi355 {
+
+constexpr int kSellRows = 16;          // block rows per slice = quads per wave
+constexpr int kSellStepDoubles = 256;  // 16 blocks x 16 values
+constexpr int kSellPadSteps = 24;      // steps of padding behind the last one: the stream's loads run ahead unclamped (3 * D <= 24)
+constexpr unsigned kSellPadCol = 0x80000000u;   // column entry of a padding place (a row shorter than its slice): bit 31; x is read at node 0, nothing is multiplied
+constexpr unsigned kSellFirstCol = 0x40000000u; // set on all 16 entries of the first step of every slice: where the sums of one slice end
+constexpr unsigned kSellColMask = 0x3fffffffu;  // (block columns stay below 2^30: 4 * 8 bytes per node already make that 32 GB of x)
+
+struct SellView {
+    const double* val;     // [nsteps + kSellPadSteps][2][64][2]
+    const unsigned* col;   // [nsteps + kSellPadSteps][16]; bit 31 (kSellPadCol) where a row has no block at that step, bit 30 on a slice's first step
+    const int* sptr;       // [nslices + 3] first step of each slice (three terminators, so that look-ahead reads stay in bounds)
+    const int* wrng;       // [nwaves + 1] slices of each wave
+    int nslices, nbrows;
+};
+
+// host: the slice table of a block pattern — sptr (with its three terminators), the sliced column stream, the wave ranges
+// balanced by steps
+struct SellPlanHost {
+    int nslices = 0, nwaves = 0;
+    long long nsteps = 0;
+    std::vector<int> sptr, wrng;
+    std::vector<unsigned> col;
+};
+
+// waves: contiguous slice ranges of (nearly) equal step counts; a multiple of 32 (8 XCDs x 4 waves per workgroup)
+inline void build_sell_wave_ranges(const SellPlanHost& P, int nwaves_max, std::vector<int>& wrng, int& nwaves);
+
+inline void build_sell_plan(int nbrows, const int* ptrow, const int* indcol, int nwaves_max, SellPlanHost& P)
+{
+    P.nslices = (nbrows + kSellRows - 1) / kSellRows;
+    P.sptr.assign((size_t)P.nslices + 3, 0);
+    long long t = 0;
+    for (int s = 0; s < P.nslices; s++) {
+        int L = 1; // a slice of empty rows still takes one (padding) step: a boundary is then always a step apart from the next
+        for (int r = 0; r < kSellRows && kSellRows * s + r < nbrows; r++) L = std::max(L, ptrow[kSellRows * s + r + 1] - ptrow[kSellRows * s + r]);
+        P.sptr[s] = (int)t;
+        t += L;
+    }
+    P.col.assign((size_t)(t + kSellPadSteps) * kSellRows, kSellPadCol);
+    for (int s = 0; s < P.nslices; s++)
+        for (int r = 0; r < kSellRows && kSellRows * s + r < nbrows; r++) {
+            const int b0 = ptrow[kSellRows * s + r], n = ptrow[kSellRows * s + r + 1] - b0;
+            for (int j = 0; j < n; j++) P.col[((size_t)P.sptr[s] + j) * kSellRows + r] = (unsigned)indcol[b0 + j];
+        }
+    for (int s = 0; s < P.nslices; s++)
+        for (int r = 0; r < kSellRows; r++) P.col[(size_t)P.sptr[s] * kSellRows + r] |= kSellFirstCol;
+    for (int r = 0; r < kSellRows; r++) P.col[(size_t)t * kSellRows + r] |= kSellFirstCol; // (the step behind the last slice: never consumed)
+    P.nsteps = t;
+    P.sptr[P.nslices] = P.sptr[P.nslices + 1] = P.sptr[P.nslices + 2] = (int)t;
+    build_sell_wave_ranges(P, nwaves_max, P.wrng, P.nwaves);
+}
+
+inline void build_sell_wave_ranges(const SellPlanHost& P, int nwaves_max, std::vector<int>& wrng, int& nwaves)
+{
+    const int W = std::min(nwaves_max, std::max(32, (P.nslices / 2 + 31) / 32 * 32));
+    nwaves = W;
+    wrng.assign((size_t)W + 1, P.nslices);
+    wrng[0] = 0;
+    int s = 0;
+    for (int w = 1; w < W; w++) {
+        const long long target = P.nsteps * w / W;
+        while (s < P.nslices && P.sptr[s] < target) s++;
+        wrng[w] = s;
+    }
+}
+
+typedef double sell_v2d __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__device__ __forceinline__ sell_v2d sell_ld(const sell_v2d* p)
+{
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+// fills the sliced copy from the row-major blocks: one wave per slice (setup and value refreshes; never per product)
+__global__ __launch_bounds__(64) void bcsr4_to_sell_kernel(int nslices, int nbrows, const int* __restrict__ ptrow, const double* __restrict__ coef,
+                                                           const int* __restrict__ sptr, double* __restrict__ val)
+{
+    const int lane = threadIdx.x, r = lane >> 2, q = lane & 3;
+    for (int s = blockIdx.x; s < nslices; s += gridDim.x) {
+        const int bi = kSellRows * s + r;
+        const int b0 = bi < nbrows ? ptrow[bi] : 0, n = bi < nbrows ? ptrow[bi + 1] - b0 : 0;
+        const int t0 = sptr[s], L = sptr[s + 1] - t0;
+        for (int j = 0; j < L; j++) {
+            sell_v2d lo = {0.0, 0.0}, hi = {0.0, 0.0};
+            if (j < n) {
+                const sell_v2d* src = reinterpret_cast<const sell_v2d*>(coef + 16 * (size_t)(b0 + j) + 4 * q);
+                lo = src[0];
+                hi = src[1];
+            }
+            sell_v2d* dst = reinterpret_cast<sell_v2d*>(val + (size_t)(t0 + j) * kSellStepDoubles);
+            dst[lane] = lo;
+            dst[64 + lane] = hi;
+        }
+    }
+}
+
+// D steps of values and x in flight per lane, the block columns of D more.  One wave = one contiguous range of slices.
+// Workgroups of 256 threads = 4 independent waves; workgroup b is taken as logical workgroup (b % 8) * (G / 8) + b / 8, so that
+// the workgroups that share an XCD (b, b + 8, ...) stream neighbouring slices and share their x lines in that XCD's L2.
+// The loop never loads a row pointer or a slice table: where a slice begins is a flag in the column stream it is reading anyway
+// (kSellFirstCol on every entry of a slice's first step), read back through readfirstlane so that the branch is a scalar one.
+// Each stage is refilled AFTER its old contents have been multiplied, into the same registers: hipcc then needs no copies at the
+// back edge and keeps counted waits around the loop (with the refill in front of the fmas it drained every load once per trip).
+template <int D, bool NT>
+__global__ __launch_bounds__(256) void spmv_bcsr4_sell(SellView S, const double* __restrict__ x, double* __restrict__ y, int nwg)
+{
+    const int per = nwg >> 3;
+    const int lwg = per > 0 && (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(lwg * 4 + ((int)threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, r = lane >> 2;
+    const int s_begin = __builtin_amdgcn_readfirstlane(S.wrng[wave]);
+    const int s_end = __builtin_amdgcn_readfirstlane(S.wrng[wave + 1]);
+    if (s_begin >= s_end) return;
+    const int t0 = __builtin_amdgcn_readfirstlane(S.sptr[s_begin]);
+    const int t_end = __builtin_amdgcn_readfirstlane(S.sptr[s_end]);
+    int s = s_begin - 1; // the range's first step carries the flag too: the boundary code runs there and counts s up to s_begin
+
+    const sell_v2d* vbase = reinterpret_cast<const sell_v2d*>(S.val) + lane;
+    const unsigned* cbase = S.col + r;
+    sell_v2d a01[D], a23[D], x01[D], x23[D];
+    unsigned cn[D];  // column entries of steps t + D + d (one round ahead of the values and x)
+    unsigned fl[D];  // flags of the step whose values stage d holds: bit 1 padding place, bit 0 first step of a slice
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const sell_v2d* p = vbase + (size_t)(t0 + d) * (kSellStepDoubles / 2);
+        a01[d] = sell_ld<NT>(p);
+        a23[d] = sell_ld<NT>(p + 64);
+        cn[d] = cbase[(size_t)(t0 + d) * kSellRows];
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        fl[d] = cn[d] >> 30;
+        const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(x + 4 * (size_t)(cn[d] & kSellColMask));
+        x01[d] = xb[0];
+        x23[d] = xb[1];
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) cn[d] = cbase[(size_t)(t0 + D + d) * kSellRows];
+
+    double acc = 0.0;
+    for (int t = t0; t < t_end; t += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int i = t + d; // the step consumed now
+            if (i < t_end) { // (wave-uniform)
+                const unsigned f = fl[d];
+                if (__builtin_amdgcn_readfirstlane(f) & 1u) { // a slice begins: the one before it is complete — its 64 rows go out as one 512-byte store
+                    const int bi = kSellRows * s + r;
+                    if (i != t0 && bi < S.nbrows) y[4 * (size_t)bi + (lane & 3)] = acc;
+                    acc = 0.0;
+                    s++;
+                }
+                double n = fma(a01[d].x, x01[d].x, acc);
+                n = fma(a01[d].y, x01[d].y, n);
+                n = fma(a23[d].x, x23[d].x, n);
+                n = fma(a23[d].y, x23[d].y, n);
+                acc = (f & 2u) ? acc : n; // padding places are not multiplied
+            }
+            // refill stage d with step i + D (its column arrived a round ago), then ask for the column of step i + 2 D
+            const sell_v2d* p = vbase + (size_t)(i + D) * (kSellStepDoubles / 2);
+            a01[d] = sell_ld<NT>(p);
+            a23[d] = sell_ld<NT>(p + 64);
+            const unsigned c = cn[d];
+            fl[d] = c >> 30;
+            const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(x + 4 * (size_t)(c & kSellColMask));
+            x01[d] = xb[0];
+            x23[d] = xb[1];
+            // (the old column entry is dead from here: pinning its last uses in front of the reload lets the new entry land in the same
+            // register — left to itself hipcc computed the flags at the bottom of the loop, kept both entries alive, copied at the back
+            // edge and put an s_waitcnt vmcnt(0) in front of the copies: every load drained once per trip)
+            asm volatile("" ::"v"(fl[d]), "v"(xb));
+            cn[d] = cbase[(size_t)(i + 2 * D) * kSellRows];
+        }
+    }
+    const int bi = kSellRows * s + r;
+    if (bi < S.nbrows) y[4 * (size_t)bi + (lane & 3)] = acc;
+}
+
+} // namespace mi355

@@ -109,6 +109,7 @@ def lib():
         "mi_ring_plan_lean": [i, _vp, _vp, i, P(i)],
         "mi_csr_tile_info": [_vp, P(i), P(i), P(d), P(d), P(i)],
         "mi_bcsr4_tile_info": [_vp, P(i), P(i), P(d), P(d)],
+        "mi_bcsr4_sell_info": [_vp, P(i), P(i), P(ll), P(d), P(d)],
         "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
         "mi_csr_placement_info": [_vp, P(i), P(i), P(d), i],
         "mi_vec_alloc_placed": [_vp, i, i, P(_vp), P(d), i, P(i)],

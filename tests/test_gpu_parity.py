@@ -964,3 +964,68 @@ def test_mring_with_second_round_workgroups_is_bitwise(monkeypatch):
             y.fill_(float("nan"))
         A.close()
     assert late > 0, "the test matrix no longer produces second-round workgroups: pick another"
+
+
+@pytest.mark.parametrize("form", ["0", "1", "2", "3"])
+def test_blocked_product_from_the_sliced_copy(form, monkeypatch):
+    """spmv_bcsr4_sell (spmv_bcsr_sell.hpp; SpMV_BCSR*, mpk/SpMV.cpp:90-219): the sliced copy of the block values streamed by
+    persistent waves.  Each variant forced (MI355_BCSR_SELL_FORM): bit-equal to the oracle's SpMV_BCSR_FMA restatement on the FE matrix
+    (through the BCSR API and, as the blocked copy of a CSR handle, through SpMV_CSR), on ragged patterns — empty block rows, a row count
+    that is no multiple of the slice, rows much shorter than their slice (padding places read x at node 0 and must not be multiplied: x is
+    infinite there), more slices than waves and fewer —, and after value refreshes (the sliced copy follows the blocks)."""
+    monkeypatch.setenv("MI355_BCSR_SELL", "1")
+    monkeypatch.setenv("MI355_BCSR_SELL_FORM", form)
+    L = mpk.lib()
+    import ctypes
+
+    def sell_form(handle):
+        b, f = ctypes.c_int(), ctypes.c_int()
+        mpk.check(L.mi_bcsr4_sell_info(handle, ctypes.byref(b), ctypes.byref(f), None, None, None))
+        return b.value, f.value
+
+    # the FE matrix, BCSR API
+    p, c, v = synth.fe_matrix(20)
+    n = len(p) - 1
+    bp, bc, bv = synth.csr_to_bcsr4(p, c, v)
+    x = synth.x_sin(0, n)
+    B = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
+    assert sell_form(B.handle) == (1, int(form))
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        mpk.SpMV_BCSR(y, dev(x), B)
+    assert_bit_equal(y.cpu().numpy(), O.spmv_bcsr4(bp, bc, bv, x), f"FE matrix, sliced form {form}")
+    bv2 = bv * np.cos(np.arange(len(bv)))
+    B.update_values(bv2)
+    mpk.SpMV_BCSR(y, dev(x), B)
+    assert_bit_equal(y.cpu().numpy(), O.spmv_bcsr4(bp, bc, bv2, x), "after mi_bcsr4_update_values")
+    # the same matrix as a CSR handle: AUTO runs the blocked copy (forced here), values refreshed through mi_csr_update_values
+    A = mpk.csrmatrix(n, p, c, v).set_kernel("bcsr4")
+    y1 = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(y1, dev(x), A)
+    assert "sell" in A.kernel_name(), A.kernel_name()
+    assert_bit_equal(y1.cpu().numpy(), O.spmv(p, c, v, x), "CSR API over the sliced blocked copy")
+    v2 = v * np.sin(1.0 + np.arange(len(v)))
+    A.update_values(v2)
+    mpk.SpMV_CSR(y1, dev(x), A)
+    assert_bit_equal(y1.cpu().numpy(), O.spmv(p, c, v2, x), "after mi_csr_update_values")
+    # ragged block patterns
+    rng = np.random.default_rng(11)
+    for nbr, nbc, maxlen in ((1, 7, 5), (15, 40, 9), (16, 16, 1), (17, 300, 30), (1000, 1000, 12), (70_001, 70_001, 6)):
+        lens = rng.integers(0, maxlen + 1, nbr)
+        lens[rng.random(nbr) < 0.2] = 0            # empty block rows
+        if nbr > 40:
+            lens[nbr // 2] = 4 * maxlen            # one long row: its slice is mostly padding
+        lens = np.minimum(lens, nbc)
+        bp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        lens = np.minimum(lens, nbc - 1)
+        bp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        # no block names block column 0, and x is infinite there: padding places read x at node 0 and must not multiply it (0 * inf = NaN)
+        bc = np.concatenate([1 + rng.choice(nbc - 1, size=l, replace=False) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+        bv = rng.uniform(-1, 1, 16 * len(bc))
+        xx = rng.uniform(-1, 1, 4 * nbc)
+        xx[:4] = np.inf
+        B = mpk.bcsr4x4_matrix(nbr, bp, bc, bv, nbcols=nbc)
+        yy = torch.full((4 * nbr,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_BCSR(yy, dev(xx), B)
+        assert sell_form(B.handle) == (1, int(form))
+        assert_bit_equal(yy.cpu().numpy(), O.spmv_bcsr4(bp, bc, bv, xx), f"ragged {nbr} x {nbc}, sliced form {form}")
