@@ -390,9 +390,10 @@ def main():
         mpk.check(mpk.lib().mi_bcsr4_sell_info(A.handle, _ct.byref(sb), _ct.byref(sf), _ct.byref(ss), _ct.byref(spad), sus))
         bcsr_forms = dict(us_row_per_quad=round(bt[2].value, 2), us_row_per_quad_x_tile=round(bt[3].value, 2), sliced_copy_built=bool(sb.value),
                           sliced_form_in_use=sf.value, sliced_steps=ss.value, sliced_padding=round(spad.value, 5),
-                          us_sliced=dict(d4_nt=round(sus[0], 2), d4_temporal=round(sus[1], 2), d6_nt=round(sus[2], 2), d4_nt_4waves=round(sus[3], 2)))
+                          us_sliced=dict(one_wave_per_simd_d8_nt=round(sus[0], 2), one_wave_per_simd_d8_temporal=round(sus[1], 2), two_waves_per_simd_d4_nt=round(sus[2], 2),
+                                         one_wave_per_simd_d12_nt=round(sus[3], 2)))
         if sf.value >= 0:
-            kernel_name = ["spmv_bcsr4_sell<4, true>", "spmv_bcsr4_sell<4, false>", "spmv_bcsr4_sell<6, true>", "spmv_bcsr4_sell<4, true>"][sf.value]
+            kernel_name = ["spmv_bcsr4_sell<8, true, 0, 2, 4>", "spmv_bcsr4_sell<8, false, 0, 2, 4>", "spmv_bcsr4_sell<4, true, 0, 2, 8>", "spmv_bcsr4_sell<12, true, 0, 2, 4>"][sf.value]
         ring_cfg, ring_runs, ring_bad, ring_frac = 0, 0, 0, 0.0
         x = torch.from_numpy(x_host).cuda()
         ys = [torch.empty(n, dtype=torch.float64, device="cuda")]

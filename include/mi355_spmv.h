@@ -331,11 +331,12 @@ int mi_bcsr4_tile_info(mi_bcsr4_t A, int* built, int* in_use, double* us_plain, 
 /* Third form (round 4, spmv_bcsr_sell.hpp): a SLICED copy of the block values made at mi_bcsr4_create for matrices of >= 100 000 blocks
  * — 16 consecutive block rows per slice, padded to the slice's longest row, step j of a slice = the j-th block of each of its rows as
  * two contiguous kilobytes — streamed by persistent waves, each over one contiguous range of slices, with unconditional counted loads
- * (non-temporal where that measures faster) that never look at a row boundary.  Same lanes per row, same fma order, same bits.  Four
- * variants are timed against the two forms above at create and the fastest of all runs (MI355_BCSR_SELL=0 never builds it, =1 takes
- * variant 0 unmeasured, MI355_BCSR_SELL_FORM=0..3 a given one).  Unmapped products only: the blocked copy of a relabelled matrix keeps
- * the forms above.  *form_in_use: -1 none; 0 four steps of prefetch, non-temporal value loads; 1 the same with temporal loads; 2 six
- * steps, non-temporal (0-2: two waves per SIMD); 3 as 0 with four waves per SIMD;
+ * (non-temporal where that measures faster) that never look at a row boundary; a slice's sums are parked in LDS and stored behind the
+ * wave's last load (a store issued among the loads costs the read stream many times its bytes).  Same lanes per row, same fma order,
+ * same bits.  Four variants are timed against the two forms above at create and the fastest of all runs (MI355_BCSR_SELL=0 never builds
+ * it, =1 takes variant 0 unmeasured, MI355_BCSR_SELL_FORM=0..3 a given one).  Unmapped products only: the blocked copy of a relabelled
+ * matrix keeps the forms above.  *form_in_use: -1 none; 0 one wave per SIMD, eight steps of prefetch, non-temporal value loads; 1 the
+ * same with temporal loads; 2 two waves per SIMD (one workgroup of eight waves per CU), four steps, non-temporal; 3 as 0 with twelve steps;
  * *padding = padded places / blocks - 1; us[f] = microseconds per launch measured for variant f (0: not measured). */
 int mi_bcsr4_sell_info(mi_bcsr4_t A, int* built, int* form_in_use, long long* steps, double* padding, double us[4]);
 /* new block values (16 per block, row-major) for an unchanged block pattern; see mi_csr_update_values */

@@ -106,8 +106,8 @@ extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const i
         const bool forced = se && !strcmp(se, "1");
         if (!(se && !strcmp(se, "0")) && (forced || nb >= 100000) && nbcols < (1 << 30)) {
             SellPlanHost P, P2;
-            build_sell_plan(nbrows, ptrow, indcol, 2048, P);
-            build_sell_wave_ranges(P, 4096, P2.wrng, P2.nwaves);
+            build_sell_plan(nbrows, ptrow, indcol, 1024, P);
+            build_sell_wave_ranges(P, 2048, P2.wrng, P2.nwaves);
             const size_t vbytes = sizeof(double) * (size_t)(P.nsteps + kSellPadSteps) * kSellStepDoubles;
             if ((e = hipMalloc(&A->d_sell_val, vbytes)) != hipSuccess || (e = hipMalloc(&A->d_sell_col, sizeof(unsigned) * P.col.size())) != hipSuccess ||
                 (e = hipMalloc(&A->d_sell_sptr, sizeof(int) * P.sptr.size())) != hipSuccess || (e = hipMalloc(&A->d_sell_wrng, sizeof(int) * P.wrng.size())) != hipSuccess ||
@@ -326,14 +326,16 @@ int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bo
             int rc = sell_fill(A, (hipStream_t)s);
             if (rc) return rc;
         }
-        const bool four = A->sell_form == 3;
-        SellView S{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, four ? A->d_sell_wrng2 : A->d_sell_wrng, A->sell_nslices, A->nbrows};
-        const int swg = (four ? A->sell_nwaves2 : A->sell_nwaves) / 4;
+        // forms (mi_bcsr4_sell_info): 0 / 1 / 3 one wave per SIMD — one workgroup of four waves per CU, 8 (12) steps of prefetch,
+        // non-temporal / temporal / non-temporal; 2 one workgroup of eight waves per CU, 4 steps, non-temporal.  All park y in LDS.
+        const bool two = A->sell_form == 2;
+        SellView S{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, two ? A->d_sell_wrng2 : A->d_sell_wrng, A->sell_nslices, A->nbrows};
+        const int swg = two ? A->sell_nwaves2 / 8 : A->sell_nwaves / 4;
         switch (A->sell_form) {
-        case 0: hipLaunchKernelGGL((spmv_bcsr4_sell<4, true>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
-        case 1: hipLaunchKernelGGL((spmv_bcsr4_sell<4, false>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
-        case 2: hipLaunchKernelGGL((spmv_bcsr4_sell<6, true>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
-        default: hipLaunchKernelGGL((spmv_bcsr4_sell<4, true>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
+        case 0: hipLaunchKernelGGL((spmv_bcsr4_sell<8, true, 0, 2, 4>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
+        case 1: hipLaunchKernelGGL((spmv_bcsr4_sell<8, false, 0, 2, 4>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
+        case 2: hipLaunchKernelGGL((spmv_bcsr4_sell<4, true, 0, 2, 8>), dim3((unsigned)swg), dim3(512), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
+        default: hipLaunchKernelGGL((spmv_bcsr4_sell<12, true, 0, 2, 4>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
         }
         HIP_TRY(hipGetLastError());
         return MI_OK;

@@ -1504,7 +1504,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     case MI_KERNEL_ROWPAR: return "spmv_csr_rowpar";
     case MI_KERNEL_BCSR4: {
         const mi_bcsr4_s* B = A->blocked;
-        static const char* const sell_names[4] = {"spmv_bcsr4_sell<4, true>", "spmv_bcsr4_sell<4, false>", "spmv_bcsr4_sell<6, true>", "spmv_bcsr4_sell<4, true>"};
+        static const char* const sell_names[4] = {"spmv_bcsr4_sell<8, true, 0, 2, 4>", "spmv_bcsr4_sell<8, false, 0, 2, 4>", "spmv_bcsr4_sell<4, true, 0, 2, 8>", "spmv_bcsr4_sell<12, true, 0, 2, 4>"};
         if (B && B->sell_form >= 0 && B->d_sell_val && !B->d_browmap) return sell_names[B->sell_form & 3];
         return B && B->use_tile && B->d_tl_ptr ? "spmv_bcsr4_tile<2>" : "spmv_bcsr4<2>";
     }

@@ -210,13 +210,12 @@ struct mi_bcsr4_s {
     double* d_sell_val = nullptr;
     unsigned* d_sell_col = nullptr;
     int* d_sell_sptr = nullptr;
-    int* d_sell_wrng = nullptr;  // slice ranges of the waves: [sell_nwaves + 1] for 2 waves per SIMD ...
-    int* d_sell_wrng2 = nullptr; // ... and [sell_nwaves2 + 1] for 4
+    int* d_sell_wrng = nullptr;  // slice ranges of the waves: [sell_nwaves + 1] for ONE wave per SIMD (1024 waves) ...
+    int* d_sell_wrng2 = nullptr; // ... and [sell_nwaves2 + 1] for two (2048)
     int sell_nslices = 0, sell_nwaves = 0, sell_nwaves2 = 0;
     long long sell_nsteps = 0;
     bool sell_stale = false;  // d_coef changed since the sliced copy was filled: refilled on the next product's stream
-    int sell_form = -1;       // -1: not in use; else the variant the create-time measurement kept: 0 D=4 nt, 1 D=4 temporal, 2 D=6 nt (two waves per
-                              // SIMD each), 3 D=4 nt with four waves per SIMD
+    int sell_form = -1;       // -1: not in use; else the variant the create-time measurement kept (kSellForms, capi_bcsr.hip)
     double tune_us_sell[4] = {0, 0, 0, 0};
     // x tiles of the multi-vector product (spmm_tile.hpp): lists per group of 128 block rows (st) and of 64 (st64: the eight-column
     // form with two quads per block row), built at the first product

@@ -19,7 +19,15 @@
 // so that each of the wave's two 16-byte loads per step reads one contiguous KiB — whole lines, once — and may be non-temporal.
 // A wave is PERSISTENT and owns a contiguous range of slices: its whole input is one contiguous stream (values) beside a second
 // (block columns, 64 B per step), prefetched D steps ahead with unconditional, counted loads that never look at a row or slice
-// boundary; the boundary (every ~15 steps, wave-uniform since slices are padded) only decides when the accumulators are stored.
+// boundary; the boundary (every ~15 steps, wave-uniform since slices are padded) only decides when the accumulators are set aside.
+// What tools/sell_bench.hip measured on the way (FE-shaped pattern, 328 509 block rows; profiles/r04_sell_bench.txt):
+//   * the product with each slice's 512 bytes of y stored as they complete: 117 us — and 95.5 us with the stores compiled out: 10 MB of
+//     stores among the loads cost 21 us, whatever their flavour (non-temporal 117.8, write-through 115.9).  PARKED in LDS and stored
+//     behind the wave's last load: 105 us.  (A store among streaming reads costs the read stream many times its bytes: the CSR ring
+//     kernel met the same effect in round 1.)
+//   * of two workgroups on a CU — and of two waves on a SIMD — the one dispatched first takes the memory pipeline and ends ~40 us before
+//     the other, which then runs alone and under-subscribed (trace: 1 024 waves end within 15 us, the other 1 024 another 35 us later).
+//     ONE wave per SIMD with a deeper pipeline (D = 8) ends within 15 us: 100.6 us (0.83 of 8 TB/s on the 132 B / block model).
 // x is gathered through L1 / L2 as in spmv_bcsr4 (columns one round ahead of x): measured there, its source does not matter.
 // Padding steps are never multiplied (a lane past its row's end keeps its sum: fma(0, x, s) could flip a -0).
 #pragma once
@@ -32,7 +40,7 @@ namespace mi355 {
 
 constexpr int kSellRows = 16;          // block rows per slice = quads per wave
 constexpr int kSellStepDoubles = 256;  // 16 blocks x 16 values
-constexpr int kSellPadSteps = 24;      // steps of padding behind the last one: the stream's loads run ahead unclamped (3 * D <= 24)
+constexpr int kSellPadSteps = 48;      // steps of padding behind the last one: the stream's loads run ahead unclamped (3 * D <= 48)
 constexpr unsigned kSellPadCol = 0x80000000u;   // column entry of a padding place (a row shorter than its slice): bit 31; x is read at node 0, nothing is multiplied
 constexpr unsigned kSellFirstCol = 0x40000000u; // set on all 16 entries of the first step of every slice: where the sums of one slice end
 constexpr unsigned kSellColMask = 0x3fffffffu;  // (block columns stay below 2^30: 4 * 8 bytes per node already make that 32 GB of x)
@@ -134,12 +142,23 @@ __global__ __launch_bounds__(64) void bcsr4_to_sell_kernel(int nslices, int nbro
 // (kSellFirstCol on every entry of a slice's first step), read back through readfirstlane so that the branch is a scalar one.
 // Each stage is refilled AFTER its old contents have been multiplied, into the same registers: hipcc then needs no copies at the
 // back edge and keeps counted waits around the loop (with the refill in front of the fmas it drained every load once per trip).
-template <int D, bool NT>
-__global__ __launch_bounds__(256) void spmv_bcsr4_sell(SellView S, const double* __restrict__ x, double* __restrict__ y, int nwg)
+// YM: how a finished slice's 64 sums reach y.  0: one 512-byte store at once; 1: the same, non-temporal; 3: write-through (sc1);
+//     2: PARKED in LDS (kSellPark slices per wave) and stored when the park is full or the wave's range ends — for matrices whose
+//     waves own no more slices than the park holds, every store of the launch is issued behind the wave's last load.
+// ABL (tools/sell_bench.hip only; results invalid): 1 no x gather (x entries taken from a register), 2 no y stores, 4 no column stream
+constexpr int kSellPark = 32;
+// NW: waves per workgroup.  The waves of ONE workgroup advance alike; of two workgroups on a CU the one dispatched first takes the
+// memory pipeline and ends 40 us before the other (tools/sell_bench.hip, trace), which then runs alone and under-subscribed: one
+// workgroup of 8 waves per CU, not two of 4.
+template <int D, bool NT, int ABL = 0, int YM = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void spmv_bcsr4_sell(SellView S, const double* __restrict__ x, double* __restrict__ y, int nwg)
 {
+    __shared__ double s_park[YM == 2 ? NW * kSellPark * 64 : 1];
+    double* park = s_park + (YM == 2 ? ((int)threadIdx.x >> 6) * kSellPark * 64 + ((int)threadIdx.x & 63) : 0);
+    int parked = 0; // (wave-uniform)
     const int per = nwg >> 3;
     const int lwg = per > 0 && (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(lwg * 4 + ((int)threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane(lwg * NW + ((int)threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, r = lane >> 2;
     const int s_begin = __builtin_amdgcn_readfirstlane(S.wrng[wave]);
     const int s_end = __builtin_amdgcn_readfirstlane(S.wrng[wave + 1]);
@@ -164,13 +183,39 @@ __global__ __launch_bounds__(256) void spmv_bcsr4_sell(SellView S, const double*
     for (int d = 0; d < D; d++) {
         fl[d] = cn[d] >> 30;
         const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(x + 4 * (size_t)(cn[d] & kSellColMask));
-        x01[d] = xb[0];
-        x23[d] = xb[1];
+        if (ABL & 1) {
+            x01[d] = x23[d] = sell_v2d{1.0 + lane, 0.5};
+        } else {
+            x01[d] = xb[0];
+            x23[d] = xb[1];
+        }
     }
 #pragma unroll
     for (int d = 0; d < D; d++) cn[d] = cbase[(size_t)(t0 + D + d) * kSellRows];
 
     double acc = 0.0;
+    // the sums of slice `sl` are complete
+    auto emit = [&](int sl, double v) {
+        const int bi = kSellRows * sl + r;
+        double* dst = y + 4 * (size_t)bi + (lane & 3);
+        if ((ABL & 2) && v != 123.456) return;
+        if (YM == 2) {
+            park[parked * 64] = v;
+            parked++;
+            if (parked == kSellPark) {
+#pragma unroll
+                for (int j = 0; j < kSellPark; j++) {
+                    const int bj = kSellRows * (sl - (kSellPark - 1) + j) + r;
+                    if (bj < S.nbrows) y[4 * (size_t)bj + (lane & 3)] = park[j * 64];
+                }
+                parked = 0;
+            }
+        } else if (bi < S.nbrows) {
+            if (YM == 1) __builtin_nontemporal_store(v, dst);
+            else if (YM == 3) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = v;
+        }
+    };
     for (int t = t0; t < t_end; t += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -178,8 +223,7 @@ __global__ __launch_bounds__(256) void spmv_bcsr4_sell(SellView S, const double*
             if (i < t_end) { // (wave-uniform)
                 const unsigned f = fl[d];
                 if (__builtin_amdgcn_readfirstlane(f) & 1u) { // a slice begins: the one before it is complete — its 64 rows go out as one 512-byte store
-                    const int bi = kSellRows * s + r;
-                    if (i != t0 && bi < S.nbrows) y[4 * (size_t)bi + (lane & 3)] = acc;
+                    if (i != t0) emit(s, acc);
                     acc = 0.0;
                     s++;
                 }
@@ -196,17 +240,34 @@ __global__ __launch_bounds__(256) void spmv_bcsr4_sell(SellView S, const double*
             const unsigned c = cn[d];
             fl[d] = c >> 30;
             const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(x + 4 * (size_t)(c & kSellColMask));
-            x01[d] = xb[0];
-            x23[d] = xb[1];
+            if (!(ABL & 1)) {
+                x01[d] = xb[0];
+                x23[d] = xb[1];
+            }
             // (the old column entry is dead from here: pinning its last uses in front of the reload lets the new entry land in the same
             // register — left to itself hipcc computed the flags at the bottom of the loop, kept both entries alive, copied at the back
             // edge and put an s_waitcnt vmcnt(0) in front of the copies: every load drained once per trip)
             asm volatile("" ::"v"(fl[d]), "v"(xb));
-            cn[d] = cbase[(size_t)(i + 2 * D) * kSellRows];
+            if (!(ABL & 4)) cn[d] = cbase[(size_t)(i + 2 * D) * kSellRows];
         }
     }
-    const int bi = kSellRows * s + r;
-    if (bi < S.nbrows) y[4 * (size_t)bi + (lane & 3)] = acc;
+    emit(s, acc);
+    unsigned long long t_loads_done = 0;
+    if (ABL & 8) t_loads_done = __builtin_amdgcn_s_memrealtime();
+    if (YM == 2 && !(ABL & 16))
+        for (int j = 0; j < parked; j++) { // what is still parked: the slices s - parked + 1 .. s
+            const int bj = kSellRows * (s - parked + 1 + j) + r;
+            if (bj < S.nbrows) y[4 * (size_t)bj + (lane & 3)] = park[j * 64];
+        }
+    if (ABL & 8) { // TRACE (tools/sell_bench.hip): when this wave's loop ended and when its stores were out, 100 MHz ticks, behind y
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end_all = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* tr = reinterpret_cast<unsigned long long*>(y + 4 * (size_t)S.nbrows) + 2 * (size_t)wave;
+            tr[0] = t_loads_done;
+            tr[1] = t_end_all;
+        }
+    }
 }
 
 } // namespace mi355
