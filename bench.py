@@ -866,7 +866,7 @@ def main():
         if pl["values"]:
             out["kernel_info"]["placement_draws_us"] = dict(pl, note="mi_csr_create timed the chosen kernel on fresh device copies of the value array, then of the 16-bit column "
                                                                   "stream, and kept the fastest of each (first entry: as first allocated); where the arrays — the caller's x and y "
-                                                                  "included — lie in device memory moves a WARM launch by up to 15 %, a cold one not at all (DESIGN 4.12)")
+                                                                  "included — lie in device memory moves a WARM launch by up to 15 %, a cold one not at all (profiles/NOTES.md §4.12)")
         ti = A.tile_info()
         if ti["built"]:
             out["kernel_info"]["tile_plan"] = dict(row_blocks=ti["nblk"], distinct_columns_per_nnz=round(ti["unique_per_nnz"], 4))

@@ -153,7 +153,7 @@ int mi_csr_set_kernel(mi_csr_t A, int kernel_id);
 int mi_csr_ring_info(mi_csr_t A, int* config_id, int* runs, int* runs_not_ringable, double* nnz_fraction_ringable);
 /* Shape of the ring plan in use: row blocks, whether the LEAN instantiation runs, blocks of prefetch.  Matrices of >= 20 M
  * nonzeros take row blocks cut at the nonzero count, smaller ones blocks ending on multiples of 64 rows (the first shape's
- * rate does not depend on where the caller's x and y lie in device memory, the second's does: DESIGN.md 4.1).  With
+ * rate does not depend on where the caller's x and y lie in device memory, the second's does: profiles/NOTES.md §4.1).  With
  * MI355_RING_SHAPE_COMPARE=1 in the environment mi_csr_create also times the other shape on its scratch vectors
  * (microseconds per launch; 0 = not compared). */
 int mi_csr_ring_shape_info(mi_csr_t A, int* blocks, int* lean, int* depth, double* us_aligned, double* us_unaligned);
@@ -188,14 +188,14 @@ int mi_csr_tile_info(mi_csr_t A, int* built, int* nblk, double* unique_per_nnz, 
  * aligned slot segments, over-long rows unlisted) and report its size.  threads = 0: as many as the library would use. */
 int mi_tile_plan_probe(int n, const int* ptrow, const int* indcol, int threads, int* nblk, long long* distinct_total,
                        int* max_distinct, long long* nnz_listed);
-/* Placement draws: for matrices beyond the caches (>= 20 M nonzeros, a CSR kernel chosen) mi_csr_create times the
+/* Placement draws (profiles/NOTES.md §4.12): for matrices beyond the caches (>= 20 M nonzeros, a CSR kernel chosen) mi_csr_create times the
  * chosen kernel on a few fresh device copies of the value array, then of the 16-bit column stream, and keeps the fastest copy of
  * each — where these arrays lie in device memory moves a warm launch by up to 15 %.  us[0 .. *n_values) = microseconds per launch
  * with the value array as first allocated ([0]) and after each draw; us[*n_values .. *n_total) the same for the column stream
  * (cap = length of us; both counts 0: no draws were made).  MI355_PLACEMENT_DRAWS=0 turns the draws off, =N sets their number
  * (default 12 for the value array, capped so that the copies fit an eighth of the free device memory; half as many for the stream). */
 int mi_csr_placement_info(mi_csr_t A, int* n_values, int* n_total, double* us, int cap);
-/* The same for the CALLER's vectors (round 3): on some MI355X boxes a product with A runs 126 or 141-143 us by which
+/* The same for the CALLER's vectors (round 3, profiles/NOTES.md §4.12): on some MI355X boxes a product with A runs 126 or 141-143 us by which
  * physical memory its x and y were handed — in windows that follow the order of allocation — whatever the kernel does.  A solver that
  * keeps its vectors for many products (src/solve_newton.c:1265: one KSPSolve, hundreds of MatMults) can let the library place them:
  * mi_vec_alloc_placed allocates nvec device vectors of max(rows, columns) doubles each (zero-filled, 256-byte aligned) for use with A,

@@ -227,7 +227,7 @@ static int fill_ring_table(RingTable& R, const RingPlanHost& best, int n, const 
 
 static int time_handle(mi_csr_t A, int warm, int timed, double* us);
 
-// Placement draws (round 3; FROZEN in round 4: no further work goes into it).  WHERE the value array lies in device
+// Placement draws (round 3, profiles/NOTES.md §4.12; FROZEN in round 4: no further work goes into it).  WHERE the value array lies in device
 // memory moves a warm launch of the streaming kernels by up to 15 % on some boxes (tools/placement_lottery.py: 137-139 us against 158-166
 // for handles of one and the same matrix and plan in one process; the coefficient array decides, the 16-bit column stream adds a few us,
 // row pointers and plan records nothing; no allocation flag or address property found that predicts it).  So for matrices beyond the
@@ -1292,7 +1292,7 @@ extern "C" int mi_csr_placement_info(mi_csr_t A, int* n_values, int* n_total, do
     return MI_OK;
 }
 
-// Placement draws for the caller's vectors (include/mi355_spmv.h)
+// Placement draws for the caller's vectors (include/mi355_spmv.h; profiles/NOTES.md §4.12)
 extern "C" int mi_vec_alloc_placed(mi_csr_t A, int nvec, int draws, double** d_vecs, double* us, int cap, int* n_us)
 {
     CHECK_ARG(A && nvec >= 1 && d_vecs && cap >= 0 && (cap == 0 || us), "bad argument");

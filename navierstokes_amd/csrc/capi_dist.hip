@@ -329,7 +329,7 @@ int dist_ortho(mi_dist_s* D, const mi_dist_vec_s* b, const mi_dist_vec_s* x1, mi
     int rc = dist_dot(D, b, x1, &beta);
     if (rc) return rc;
     if (beta_out) *beta_out = beta;
-    const double a = -(alpha * beta); // the reference's object code: one vfnmadd behind a rounded alpha * beta
+    const double a = -(alpha * beta); // the reference's object code: one vfnmadd behind a rounded alpha * beta (profiles/NOTES.md §2)
     return D->pool.run([&](int r) -> int {
         const DistRank& me = D->R[r];
         if (!me.n_local) return MI_OK;

@@ -12,11 +12,11 @@
 // The groups are CLUSTERS of the block graph (capi_bcsr.hip: build_spmm_tile_plan — breadth-first balls), not runs of consecutive
 // rows: a ball of 128 nodes of a 3-D mesh touches ~2.5 distinct columns per row where 128 consecutive nodes touch 5.1, which
 // halves the gather and the LDS footprint (three workgroups per CU at four columns).
-// Measured (FE matrix, 1.31 M rows; DESIGN.md §4.8, profiles/r03_spmm_tile_ablation.txt): four columns 168-179 -> 148-157 us in every
+// Measured (FE matrix, 1.31 M rows; profiles/NOTES.md §4.8, profiles/r03_spmm_tile_ablation.txt): four columns 168-179 -> 148-157 us in every
 // tile form built; eight columns 227-237 -> 180-192 us with eight lanes per block row and non-temporal coefficient loads
 // (spmm_bcsr4_otile below).  Compiling pieces out of this kernel shows where the rest goes: no gather 133 us, no Y stores 128-131,
 // neither 114 (= the single-vector kernel's coefficient stream) — about 20 us each, additive, neither explained by bytes (PMC: the
-// stores add no fetch traffic; the gathers 157 MB of 809): the stores are the memory-side read/write turnaround of DESIGN §4.4, the
+// stores add no fetch traffic; the gathers 157 MB of 809): the stores are the memory-side read/write turnaround of profiles/NOTES.md §4.4, the
 // gather two dependent round trips per workgroup.  Persistent workgroups with the next tile's x blocks staged in registers were
 // built twice and measured slower (231 / 164-170 us at four columns: vmcnt counts in issue order, and the staging costs registers).
 // Arithmetic: exactly spmm_bcsr4's (ARITH 0: one fma chain per row and column, bit-equal to SpMV_BCSR_FMA; ARITH 1: per-block

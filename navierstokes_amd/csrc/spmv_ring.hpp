@@ -4,7 +4,7 @@
 // FE-ordered matrices; spmv_kernels.hpp holds the general fallbacks.
 //
 // Why this shape (all numbers measured on MI355X with tools/kbench on the 5 M row /
-// 75 M nnz S15 matrix; DESIGN.md has the table):
+// 75 M nnz S15 matrix; profiles/NOTES.md §4.4 has the table):
 //   * a CSR-stream kernel that gathers x[col] from global memory tops out near
 //     3.0-3.4 TB/s algorithmic: 75 M eight-byte gathers are one L1 tag lookup each
 //     and a 64/128-byte L2 line per miss, i.e. the gather, not HBM, is the bound;

@@ -6,7 +6,7 @@
 // block of 2048 nonzeros (~137 rows) of a 3-D mesh in Cuthill-McKee order touches ~570 distinct columns (measured:
 // 0.28 per nonzero; a random band like S15: 0.79) — but their span grows like n^(2/3) (10 k columns at 330 k nodes,
 // 60 k at 5 M), far beyond any contiguous LDS window, so the ring kernel cannot serve them and the stream kernel pays
-// one 8-byte L1 gather per NONZERO (its bound: 3.3-3.4 TB/s).  With the block's distinct columns listed,
+// one 8-byte L1 gather per NONZERO (its bound: 3.3-3.4 TB/s, profiles/NOTES.md §4.2).  With the block's distinct columns listed,
 // the kernel gathers each ONCE (sorted, so neighbouring lanes share lines) into an LDS tile and every per-nonzero
 // access is a ds_read through a 16-bit index: 3-4x fewer global gathers, and the column stream shrinks from 4 to
 // 2 + 4u bytes per nonzero (u = distinct columns per nonzero).

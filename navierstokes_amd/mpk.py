@@ -338,7 +338,7 @@ class csrmatrix:
     def alloc_vectors(self, nvec=2, draws=8):
         """nvec device vectors (torch float64 tensors of length n, zero-filled) placed for products with this matrix —
         mi_vec_alloc_placed: the library allocates `draws` candidate x / y pairs, times y = A x on each and keeps the fastest
-        (where a vector lies in device memory moves a product by up to 12 % on some boxes).
+        (where a vector lies in device memory moves a product by up to 12 % on some boxes, profiles/NOTES.md §4.12).
         Returns (tensors, us_per_candidate_pair).  The memory belongs to the returned tensors' `_placed` owner: it is released
         when the last of them is garbage-collected."""
         import torch

@@ -351,7 +351,7 @@ def test_block_shape_of_large_and_small_matrices(monkeypatch):
 
 
 def test_vectors_placed_by_the_library():
-    """mi_vec_alloc_placed (round 3): x and y allocated by the library after timing candidate pairs.  Placement is a matter
+    """mi_vec_alloc_placed (round 3, profiles/NOTES.md §4.12): x and y allocated by the library after timing candidate pairs.  Placement is a matter
     of speed only — the product on placed vectors is the reference's fma chain bit for bit (mpk/SpMV.cpp:23-56) — candidates are timed
     only for matrices beyond the caches, and the vectors come zero-filled and are released with their tensors."""
     n = 1_400_000  # 21 M nonzeros: candidates are timed

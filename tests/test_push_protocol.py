@@ -19,7 +19,7 @@ no schedule deadlocks.  Neighbour sets are symmetric (the planner's rule: a rank
 receives from), couplings are random DIRECTED graphs, so ranks that send without receiving — an upwind stencil,
 the last rank of an upper-triangular band — occur, and the two forms are mixed freely across ranks.
 
-Result recorded in DESIGN.md §6: with the gate the protocol holds for every mix of forms (so the round-2 rule
+Result recorded in profiles/NOTES.md §6: with the gate the protocol holds for every mix of forms (so the round-2 rule
 "one form for all ranks" is a matter of balance, not of safety); without it the model exhibits the overwrite
 the advisor described within a few schedules.
 """

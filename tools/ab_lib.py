@@ -10,7 +10,7 @@ if kind == "mesh":  # n = cells per edge of the Kuhn box (P1 pressure operator)
 else:
     p, c, v = synth.rows(kind, n)
 H = int(os.environ.get("MI355_AB_HANDLES", "1"))  # several handles of the one matrix and several x / y pairs: each array has its own
-XY = int(os.environ.get("MI355_AB_XY", "1"))       # placement in device memory — min / median over them say more than one draw
+XY = int(os.environ.get("MI355_AB_XY", "1"))       # placement in device memory (profiles/NOTES.md §4.12) — min / median over them say more than one draw
 xh = torch.from_numpy(synth.x_sin(0, n))
 pairs = [(xh.cuda(), torch.empty(n, dtype=torch.float64, device="cuda")) for _ in range(XY)]
 warm, cold = [], []

@@ -1,4 +1,4 @@
-"""Does device memory allocated (and kept) BEFORE the matrix move the create-time placement draws?
+"""Does device memory allocated (and kept) BEFORE the matrix move the create-time placement draws (profiles/NOTES.md §4.12)?
 usage: python tools/ballast_probe.py <ballast GB>"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

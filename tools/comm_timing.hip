@@ -5,7 +5,7 @@
 // A size-1 RCCL communicator sends `count` doubles to itself through the same grouped send/recv call
 // sequence the library issues, with the cross-stream hand-offs done (a) by HIP events, (b) by the
 // flag kernels of handoff_kernels.hpp, (c) as one ncclAllToAllv.  Prints host time to enqueue and
-// device time per step.  (This code lived inside mi_comm_selftest in round 1; DESIGN.md §6 quotes its
+// device time per step.  (This code lived inside mi_comm_selftest in round 1; profiles/NOTES.md §6 quotes its
 // numbers.)
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 // fence_cost.hip — what does an agent-scope release / acquire pair cost a workgroup on MI355X
 // (eight XCD-private L2s: release = write back dirty L2 lines, acquire = invalidate)?  Sizes the
-// inter-workgroup hand-off a single-launch matrix-powers kernel would need.
+// inter-workgroup hand-off a single-launch matrix-powers kernel would need (profiles/NOTES.md §4.6).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,4 +1,4 @@
-"""Does the spread of the warm rate come with the product's temporal footprint reaching the Infinity Cache's 256 MB?
+"""Does the spread of the warm rate (profiles/NOTES.md §4.12) come with the product's temporal footprint reaching the Infinity Cache's 256 MB?
 S15 matrices of growing size, each timed on several x / y pairs: temporal footprint = 2 B/nnz column stream + 4 B/row pointers + 8 + 8 B/row.
 usage: python tools/footprint_probe.py [n ...]"""
 import os, sys

@@ -1,5 +1,5 @@
 // Dev tool: what survives in the 256 MB Infinity Cache when a large array streams through it?  The product's warm launches differ by
-// 15 % with the placement of their arrays; this isolates the mechanism with plain read sweeps:
+// 15 % with the placement of their arrays (profiles/NOTES.md §4.12); this isolates the mechanism with plain read sweeps:
 //   R = a "re-used" buffer (r MB), S = a "streamed" buffer (s MB).  Loop: read R, read S with load flavour m, then TIME the next read
 //   of R.  R served from HBM: r / ~5.5 TB/s; R still cached: faster.  Flavours of the S loads: plain, nt, sc1, sc0 sc1, sc0 sc1 nt,
 //   sc0 nt, sc1 nt.  Several fresh allocations of R and S per configuration (placement).

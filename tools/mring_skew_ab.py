@@ -1,6 +1,6 @@
 """Dev tool: run lengths of the multi-window ring kernel, A/B on ONE placement (mi_debug_mring_replan rewrites the plan into the arrays the
-handle already has — two handles of one matrix differ by more than the effect).  The two workgroups of a CU do not share it
-evenly: with equal runs the older finishes at ~88 % of the launch; giving it the longer run lets both end together.
+handle already has — two handles of one matrix differ by more than the effect, profiles/NOTES.md §4.12).  The two workgroups of a CU do not share it
+evenly (profiles/NOTES.md §4.10): with equal runs the older finishes at ~88 % of the launch; giving it the longer run lets both end together.
 Usage: python tools/mring_skew_ab.py [cells] [skews ...]   (MRING_AB_ORDER=rcm: the relabelled order)"""
 import sys, os, ctypes
 import numpy as np, torch

@@ -1,4 +1,4 @@
-"""What mi_vec_alloc_placed buys: a C4 product on torch-allocated x / y against vectors the library placed by timing candidate pairs."""
+"""What mi_vec_alloc_placed buys (profiles/NOTES.md §4.12): a C4 product on torch-allocated x / y against vectors the library placed by timing candidate pairs."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,4 +1,4 @@
-"""What decides the discrete warm/cold levels of the ring kernel at C4?  Handles of one matrix with the block shape forced
+"""What decides the discrete warm/cold levels of the ring kernel at C4 (profiles/NOTES.md §4.12)?  Handles of one matrix with the block shape forced
 (MI355_RING_ROW_ALIGN=1 | 64 at create) and left to the create-time measurement, each timed on several x / y pairs.
 usage: python tools/state_probe.py [n]"""
 import os, sys

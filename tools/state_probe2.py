@@ -1,4 +1,4 @@
-"""Which vector's placement moves the whole-wave ring plan at C4, and is it a matter of the virtual address (an offset
+"""Which vector's placement moves the whole-wave ring plan at C4 (profiles/NOTES.md §4.12), and is it a matter of the virtual address (an offset
 inside one allocation changes it) or of the physical pages (it does not)?   usage: python tools/state_probe2.py [n]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

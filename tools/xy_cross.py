@@ -1,4 +1,4 @@
-"""Which of the caller's vectors decides the placement level: every x with every y on one C4 handle (blocks cut at the nonzero count)."""
+"""Which of the caller's vectors decides the placement level (profiles/NOTES.md §4.12): every x with every y on one C4 handle (blocks cut at the nonzero count)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
