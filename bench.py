@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4", "tile", "mring"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--exchange", default=None, choices=["auto", "native", "push", "torch"], help="N > 1: which halo exchange drives the step")
+    ap.add_argument("--exchange", default=None, choices=["auto", "native", "allgather", "push", "torch"], help="N > 1: which halo exchange drives the step")
     ap.add_argument("--cold", action="store_true", help="evict L2/Infinity Cache before every timed step")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold single-shot and in-pipeline measurements")
     ap.add_argument("--plain-vectors", action="store_true", help="(the default since round 4; accepted for old command lines) x and y of the timed region are plain torch allocations")
@@ -492,7 +492,7 @@ def main():
         # Every candidate exchange is brought up (collective), must equal the torch.distributed exchange bit for bit (DistCSR's
         # self-check), survive a dry run without a wait giving up on any rank, and is then timed; the fastest survivor runs the
         # timed region.  --exchange push|native|torch restricts the candidates to one (plus torch as the way out).
-        want = [args.exchange] if args.exchange in ("push", "native", "torch") else ["push", "native", "torch"]
+        want = [args.exchange] if args.exchange in ("push", "native", "allgather", "torch") else ["push", "native", "allgather", "torch"]
         if "torch" not in want:
             want.append("torch")
         probe_steps = max(5, min(args.steps, 50))
@@ -504,8 +504,8 @@ def main():
             except D.DistSetupError as e:  # raised on every rank alike
                 probes[ex] = dict(ok=False, note=str(e)[:200])
                 continue
-            got = "push" if dcx.push else ("native" if dcx.native else "torch")
-            if ex == "native" or dcx.rccl_ranks:
+            got = "push" if dcx.push else (("allgather" if dcx.allgather else "native") if dcx.native else "torch")
+            if ex in ("native", "allgather") or dcx.rccl_ranks:
                 rccl_ranks = dcx.rccl_ranks
             if got != ex:  # (a collective outcome: the same on every rank)
                 probes[ex] = dict(ok=False, note=f"did not come up on every rank, or failed its bitwise self-check against the torch.distributed exchange (DistCSR fell to '{got}')")
@@ -556,6 +556,7 @@ def main():
             probes[ex] = dict(ok=True, step_us=round(us, 2),
                               form=("ONE launch per step" if dcx.push_fused else "four launches per step") if ex == "push" else
                                    ("RCCL send/recv on the partition's comm stream, events" if ex == "native" else
+                                    "ONE ncclAllGather of every rank's boundary slice on the comm stream, events" if ex == "allgather" else
                                     ("all_to_all_single over RCCL" if dcx._nccl else "host-staged (non-NCCL backend, development)")))
             alive[ex] = (dcx, stepx, xx, yy, pb)
         if not alive:
@@ -586,7 +587,8 @@ def main():
         us_step = probes[chosen]["step_us"]
         halo_info = dict(n_halo=dc.n_halo, n_send=dc.n_send, interior_rows=dc.n_interior, boundary_rows=dc.n_boundary,
                          exchange=("peer push over HIP IPC windows, no RCCL (mi_part_spmv_push_dev), " + probes[chosen]["form"]) if chosen == "push"
-                         else ("native RCCL send/recv (mi_part_spmv_dev)" if chosen == "native" else "torch.distributed " + probes[chosen]["form"]),
+                         else ("native RCCL send/recv (mi_part_spmv_dev)" if chosen == "native" else
+                               "native RCCL all-gather of boundary slices (mi_part_spmv_dev, mi_part_allgather_setup)" if chosen == "allgather" else "torch.distributed " + probes[chosen]["form"]),
                          chosen=chosen, chosen_by=("--exchange" if args.exchange in alive else f"fastest of the survivors over {probe_steps} steps, slowest rank's time"),
                          exchanges=probes,
                          exchange_bytes_per_step=dict(sent_all_ranks=int(tb[0]), received_all_ranks=int(tb[1]), sent_max_rank=int(tb_max[0]),

@@ -442,6 +442,17 @@ int mi_part_comm_info(mi_part_t P, int* comm_ranks, int* comm_rank);
 int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s);
 /* MI_OK, or MI_ERR_HIP once a hand-off wait has given up (call after synchronising; no GPU work, no copy) */
 int mi_part_status(mi_part_t P);
+/* The ALL-GATHER form of that step, for wide halos (an FE slab partition: a whole mesh plane per neighbour, 38 648 ghosts of 163 048
+ * rows at N = 8): instead of one grouped ncclSend / ncclRecv pair per neighbour, every rank contributes ONE fixed-size slice — the
+ * entries anybody needs from it, i.e. the sorted union of its send lists, padded to the largest such union M — to one ncclAllGather
+ * on the comm stream, and every ghost is picked out of the gathered nranks x M buffer (BASELINE north_star: "RCCL all-gather of halo x
+ * entries over xGMI overlapped with interior SpMV").  Set-up (collective, after mi_part_comm_init): mi_part_send_union on every rank,
+ * all-gather the counts and the GLOBAL ids (local id + the rank's first row) by any side channel, mi_part_allgather_setup with all of
+ * them; mi_part_set_allgather(P, 1) on EVERY rank (or on none) selects the form for mi_part_spmv_dev.  Same bits either way. */
+int mi_part_send_union(mi_part_t P, int* count, const int** local_idx /* ascending local ids; valid until the handle is destroyed */);
+int mi_part_allgather_setup(mi_part_t P, const int* counts /* [nranks] */, const long long* ids /* every rank's union as global ids, rank after rank */);
+int mi_part_set_allgather(mi_part_t P, int on);
+int mi_part_allgather_info(mi_part_t P, int* ready, int* in_use, int* slice /* M */);
 /* ---- halo exchange by peer push (no RCCL, one stream) -------------------------
  * Each rank's kernel writes the x entries a neighbour needs straight into a receive window in the NEIGHBOUR's memory
  * (HIP IPC mapping; xGMI between GPUs) and raises a flag there; the receiver's kernel waits for its neighbours' flags and

@@ -33,6 +33,7 @@
 namespace {
 
 enum { kExEvent = 0, kExPush = 1, kExRccl = 2 };
+constexpr long long kDistAllGatherHalo = 16384; // ghosts of the widest rank from which the RCCL step all-gathers boundary slices
 const char* const kExNames[3] = {"event", "push", "rccl"};
 
 struct DistRank {
@@ -166,6 +167,7 @@ struct mi_dist_s {
     int distinct_devices = 0;
     int exchange = kExEvent;
     bool fused = false;       // push: every rank runs the one-launch form
+    bool allgather = false;   // rccl: the all-gather form of the exchange (wide halos)
     std::string note;         // how the exchange was chosen (what was tried, why it was dropped)
     Pool pool;
     std::mutex api_mu;        // one API call at a time per handle
@@ -428,6 +430,35 @@ int try_rccl(mi_dist_s* D, bool* ok, std::string* why)
         *why = g_err;
         return MI_OK;
     }
+    // wide halos (FE slab partitions) take the all-gather form of the step: one ncclAllGather of every rank's boundary slice instead
+    // of a send / recv pair per neighbour.  One address space: every rank's union list is read off its plan.
+    // MI355_PART_EXCHANGE=allgather | sendrecv forces the form.
+    const char* fe = getenv("MI355_PART_EXCHANGE");
+    long long hmax = 0;
+    for (const DistRank& r : D->R) hmax = std::max<long long>(hmax, r.part->plan.n_halo);
+    const bool want_ag = fe ? !strcmp(fe, "allgather") : hmax >= kDistAllGatherHalo;
+    if (want_ag) {
+        const int N = D->nranks;
+        std::vector<int> counts((size_t)N, 0);
+        std::vector<long long> ids;
+        for (int r = 0; r < N; r++) {
+            const int* loc = nullptr;
+            if (mi_part_send_union(D->R[r].part, &counts[r], &loc) != MI_OK) {
+                *why = g_err;
+                return MI_OK;
+            }
+            for (int i = 0; i < counts[r]; i++) ids.push_back(D->R[r].row0 + loc[i]);
+        }
+        rc = D->pool.run([&](int r) -> int {
+            int c = mi_part_allgather_setup(D->R[r].part, counts.data(), ids.data());
+            return c ? c : mi_part_set_allgather(D->R[r].part, 1);
+        });
+        if (rc) {
+            *why = "all-gather form: " + g_err;
+            return MI_OK;
+        }
+        D->allgather = true;
+    }
     *ok = true;
     return MI_OK;
 }
@@ -641,7 +672,11 @@ extern "C" int mi_dist_info(mi_dist_t D, int* nranks, int* distinct_devices, int
     return MI_OK;
 }
 
-extern "C" const char* mi_dist_exchange_name(mi_dist_t D) { return D ? kExNames[D->exchange] : ""; }
+extern "C" const char* mi_dist_exchange_name(mi_dist_t D)
+{
+    if (!D) return "";
+    return D->exchange == kExRccl && D->allgather ? "rccl-allgather" : kExNames[D->exchange];
+}
 extern "C" const char* mi_dist_exchange_note(mi_dist_t D) { return D ? D->note.c_str() : ""; }
 
 extern "C" int mi_dist_rank_info(mi_dist_t D, int rank, int* device, long long* row_start, int* n_local, int* n_halo, long long* nnz_local,

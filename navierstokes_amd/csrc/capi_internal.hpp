@@ -248,6 +248,15 @@ struct mi_part_s {
     // step cheaper in the one-GPU harness but have not run against real multi-GPU RCCL yet: opt in with
     // MI355_PART_HANDOFF=flags.
     bool flag_handoff = false;
+    // the all-gather form of the RCCL exchange (wide halos): every rank contributes the M-entry slice of ITS entries that anybody
+    // needs (the sorted union of its send lists, padded to the largest), one ncclAllGather, each ghost picked out of the N x M result
+    std::vector<int> ag_union;   // local ids, ascending
+    int ag_slice = 0;            // M
+    int* d_ag_idx = nullptr;     // [M] my union, padded with entry 0
+    int* d_ag_src = nullptr;     // [n_halo] where ghost h lies in the gathered buffer
+    double* d_ag_send = nullptr; // [M]
+    double* d_ag_recv = nullptr; // [nranks * M]
+    bool ag_ready = false, ag_use = false;
     // peer-push exchange (push_exchange.hpp): my receive window, the peers' windows I write to
     void* win = nullptr;          // [flags: nranks x 64 B][pad][data: 2 x n_halo doubles]
     bool win_uncached = false, win_registered = false;

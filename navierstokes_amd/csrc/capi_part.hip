@@ -30,6 +30,13 @@ static void part_comm_release(mi_part_s* P)
     P->comm_stream = nullptr;
     P->ev_pack = P->ev_comm = nullptr;
     if (P->d_sendbuf) dfree(P->d_sendbuf);
+    dfree(P->d_ag_idx);
+    dfree(P->d_ag_src);
+    dfree(P->d_ag_send);
+    dfree(P->d_ag_recv);
+    P->d_ag_idx = P->d_ag_src = nullptr;
+    P->d_ag_send = P->d_ag_recv = nullptr;
+    P->ag_ready = P->ag_use = false;
     if (P->d_flags) dfree(P->d_flags);
     if (P->h_timeouts) (void)hipHostFree(P->h_timeouts);
     for (void* m : P->ipc_opened) (void)hipIpcCloseMemHandle(m);
@@ -359,7 +366,14 @@ extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local,
         HIP_TRY(hipEventRecord(P->ev_pack, s));
         HIP_TRY(hipStreamWaitEvent(P->comm_stream, P->ev_pack, 0));
     }
-    if (pl.sends_contiguous) { // banded partitions: the neighbours' ghosts are slices of x, sent in place
+    if (P->ag_use && P->ag_ready) {
+        // wide halos (an FE slab's boundary planes): ONE ncclAllGather of fixed-size slices instead of a grouped send / recv per
+        // neighbour — north_star's collective.  My slice = the entries anybody needs from me; every ghost is then picked out of
+        // the gathered N x M buffer into the halo part of x (16 bytes of index arithmetic per ghost, no per-peer offsets).
+        if ((rc = mi_gather_dev(P->ag_slice, P->d_ag_idx, d_x_ext, P->d_ag_send, P->comm_stream))) return rc;
+        NCCL_TRY(g_rccl.AllGather(P->d_ag_send, P->d_ag_recv, (size_t)P->ag_slice, kNcclDouble, P->comm, P->comm_stream));
+        if ((rc = mi_gather_dev(pl.n_halo, P->d_ag_src, P->d_ag_recv, d_x_ext + pl.n_local, P->comm_stream))) return rc;
+    } else if (pl.sends_contiguous) { // banded partitions: the neighbours' ghosts are slices of x, sent in place
         if ((rc = enqueue_exchange(pl, P->comm, nullptr, d_x_ext + pl.n_local, P->comm_stream, d_x_ext))) return rc;
     } else {
         if ((rc = mi_gather_dev((int)pl.send_idx.size(), P->d_send_idx, d_x_ext, P->d_sendbuf, P->comm_stream))) return rc;
@@ -372,6 +386,84 @@ extern "C" int mi_part_spmv_dev(mi_part_t P, double* d_x_ext, double* d_y_local,
     if (P->flag_handoff) hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, s, P->d_flags + 1, step, P->d_timeouts);
     else HIP_TRY(hipStreamWaitEvent(s, P->ev_comm, 0));
     HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// ---- the all-gather form of the RCCL exchange ---------------------------------------------------------------------------------
+extern "C" int mi_part_send_union(mi_part_t P, int* count, const int** local_idx)
+{
+    CHECK_ARG(P && count, "null argument");
+    if (!P->plan.sends_set) return fail(MI_ERR_STATE, "mi_part_set_send_ids was never called");
+    if (P->ag_union.empty() && !P->plan.send_idx.empty()) {
+        P->ag_union = P->plan.send_idx;
+        std::sort(P->ag_union.begin(), P->ag_union.end());
+        P->ag_union.erase(std::unique(P->ag_union.begin(), P->ag_union.end()), P->ag_union.end());
+    }
+    *count = (int)P->ag_union.size();
+    if (local_idx) *local_idx = P->ag_union.data();
+    return MI_OK;
+}
+
+extern "C" int mi_part_allgather_setup(mi_part_t P, const int* counts, const long long* ids)
+{
+    CHECK_ARG(P && counts, "null argument");
+    if (!P->finalized) return fail(MI_ERR_STATE, "partition not finalized");
+    if (!rccl_load() || !g_rccl.AllGather) return fail(MI_ERR_UNSUPPORTED, "ncclAllGather is not available in the resolved RCCL");
+    const PartPlan& pl = P->plan;
+    const int R = pl.nranks;
+    int mine = 0;
+    int rc = mi_part_send_union(P, &mine, nullptr);
+    if (rc) return rc;
+    if (counts[pl.rank] != mine) return fail(MI_ERR_ARG, "counts[rank] is not this rank's union (mi_part_send_union)");
+    int M = 1;
+    std::vector<size_t> off((size_t)R + 1, 0);
+    for (int p = 0; p < R; p++) {
+        CHECK_ARG(counts[p] >= 0, "negative count");
+        M = std::max(M, counts[p]);
+        off[p + 1] = off[p] + (size_t)counts[p];
+    }
+    CHECK_ARG(off[R] == 0 || ids, "null ids");
+    std::vector<int> src((size_t)std::max(pl.n_halo, 1), 0);
+    for (int p = 0; p < R; p++)
+        for (int i = 0; i < pl.recv_counts[p]; i++) {
+            const long long g = pl.halo_ids[pl.recv_offsets[p] + i];
+            const long long* b = ids + off[p];
+            const long long* e = b + counts[p];
+            const long long* it = std::lower_bound(b, e, g);
+            if (it == e || *it != g) return fail(MI_ERR_STATE, "a ghost of this rank is missing from its owner's union: the lists are not those of this partition");
+            src[pl.recv_offsets[p] + i] = p * M + (int)(it - b);
+        }
+    std::vector<int> idx((size_t)M, 0); // padded with entry 0 (n_local > 0 whenever anything is sent; an empty rank gathers x[0] of a 1-entry buffer)
+    for (int i = 0; i < mine; i++) idx[i] = P->ag_union[i];
+    dfree(P->d_ag_idx); dfree(P->d_ag_src); dfree(P->d_ag_send); dfree(P->d_ag_recv);
+    P->d_ag_idx = P->d_ag_src = nullptr;
+    P->d_ag_send = P->d_ag_recv = nullptr;
+    HIP_TRY(hipMalloc(&P->d_ag_idx, sizeof(int) * idx.size()));
+    HIP_TRY(hipMalloc(&P->d_ag_src, sizeof(int) * src.size()));
+    HIP_TRY(hipMalloc(&P->d_ag_send, sizeof(double) * (size_t)M));
+    HIP_TRY(hipMalloc(&P->d_ag_recv, sizeof(double) * (size_t)M * R));
+    HIP_TRY(hipMemcpy(P->d_ag_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->d_ag_src, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(P->d_ag_send, 0, sizeof(double) * (size_t)M));
+    P->ag_slice = M;
+    P->ag_ready = true;
+    return MI_OK;
+}
+
+extern "C" int mi_part_set_allgather(mi_part_t P, int on)
+{
+    CHECK_ARG(P, "null handle");
+    if (on && !P->ag_ready) return fail(MI_ERR_STATE, "mi_part_allgather_setup was not called");
+    P->ag_use = on != 0;
+    return MI_OK;
+}
+
+extern "C" int mi_part_allgather_info(mi_part_t P, int* ready, int* in_use, int* slice)
+{
+    CHECK_ARG(P, "null handle");
+    if (ready) *ready = P->ag_ready ? 1 : 0;
+    if (in_use) *in_use = P->ag_use && P->ag_ready ? 1 : 0;
+    if (slice) *slice = P->ag_slice;
     return MI_OK;
 }
 

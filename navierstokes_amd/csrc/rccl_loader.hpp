@@ -29,6 +29,7 @@ struct Rccl {
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     int (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t) = nullptr; // optional
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr; // optional (the wide-halo form of the step)
     int (*CommCount)(void*, int*) = nullptr;    // optional: what the communicator itself says its size is
     int (*CommUserRank)(void*, int*) = nullptr; // optional
 };
@@ -77,6 +78,7 @@ inline bool rccl_load()
     R.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
     R.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
     R.AllToAllv = (int (*)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t))dlsym(h, "ncclAllToAllv");
+    R.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
     R.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
     R.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
     R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv && R.GetErrorString;

@@ -60,6 +60,7 @@ class DistSetupError(RuntimeError):
 
 class DistCSR:
     """This rank's share of a row-partitioned csrmatrix."""
+    ALLGATHER_HALO = 16384  # ghosts of the widest rank from which the native (RCCL) step all-gathers boundary slices
 
     def _agree(self, err, phase):
         """Collective: every rank learns whether `phase` failed anywhere.  err: None or this rank's exception."""
@@ -176,7 +177,9 @@ class DistCSR:
             self.push_fused = False
             # "auto" (default): push, else native, else torch — each step down only after the collective self-check below
             self.exchange = exchange or os.environ.get("MI355_DIST_EXCHANGE", "auto")
-            assert self.exchange in ("auto", "native", "push", "torch"), self.exchange
+            # "allgather" = native with the all-gather form of the RCCL exchange forced (mi_part_allgather_setup); "native" under
+            # "auto" takes that form by itself when the widest rank's halo has >= ALLGATHER_HALO ghosts (FE slab partitions)
+            assert self.exchange in ("auto", "native", "allgather", "push", "torch"), self.exchange
             self.push = self.native = False
         else:
             self.native = False
@@ -197,7 +200,8 @@ class DistCSR:
         if self.push and not self._native_selfcheck():
             self.push = self.push_fused = False
             mpk.lib().mi_part_push_disable(self._h)
-        if compute is None and not self.push and self.exchange in ("auto", "native"):
+        self.allgather = False
+        if compute is None and not self.push and self.exchange in ("auto", "native", "allgather"):
             self.native = self._try_native_exchange()
         if self.native and not self._native_selfcheck():
             self.native = False  # collective decision: every rank falls back to the torch.distributed exchange
@@ -235,7 +239,36 @@ class DistCSR:
                 self.rccl_ranks = cnt.value  # ncclCommCount of the communicator just made
         flag.fill_(1 if rc == 0 and self.rccl_ranks in (0, self.nranks) else 0)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        return int(flag) == 1
+        if int(flag) != 1:
+            return False
+        # the all-gather form for wide halos: every rank's union of send lists (as global ids) goes to every rank
+        hmax = torch.tensor([self.n_halo], dtype=torch.int64, device=self.device)
+        dist.all_reduce(hmax, op=dist.ReduceOp.MAX, group=self.group)
+        import os
+        forced = os.environ.get("MI355_PART_EXCHANGE")
+        want = (self.exchange == "allgather" or forced == "allgather" or
+                (self.exchange == "auto" and forced != "sendrecv" and int(hmax) >= self.ALLGATHER_HALO))
+        if want:
+            cnt, ptr = _c.c_int(), _vp()
+            rc = L.mi_part_send_union(self._h, _c.byref(cnt), _c.byref(ptr))
+            mine = (np.ctypeslib.as_array(_c.cast(ptr, _c.POINTER(_c.c_int)), shape=(cnt.value,)).astype(np.int64) + int(self.row_starts[self.rank])
+                    if rc == 0 and cnt.value else np.zeros(0, np.int64))
+            every = [None] * self.nranks
+            dist.all_gather_object(every, (rc, mine), group=self.group)
+            ok = all(e[0] == 0 for e in every)
+            if ok:
+                counts = np.ascontiguousarray([len(e[1]) for e in every], dtype=np.int32)
+                ids = np.ascontiguousarray(np.concatenate([e[1] for e in every] + [np.zeros(0, np.int64)]), dtype=np.int64)
+                ok = L.mi_part_allgather_setup(self._h, counts.ctypes.data, ids.ctypes.data) == 0 and L.mi_part_set_allgather(self._h, 1) == 0
+            flag.fill_(1 if ok else 0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if int(flag) != 1:  # the form is collective: nobody uses it unless everybody can
+                L.mi_part_set_allgather(self._h, 0)
+                if self.exchange == "allgather":
+                    return False
+            else:
+                self.allgather = True
+        return True
 
     def _try_push_exchange(self):
         """Set up the peer-push exchange (include/mi355_spmv.h: mi_part_push_*): every rank exports its receive window,

@@ -168,6 +168,10 @@ def lib():
         "mi_part_comm_info": [_vp, P(i), P(i)],
         "mi_part_spmv_dev": [_vp, _vp, _vp, _vp],
         "mi_comm_selftest": [i, P(d)],
+        "mi_part_send_union": [_vp, P(i), P(_vp)],
+        "mi_part_allgather_setup": [_vp, _vp, _vp],
+        "mi_part_set_allgather": [_vp, i],
+        "mi_part_allgather_info": [_vp, P(i), P(i), P(i)],
         "mi_dist_create": [i, i, _vp, _vp, _vp, P(_vp)],
         "mi_dist_destroy": [_vp],
         "mi_dist_info": [_vp, P(i), P(i), P(i), P(i), P(ll), P(ll)],

@@ -38,7 +38,7 @@ def capi(N):
         info = D.info()
         assert info["nranks"] == N and sum(r["n_local"] for r in info["ranks"]) == n, info
         if want != "auto":
-            assert info["exchange"] == want, info
+            assert info["exchange"].split("-")[0] == want, info
         x = synth.x_sin(0, n)
         y = np.full(n, np.nan)
         D.spmv(y, x)

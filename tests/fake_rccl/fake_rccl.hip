@@ -5,7 +5,7 @@
 // exchange on a comm stream, interior rows beside them, boundary rows behind the exchange) could
 // not be run there.  This file is a stand-in for librccl with just the entry points that step
 // resolves by name (ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclGroupStart/End,
-// ncclSend, ncclRecv, ncclGetErrorString), for ranks that are THREADS of one process sharing one
+// ncclSend, ncclRecv, ncclAllGather, ncclGetErrorString), for ranks that are THREADS of one process sharing one
 // GPU.  A send copies its payload into a device mailbox on the caller's stream and publishes an
 // event; a receive blocks the calling host thread until the matching message is published, makes
 // its stream wait for the event and copies the payload out.  Every rank posts all sends of a
@@ -176,6 +176,24 @@ extern "C" int ncclRecv(void* buf, size_t count, int dtype, int peer, void* comm
         return 0;
     }
     return run_recv(o);
+}
+
+// every rank's `count` doubles to every rank, rank p's slice at recvbuf + p * count (ncclAllGather of rccl.h).  Built from the
+// mailbox pieces above: my slice goes out to every peer first, then theirs are awaited — all ranks send before any blocks, so the
+// collective cannot deadlock; the local slice is a plain copy on the caller's stream.
+extern "C" int ncclAllGather(const void* sendbuf, void* recvbuf, size_t count, int dtype, void* comm, hipStream_t s)
+{
+    if (dtype != 8) return 4;
+    Comm* c = static_cast<Comm*>(comm);
+    const int n = c->w->nranks;
+    for (int p = 0; p < n; p++)
+        if (p != c->rank)
+            if (int rc = run_send(Op{true, const_cast<void*>(sendbuf), count * 8, p, c, s})) return rc;
+    if (hipMemcpyAsync(static_cast<char*>(recvbuf) + (size_t)c->rank * count * 8, sendbuf, count * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+    for (int p = 0; p < n; p++)
+        if (p != c->rank)
+            if (int rc = run_recv(Op{false, static_cast<char*>(recvbuf) + (size_t)p * count * 8, count * 8, p, c, s})) return rc;
+    return 0;
 }
 
 extern "C" const char* ncclGetErrorString(int rc)

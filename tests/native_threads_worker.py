@@ -30,13 +30,22 @@ def main():
     L = mpk.lib()
     if not push:
         mpk.check(L.mi_comm_available())
-    Pg, Cg, Vg = synth.rows(kind, n, w=w)
-    rs = D.balanced_row_starts(n, N, np.diff(Pg))
+    allgather = os.environ.get("MI355_TEST_ALLGATHER") == "1"  # the all-gather form of the RCCL step (wide halos)
+    if kind == "fe":  # the FE matrix on an n^3-cell box: node-aligned cuts, a whole mesh plane per neighbour as halo
+        Pg, Cg, Vg = synth.fe_matrix(n)
+        n = len(Pg) - 1
+        rs = D.balanced_row_starts(n, N, np.diff(Pg), align=4)
+    else:
+        Pg, Cg, Vg = synth.rows(kind, n, w=w)
+        rs = D.balanced_row_starts(n, N, np.diff(Pg))
     # ---- setup on the main thread: plans, id exchange (all ranks live here), finalize
     parts, meta = [], []
     for r in range(N):
         lo, hi = int(rs[r]), int(rs[r + 1])
-        p, c, v = synth.rows(kind, n, lo, hi, w=w)
+        if kind == "fe":
+            p, c, v = (Pg[lo:hi + 1] - Pg[lo]).astype(np.int32), Cg[Pg[lo]:Pg[hi]].copy(), Vg[Pg[lo]:Pg[hi]].copy()
+        else:
+            p, c, v = synth.rows(kind, n, lo, hi, w=w)
         h = vp()
         mpk.check(L.mi_part_create(N, r, rs.ctypes.data, p.ctypes.data, c.ctypes.data, v.ctypes.data, ctypes.byref(h)))
         rc = np.zeros(N, np.int32)
@@ -69,6 +78,18 @@ def main():
     else:
         mpk.check(L.mi_comm_unique_id(idbuf))
         step_fn = L.mi_part_spmv_dev
+    ag_counts = ag_ids = None
+    if allgather:  # every rank's union of send lists as global ids (what a distributed host all-gathers by a side channel)
+        cnts, lists = [], []
+        for r in range(N):
+            cnt, ptr = ctypes.c_int(), vp()
+            mpk.check(L.mi_part_send_union(parts[r], ctypes.byref(cnt), ctypes.byref(ptr)))
+            loc = (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int)), shape=(cnt.value,)).astype(np.int64)
+                   if cnt.value else np.zeros(0, np.int64))
+            cnts.append(cnt.value)
+            lists.append(loc + meta[r]["lo"])
+        ag_counts = np.ascontiguousarray(cnts, dtype=np.int32)
+        ag_ids = np.ascontiguousarray(np.concatenate(lists + [np.zeros(0, np.int64)]), dtype=np.int64)
     Y = O.spmk_chain(4, Pg, Cg, Vg, synth.x_sin(0, n))
     results = [None] * N
 
@@ -81,10 +102,16 @@ def main():
             nl, nh = nl.value, nh.value
             if not push:
                 mpk.check(L.mi_part_comm_init(h, ctypes.create_string_buffer(idbuf.raw, 128)))  # collective over the threads
+                if allgather:
+                    mpk.check(L.mi_part_allgather_setup(h, ag_counts.ctypes.data, ag_ids.ctypes.data))
+                    mpk.check(L.mi_part_set_allgather(h, 1))
+                    use = ctypes.c_int()
+                    mpk.check(L.mi_part_allgather_info(h, None, ctypes.byref(use), None))
+                    assert use.value == 1
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 bufs = [torch.zeros(nl + nh, dtype=torch.float64, device="cuda") for _ in range(5)]
-                bufs[0][:nl] = torch.from_numpy(synth.x_sin(lo, hi)).cuda()
+                bufs[0][:nl] = torch.from_numpy(synth.x_sin(lo, hi)).cuda()  # (x_sin of the global index: any rank can make its slice)
                 sp = vp(st.cuda_stream)
                 for k in range(4):  # powers: output of step k is the owned part of step k+1's input
                     mpk.check(step_fn(h, vp(bufs[k].data_ptr()), vp(bufs[k + 1].data_ptr()), sp))

@@ -36,7 +36,7 @@ def test_bench_gpus_2_on_one_card_prints_one_json_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["parity"]["bitwise"] is True and d["scaling"] == "strong"
     h = d["halo"]
-    assert set(h["exchanges"]) == {"push", "native", "torch"} and h["exchanges"][h["chosen"]]["ok"]
+    assert set(h["exchanges"]) == {"push", "native", "allgather", "torch"} and h["exchanges"][h["chosen"]]["ok"]
     assert h["exchanges"]["push"]["ok"], h["exchanges"]["push"]           # separate processes: the IPC windows must come up
     assert h["exchange_bytes_per_step"]["sent_all_ranks"] > 0 and h["overlap"]["compute_only_us"] > 0
     assert h["torch_world"] == 2 and "rccl_ranks" in h

@@ -39,8 +39,11 @@ def test_one_handle_over_n_ranks_rccl_exchange(N):
     """The RCCL form of the step (mi_part_comm_init + mi_part_spmv_dev per worker thread) with the in-process librccl stand-in."""
     if not os.path.exists(FAKE):
         pytest.skip("tests/fake_rccl not built")
-    out = run_worker("capi", N, {"MI355_DIST_EXCHANGE": "rccl", "MI355_RCCL_LIBRARY": FAKE})
-    assert out.count("exchange=rccl") == 5, out
+    out = run_worker("capi", N, {"MI355_DIST_EXCHANGE": "rccl", "MI355_RCCL_LIBRARY": FAKE, "MI355_PART_EXCHANGE": "sendrecv"})
+    assert out.count("exchange=rccl ") == 5, out
+    # ... and its all-gather form (one ncclAllGather of every rank's boundary slice), forced for every matrix
+    out = run_worker("capi", N, {"MI355_DIST_EXCHANGE": "rccl", "MI355_RCCL_LIBRARY": FAKE, "MI355_PART_EXCHANGE": "allgather"})
+    assert out.count("exchange=rccl-allgather") == 5, out
 
 
 @pytest.mark.gpu

@@ -545,6 +545,26 @@ def test_native_step_multirank_threads(kind, n, w, ranks, dense, mode):
     assert "NATIVE_THREADS_RESULT" in r.stdout
 
 
+@pytest.mark.parametrize("kind,n,ranks", [("fe", 20, 8), ("fe", 16, 3), ("s15", 240_000, 4)])
+def test_native_step_allgather_form_multirank_threads(kind, n, ranks):
+    """The ALL-GATHER form of the RCCL step (mi_part_allgather_setup; BASELINE north_star's collective): every rank contributes the
+    slice of its entries that anybody needs, one ncclAllGather, ghosts picked out of the gathered buffer — for the FE slab partition
+    (a whole mesh plane per neighbour) over 8 rank threads with the in-process librccl stand-in, and for a band.  Every power of
+    A x .. A^4 x and 40 unsynchronised repetitions bitwise against the oracle on every rank."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        pytest.skip("tests/fake_rccl not built")
+    env = dict(os.environ, MI355_RCCL_LIBRARY=fake, OMP_NUM_THREADS="1", MI355_TEST_ALLGATHER="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native_threads_worker.py"), kind, str(n), "2000", str(ranks)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "NATIVE_THREADS_RESULT" in r.stdout
+
+
 @pytest.mark.parametrize("kind,n", [("s15", 300_000), ("svar", 250_000)])
 def test_ring_variants_are_bit_identical(kind, n, monkeypatch):
     """Every instantiation of the ring kernel mi_csr_create may pick — temporal / non-temporal value loads,
