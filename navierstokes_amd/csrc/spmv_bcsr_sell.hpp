@@ -20,6 +20,11 @@
 // A wave is PERSISTENT and owns a contiguous range of slices: its whole input is one contiguous stream (values) beside a second
 // (block columns, 64 B per step), prefetched D steps ahead with unconditional, counted loads that never look at a row or slice
 // boundary; the boundary (every ~15 steps, wave-uniform since slices are padded) only decides when the accumulators are set aside.
+// Tried and dropped: a POOL of the last 2-12 % of the slices taken dynamically (one returning atomic per grab, issued when the wave's
+// pipeline is empty) to even out the 15 us over which the waves end — two atomics per wave on one line (the failed grab, the "I am
+// through" count that re-arms the pool) are 2 048 serialized atomics at the end of the launch: 140 us with an EMPTY pool.  Which
+// waves end late is only half systematic (correlation 0.5-0.7 between launches; it follows the physical XCD placement, which
+// alternates), so static re-weighting has nothing stable to hold on to.
 // What tools/sell_bench.hip measured on the way (FE-shaped pattern, 328 509 block rows; profiles/r04_sell_bench.txt):
 //   * the product with each slice's 512 bytes of y stored as they complete: 117 us — and 95.5 us with the stores compiled out: 10 MB of
 //     stores among the loads cost 21 us, whatever their flavour (non-temporal 117.8, write-through 115.9).  PARKED in LDS and stored
@@ -63,7 +68,7 @@ struct SellPlanHost {
 };
 
 // waves: contiguous slice ranges of (nearly) equal step counts; a multiple of 32 (8 XCDs x 4 waves per workgroup)
-inline void build_sell_wave_ranges(const SellPlanHost& P, int nwaves_max, std::vector<int>& wrng, int& nwaves);
+inline void build_sell_wave_ranges(const SellPlanHost& P, int nwaves_max, std::vector<int>& wrng, int& nwaves, int nslices_static = -1);
 
 inline void build_sell_plan(int nbrows, const int* ptrow, const int* indcol, int nwaves_max, SellPlanHost& P)
 {
@@ -90,16 +95,19 @@ inline void build_sell_plan(int nbrows, const int* ptrow, const int* indcol, int
     build_sell_wave_ranges(P, nwaves_max, P.wrng, P.nwaves);
 }
 
-inline void build_sell_wave_ranges(const SellPlanHost& P, int nwaves_max, std::vector<int>& wrng, int& nwaves)
+// nslices_static >= 0: the ranges cover the slices [0, nslices_static) only (the rest is the pool of the POOL form)
+inline void build_sell_wave_ranges(const SellPlanHost& P, int nwaves_max, std::vector<int>& wrng, int& nwaves, int nslices_static)
 {
+    const int NS = nslices_static >= 0 ? std::min(nslices_static, P.nslices) : P.nslices;
     const int W = std::min(nwaves_max, std::max(32, (P.nslices / 2 + 31) / 32 * 32));
     nwaves = W;
-    wrng.assign((size_t)W + 1, P.nslices);
+    wrng.assign((size_t)W + 1, NS);
     wrng[0] = 0;
+    const long long steps = P.sptr[NS];
     int s = 0;
     for (int w = 1; w < W; w++) {
-        const long long target = P.nsteps * w / W;
-        while (s < P.nslices && P.sptr[s] < target) s++;
+        const long long target = steps * w / W;
+        while (s < NS && P.sptr[s] < target) s++;
         wrng[w] = s;
     }
 }
@@ -154,46 +162,24 @@ template <int D, bool NT, int ABL = 0, int YM = 0, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void spmv_bcsr4_sell(SellView S, const double* __restrict__ x, double* __restrict__ y, int nwg)
 {
     __shared__ double s_park[YM == 2 ? NW * kSellPark * 64 : 1];
+    __shared__ int s_pid[YM == 2 ? NW * kSellPark : 1];
     double* park = s_park + (YM == 2 ? ((int)threadIdx.x >> 6) * kSellPark * 64 + ((int)threadIdx.x & 63) : 0);
+    int* pid = s_pid + (YM == 2 ? ((int)threadIdx.x >> 6) * kSellPark : 0);
     int parked = 0; // (wave-uniform)
     const int per = nwg >> 3;
     const int lwg = per > 0 && (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(lwg * NW + ((int)threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, r = lane >> 2;
-    const int s_begin = __builtin_amdgcn_readfirstlane(S.wrng[wave]);
-    const int s_end = __builtin_amdgcn_readfirstlane(S.wrng[wave + 1]);
-    if (s_begin >= s_end) return;
-    const int t0 = __builtin_amdgcn_readfirstlane(S.sptr[s_begin]);
-    const int t_end = __builtin_amdgcn_readfirstlane(S.sptr[s_end]);
-    int s = s_begin - 1; // the range's first step carries the flag too: the boundary code runs there and counts s up to s_begin
-
     const sell_v2d* vbase = reinterpret_cast<const sell_v2d*>(S.val) + lane;
     const unsigned* cbase = S.col + r;
-    sell_v2d a01[D], a23[D], x01[D], x23[D];
-    unsigned cn[D];  // column entries of steps t + D + d (one round ahead of the values and x)
-    unsigned fl[D];  // flags of the step whose values stage d holds: bit 1 padding place, bit 0 first step of a slice
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        const sell_v2d* p = vbase + (size_t)(t0 + d) * (kSellStepDoubles / 2);
-        a01[d] = sell_ld<NT>(p);
-        a23[d] = sell_ld<NT>(p + 64);
-        cn[d] = cbase[(size_t)(t0 + d) * kSellRows];
-    }
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        fl[d] = cn[d] >> 30;
-        const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(x + 4 * (size_t)(cn[d] & kSellColMask));
-        if (ABL & 1) {
-            x01[d] = x23[d] = sell_v2d{1.0 + lane, 0.5};
-        } else {
-            x01[d] = xb[0];
-            x23[d] = xb[1];
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < D; d++) cn[d] = cbase[(size_t)(t0 + D + d) * kSellRows];
 
-    double acc = 0.0;
+    auto flush = [&]() {
+        for (int j = 0; j < parked; j++) {
+            const int bj = kSellRows * pid[j] + r;
+            if (bj < S.nbrows) y[4 * (size_t)bj + (lane & 3)] = park[j * 64];
+        }
+        parked = 0;
+    };
     // the sums of slice `sl` are complete
     auto emit = [&](int sl, double v) {
         const int bi = kSellRows * sl + r;
@@ -201,64 +187,89 @@ __global__ __launch_bounds__(64 * NW) void spmv_bcsr4_sell(SellView S, const dou
         if ((ABL & 2) && v != 123.456) return;
         if (YM == 2) {
             park[parked * 64] = v;
+            if (lane == 0) pid[parked] = sl;
             parked++;
-            if (parked == kSellPark) {
-#pragma unroll
-                for (int j = 0; j < kSellPark; j++) {
-                    const int bj = kSellRows * (sl - (kSellPark - 1) + j) + r;
-                    if (bj < S.nbrows) y[4 * (size_t)bj + (lane & 3)] = park[j * 64];
-                }
-                parked = 0;
-            }
+            if (parked == kSellPark) flush();
         } else if (bi < S.nbrows) {
             if (YM == 1) __builtin_nontemporal_store(v, dst);
             else if (YM == 3) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else *dst = v;
         }
     };
-    for (int t = t0; t < t_end; t += D) {
+
+    const int s_begin = __builtin_amdgcn_readfirstlane(S.wrng[wave]);
+    const int s_end = __builtin_amdgcn_readfirstlane(S.wrng[wave + 1]);
+    {
+        if (s_begin < s_end) {
+            const int t0 = __builtin_amdgcn_readfirstlane(S.sptr[s_begin]);
+            const int t_end = __builtin_amdgcn_readfirstlane(S.sptr[s_end]);
+            int s = s_begin - 1; // the range's first step carries the flag too: the boundary code runs there and counts s up to s_begin
+            sell_v2d a01[D], a23[D], x01[D], x23[D];
+            unsigned cn[D];  // column entries of steps t + D + d (one round ahead of the values and x)
+            unsigned fl[D];  // flags of the step whose values stage d holds: bit 1 padding place, bit 0 first step of a slice
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            const int i = t + d; // the step consumed now
-            if (i < t_end) { // (wave-uniform)
-                const unsigned f = fl[d];
-                if (__builtin_amdgcn_readfirstlane(f) & 1u) { // a slice begins: the one before it is complete — its 64 rows go out as one 512-byte store
-                    if (i != t0) emit(s, acc);
-                    acc = 0.0;
-                    s++;
+            for (int d = 0; d < D; d++) {
+                const sell_v2d* p = vbase + (size_t)(t0 + d) * (kSellStepDoubles / 2);
+                a01[d] = sell_ld<NT>(p);
+                a23[d] = sell_ld<NT>(p + 64);
+                cn[d] = cbase[(size_t)(t0 + d) * kSellRows];
+            }
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                fl[d] = cn[d] >> 30;
+                const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(x + 4 * (size_t)(cn[d] & kSellColMask));
+                if (ABL & 1) {
+                    x01[d] = x23[d] = sell_v2d{1.0 + lane, 0.5};
+                } else {
+                    x01[d] = xb[0];
+                    x23[d] = xb[1];
                 }
-                double n = fma(a01[d].x, x01[d].x, acc);
-                n = fma(a01[d].y, x01[d].y, n);
-                n = fma(a23[d].x, x23[d].x, n);
-                n = fma(a23[d].y, x23[d].y, n);
-                acc = (f & 2u) ? acc : n; // padding places are not multiplied
             }
-            // refill stage d with step i + D (its column arrived a round ago), then ask for the column of step i + 2 D
-            const sell_v2d* p = vbase + (size_t)(i + D) * (kSellStepDoubles / 2);
-            a01[d] = sell_ld<NT>(p);
-            a23[d] = sell_ld<NT>(p + 64);
-            const unsigned c = cn[d];
-            fl[d] = c >> 30;
-            const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(x + 4 * (size_t)(c & kSellColMask));
-            if (!(ABL & 1)) {
-                x01[d] = xb[0];
-                x23[d] = xb[1];
+#pragma unroll
+            for (int d = 0; d < D; d++) cn[d] = cbase[(size_t)(t0 + D + d) * kSellRows];
+
+            double acc = 0.0;
+            for (int t = t0; t < t_end; t += D) {
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    const int i = t + d; // the step consumed now
+                    if (i < t_end) { // (wave-uniform)
+                        const unsigned f = fl[d];
+                        if (__builtin_amdgcn_readfirstlane(f) & 1u) { // a slice begins: the one before it is complete
+                            if (i != t0) emit(s, acc);
+                            acc = 0.0;
+                            s++;
+                        }
+                        double n = fma(a01[d].x, x01[d].x, acc);
+                        n = fma(a01[d].y, x01[d].y, n);
+                        n = fma(a23[d].x, x23[d].x, n);
+                        n = fma(a23[d].y, x23[d].y, n);
+                        acc = (f & 2u) ? acc : n; // padding places are not multiplied
+                    }
+                    // refill stage d with step i + D (its column arrived a round ago), then ask for the column of step i + 2 D
+                    const sell_v2d* p = vbase + (size_t)(i + D) * (kSellStepDoubles / 2);
+                    a01[d] = sell_ld<NT>(p);
+                    a23[d] = sell_ld<NT>(p + 64);
+                    const unsigned c = cn[d];
+                    fl[d] = c >> 30;
+                    const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(x + 4 * (size_t)(c & kSellColMask));
+                    if (!(ABL & 1)) {
+                        x01[d] = xb[0];
+                        x23[d] = xb[1];
+                    }
+                    // (the old column entry is dead from here: pinning its last uses in front of the reload lets the new entry land in the
+                    // same register — left to itself hipcc computed the flags at the bottom of the loop, kept both entries alive, copied at
+                    // the back edge and put an s_waitcnt vmcnt(0) in front of the copies: every load drained once per trip)
+                    asm volatile("" ::"v"(fl[d]), "v"(xb));
+                    if (!(ABL & 4)) cn[d] = cbase[(size_t)(i + 2 * D) * kSellRows];
+                }
             }
-            // (the old column entry is dead from here: pinning its last uses in front of the reload lets the new entry land in the same
-            // register — left to itself hipcc computed the flags at the bottom of the loop, kept both entries alive, copied at the back
-            // edge and put an s_waitcnt vmcnt(0) in front of the copies: every load drained once per trip)
-            asm volatile("" ::"v"(fl[d]), "v"(xb));
-            if (!(ABL & 4)) cn[d] = cbase[(size_t)(i + 2 * D) * kSellRows];
+            emit(s, acc);
         }
     }
-    emit(s, acc);
     unsigned long long t_loads_done = 0;
     if (ABL & 8) t_loads_done = __builtin_amdgcn_s_memrealtime();
-    if (YM == 2 && !(ABL & 16))
-        for (int j = 0; j < parked; j++) { // what is still parked: the slices s - parked + 1 .. s
-            const int bj = kSellRows * (s - parked + 1 + j) + r;
-            if (bj < S.nbrows) y[4 * (size_t)bj + (lane & 3)] = park[j * 64];
-        }
+    if (YM == 2 && !(ABL & 16)) flush(); // what is still parked
     if (ABL & 8) { // TRACE (tools/sell_bench.hip): when this wave's loop ended and when its stores were out, 100 MHz ticks, behind y
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end_all = __builtin_amdgcn_s_memrealtime();

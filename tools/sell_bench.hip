@@ -4,6 +4,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Inavierstokes_amd/csrc -o tools/sell_bench tools/sell_bench.hip && ./tools/sell_bench
 #include "spmv_bcsr_sell.hpp"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -152,5 +153,35 @@ int main(int argc, char** argv)
     trace("TRACE parked, one wave per SIMD, D=12", [&] { hipLaunchKernelGGL((spmv_bcsr4_sell<12, true, 8, 2, 4>), dim3(g3), dim3(256), 0, nullptr, S3, x, y, g3); }, P3.nwaves);
     trace("TRACE direct", [&] { hipLaunchKernelGGL((spmv_bcsr4_sell<4, true, 8, 0>), dim3(g1), dim3(256), 0, nullptr, S1, x, y, g1); }, P.nwaves);
     line("parked, final stores skipped (invalid)", run<4, true, 16, 2>(S1, P.nwaves, x, y, R));
+    { // is it the same waves that end late, launch after launch?  correlation of the per-wave loop ends of traced launches (one wave per SIMD, D = 8)
+        std::vector<std::vector<double>> ends;
+        for (int rep = 0; rep < 4; rep++) {
+            for (int i = 0; i < 3; i++) hipLaunchKernelGGL((spmv_bcsr4_sell<8, true, 0, 2, 4>), dim3(g3), dim3(256), 0, nullptr, S3, x, y, g3);
+            hipLaunchKernelGGL((spmv_bcsr4_sell<8, true, 8, 2, 4>), dim3(g3), dim3(256), 0, nullptr, S3, x, y, g3);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> tr(2 * (size_t)P3.nwaves);
+            CK(hipMemcpy(tr.data(), y + 4 * (size_t)nbr, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
+            unsigned long long lo = ~0ull;
+            for (int w = 0; w < P3.nwaves; w++) lo = std::min(lo, tr[2 * w]);
+            std::vector<double> e(P3.nwaves);
+            for (int w = 0; w < P3.nwaves; w++) e[w] = (tr[2 * w] - lo) / 100.0;
+            ends.push_back(e);
+        }
+        auto corr = [&](const std::vector<double>& a, const std::vector<double>& b) {
+            double ma = 0, mb = 0; const int n = (int)a.size();
+            for (int i = 0; i < n; i++) { ma += a[i]; mb += b[i]; }
+            ma /= n; mb /= n;
+            double sab = 0, saa = 0, sbb = 0;
+            for (int i = 0; i < n; i++) { sab += (a[i] - ma) * (b[i] - mb); saa += (a[i] - ma) * (a[i] - ma); sbb += (b[i] - mb) * (b[i] - mb); }
+            return sab / sqrt(saa * sbb + 1e-30);
+        };
+        printf("per-wave loop-end correlation between traced launches (launched behind 3 untraced ones): 0-1 %.3f, 0-2 %.3f, 1-3 %.3f, 2-3 %.3f\n", corr(ends[0], ends[1]), corr(ends[0], ends[2]), corr(ends[1], ends[3]), corr(ends[2], ends[3]));
+        // by CU (4 waves of a workgroup) and by XCD label: mean end per group in launch 0 vs launch 1
+        double x0[8] = {0}, x1[8] = {0};
+        for (int w = 0; w < P3.nwaves; w++) { const int xcd = (w / 4) / (P3.nwaves / 4 / 8); x0[xcd] += ends[0][w] / (P3.nwaves / 8); x1[xcd] += ends[1][w] / (P3.nwaves / 8); }
+        printf("mean loop end per XCD label, launch 0:"); for (int k = 0; k < 8; k++) printf(" %.1f", x0[k]);
+        printf("   launch 1:"); for (int k = 0; k < 8; k++) printf(" %.1f", x1[k]);
+        printf("\n");
+    }
     return 0;
 }
