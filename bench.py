@@ -410,14 +410,16 @@ def main():
             step()  # the first product of the handle at this column count times the gather and the tile form and keeps the faster
             torch.cuda.synchronize()
             si = [_ct.c_int(), _ct.c_int(), _ct.c_int()]
-            us3 = (_ct.c_double * 4)()
+            us3 = (_ct.c_double * 5)()
             mpk.check(mpk.lib().mi_bcsr4_spmm_info(A.handle, nvec, _ct.byref(si[0]), _ct.byref(si[1]), _ct.byref(si[2]), us3))
-            spmm_info = dict(tile_built=bool(si[0].value), form_in_use=["gather", "tile", "octet tile", "octet tile, non-temporal coefficients"][si[1].value], longest_list=si[2].value,
-                             us_by_form=dict(gather=round(us3[0], 2), tile=round(us3[1], 2), octet_tile=round(us3[2], 2), octet_tile_nt=round(us3[3], 2)))
+            spmm_info = dict(tile_built=bool(si[0].value), form_in_use=["gather", "tile", "octet tile", "octet tile, non-temporal coefficients", "sliced stream"][si[1].value], longest_list=si[2].value,
+                             us_by_form=dict(gather=round(us3[0], 2), tile=round(us3[1], 2), octet_tile=round(us3[2], 2), octet_tile_nt=round(us3[3], 2), sliced_stream=round(us3[4], 2)))
             if si[1].value == 1:
                 kernel_name = f"spmm_bcsr4_tile<{nvec}, 0, 3>"
             elif si[1].value in (2, 3):
                 kernel_name = f"spmm_bcsr4_otile<{nvec}, 0, 4, {'true' if si[1].value == 3 else 'false'}>"
+            elif si[1].value == 4:
+                kernel_name = f"spmm_bcsr4_sell<{nvec}, 0, 6, true>"
         else:
             def step():
                 mpk.SpMV_BCSR(ys[0], x, A)

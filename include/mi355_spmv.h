@@ -362,14 +362,16 @@ enum { MI_ARITH_CHAIN = 0, MI_ARITH_BLOCKACC = 1 };
 int mi_bcsr4_spmm(mi_bcsr4_t A, int s, const double* X, long long ldx, double* Y, long long ldy, int arith);          /* host */
 int mi_bcsr4_spmm_dev(mi_bcsr4_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, int arith,
                       mi_stream_t st);
-/* The product exists in four forms with the same bits.  0: x blocks gathered through L1/L2 per block (spmm_bcsr4 / spmm_bcsr4_quad).
+/* The product exists in five forms with the same bits.  0: x blocks gathered through L1/L2 per block (spmm_bcsr4 / spmm_bcsr4_quad).
  * 1: tiles of up to 128 block rows — clusters of the block graph — gather the S columns of their distinct block columns ONCE into LDS
  * and the loop waits for coefficients only (spmm_bcsr4_tile, up to four columns).  2 / 3: the same with EIGHT lanes per block row
  * (64-row tiles; one 16-byte coefficient load per lane and block, the two halves of a row swapped through DPP; even column counts),
  * coefficients loaded temporally / non-temporally (spmm_bcsr4_otile).  The lists are built at the first product; the first product of
- * a handle at a column count times the possible forms and keeps the fastest (MI355_SPMM_TILE=0..3 forces one).  *form_in_use = what
+ * a handle at a column count times the possible forms and keeps the fastest (MI355_SPMM_TILE=0..4 forces one).  4 (round 4): the
+ * SLICED stream of mi_bcsr4_sell_info with S sums per lane (spmm_bcsr4_sell; four or eight columns, unmapped products): the x blocks
+ * shared inside the quad through DPP, a finished slice's sums parked in LDS and stored behind the loads.  *form_in_use = what
  * the next product runs; us[f] = microseconds per launch measured for form f (0: not possible / not yet measured). */
-int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* form_in_use, int* longest_list, double us[4]);
+int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* form_in_use, int* longest_list, double us[5]);
 /* the same for a CSR handle (MI_ARITH_CHAIN bits = SpMV_CSR_FMA per column): one launch over the blocked copy when the
  * matrix has exact 4x4 node-block structure, else s single-vector launches */
 int mi_spmm_dev(mi_csr_t A, int s, const double* d_X, long long ldx, double* d_Y, long long ldy, mi_stream_t st);

@@ -589,11 +589,15 @@ static const SpmmTilePlan* spmm_plan_of(const mi_bcsr4_s* A, int s)
     return Pl;
 }
 
-enum { kSpmmGather = 0, kSpmmTile = 1, kSpmmOct = 2, kSpmmOctNt = 3, kSpmmForms = 4 };
+enum { kSpmmGather = 0, kSpmmTile = 1, kSpmmOct = 2, kSpmmOctNt = 3, kSpmmSell = 4, kSpmmForms = 5 };
 
-static bool spmm_form_possible(const mi_bcsr4_s* A, int s, int form)
+static int sell_fill(mi_bcsr4_t A, hipStream_t s);
+
+static bool spmm_form_possible(const mi_bcsr4_s* A, int s, int form, bool mapped = false)
 {
     if (form == kSpmmGather) return true;
+    // the sliced stream (spmm_bcsr4_sell): four or eight columns, unmapped products of a handle that holds the sliced copy
+    if (form == kSpmmSell) return (s == 4 || s == 8) && A->d_sell_val && !mapped;
     if (form == kSpmmTile) return spmm_plan_of(A, s) != nullptr;
     return s % 2 == 0 && A->st64.d_ptr && spmm_tile_lds(&A->st64, s) <= kLdsBytesPerCU;
 }
@@ -623,7 +627,21 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
         // four forms, same bits: gather kernels; LDS tile with four lanes per block row (up to four columns); LDS tile with eight
         // lanes per block row (even column counts), coefficients loaded temporally or non-temporally.  The first product of a handle
         // at a column count times the possible ones and keeps the fastest (MI355_SPMM_TILE=0..3 forces a form)
+        const bool mapped = V.browmap != nullptr;
         auto run = [&](int form) -> hipError_t {
+            if (form == kSpmmSell) {
+                if (A->sell_stale && sell_fill(A, st) != MI_OK) return hipErrorUnknown;
+                SellView Sv{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, A->d_sell_wrng, A->sell_nslices, A->nbrows};
+                const int swg = A->sell_nwaves / 4;
+                if (m == 4) {
+                    if (arith == MI_ARITH_CHAIN) hipLaunchKernelGGL((spmm_bcsr4_sell<4, 0, 6, true>), dim3((unsigned)swg), dim3(256), 0, st, Sv, Xj, ldx, Yj, ldy, swg);
+                    else hipLaunchKernelGGL((spmm_bcsr4_sell<4, 1, 6, true>), dim3((unsigned)swg), dim3(256), 0, st, Sv, Xj, ldx, Yj, ldy, swg);
+                } else {
+                    if (arith == MI_ARITH_CHAIN) hipLaunchKernelGGL((spmm_bcsr4_sell<8, 0, 6, true>), dim3((unsigned)swg), dim3(256), 0, st, Sv, Xj, ldx, Yj, ldy, swg);
+                    else hipLaunchKernelGGL((spmm_bcsr4_sell<8, 1, 6, true>), dim3((unsigned)swg), dim3(256), 0, st, Sv, Xj, ldx, Yj, ldy, swg);
+                }
+                return hipGetLastError();
+            }
             if (form == kSpmmTile) return spmm_tile_launch(A, spmm_plan_of(A, m), V, m, arith, Xj, ldx, Yj, ldy, st);
             if (form == kSpmmOct || form == kSpmmOctNt) return spmm_otile_launch(A, &A->st64, V, m, arith, form == kSpmmOctNt, Xj, ldx, Yj, ldy, st);
             launch_spmm_gather(V, m, arith, Xj, ldx, Yj, ldy, st);
@@ -631,21 +649,25 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
         };
         int form = kSpmmGather;
         const bool capturing = stream_is_capturing(st); // no first-use measurement (it synchronises) and no plan upload under capture
-        if (capturing && A->st_state == 1 && A->spmm_choice[m] > 0) form = A->spmm_choice[m] - 1;
-        if (!capturing && build_spmm_tile(A) == 1) {
+        if (capturing && A->spmm_choice[m] > 0 && (A->st_state == 1 || A->spmm_choice[m] - 1 == kSpmmSell) &&
+            !(A->spmm_choice[m] - 1 == kSpmmSell && (A->sell_stale || mapped)))
+            form = A->spmm_choice[m] - 1;
+        const bool tiles = !capturing && build_spmm_tile(A) == 1;
+        if (!capturing && (tiles || spmm_form_possible(A, m, kSpmmSell, mapped))) {
             const char* e = getenv("MI355_SPMM_TILE");
             const int forced = e ? atoi(e) : -1;
-            if (forced >= 0 && forced < kSpmmForms) form = spmm_form_possible(A, m, forced) ? forced : kSpmmGather;
+            auto possible = [&](int f) { return (f == kSpmmGather || f == kSpmmSell || tiles) && spmm_form_possible(A, m, f, mapped); };
+            if (forced >= 0 && forced < kSpmmForms) form = possible(forced) ? forced : kSpmmGather;
             else {
                 if (A->spmm_choice[m] == 0) {
                     hipEvent_t e0 = nullptr, e1 = nullptr;
                     int best = kSpmmGather;
                     if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-                        double us[kSpmmForms] = {0, 0, 0, 0};
+                        double us[kSpmmForms] = {0, 0, 0, 0, 0};
                         bool ok = true;
                         for (int round = 0; round < 2 && ok; round++)
                             for (int f = 0; f < kSpmmForms && ok; f++) {
-                                if (!spmm_form_possible(A, m, f)) continue;
+                                if (!possible(f)) continue;
                                 for (int i = 0; i < 2 && ok; i++) ok = run(f) == hipSuccess;
                                 (void)hipEventRecord(e0, st);
                                 for (int i = 0; i < 5 && ok; i++) ok = run(f) == hipSuccess;
@@ -667,6 +689,7 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
                     A->spmm_choice[m] = 1 + best;
                 }
                 form = A->spmm_choice[m] - 1;
+                if (!possible(form)) form = kSpmmGather; // (e.g. the measured choice was the sliced form and this product is a mapped one)
             }
         }
         hipError_t er = run(form);
@@ -676,7 +699,7 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
     return MI_OK;
 }
 
-extern "C" int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* form_in_use, int* longest_list, double us[4])
+extern "C" int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* form_in_use, int* longest_list, double us[5])
 {
     CHECK_ARG(A && s >= 1 && s <= 8, "bad argument");
     if (tile_built) *tile_built = A->st_state == 1;
@@ -684,8 +707,9 @@ extern "C" int mi_bcsr4_spmm_info(mi_bcsr4_t A, int s, int* tile_built, int* for
         const char* e = getenv("MI355_SPMM_TILE");
         const int forced = e ? atoi(e) : -1;
         int form = kSpmmGather;
-        if (A->st_state == 1) {
-            if (forced >= 0 && forced < kSpmmForms) form = spmm_form_possible(A, s, forced) ? forced : kSpmmGather;
+        if (A->st_state == 1 || spmm_form_possible(A, s, kSpmmSell)) {
+            auto possible = [&](int f) { return (f == kSpmmGather || f == kSpmmSell || A->st_state == 1) && spmm_form_possible(A, s, f); };
+            if (forced >= 0 && forced < kSpmmForms) form = possible(forced) ? forced : kSpmmGather;
             else if (A->spmm_choice[s] > 0) form = A->spmm_choice[s] - 1;
         }
         *form_in_use = form;

@@ -222,8 +222,9 @@ struct mi_bcsr4_s {
     SpmmTilePlan st, st64;
     int st_state = 0;         // 0 not tried, 1 built, -1 not possible
     int spmm_choice[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // per column count <= 8: 0 not measured, else 1 + the form that measured fastest
-    double spmm_us[9][4] = {};                         // [s][form] microseconds per launch: 0 gather kernels, 1 tile (four lanes per block row),
-                                                       // 2 / 3 tile with eight lanes per block row, temporal / non-temporal coefficient loads
+    double spmm_us[9][5] = {};                         // [s][form] microseconds per launch: 0 gather kernels, 1 tile (four lanes per block row),
+                                                       // 2 / 3 tile with eight lanes per block row, temporal / non-temporal coefficient loads,
+                                                       // 4 the sliced stream (spmm_bcsr4_sell)
     double* d_x = nullptr;
     double* d_y = nullptr;
     std::vector<double*> d_pow;

@@ -41,6 +41,8 @@
 #include <algorithm>
 #include <vector>
 
+#include "spmv_kernels.hpp" // quad_bcast, spmm_block_update (the multi-vector form below)
+
 namespace mi355 {
 
 constexpr int kSellRows = 16;          // block rows per slice = quads per wave
@@ -279,6 +281,129 @@ __global__ __launch_bounds__(64 * NW) void spmv_bcsr4_sell(SellView S, const dou
             tr[1] = t_end_all;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The multi-vector product on the same stream: Y[:, j] = A X[:, j], j < S (S = 4 or 8), the matrix read once
+// (MatMatMult_SeqBAIJ_4_AVX2, src/kernels/spmm_avx2.c:7-109; dense column-major X, Y).  Same waves, slices and flags as
+// spmv_bcsr4_sell; lane (r, q) keeps S sums (row 4 bi + q of every column) and LOADS the x blocks of the columns q, q + 4 only —
+// the quad shares them through DPP (quad_bcast), so a step issues 2 + 2 S / 4 sixteen-byte loads per lane, as few as the
+// single-vector product at four columns.  Each (row, column) sum is one lane's sequential chain: ARITH_CHAIN = the bits of
+// SpMV_BCSR_FMA per column, ARITH_BLOCKACC = spmm_avx2.c's per-block partial sums (spmm_block_update, spmv_kernels.hpp).
+// A finished slice's 64 x S sums are parked in LDS (PARK slices per wave) and stored column by column — 512 contiguous bytes
+// each — when the park is full or the wave's range ends.
+template <int S, int ARITH, int D, bool NT>
+__global__ __launch_bounds__(256) void spmm_bcsr4_sell(SellView Sv, const double* __restrict__ X, long long ldx, double* __restrict__ Y, long long ldy, int nwg)
+{
+    static_assert(S == 4 || S == 8, "the sliced multi-vector form is built for four and eight columns");
+    constexpr int G = S / 4;
+    constexpr int PARK = S == 4 ? 16 : 8; // 4 waves x PARK x S x 512 B = 128 KB of LDS: one workgroup per CU, one wave per SIMD
+    __shared__ double s_park[4 * PARK * S * 64];
+    __shared__ int s_pid[4 * PARK];
+    double* park = s_park + ((int)threadIdx.x >> 6) * PARK * S * 64 + ((int)threadIdx.x & 63);
+    int* pid = s_pid + ((int)threadIdx.x >> 6) * PARK;
+    int parked = 0;
+    const int per = nwg >> 3;
+    const int lwg = per > 0 && (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(lwg * 4 + ((int)threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, r = lane >> 2, q = lane & 3;
+    const int s_begin = __builtin_amdgcn_readfirstlane(Sv.wrng[wave]);
+    const int s_end = __builtin_amdgcn_readfirstlane(Sv.wrng[wave + 1]);
+    if (s_begin >= s_end) return;
+    const int t0 = __builtin_amdgcn_readfirstlane(Sv.sptr[s_begin]);
+    const int t_end = __builtin_amdgcn_readfirstlane(Sv.sptr[s_end]);
+    int s = s_begin - 1;
+    const sell_v2d* vbase = reinterpret_cast<const sell_v2d*>(Sv.val) + lane;
+    const unsigned* cbase = Sv.col + r;
+    const double* Xq = X + (size_t)q * ldx; // this lane's first column; its others are 4 * ldx apart
+
+    auto flush = [&]() {
+        for (int j = 0; j < parked; j++) {
+            const int bj = kSellRows * pid[j] + r;
+            if (bj < Sv.nbrows) {
+#pragma unroll
+                for (int c = 0; c < S; c++) Y[(size_t)c * ldy + 4 * (size_t)bj + q] = park[(j * S + c) * 64];
+            }
+        }
+        parked = 0;
+    };
+    double acc[S];
+#pragma unroll
+    for (int c = 0; c < S; c++) acc[c] = 0.0;
+    auto emit = [&](int sl) {
+#pragma unroll
+        for (int c = 0; c < S; c++) park[(parked * S + c) * 64] = acc[c];
+        if (lane == 0) pid[parked] = sl;
+        parked++;
+        if (parked == PARK) flush();
+    };
+
+    sell_v2d a01[D], a23[D], x01[D][G], x23[D][G];
+    unsigned cn[D], fl[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const sell_v2d* p = vbase + (size_t)(t0 + d) * (kSellStepDoubles / 2);
+        a01[d] = sell_ld<NT>(p);
+        a23[d] = sell_ld<NT>(p + 64);
+        cn[d] = cbase[(size_t)(t0 + d) * kSellRows];
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        fl[d] = cn[d] >> 30;
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(Xq + (size_t)(4 * u) * ldx + 4 * (size_t)(cn[d] & kSellColMask));
+            x01[d][u] = xb[0];
+            x23[d][u] = xb[1];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) cn[d] = cbase[(size_t)(t0 + D + d) * kSellRows];
+
+    for (int t = t0; t < t_end; t += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int i = t + d;
+            if (i < t_end) { // (wave-uniform)
+                const unsigned f = fl[d];
+                if (__builtin_amdgcn_readfirstlane(f) & 1u) {
+                    if (i != t0) emit(s);
+#pragma unroll
+                    for (int c = 0; c < S; c++) acc[c] = 0.0;
+                    s++;
+                }
+                const bool pad = (f & 2u) != 0; // uniform within the quad (its four lanes share the block row): DPP sources are live either way
+                const double2 c01 = make_double2(a01[d].x, a01[d].y), c23 = make_double2(a23[d].x, a23[d].y);
+#pragma unroll
+                for (int u = 0; u < G; u++) { // columns 4u + K come from lane K of the quad
+                    const double n0 = spmm_block_update<ARITH>(acc[4 * u + 0], c01, c23, quad_bcast<0>(x01[d][u].x), quad_bcast<0>(x01[d][u].y), quad_bcast<0>(x23[d][u].x), quad_bcast<0>(x23[d][u].y));
+                    const double n1 = spmm_block_update<ARITH>(acc[4 * u + 1], c01, c23, quad_bcast<1>(x01[d][u].x), quad_bcast<1>(x01[d][u].y), quad_bcast<1>(x23[d][u].x), quad_bcast<1>(x23[d][u].y));
+                    const double n2 = spmm_block_update<ARITH>(acc[4 * u + 2], c01, c23, quad_bcast<2>(x01[d][u].x), quad_bcast<2>(x01[d][u].y), quad_bcast<2>(x23[d][u].x), quad_bcast<2>(x23[d][u].y));
+                    const double n3 = spmm_block_update<ARITH>(acc[4 * u + 3], c01, c23, quad_bcast<3>(x01[d][u].x), quad_bcast<3>(x01[d][u].y), quad_bcast<3>(x23[d][u].x), quad_bcast<3>(x23[d][u].y));
+                    acc[4 * u + 0] = pad ? acc[4 * u + 0] : n0; // padding places are not multiplied
+                    acc[4 * u + 1] = pad ? acc[4 * u + 1] : n1;
+                    acc[4 * u + 2] = pad ? acc[4 * u + 2] : n2;
+                    acc[4 * u + 3] = pad ? acc[4 * u + 3] : n3;
+                }
+            }
+            const sell_v2d* p = vbase + (size_t)(i + D) * (kSellStepDoubles / 2);
+            a01[d] = sell_ld<NT>(p);
+            a23[d] = sell_ld<NT>(p + 64);
+            const unsigned c = cn[d];
+            fl[d] = c >> 30;
+            const double* xrow = Xq + 4 * (size_t)(c & kSellColMask);
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const sell_v2d* xb = reinterpret_cast<const sell_v2d*>(xrow + (size_t)(4 * u) * ldx);
+                x01[d][u] = xb[0];
+                x23[d][u] = xb[1];
+            }
+            asm volatile("" ::"v"(fl[d]), "v"(xrow)); // (the old column entry dies here: see spmv_bcsr4_sell)
+            cn[d] = cbase[(size_t)(i + 2 * D) * kSellRows];
+        }
+    }
+    emit(s);
+    flush();
 }
 
 } // namespace mi355

@@ -128,15 +128,18 @@ def test_krylov_basis_orthonormal():
         assert O.rel_error(lhs, rhs) <= 1e-12
 
 
-@pytest.mark.parametrize("form", ["1", "2", "3"])
+@pytest.mark.parametrize("form", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("s", [2, 4, 6, 8, 11])
 def test_spmm_every_tile_form_bitwise(form, s, monkeypatch):
     """The multi-vector product's tile forms forced on (MI355_SPMM_TILE: 1 = four lanes per block row, 2 / 3 = eight lanes per block
     row with temporal / non-temporal coefficient loads; a form that does not exist for a column count falls back to the gather
     kernels): tiles are breadth-first clusters of the block graph, rows of a tile are not consecutive — every column bit-equal to
     the oracle in both associations, on an FE matrix, on the same matrix under a random node numbering, and on a matrix with empty
-    block rows and a block-row count that is no multiple of the tile size."""
+    block rows and a block-row count that is no multiple of the tile size.  Form 4 (round 4) is the sliced stream (spmm_bcsr4_sell:
+    four and eight columns; eleven = a batch of eight through it and three through the gather kernels)."""
     monkeypatch.setenv("MI355_SPMM_TILE", form)
+    if form == "4":
+        monkeypatch.setenv("MI355_BCSR_SELL", "1")  # (these matrices are below the size from which the sliced copy is built by itself)
     mats = []
     p, c, v = synth.fe_matrix(13, 11, 9)
     mats.append(("fe", p, c, v))
@@ -154,6 +157,11 @@ def test_spmm_every_tile_form_bitwise(form, s, monkeypatch):
             bc, bv = bc[sel], bv.reshape(-1, 16)[sel].reshape(-1)
         A = mpk.bcsr4x4_matrix(n // 4, bp, bc, bv, nbcols=n // 4)
         X = _vectors(n, s)
+        if form == "4" and s in (4, 8):
+            import ctypes
+            fi = ctypes.c_int(-1)
+            mpk.check(mpk.lib().mi_bcsr4_spmm_info(A.handle, s, None, ctypes.byref(fi), None, None))
+            assert fi.value == 4, fi.value
         for arith, orc in (("chain", O.spmv_bcsr4), ("blockacc", O.spmv_bcsr4_blockacc)):
             for rep in range(2):
                 Y = torch.full((s, n), float("nan"), dtype=torch.float64, device="cuda")

@@ -25,6 +25,7 @@ for s in "$@"; do
     bench_mp) MI355_FORCE_DEVICE=0 MI355_BENCH_BACKEND=gloo step r4_bench_mp2 400 python bench.py --gpus 2 --workload c2 --steps 50 --warmup 5 ;;
     sell)     step r4_sell 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sliced_copy or bcsr or fe_matrix" ;;
     ag)       step r4_ag 900 python -m pytest tests/test_gpu_parity.py tests/test_dist_single_process.py tests/test_bench_launch.py -x -q -m gpu -k "allgather or rccl_exchange or multirank_threads or bench_gpus_2" ;;
+    spmm)     step r4_spmm 900 python -m pytest tests/test_spmm_gpu.py -x -q -m gpu && step r4_bench_spmm4 200 python bench.py --workload fe_spmm4 && step r4_bench_spmm8 200 python bench.py --workload fe_spmm8 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
