@@ -425,10 +425,13 @@ def main():
                 mpk.SpMV_BCSR(ys[0], x, A)
         halo_info = None
     elif world == 1:
+        t_gen = time.perf_counter() - t_setup  # (generating the synthetic matrix on the host: not the library's time)
         A = mpk.csrmatrix(n, p, c, v)
         if args.kernel != "auto":
             A.set_kernel(args.kernel)
+        t_create = time.perf_counter()
         _ = A.handle
+        t_create = time.perf_counter() - t_create
         kernel_name = A.kernel_name()
         ring_cfg, ring_runs, ring_bad, ring_frac = A.ring_info()
         x = torch.from_numpy(x_host).cuda()
@@ -890,18 +893,37 @@ def main():
     if halo_info is not None:
         out["halo"] = halo_info
     out["setup_s"] = round(t_setup, 2)
+    if world == 1 and not bcsr:
+        out["setup_breakdown_s"] = dict(generate_matrix_on_host=round(t_gen, 2), mi_csr_create=round(t_create, 2),
+                                        note="mi_csr_create = upload + plans + the create-time measurements (kernel candidates, placement draws)")
     if world > 1 and not args.no_single_process_extra and kind in ("s15", "fe") and not args.cold:
-        # the same workload through ONE process (mi_dist_*): the other ranks wait on the HOST (a gloo group — an RCCL barrier would
-        # keep a kernel spinning on their GPUs while the child measures)
-        import datetime
-        side = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+        # the same workload through ONE process (mi_dist_*), as a child of rank 0.  The other ranks wait on the HOST — a key in the
+        # process group's own TCP store — so that no collective kernel spins on their GPUs while the child measures; everything here
+        # is bounded (child: 200 s; the wait: 260 s) and a failure costs the line nothing but the field.
         torch.cuda.synchronize()
-        dist.barrier(group=side)
+        key = "mi355_single_process_done"
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:  # noqa: BLE001
+            store = None
         if rank == 0:
-            out["single_process"] = run_single_process_child(args)
-            out["single_process"]["note"] = ("the same workload driven by ONE process over the N devices (python bench.py --gpus N --single-process: mi_dist_create, a worker "
-                                             "thread per rank), run as a child of rank 0 after the timed region while the other ranks wait on the host; never `value`")
-        dist.barrier(group=side)
+            try:
+                out["single_process"] = run_single_process_child(args, timeout_s=200)
+            except Exception as e:  # noqa: BLE001
+                out["single_process"] = dict(ok=False, note=f"{type(e).__name__}: {str(e)[:200]}")
+            out["single_process"]["note2"] = ("the same workload driven by ONE process over the N devices (python bench.py --gpus N --single-process: mi_dist_create, a worker "
+                                              "thread per rank), run as a child of rank 0 after the timed region while the other ranks wait on the host; never `value`")
+            if store is not None:
+                try:
+                    store.set(key, "1")
+                except Exception:  # noqa: BLE001
+                    pass
+        elif store is not None:
+            import datetime
+            try:
+                store.wait([key], datetime.timedelta(seconds=260))
+            except Exception:  # noqa: BLE001 — rank 0 never got there: nothing to wait for any longer
+                pass
     if rank == 0 and world == 1 and not bcsr and k == 1 and not args.no_cpu_baseline:
         # the reference's calling convention (host pointers): x H2D + kernel + y D2H per call; never `value`
         xh, yh = x_host, np.empty(n)
