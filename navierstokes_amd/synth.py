@@ -72,6 +72,31 @@ def rows(kind, n, rb=0, re=None, seed=DEFAULT_SEED, w=DEFAULT_W):
     if re is None:
         re = n
     lib = _lib()
+    if re - rb >= 1_000_000:  # large ranges: the generator is counter-based per row, so chunks of rows go to threads (ctypes drops the GIL)
+        import concurrent.futures as cf
+        import os
+        T = max(1, min(16, os.cpu_count() or 1))
+        cuts = [rb + (re - rb) * t // T for t in range(T + 1)]
+        with cf.ThreadPoolExecutor(T) as ex:
+            counts = list(ex.map(lambda t: lib.synth_count(kind, seed, n, w, cuts[t], cuts[t + 1]), range(T)))
+            offs = np.concatenate([[0], np.cumsum(counts)])
+            nnz = int(offs[-1])
+            if nnz >= 2**31:
+                raise ValueError("row range holds >= 2^31 nonzeros; int32 indices (mpk/SpMV.h:20-22) overflow")
+            ptrow = np.empty(re - rb + 1, np.int32)
+            indcol = np.empty(nnz, np.int32)
+            coef = np.empty(nnz, np.float64)
+
+            def piece(t):
+                pt = np.empty(cuts[t + 1] - cuts[t] + 1, np.int32)
+                rc = lib.synth_rows(kind, seed, n, w, cuts[t], cuts[t + 1], pt, indcol[offs[t]:offs[t + 1]], coef[offs[t]:offs[t + 1]])
+                ptrow[cuts[t] - rb:cuts[t + 1] - rb] = pt[:-1] + np.int32(offs[t])
+                return rc
+            rcs = list(ex.map(piece, range(T)))
+        ptrow[-1] = nnz
+        if any(rcs):
+            raise ValueError(f"synth_rows({kind=}, {n=}, {w=}, {rb=}, {re=}) rejected its arguments")
+        return ptrow, indcol, coef
     nnz = lib.synth_count(kind, seed, n, w, rb, re)
     if nnz >= 2**31:
         raise ValueError("row range holds >= 2^31 nonzeros; int32 indices (mpk/SpMV.h:20-22) overflow")
