@@ -299,7 +299,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4", "tile", "mring"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "ring", "rowpar", "bcsr4", "tile", "mring", "sstream"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--exchange", default=None, choices=["auto", "native", "allgather", "push", "torch"], help="N > 1: which halo exchange drives the step")
@@ -850,7 +850,7 @@ def main():
         tune, nt = A.tune_detail()
         out["kernel_info"] = dict(kernel=kernel_name, ring_config=ring_cfg, runs=ring_runs, runs_on_plain_path=ring_bad,
                                   nnz_fraction_ring=round(ring_frac, 4), nontemporal_values=nt,
-                                  matrix_stream_bytes_per_nnz=10 if "ring<" in kernel_name else (8.25 if "bcsr4" in kernel_name else
+                                  matrix_stream_bytes_per_nnz=10 if ("ring<" in kernel_name or "sstream<" in kernel_name) else (8.25 if "bcsr4" in kernel_name else
                                                               round(10 + 4 * A.tile_info()["unique_per_nnz"], 2) if "tile" in kernel_name else 12),
                                   autotune_us={k_: round(v_, 1) for k_, v_ in tune.items()})
         if "spmv_csr_ring<" in kernel_name:
@@ -874,6 +874,9 @@ def main():
             out["kernel_info"]["placement_draws_us"] = dict(pl, note="mi_csr_create timed the chosen kernel on fresh device copies of the value array, then of the 16-bit column "
                                                                   "stream, and kept the fastest of each (first entry: as first allocated); where the arrays — the caller's x and y "
                                                                   "included — lie in device memory moves a WARM launch by up to 15 %, a cold one not at all (profiles/NOTES.md §4.12)")
+        si_ = A.sstream_info()
+        if si_["built"]:
+            out["kernel_info"]["sliced_stream"] = {k_: (round(v_, 4) if isinstance(v_, float) else v_) for k_, v_ in si_.items()}
         ti = A.tile_info()
         if ti["built"]:
             out["kernel_info"]["tile_plan"] = dict(row_blocks=ti["nblk"], distinct_columns_per_nnz=round(ti["unique_per_nnz"], 4))

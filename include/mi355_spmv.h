@@ -65,6 +65,9 @@ enum {
                             * same bits from 8.25 instead of 12 matrix bytes per nonzero */
     MI_KERNEL_MRING = 6,   /* the ring kernel with five independent sliding windows: 3-D mesh operators, whose rows reach into a
                             * few narrow column clusters whole mesh planes apart (any mesh size) */
+    MI_KERNEL_SSTREAM = 7, /* (round 4) the matrix as ONE contiguous stream per wave: a sliced copy (128-row slices, 16 bytes of values per
+                            * lane and step, a 32-bit word of LDS slots and flags), a lane per row pair, x in an LDS ring that slides with
+                            * the rows, y parked in LDS — banded matrices with near-uniform row lengths (spmv_sstream.hpp) */
     MI_KERNEL_TILE = 5     /* per row block the DISTINCT columns are gathered once into an LDS tile, nonzeros address it
                             * through a 16-bit stream: wide-band matrices whose neighbouring rows share columns (P1
                             * operators on unstructured 3-D meshes), which the ring's contiguous window cannot hold */
@@ -207,6 +210,18 @@ int mi_csr_placement_info(mi_csr_t A, int* n_values, int* n_total, double* us, i
  * Results do not depend on where a vector lies: placement is a matter of speed only. */
 int mi_vec_alloc_placed(mi_csr_t A, int nvec, int draws, double** d_vecs, double* us, int cap, int* n_us);
 int mi_vec_free_placed(double* d_vec);
+/* Sliced-stream kernel (MI_KERNEL_SSTREAM, spmv_sstream.hpp): mi_csr_create plans it for unmapped matrices of >= 200 000 nonzeros whose
+ * rounds of 512 rows fit an 8192-column LDS window that slides forward by at most 1024 columns per round and whose 128-row slices pad by
+ * at most 12 % (MI355_SSTREAM=0 never, =1 plan whatever the size), builds the sliced copy (10 bytes per nonzero beside the CSR arrays)
+ * and times it — 8 / 12 steps of prefetch, non-temporal / temporal value loads — against the other candidates.  *built = 1 if the handle
+ * holds the copy; *padding = padded places per nonzero; us[0..3] = microseconds per launch for D = 8 nt, D = 8 temporal, D = 12 nt,
+ * D = 12 temporal (0 = not timed); *form = the variant in use (index into us).  y must be 16-byte aligned (else the handle's next-best
+ * kernel runs that product). */
+int mi_csr_sstream_info(mi_csr_t A, int* built, int* rounds, long long* steps, double* padding, double us[4], int* form);
+/* host-only: build that plan exactly as mi_csr_create would and REPLAY it against the matrix (MI_ERR_STATE names the first violation:
+ * every nonzero's slot is its column's ring slot and the column lies inside the window when its round runs; padding places are flagged).
+ * *eligible = 0 with the reason in mi_last_error() when the matrix does not qualify. */
+int mi_sstream_plan_probe(int n, int ncols, const int* ptrow, const int* indcol, int* eligible, int* rounds, long long* steps, double* padding);
 /* Multi-window ring kernel (MI_KERNEL_MRING, mring_plan.hpp): mi_csr_create plans it for matrices the single ring does not serve
  * and keeps the plan when it serves >= 90 % of the nonzeros (MI355_MRING=0 never, =1 always keep); mi_csr_set_kernel builds it
  * on request.  us[0..1] = measured microseconds per launch, temporal / non-temporal value loads (MI355_MRING_NT=0|1 forces). */

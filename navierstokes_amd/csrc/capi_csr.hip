@@ -1,6 +1,7 @@
 // capi_csr.hip: CSR handles — create (plans, autotuner, relabelling), update, info, products — part of libmi355spmv.so (see capi_internal.hpp for the layout of the library).
 // Built for gfx950 only; no CPU fallback anywhere: every compute entry point needs a HIP device.
 #include "capi_internal.hpp"
+#include "spmv_sstream.hpp"
 #include "reorder.hpp"
 #include "mring_plan.hpp"
 #include "tile_plan.hpp"
@@ -44,6 +45,84 @@ static void free_mring(mi_csr_t A)
     dfree(A->mring.d_rng);
     dfree(A->mring.d_slots);
     A->mring = MringTable();
+}
+
+static void free_sstream(mi_csr_t A)
+{
+    dfree(A->ss.d_val);
+    dfree(A->ss.d_slot);
+    dfree(A->ss.d_wptr);
+    dfree(A->ss.d_rptr);
+    dfree(A->ss.d_win);
+    dfree(A->ss.d_slice_step);
+    dfree(A->ss.d_slice_len);
+    A->ss = SstreamTable();
+}
+
+constexpr double kSsMaxPadding = 0.12; // padded places per nonzero from which the sliced copy is not worth its bytes
+
+// The sliced copy of the sliced-stream kernel (spmv_sstream.hpp): plan + slot stream on the host, values filled on the device from the
+// handle's CSR values at the first product.  MI_OK with A->ss left empty when the matrix is not eligible.
+static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol)
+{
+    if (A->ss.d_val) return MI_OK;
+    SsPlanHost P;
+    build_sstream_plan(A->n, A->ncols, ptrow, indcol, kSsMaxPadding, P);
+    if (!P.eligible) return MI_OK;
+    SstreamTable& T = A->ss;
+    hipError_t e;
+    const size_t vbytes = sizeof(ss_v2d) * (size_t)(P.steps + kSsPadSteps) * 64;
+    if ((e = hipMalloc(&T.d_val, vbytes)) != hipSuccess || (e = hipMalloc(&T.d_slot, sizeof(unsigned) * P.slot.size())) != hipSuccess ||
+        (e = hipMalloc(&T.d_wptr, sizeof(int) * P.wptr.size())) != hipSuccess || (e = hipMalloc(&T.d_rptr, sizeof(int) * P.rptr.size())) != hipSuccess ||
+        (e = hipMalloc(&T.d_win, sizeof(int2) * P.win.size())) != hipSuccess || (e = hipMalloc(&T.d_slice_step, sizeof(int) * P.slice_step.size())) != hipSuccess ||
+        (e = hipMalloc(&T.d_slice_len, sizeof(int) * P.slice_len.size())) != hipSuccess ||
+        (e = hipMemset((char*)T.d_val + sizeof(ss_v2d) * (size_t)P.steps * 64, 0, sizeof(ss_v2d) * (size_t)kSsPadSteps * 64)) != hipSuccess ||
+        (e = hipMemcpy(T.d_slot, P.slot.data(), sizeof(unsigned) * P.slot.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_wptr, P.wptr.data(), sizeof(int) * P.wptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_rptr, P.rptr.data(), sizeof(int) * P.rptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_win, P.win.data(), sizeof(int2) * P.win.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_slice_step, P.slice_step.data(), sizeof(int) * P.slice_step.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(T.d_slice_len, P.slice_len.data(), sizeof(int) * P.slice_len.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        free_sstream(A);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return MI_OK; } // no room for a second copy of the matrix: the other kernels serve it
+        return fail(MI_ERR_HIP, std::string("sliced copy: ") + hipGetErrorString(e));
+    }
+    T.nwg = P.nwg;
+    T.rounds = P.rounds;
+    T.steps = P.steps;
+    T.padding = (double)P.pad_places / (double)A->nnz;
+    T.stale = true;
+    T.nt = 10.0 * (double)A->nnz + 16.0 * (double)A->n > 0.75 * 256e6; // beyond the Infinity Cache: stream past it
+    T.deep = T.nt;
+    if (const char* fe = getenv("MI355_SSTREAM_FORM")) { // tests: one variant (0 D=8 nt, 1 D=8 temporal, 2 D=12 nt, 3 D=12 temporal)
+        const int f = atoi(fe);
+        T.nt = (f & 1) == 0;
+        T.deep = f >= 2;
+    }
+    return MI_OK;
+}
+
+// y = A x through the sliced-stream kernel (the caller has checked that the handle holds the copy and that y is 16-byte aligned)
+int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s)
+{
+    SstreamTable& T = A->ss;
+    if (T.stale) { // the CSR values changed (or were never copied): refill the sliced values on this stream, in front of the product
+        const int nslices = 4 * T.rounds;
+        hipLaunchKernelGGL(csr_to_sstream_kernel, dim3((unsigned)std::min(nslices, 16384)), dim3(64), 0, s, nslices, A->n, A->d_ptrow, A->d_coef, T.d_slice_step,
+                           T.d_slice_len, reinterpret_cast<ss_v2d*>(T.d_val));
+        HIP_TRY(hipGetLastError());
+        T.stale = false;
+    }
+    SsView S{reinterpret_cast<const ss_v2d*>(T.d_val), T.d_slot, T.d_wptr, T.d_rptr, reinterpret_cast<const int2*>(T.d_win), T.nwg, A->n, A->ncols};
+    if (T.deep) {
+        if (T.nt) hipLaunchKernelGGL((spmv_sstream<12, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
+        else hipLaunchKernelGGL((spmv_sstream<12, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
+    } else {
+        if (T.nt) hipLaunchKernelGGL((spmv_sstream<8, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
+        else hipLaunchKernelGGL((spmv_sstream<8, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
 }
 
 // Plan of the multi-window ring kernel (host arrays of the caller, or nullptr: the handle's device copy is read back)
@@ -454,6 +533,20 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
             if (!asked && A->mring.ok_fraction < 0.90) free_mring(A);
         }
     }
+    // ... and the sliced copy of the sliced-stream kernel (spmv_sstream.hpp): unmapped matrices whose rounds of 512 rows fit the LDS
+    // window and whose slices pad little; MI355_SSTREAM=0 never, =1 whatever the size
+    {
+        const char* se = getenv("MI355_SSTREAM");
+        const char* ke = getenv("MI355_SPMV_KERNEL");
+        const bool asked = (se && !strcmp(se, "1")) || (ke && !strcmp(ke, "sstream"));
+        if (n > 0 && nnz > 0 && !rowmap && !(ghost_lo < ghost_hi) && !(se && !strcmp(se, "0")) && (asked || nnz >= 200000)) {
+            const int rcs = build_sstream(A, ptrow, indcol);
+            if (rcs != MI_OK) {
+                mi_csr_destroy(A);
+                return rcs;
+            }
+        }
+    }
     // FE matrices: a blocked copy for the BCSR 4x4 kernel (same bits, 8.25 instead of 12 B per nonzero)
     // (a row map that moves whole nodes — rowmap[4b + q] = rowmap[4b] + q, 4-aligned — becomes a block-row map)
     bool node_map = rowmap != nullptr && !offset_only && n % 4 == 0;
@@ -498,6 +591,7 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         else if (!strcmp(e, "bcsr4") && A->blocked) A->auto_kernel = MI_KERNEL_BCSR4;
         else if (!strcmp(e, "tile") && A->tile.d_desc) A->auto_kernel = MI_KERNEL_TILE;
         else if (!strcmp(e, "mring") && A->mring.d_plan) A->auto_kernel = MI_KERNEL_MRING;
+        else if (!strcmp(e, "sstream") && A->ss.d_val) A->auto_kernel = MI_KERNEL_SSTREAM;
         else forced_kernel = false;
     }
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
@@ -607,6 +701,38 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
             A->kernel = MI_KERNEL_AUTO;
             const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : (A->auto_kernel == MI_KERNEL_MRING ? best_mring : best_stream));
             if (better(A->tune_us_bcsr, best_csr)) A->auto_kernel = MI_KERNEL_BCSR4;
+        }
+        if (A->ss.d_val && !getenv("MI355_SSTREAM_FORM")) { // the sliced stream against whatever won so far: 8 / 12 steps of prefetch x non-temporal / temporal value loads
+            const double best_so_far = A->auto_kernel == MI_KERNEL_BCSR4 ? A->tune_us_bcsr
+                                       : A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : (A->auto_kernel == MI_KERNEL_MRING ? best_mring : best_stream));
+            A->kernel = MI_KERNEL_SSTREAM;
+            double bs = 0.0;
+            int bf = -1;
+            for (int round = 0; round < 2; round++)
+                for (int f = 0; f < 4; f++) {
+                    A->ss.nt = (f & 1) == 0;
+                    A->ss.deep = f >= 2;
+                    for (int w = 0; w < 3; w++)
+                        if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+                    TRY_OR_CLEAN(hipEventRecord(e0, nullptr));
+                    const int timed = nnz < 40000000 ? 12 : 6;
+                    for (int w = 0; w < timed; w++)
+                        if (launch_spmv(A, tx, ty, nullptr) != MI_OK) break;
+                    TRY_OR_CLEAN(hipEventRecord(e1, nullptr));
+                    TRY_OR_CLEAN(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    TRY_OR_CLEAN(hipEventElapsedTime(&ms, e0, e1));
+                    const double t = ms * 1e3 / timed;
+                    A->ss.tune_us[f] = A->ss.tune_us[f] > 0 ? std::min(A->ss.tune_us[f], t) : t;
+                }
+            for (int f = 0; f < 4; f++)
+                if (A->ss.tune_us[f] > 0 && (bf < 0 || A->ss.tune_us[f] < bs)) { bs = A->ss.tune_us[f]; bf = f; }
+            A->kernel = MI_KERNEL_AUTO;
+            if (bf >= 0) {
+                A->ss.nt = (bf & 1) == 0;
+                A->ss.deep = bf >= 2;
+                if (better(bs, best_so_far)) A->auto_kernel = MI_KERNEL_SSTREAM;
+            }
         }
         // every further comparison on the SAME x / y scratch: where a vector lies in device memory moves a launch by a few per cent
         auto time_now = [&](int warm, int timed, double* us_out) -> int {
@@ -731,6 +857,7 @@ static void release_natural_arrays(mi_csr_t A)
     A->ring = RingTable();
     free_tile(A);
     free_mring(A);
+    free_sstream(A);
     mi_bcsr4_destroy(A->blocked);
     A->blocked = nullptr;
 }
@@ -932,6 +1059,7 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     dfree(A->ring.d_slots);
     free_tile(A);
     free_mring(A);
+    free_sstream(A);
     mi_bcsr4_destroy(A->blocked);
     mi_csr_destroy(A->inner);
     dfree(A->d_iperm);
@@ -965,6 +1093,7 @@ __global__ __launch_bounds__(kWG) void bcsr4_values_from_csr_kernel(int nbrows, 
 
 static int refresh_blocked_values(mi_csr_t A, hipStream_t s)
 {
+    if (A->ss.d_val) A->ss.stale = true; // (every value refresh comes by here) the sliced copy follows on the next product's stream
     if (!A->blocked || A->blocked->nbrows == 0) return MI_OK;
     const long long threads = 4LL * A->blocked->nbrows;
     hipLaunchKernelGGL(bcsr4_values_from_csr_kernel, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, s,
@@ -1040,6 +1169,7 @@ int resolve_kernel(const mi_csr_s* A)
     if (k == MI_KERNEL_BCSR4 && !A->blocked) k = MI_KERNEL_STREAM;
     if (k == MI_KERNEL_TILE && !A->tile.d_desc) k = MI_KERNEL_STREAM;
     if (k == MI_KERNEL_MRING && !A->mring.d_plan) k = MI_KERNEL_STREAM;
+    if (k == MI_KERNEL_SSTREAM && !A->ss.d_val) k = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     return k;
 }
 
@@ -1230,6 +1360,40 @@ extern "C" int mi_spmk_plan_probe(int n, const int* ptrow, const int* indcol, in
     *eligible = md <= 64 ? 1 : 0;
     if (runs) *runs = W;
     if (max_deps) *max_deps = md;
+    return MI_OK;
+}
+
+extern "C" int mi_csr_sstream_info(mi_csr_t A, int* built, int* rounds, long long* steps, double* padding, double us[4], int* form)
+{
+    CHECK_ARG(A, "null handle");
+    if (A->inner) A = A->inner;
+    if (built) *built = A->ss.d_val != nullptr;
+    if (rounds) *rounds = A->ss.rounds;
+    if (steps) *steps = A->ss.steps;
+    if (padding) *padding = A->ss.padding;
+    if (us)
+        for (int f = 0; f < 4; f++) us[f] = A->ss.tune_us[f];
+    if (form) *form = A->ss.d_val ? (A->ss.deep ? 2 : 0) + (A->ss.nt ? 0 : 1) : -1;
+    return MI_OK;
+}
+
+extern "C" int mi_sstream_plan_probe(int n, int ncols, const int* ptrow, const int* indcol, int* eligible, int* rounds, long long* steps, double* padding)
+{
+    CHECK_ARG(n >= 0 && ncols >= 0 && ptrow && ptrow[0] == 0 && eligible, "bad argument");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    for (int i = 0; i < n; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
+    for (int k = 0; k < ptrow[n]; k++) CHECK_ARG(indcol[k] >= 0 && indcol[k] < ncols, "column index outside [0, ncols)");
+    SsPlanHost P;
+    build_sstream_plan(n, ncols, ptrow, indcol, kSsMaxPadding, P);
+    *eligible = P.eligible ? 1 : 0;
+    if (rounds) *rounds = P.rounds;
+    if (steps) *steps = P.steps;
+    if (padding) *padding = ptrow[n] > 0 ? (double)P.pad_places / (double)ptrow[n] : 0.0;
+    if (!P.eligible) {
+        g_err = std::string("not eligible: ") + P.why;
+        return MI_OK;
+    }
+    if (const char* bad = check_sstream_plan(P, n, ptrow, indcol)) return fail(MI_ERR_STATE, std::string("sliced-stream plan: ") + bad);
     return MI_OK;
 }
 
@@ -1462,7 +1626,10 @@ extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
 {
     CHECK_ARG(A, "null handle");
     if (A->inner) A = A->inner;
-    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_MRING, "unknown kernel id");
+    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_SSTREAM, "unknown kernel id");
+    if (kernel_id == MI_KERNEL_SSTREAM && !A->ss.d_val)
+        return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_SSTREAM: the handle holds no sliced copy (the matrix is row-mapped, too small, pads too much, or its rows do "
+                                        "not fit the sliding LDS window: mi_sstream_plan_probe says which)");
     if (kernel_id == MI_KERNEL_BCSR4 && !A->blocked)
         return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_BCSR4: this matrix has no exact 4x4 block structure (or is row-mapped)");
     if (kernel_id == MI_KERNEL_TILE) { // the plan is built on first request if mi_csr_create did not keep one
@@ -1512,6 +1679,11 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
         static thread_local char nm[96];
         snprintf(nm, sizeof nm, "spmv_csr_mring<%d, %d, %d, %d, %s, %s, %s>", kMringThreads, kMringNnzb, A->mring.depth, kMringMaxB,
                  A->d_rowmap ? "true" : "false", A->mring.nt ? "true" : "false", A->mring.skew ? "true" : "false");
+        return nm;
+    }
+    case MI_KERNEL_SSTREAM: {
+        static thread_local char nm[64];
+        snprintf(nm, sizeof nm, "spmv_sstream<%d, %s, 0>", A->ss.deep ? 12 : 8, A->ss.nt ? "true" : "false");
         return nm;
     }
     case MI_KERNEL_TILE: {

@@ -123,6 +123,24 @@ struct TileTable {
     bool skew = false;                 // padded staging layout (see RingTable::skew)
 };
 
+// the sliced copy of the sliced-stream kernel (spmv_sstream.hpp); valid iff d_val != nullptr
+struct SstreamTable {
+    void* d_val = nullptr;        // ss_v2d [steps + pad][64]
+    unsigned* d_slot = nullptr;
+    int* d_wptr = nullptr;
+    int* d_rptr = nullptr;
+    int* d_win = nullptr;         // int2 per round
+    int* d_slice_step = nullptr;  // per slice (4 * round + wave): first step, steps — for value refills
+    int* d_slice_len = nullptr;
+    int nwg = 0, rounds = 0;
+    long long steps = 0;
+    double padding = 0.0;         // padded places per nonzero
+    bool nt = true;               // non-temporal value loads (measured at create)
+    bool deep = true;             // twelve steps of prefetch instead of eight (measured at create)
+    bool stale = false;           // the CSR values changed since the sliced values were filled: refilled on the next product's stream
+    double tune_us[4] = {0, 0, 0, 0}; // D = 8 nt, D = 8 temporal, D = 12 nt, D = 12 temporal
+};
+
 struct mi_csr_s {
     int device = 0;
     int n = 0, ncols = 0;
@@ -138,6 +156,7 @@ struct mi_csr_s {
     RingTable ring;           // valid iff ring.d_plan != nullptr
     TileTable tile;           // valid iff tile.d_desc != nullptr
     double tune_us_tile = 0.0, tune_us_tile_nt = 0.0;
+    SstreamTable ss;          // valid iff ss.d_val != nullptr
     MringTable mring;         // valid iff mring.d_plan != nullptr
     double tune_us_mring = 0.0, tune_us_mring_nt = 0.0;
     int kernel = MI_KERNEL_AUTO;
@@ -340,6 +359,8 @@ hipError_t spmm_otile_launch(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const 
 int part_push_window(mi_part_s* P);
 void part_push_layout(const mi_part_s* P, long long* layout /* [2*nranks + 1] */);
 int part_push_connect_bases(mi_part_s* P, void* const* bases /* [nranks] */, const long long* layouts);
+// capi_csr.hip: the sliced-stream kernel of a handle (spmv_sstream.hpp)
+int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s);
 // capi_bcsr.hip
 // the blocked copy's values were rewritten (by whoever holds d_coef): the sliced copy follows on the next product
 static inline void bcsr4_values_changed(mi_bcsr4_s* A) { if (A && A->d_sell_val) A->sell_stale = true; }

@@ -50,7 +50,11 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
         if ((rc = gather_perm(A, d_x, xp, s))) return rc;
         return launch_spmv(A->inner, xp, d_y, s, true);
     }
-    const int kid = resolve_kernel(A);
+    int kid = resolve_kernel(A);
+    if (kid == MI_KERNEL_SSTREAM) { // (unmapped handles only hold the sliced copy)
+        if ((((uintptr_t)d_y) & 15) == 0) return launch_sstream(A, d_x, d_y, s);
+        kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // y only 8-byte aligned: the sliced kernel stores row pairs
+    }
     if (use_map) d_y += A->y_offset;
     CsrView V{};
     V.n = A->n;

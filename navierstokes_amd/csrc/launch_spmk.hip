@@ -63,7 +63,10 @@ static int spmk_setup(mi_csr_t H)
     if (H->kstep_setup) return H->kstep_setup;
     H->kstep_setup = -1;
     const RingTable& R = H->ring;
-    if (H->inner || H->n != H->ncols || resolve_kernel(H) != MI_KERNEL_RING || !R.d_plan || R.cfg.id != 4 || !R.lean || !R.all_in_loop ||
+    // (a handle whose single products run the sliced stream still holds its ring plan: the one-launch step is built on that, and the
+    // first k-step measures it against k launches of the sliced stream)
+    const int kid = resolve_kernel(H);
+    if (H->inner || H->n != H->ncols || (kid != MI_KERNEL_RING && kid != MI_KERNEL_SSTREAM) || !R.d_plan || R.ok_fraction < 0.90 || R.cfg.id != 4 || !R.lean || !R.all_in_loop ||
         R.cfg.depth == 3 || R.h_dep_ptr.empty() || R.wgs < kNXCD || R.wgs % kNXCD)
         return -1;
     int maxdep = 0;

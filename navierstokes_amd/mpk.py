@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("MI355_SPMV_LIBRARY") or os.path.join(_HERE, "csrc", "
 
 MI_OK = 0
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_RING, KERNEL_ROWPAR = 0, 1, 2, 3
-KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3, "bcsr4": 4, "tile": 5, "mring": 6}
+KERNELS = {"auto": 0, "stream": 1, "ring": 2, "rowpar": 3, "bcsr4": 4, "tile": 5, "mring": 6, "sstream": 7}
 
 _c = ctypes
 _vp = ctypes.c_void_p
@@ -111,6 +111,8 @@ def lib():
         "mi_bcsr4_tile_info": [_vp, P(i), P(i), P(d), P(d)],
         "mi_bcsr4_sell_info": [_vp, P(i), P(i), P(ll), P(d), P(d)],
         "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
+        "mi_csr_sstream_info": [_vp, P(i), P(i), P(ll), P(d), P(d), P(i)],
+        "mi_sstream_plan_probe": [i, i, _vp, _vp, P(i), P(i), P(ll), P(d)],
         "mi_csr_placement_info": [_vp, P(i), P(i), P(d), i],
         "mi_vec_alloc_placed": [_vp, i, i, P(_vp), P(d), i, P(i)],
         "mi_vec_free_placed": [_vp],
@@ -366,6 +368,16 @@ class csrmatrix:
         check(lib().mi_csr_mring_info(self.handle, _c.byref(b), _c.byref(r), _c.byref(bad), _c.byref(f), us, _c.byref(nt)))
         return dict(built=bool(b.value), runs=r.value, runs_not_served=bad.value, nnz_fraction=f.value, us=us[0], us_nt=us[1],
                     nt=bool(nt.value))
+
+    def sstream_info(self):
+        """dict(built, rounds, steps, padding, us_d8_nt, us_d8_temporal, us_d12_nt, us_d12_temporal, form) — mi_csr_sstream_info (sliced-stream kernel)."""
+        b, r, fm = _c.c_int(), _c.c_int(), _c.c_int()
+        st = _c.c_longlong()
+        pad = _c.c_double()
+        us = (_c.c_double * 4)()
+        check(lib().mi_csr_sstream_info(self.handle, _c.byref(b), _c.byref(r), _c.byref(st), _c.byref(pad), us, _c.byref(fm)))
+        return dict(built=bool(b.value), rounds=r.value, steps=st.value, padding=pad.value, us_d8_nt=us[0], us_d8_temporal=us[1], us_d12_nt=us[2],
+                    us_d12_temporal=us[3], form=fm.value)
 
     def tile_info(self):
         """dict(built, nblk, unique_per_nnz, us, us_nt, nt) — mi_csr_tile_info (the tile kernel's plan on this handle)."""

@@ -1049,3 +1049,87 @@ def test_blocked_product_from_the_sliced_copy(form, monkeypatch):
         mpk.SpMV_BCSR(yy, dev(xx), B)
         assert sell_form(B.handle) == (1, int(form))
         assert_bit_equal(yy.cpu().numpy(), O.spmv_bcsr4(bp, bc, bv, xx), f"ragged {nbr} x {nbc}, sliced form {form}")
+
+
+def _band(n, ncols, hb, per, seed, empty_every=0):
+    """rows with `per` distinct columns within +-hb of the (scaled) diagonal, ascending; every `empty_every`-th row empty"""
+    rng = np.random.default_rng(seed)
+    ptr, col = [0], []
+    for i in range(n):
+        if empty_every and i % empty_every == 3:
+            ptr.append(len(col))
+            continue
+        c0 = int(i * (ncols - 1) / max(n - 1, 1))
+        lo, hi = max(0, c0 - hb), min(ncols - 1, c0 + hb)
+        k = min(per, hi - lo + 1)
+        col.extend(sorted(rng.choice(np.arange(lo, hi + 1), size=k, replace=False).tolist()))
+        ptr.append(len(col))
+    return np.array(ptr, np.int32), np.array(col, np.int32), rng.uniform(-1, 1, len(col))
+
+
+@pytest.mark.parametrize("form", ["8nt", "8t", "12nt", "12t"])
+def test_sliced_stream_kernel(form, monkeypatch):
+    """spmv_sstream (spmv_sstream.hpp; SpMV_CSR*, mpk/SpMV.cpp:6-85): the sliced copy streamed by one wave per SIMD, a lane per row
+    pair, x in a sliding LDS ring, y parked in LDS.  Forced on (MI355_SSTREAM=1 + set_kernel) in each of its four variants: bit-equal to the
+    oracle's fma chain on S15 (sizes that are and are not multiples of the 512-row round, fewer rounds than workgroups and more), on ragged
+    rows (empty rows, an odd row count: the last lane's second row does not exist), on a rectangular matrix, with x infinite where only
+    padding places point, after value refreshes, through a y that is only 8-byte aligned (that product falls back to the ring kernel), and
+    as the kernel behind the k = 4 powers step."""
+    monkeypatch.setenv("MI355_SSTREAM", "1")
+    L = mpk.lib()
+    import ctypes
+
+    def force(A):
+        A.set_kernel("sstream")
+        h = A.handle
+        mpk.check(L.mi_csr_set_nontemporal(h, -1, -1))
+        return A
+
+    def variant(A):  # pick the variant by timing-free means: the info call reports the form in use; the env forces it at create
+        return A.sstream_info()["form"]
+
+    monkeypatch.setenv("MI355_SSTREAM_FORM", {"8nt": "0", "8t": "1", "12nt": "2", "12t": "3"}[form])
+    cases = [("s15", 300_000, 2000), ("s15", 1_000_000, 2000), ("s15", 70_001, 900), ("s15", 3_000, 300), ("s15", 1_001, 20)]
+    for kind, n, w in cases:
+        p, c, v = synth.rows(kind, n, w=w)
+        A = force(mpk.csrmatrix(n, p, c, v))
+        assert "sstream" in A.kernel_name() and variant(A) == int({"8nt": 0, "8t": 1, "12nt": 2, "12t": 3}[form]), (A.kernel_name(), A.sstream_info())
+        x = synth.x_sin(0, n)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            mpk.SpMV_CSR(y, dev(x), A)
+        assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v, x), f"{kind} n={n} w={w} {A.kernel_name()}")
+    # value refresh; the powers step on a handle whose products run the sliced stream; an 8-byte aligned y
+    n = 400_000
+    p, c, v = synth.rows("s15", n)
+    A = force(mpk.csrmatrix(n, p, c, v))
+    x = synth.x_sin(0, n)
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(y, dev(x), A)
+    v2 = v * np.cos(np.arange(len(v)))
+    A.update_values(v2)
+    mpk.SpMV_CSR(y, dev(x), A)
+    assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v2, x), "after mi_csr_update_values")
+    outs = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(4)]
+    for _ in range(2):
+        mpk.SpMkV(outs, dev(x), A)
+    Y = O.spmk_chain(4, p, c, v2, x)
+    for q in range(4):
+        assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"powers over a sliced-stream handle, power {q + 1}: {A.spmk_info(4)}")
+    ybig = torch.full((n + 1,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(ybig[1:], dev(x), A)  # y only 8-byte aligned
+    assert_bit_equal(ybig[1:].cpu().numpy(), O.spmv(p, c, v2, x), "8-byte aligned y")
+    # ragged rows, odd row count, rectangular, x infinite at a column nobody names (padding places point at slot 0x8000: never read)
+    for n, ncols, hb, per, ee in ((50_001, 50_001, 700, 9, 7), (20_000, 26_000, 1500, 12, 0), (777, 777, 60, 5, 5)):
+        p, c, v = _band(n, ncols, hb, per, seed=n, empty_every=ee)
+        e, r_, st, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_double()
+        mpk.check(L.mi_sstream_plan_probe(n, ncols, p.ctypes.data, c.ctypes.data, ctypes.byref(e), ctypes.byref(r_), ctypes.byref(st), ctypes.byref(pad)))
+        if not e.value:  # (row lengths vary too much: the handle must refuse the kernel, loudly)
+            with pytest.raises(mpk.MiError):
+                force(mpk.csrmatrix(n, p, c, v, ncols=ncols))
+            continue
+        A = force(mpk.csrmatrix(n, p, c, v, ncols=ncols))
+        x = np.random.default_rng(1).uniform(-1, 1, ncols)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(y, dev(x), A)
+        assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v, x), f"ragged {n} x {ncols}")

@@ -197,3 +197,30 @@ def test_one_launch_powers_step_dependencies_cover_every_load():
         p = np.concatenate([[0], np.cumsum(ok.sum(axis=1))])
         e, runs, md = probe(p, cols[ok], n)
         assert e == 1 and md <= 64, (n, hb, e, runs, md)
+
+
+def test_sliced_stream_plan_is_replayed_on_the_host():
+    """mi_sstream_plan_probe builds the sliced-stream kernel's plan (spmv_sstream.hpp) as mi_csr_create would and replays it: every
+    nonzero's slot is its column's ring slot, every column lies inside the sliding window when its round runs, padding places and slice
+    beginnings are flagged.  Eligible: S15 bands; not eligible (and saying why): a band wider than the LDS ring, rows whose lengths vary
+    too much inside a slice."""
+    import ctypes
+    L = mpk.lib()
+
+    def probe(p, c, n, ncols=None):
+        p = np.ascontiguousarray(p, np.int32)
+        c = np.ascontiguousarray(c, np.int32)
+        e, r, st, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_double()
+        mpk.check(L.mi_sstream_plan_probe(n, n if ncols is None else ncols, p.ctypes.data, c.ctypes.data, ctypes.byref(e), ctypes.byref(r), ctypes.byref(st), ctypes.byref(pad)))
+        return e.value, r.value, st.value, pad.value, L.mi_last_error().decode()
+
+    for n, w in ((300_000, 2000), (1_000_000, 2000), (70_001, 900), (1_000, 20), (600_000, 3400)):
+        p, c, v = synth.rows("s15", n, w=w)
+        e, rounds, steps, pad, _ = probe(p, c, n)
+        assert e == 1 and rounds == (n + 511) // 512 and pad < 0.01 and steps >= 15 * ((n + 127) // 128), (n, w, e, rounds, steps, pad)
+    p, c, v = synth.rows("s15", 200_000, w=6000)  # 12 000 columns of span: more than the ring's 8192
+    e, _, _, _, why = probe(p, c, 200_000)
+    assert e == 0 and "ring" in why, why
+    p, c, v = synth.rows("svar", 200_000, w=2000)  # 8..22 nonzeros per row: a slice pads to its longest row
+    e, _, _, pad, why = probe(p, c, 200_000)
+    assert e == 0 and "padding" in why and pad > 0.12, (pad, why)

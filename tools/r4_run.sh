@@ -26,6 +26,7 @@ for s in "$@"; do
     sell)     step r4_sell 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sliced_copy or bcsr or fe_matrix" ;;
     ag)       step r4_ag 900 python -m pytest tests/test_gpu_parity.py tests/test_dist_single_process.py tests/test_bench_launch.py -x -q -m gpu -k "allgather or rccl_exchange or multirank_threads or bench_gpus_2" ;;
     spmm)     step r4_spmm 900 python -m pytest tests/test_spmm_gpu.py -x -q -m gpu && step r4_bench_spmm4 200 python bench.py --workload fe_spmm4 && step r4_bench_spmm8 200 python bench.py --workload fe_spmm8 ;;
+    sstream)  step r4_sstream 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sliced_stream" && step r4_bench_c4 200 python bench.py && step r4_bench_c2 200 python bench.py --workload c2 && step r4_bench_c3 200 python bench.py --workload c3 ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
 done
