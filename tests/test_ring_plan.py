@@ -217,7 +217,7 @@ def test_sliced_stream_plan_is_replayed_on_the_host():
     for n, w in ((300_000, 2000), (1_000_000, 2000), (70_001, 900), (1_000, 20), (600_000, 3400)):
         p, c, v = synth.rows("s15", n, w=w)
         e, rounds, steps, pad, _ = probe(p, c, n)
-        assert e == 1 and rounds == (n + 511) // 512 and pad < 0.01 and steps >= 15 * ((n + 127) // 128), (n, w, e, rounds, steps, pad)
+        assert e == 1 and rounds == (n + 511) // 512 and pad < 0.03 and steps >= 15 * ((n + 127) // 128), (n, w, e, rounds, steps, pad)
     p, c, v = synth.rows("s15", 200_000, w=6000)  # 12 000 columns of span: more than the ring's 8192
     e, _, _, _, why = probe(p, c, 200_000)
     assert e == 0 and "ring" in why, why
