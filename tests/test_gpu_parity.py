@@ -315,7 +315,9 @@ def test_rccl_plumbing_selftest():
 def test_block_shape_of_large_and_small_matrices(monkeypatch):
     """Round 3: matrices of >= 20 M nonzeros take row blocks cut at the nonzero count (their rate does not depend on where the
     caller's vectors lie), smaller ones blocks of whole waves of rows; MI355_RING_SHAPE_COMPARE=1 times both shapes at create.
-    Either way every row is the reference's fma chain (mpk/SpMV.cpp:23-56), bit for bit."""
+    Either way every row is the reference's fma chain (mpk/SpMV.cpp:23-56), bit for bit.  (The ring kernel's shapes: the sliced stream, which
+    AUTO prefers on this matrix since round 4, is kept out of the race here.)"""
+    monkeypatch.setenv("MI355_SSTREAM", "0")
     n = 1_400_000  # 21 M nonzeros
     p, c, v = synth.rows("s15", n)
     x = synth.x_sin(0, n)
@@ -407,11 +409,30 @@ def test_full_size_c4_and_c3():
     # the create-time placement draws (value array and column stream re-copied, fastest copy kept): recorded, and the copies that
     # are kept are the ones later value updates write into
     pi = A.placement_info()
-    assert len(pi["values"]) >= 2 and len(pi["column_stream"]) >= 2 and all(t > 0 for t in pi["values"] + pi["column_stream"]), pi
+    if "sstream" in A.kernel_name():  # (round 4: AUTO runs the sliced stream here; it reads its own copy, so nothing is drawn for the CSR arrays)
+        assert pi["values"] == [] and A.sstream_info()["built"], (pi, A.sstream_info())
+    else:
+        assert len(pi["values"]) >= 2 and len(pi["column_stream"]) >= 2 and all(t > 0 for t in pi["values"] + pi["column_stream"]), pi
     v2 = v * np.cos(np.arange(len(v)))
     A.update_values(v2)
     mpk.SpMV_CSR(y, d1, A)
     assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v2, x1), "C4 after the placement draws and a value update")
+    A.close()
+    # the same with the ring kernel (the placement draws of round 3: value array and column stream re-copied, the kept copies are the ones
+    # later value updates write into)
+    A = mpk.csrmatrix(n, p, c, v).set_kernel("ring")
+    import os
+    os.environ["MI355_SSTREAM"] = "0"
+    try:
+        mpk.SpMV_CSR(y, d1, A)
+    finally:
+        del os.environ["MI355_SSTREAM"]
+    pi = A.placement_info()
+    assert len(pi["values"]) >= 2 and len(pi["column_stream"]) >= 2 and all(t > 0 for t in pi["values"] + pi["column_stream"]), pi
+    assert_bit_equal(y.cpu().numpy(), yo, "C4, ring kernel")
+    A.update_values(v2)
+    mpk.SpMV_CSR(y, d1, A)
+    assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v2, x1), "C4 (ring) after the placement draws and a value update")
     A.close()
     del p, c, v, v2
     n = 1_000_000
