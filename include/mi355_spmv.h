@@ -268,7 +268,10 @@ int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* d_y_out, mi
  * of row blocks for all k powers; a run's power p is published write-through + flag, power p + 1 waits for the flags of the runs
  * its columns name) — k <= 8, ring-served square matrices whose whole grid is resident at once; the first k-step of a handle at a
  * given k times both forms (same bits) and keeps the faster.  MI355_SPMK_FUSED=0 never, =1 always where eligible.  The handle
- * carries the step's flags: one k-step at a time per handle.  Under HIP stream capture the step is recorded as k launches (the flags'
+ * carries the step's flags: one k-step at a time per handle.  That FIRST k-step at a given k is therefore synchronous: it runs
+ * 2 rounds x 2 forms x (2 warm-up + 5 timed) extra k-steps on the caller's stream and vectors and blocks the host on an event (a few
+ * milliseconds at 1 M rows); later calls are asynchronous as documented.  If a wait of the one-launch form gives up during that
+ * measurement, the measurement stops at once and the handle runs k launches.  Under HIP stream capture the step is recorded as k launches (the flags'
  * epoch is a kernel argument; a replayed graph would present it again).  Reports what the handle does at this k (after its first k-step). */
 int mi_csr_spmk_info(mi_csr_t A, int k, int* eligible, int* one_launch, double* us_k_launches, double* us_one_launch);
 

@@ -169,6 +169,9 @@ int spmk_unmapped(mi_csr_t H, int k, const double* d_x, double* const* d_y, hipS
                 (void)hipEventElapsedTime(&ms, e0, e1);
                 const double t = ms * 1e3 / timed;
                 us[form] = us[form] > 0 ? std::min(us[form], t) : t;
+                // a wait of the one-launch form gave up (the grid is not all resident: somebody else's kernel holds CUs): every further
+                // launch of it would spin its whole budget again — the measurement ends here and the handle takes k launches
+                if (form == 1 && H->h_ktimeouts && __atomic_load_n(H->h_ktimeouts, __ATOMIC_ACQUIRE) != 0) round = 2;
             }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
