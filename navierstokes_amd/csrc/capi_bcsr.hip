@@ -320,8 +320,8 @@ int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bo
     const int nwg = (int)((threads + kWG - 1) / kWG);
     static const int chunk = getenv("MI355_BCSR_XCD_CHUNK") ? atoi(getenv("MI355_BCSR_XCD_CHUNK")) : 0;
     const int grid = nwg;
-    // the sliced form: unmapped products only (a relabelled matrix's block-row map scatters y; its twin keeps the row-per-quad kernels)
-    if (A->sell_form >= 0 && A->d_sell_val && !V.browmap && !(A->sell_stale && stream_is_capturing((hipStream_t)s))) {
+    // the sliced form (a relabelled matrix's blocked copy stores through its block-row map)
+    if (A->sell_form >= 0 && A->d_sell_val && !(A->sell_stale && stream_is_capturing((hipStream_t)s))) {
         if (A->sell_stale) {
             int rc = sell_fill(A, (hipStream_t)s);
             if (rc) return rc;
@@ -329,7 +329,7 @@ int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bo
         // forms (mi_bcsr4_sell_info): 0 / 1 / 3 one wave per SIMD — one workgroup of four waves per CU, 8 (12) steps of prefetch,
         // non-temporal / temporal / non-temporal; 2 one workgroup of eight waves per CU, 4 steps, non-temporal.  All park y in LDS.
         const bool two = A->sell_form == 2;
-        SellView S{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, two ? A->d_sell_wrng2 : A->d_sell_wrng, A->sell_nslices, A->nbrows};
+        SellView S{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, two ? A->d_sell_wrng2 : A->d_sell_wrng, A->sell_nslices, A->nbrows, V.browmap};
         const int swg = two ? A->sell_nwaves2 / 8 : A->sell_nwaves / 4;
         switch (A->sell_form) {
         case 0: hipLaunchKernelGGL((spmv_bcsr4_sell<8, true, 0, 2, 4>), dim3((unsigned)swg), dim3(256), 0, (hipStream_t)s, S, d_x, d_y, swg); break;
@@ -597,7 +597,7 @@ static bool spmm_form_possible(const mi_bcsr4_s* A, int s, int form, bool mapped
 {
     if (form == kSpmmGather) return true;
     // the sliced stream (spmm_bcsr4_sell): four or eight columns, unmapped products of a handle that holds the sliced copy
-    if (form == kSpmmSell) return (s == 4 || s == 8) && A->d_sell_val && !mapped;
+    if (form == kSpmmSell) return (s == 4 || s == 8) && A->d_sell_val; // (mapped products store through the block-row map)
     if (form == kSpmmTile) return spmm_plan_of(A, s) != nullptr;
     return s % 2 == 0 && A->st64.d_ptr && spmm_tile_lds(&A->st64, s) <= kLdsBytesPerCU;
 }
@@ -631,7 +631,7 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
         auto run = [&](int form) -> hipError_t {
             if (form == kSpmmSell) {
                 if (A->sell_stale && sell_fill(A, st) != MI_OK) return hipErrorUnknown;
-                SellView Sv{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, A->d_sell_wrng, A->sell_nslices, A->nbrows};
+                SellView Sv{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, A->d_sell_wrng, A->sell_nslices, A->nbrows, V.browmap};
                 const int swg = A->sell_nwaves / 4;
                 if (m == 4) {
                     if (arith == MI_ARITH_CHAIN) hipLaunchKernelGGL((spmm_bcsr4_sell<4, 0, 6, true>), dim3((unsigned)swg), dim3(256), 0, st, Sv, Xj, ldx, Yj, ldy, swg);

@@ -102,8 +102,9 @@ static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol)
     return MI_OK;
 }
 
-// y = A x through the sliced-stream kernel (the caller has checked that the handle holds the copy and that y is 16-byte aligned)
-int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s)
+// y = A x through the sliced-stream kernel (the caller has checked that the handle holds the copy and — unmapped rows — that y is
+// 16-byte aligned); rowmap: nullptr or the handle's row map
+int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s)
 {
     SstreamTable& T = A->ss;
     if (T.stale) { // the CSR values changed (or were never copied): refill the sliced values on this stream, in front of the product
@@ -113,7 +114,7 @@ int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s)
         HIP_TRY(hipGetLastError());
         T.stale = false;
     }
-    SsView S{reinterpret_cast<const ss_v2d*>(T.d_val), T.d_slot, T.d_wptr, T.d_rptr, reinterpret_cast<const int2*>(T.d_win), T.nwg, A->n, A->ncols};
+    SsView S{reinterpret_cast<const ss_v2d*>(T.d_val), T.d_slot, T.d_wptr, T.d_rptr, reinterpret_cast<const int2*>(T.d_win), T.nwg, A->n, A->ncols, rowmap};
     if (T.deep) {
         if (T.nt) hipLaunchKernelGGL((spmv_sstream<12, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
         else hipLaunchKernelGGL((spmv_sstream<12, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
@@ -539,7 +540,9 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         const char* se = getenv("MI355_SSTREAM");
         const char* ke = getenv("MI355_SPMV_KERNEL");
         const bool asked = (se && !strcmp(se, "1")) || (ke && !strcmp(ke, "sstream"));
-        if (n > 0 && nnz > 0 && !rowmap && !(ghost_lo < ghost_hi) && !(se && !strcmp(se, "0")) && (asked || nnz >= 200000)) {
+        // (row-mapped handles — partition pieces, the relabelled twin — included since the store goes through the map; not the fused
+        // multi-GPU step's combined piece, whose ghost columns only the ring kernel's FUSED form reads from the window)
+        if (n > 0 && nnz > 0 && !(ghost_lo < ghost_hi) && !(se && !strcmp(se, "0")) && (asked || nnz >= 200000)) {
             const int rcs = build_sstream(A, ptrow, indcol);
             if (rcs != MI_OK) {
                 mi_csr_destroy(A);
@@ -1628,7 +1631,7 @@ extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
     if (A->inner) A = A->inner;
     CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_SSTREAM, "unknown kernel id");
     if (kernel_id == MI_KERNEL_SSTREAM && !A->ss.d_val)
-        return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_SSTREAM: the handle holds no sliced copy (the matrix is row-mapped, too small, pads too much, or its rows do "
+        return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_SSTREAM: the handle holds no sliced copy (the matrix is too small, pads too much, names ghost columns, or its rows do "
                                         "not fit the sliding LDS window: mi_sstream_plan_probe says which)");
     if (kernel_id == MI_KERNEL_BCSR4 && !A->blocked)
         return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_BCSR4: this matrix has no exact 4x4 block structure (or is row-mapped)");
@@ -1672,7 +1675,7 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     case MI_KERNEL_BCSR4: {
         const mi_bcsr4_s* B = A->blocked;
         static const char* const sell_names[4] = {"spmv_bcsr4_sell<8, true, 0, 2, 4>", "spmv_bcsr4_sell<8, false, 0, 2, 4>", "spmv_bcsr4_sell<4, true, 0, 2, 8>", "spmv_bcsr4_sell<12, true, 0, 2, 4>"};
-        if (B && B->sell_form >= 0 && B->d_sell_val && !B->d_browmap) return sell_names[B->sell_form & 3];
+        if (B && B->sell_form >= 0 && B->d_sell_val) return sell_names[B->sell_form & 3];
         return B && B->use_tile && B->d_tl_ptr ? "spmv_bcsr4_tile<2>" : "spmv_bcsr4<2>";
     }
     case MI_KERNEL_MRING: {

@@ -48,12 +48,18 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
         int rc = reorder_scratch(A, s, &xp);
         if (rc) return rc;
         if ((rc = gather_perm(A, d_x, xp, s))) return rc;
+        // (y through the twin's row map: scattered 8-byte stores.  Round 4 measured the alternative — the twin writes its own numbering,
+        // whole lines, and a gather y[i] = scratch[perm[i]] follows: c2_perm 54.7 -> 59.6 us, fe_perm 123 -> 129, mesh_perm 304 -> 359.)
         return launch_spmv(A->inner, xp, d_y, s, true);
     }
     int kid = resolve_kernel(A);
-    if (kid == MI_KERNEL_SSTREAM) { // (unmapped handles only hold the sliced copy)
-        if ((((uintptr_t)d_y) & 15) == 0) return launch_sstream(A, d_x, d_y, s);
+    if (kid == MI_KERNEL_SSTREAM && !comm && !dot) {
+        const int* map = use_map ? A->d_rowmap : nullptr;
+        double* yy = d_y + (use_map ? A->y_offset : 0);
+        if (map || (((uintptr_t)yy) & 15) == 0) return launch_sstream(A, d_x, yy, map, s);
         kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // y only 8-byte aligned: the sliced kernel stores row pairs
+    } else if (kid == MI_KERNEL_SSTREAM) {
+        kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // (the fused multi-GPU step and the dot epilogue live in the ring kernel)
     }
     if (use_map) d_y += A->y_offset;
     CsrView V{};

@@ -58,6 +58,7 @@ struct SellView {
     const int* sptr;       // [nslices + 3] first step of each slice (three terminators, so that look-ahead reads stay in bounds)
     const int* wrng;       // [nwaves + 1] slices of each wave
     int nslices, nbrows;
+    const int* browmap = nullptr; // nullptr, or block row bi writes y[4 * browmap[bi] + q] (the blocked copy of a relabelled matrix, reorder.hpp)
 };
 
 // host: the slice table of a block pattern — sptr (with its three terminators), the sliced column stream, the wave ranges
@@ -178,14 +179,14 @@ __global__ __launch_bounds__(64 * NW) void spmv_bcsr4_sell(SellView S, const dou
     auto flush = [&]() {
         for (int j = 0; j < parked; j++) {
             const int bj = kSellRows * pid[j] + r;
-            if (bj < S.nbrows) y[4 * (size_t)bj + (lane & 3)] = park[j * 64];
+            if (bj < S.nbrows) y[4 * (size_t)(S.browmap ? S.browmap[bj] : bj) + (lane & 3)] = park[j * 64];
         }
         parked = 0;
     };
     // the sums of slice `sl` are complete
     auto emit = [&](int sl, double v) {
         const int bi = kSellRows * sl + r;
-        double* dst = y + 4 * (size_t)bi + (lane & 3);
+        double* dst = y + 4 * (size_t)((S.browmap && bi < S.nbrows) ? S.browmap[bi] : bi) + (lane & 3);
         if ((ABL & 2) && v != 123.456) return;
         if (YM == 2) {
             park[parked * 64] = v;
@@ -321,8 +322,9 @@ __global__ __launch_bounds__(256) void spmm_bcsr4_sell(SellView Sv, const double
         for (int j = 0; j < parked; j++) {
             const int bj = kSellRows * pid[j] + r;
             if (bj < Sv.nbrows) {
+                const size_t orow = 4 * (size_t)(Sv.browmap ? Sv.browmap[bj] : bj) + q;
 #pragma unroll
-                for (int c = 0; c < S; c++) Y[(size_t)c * ldy + 4 * (size_t)bj + q] = park[(j * S + c) * 64];
+                for (int c = 0; c < S; c++) Y[(size_t)c * ldy + orow] = park[(j * S + c) * 64];
             }
         }
         parked = 0;

@@ -50,6 +50,7 @@ struct SsView {
     const int* rptr;       // [nwg + 1] first round of each workgroup
     const int2* win;       // [rounds] {first new column, count} the window takes in before the round (a workgroup's first round: its first fill)
     int nwg, n, ncols;
+    const int* rowmap;     // nullptr, or row r writes y[rowmap[r]] (partition pieces, the relabelled twin of reorder.hpp)
 };
 
 // ---- host: the plan --------------------------------------------------------------------------------------------------------------
@@ -269,7 +270,10 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
     auto store = [&](int round, ss_v2d v) {
         const int row0 = round * kSsRound + wv * kSsSliceRows + 2 * lane;
         if ((ABL & 2) && v.x != 123.456) return;
-        if (row0 + 1 < S.n) *reinterpret_cast<ss_v2d*>(y + row0) = v;
+        if (S.rowmap) { // (wave-uniform) mapped rows: two 8-byte stores wherever the map sends them
+            if (row0 < S.n) y[S.rowmap[row0]] = v.x;
+            if (row0 + 1 < S.n) y[S.rowmap[row0 + 1]] = v.y;
+        } else if (row0 + 1 < S.n) *reinterpret_cast<ss_v2d*>(y + row0) = v;
         else if (row0 < S.n) y[row0] = v.x;
     };
     auto flush = [&]() {

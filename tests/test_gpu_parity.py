@@ -1154,3 +1154,21 @@ def test_sliced_stream_kernel(form, monkeypatch):
         y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
         mpk.SpMV_CSR(y, dev(x), A)
         assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v, x), f"ragged {n} x {ncols}")
+    # row-mapped handles (partition pieces, relabelled twins): a scattered map -> two 8-byte stores per lane; a contiguous one -> a pointer
+    # offset, odd (row pairs no longer 16-byte aligned: that product falls back) and even
+    n = 30_001
+    p, c, v = synth.rows("s15", n, w=400)
+    x = synth.x_sin(0, n)
+    yo = O.spmv(p, c, v, x)
+    rng = np.random.default_rng(9)
+    for tag, rowmap in (("scattered", rng.permutation(n + 9)[:n].astype(np.int32)), ("offset 5", (np.arange(n) + 5).astype(np.int32)),
+                        ("offset 6", (np.arange(n) + 6).astype(np.int32))):
+        A = force(mpk.csrmatrix(n, p, c, v, rowmap=rowmap))
+        y = torch.full((n + 9,), float("nan"), dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            mpk.SpMV_CSR(y, dev(x), A)
+        got = y.cpu().numpy()
+        assert_bit_equal(got[rowmap], yo, f"row-mapped ({tag}) {A.kernel_name()}")
+        rest = np.ones(n + 9, bool)
+        rest[rowmap] = False
+        assert np.isnan(got[rest]).all(), f"row-mapped ({tag}): wrote rows outside the map"

@@ -213,3 +213,51 @@ def test_products_of_one_relabelled_handle_on_two_streams(monkeypatch):
     torch.cuda.synchronize()
     assert_bit_equal(ya.cpu().numpy(), ya_ref, "stream 1")
     assert_bit_equal(yb.cpu().numpy(), yb_ref, "stream 2")
+
+
+def test_relabelled_twins_through_the_sliced_kernels(monkeypatch):
+    """Round 4: the sliced kernels store through the twin's row map (spmv_sstream: two 8-byte stores per lane; spmv_bcsr4_sell: a node's
+    four rows where the block-row map sends them), so a matrix delivered in a mesher's numbering gets them too.  Forced here; bit-equal to
+    the oracle on the matrix as delivered, caller's numbering and internal numbering, products and SpMM."""
+    monkeypatch.setenv("MI355_REORDER", "1")
+    monkeypatch.setenv("MI355_SSTREAM", "1")
+    monkeypatch.setenv("MI355_BCSR_SELL", "1")
+    # scalar band under a random numbering: RCM brings the band back, the twin holds a sliced copy
+    n = 60_000
+    p0, c0, v0 = synth.rows("s15", n, w=300)
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=1, seed=3)
+    A = mpk.csrmatrix(n, p, c, v)
+    assert A.reorder_info()["reordered"]
+    x = synth.x_sin(0, n)
+    yo = O.spmv(p, c, v, x)
+    if A.sstream_info()["built"]:  # (RCM's level sets leave rows whose columns fit the window: expected, but the planner decides)
+        A.set_kernel("sstream")
+        assert "sstream" in A.kernel_name(), A.kernel_name()
+        yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            mpk.SpMV_CSR(yd, dev(x), A)
+        assert_bit_equal(yd.cpu().numpy(), yo, f"relabelled twin through {A.kernel_name()}")
+        v2 = v * np.cos(np.arange(len(v)))
+        A.update_values(v2)
+        mpk.SpMV_CSR(yd, dev(x), A)
+        assert_bit_equal(yd.cpu().numpy(), O.spmv(p, c, v2, x), "after mi_csr_update_values")
+    else:
+        with pytest.raises(mpk.MiError):
+            A.set_kernel("sstream")
+    # FE matrix under a random node numbering: the blocked copy of the twin, sliced
+    p0, c0, v0 = synth.fe_matrix(14)
+    n = len(p0) - 1
+    p, c, v, _ = synth.permute_nodes(p0, c0, v0, block=4, seed=11)
+    x = synth.x_sin(0, n)
+    yo = O.spmv(p, c, v, x)
+    for form in "0123":
+        monkeypatch.setenv("MI355_BCSR_SELL_FORM", form)
+        A = mpk.csrmatrix(n, p, c, v)
+        assert A.reorder_info()["reordered"] and A.reorder_info()["block"] == 4
+        A.set_kernel("bcsr4")
+        assert "sell" in A.kernel_name(), A.kernel_name()
+        yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            mpk.SpMV_CSR(yd, dev(x), A)
+        assert_bit_equal(yd.cpu().numpy(), yo, f"relabelled FE matrix through {A.kernel_name()}")
+    monkeypatch.delenv("MI355_BCSR_SELL_FORM")
