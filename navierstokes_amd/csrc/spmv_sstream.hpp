@@ -232,8 +232,17 @@ __global__ __launch_bounds__(64) void csr_to_sstream_kernel(int nslices, int n, 
 // D steps of the stream in flight per lane; ONE workgroup of four waves per CU.  Workgroup b is taken as logical workgroup
 // (b % 8) * (G / 8) + b / 8 so that the workgroups that share an XCD stream neighbouring rows (their x lines meet in that XCD's L2).
 // ABL (tools/sstream_bench.hip only; invalid results): 1 no LDS gather, 2 no y stores.
-template <int D, bool NT, int ABL = 0>
-__global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __restrict__ x, double* __restrict__ y)
+// DOT (mi_spmv_dot_dev / mi_spmv_orthogonalize_dev; unmapped rows only): each lane also multiplies its two finished row sums into a running
+// sum of b[row] * y[row] — b's pair of the round is loaded a round ahead, like the window's new columns — and the workgroup writes ONE
+// partial (wave shuffle tree, then the four waves in order: deterministic for a given plan), which the consumer adds in a fixed order
+// like the ring kernel's (spmv_ring.hpp: RingDot).
+struct SsDot {
+    const double* b;  // the dot's other vector, rows' numbering
+    double* partial;  // one double per workgroup of the launch
+};
+
+template <int D, bool NT, int ABL = 0, bool DOT = false>
+__global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __restrict__ x, double* __restrict__ y, SsDot Dt = SsDot{nullptr, nullptr})
 {
     __shared__ double ring[kSsRing];
     __shared__ ss_v2d s_park[4 * kSsPark * 64];
@@ -243,7 +252,10 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
     ss_v2d* park = s_park + wv * kSsPark * 64 + lane;
     int parked = 0, park_first = 0; // (wave-uniform) the slices of rounds park_first .. park_first + parked - 1 are parked
     const int r_begin = S.rptr[g], r_end = S.rptr[g + 1];
-    if (r_begin >= r_end) return;
+    if (r_begin >= r_end) {
+        if (DOT && tid == 0) Dt.partial[g] = 0.0; // every workgroup of the launch owns one partial
+        return;
+    }
     const int t0 = __builtin_amdgcn_readfirstlane(S.wptr[g * 4 + wv]);
     const int t_end = __builtin_amdgcn_readfirstlane(S.wptr[g * 4 + wv + 1]);
     const int clast = S.ncols - 1;
@@ -265,6 +277,17 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
         a[d] = NT ? __builtin_nontemporal_load(vb + (size_t)(t0 + d) * 64) : vb[(size_t)(t0 + d) * 64];
         sl[d] = sb[(size_t)(t0 + d) * 64];
     }
+    // DOT: b's pair for this lane's rows of round `round` (0 beyond the last row: those sums are 0 too)
+    auto b_pair = [&](int round) -> ss_v2d {
+        const int row0 = round * kSsRound + wv * kSsSliceRows + 2 * lane;
+        ss_v2d v = {0.0, 0.0};
+        if (row0 + 1 < S.n) v = *reinterpret_cast<const ss_v2d*>(Dt.b + row0); // (b as aligned as y: the host checks both)
+        else if (row0 < S.n) v.x = Dt.b[row0];
+        return v;
+    };
+    ss_v2d bq = {0.0, 0.0};
+    double dacc = 0.0;
+    if (DOT) bq = b_pair(r);
     __syncthreads();
     double acc0 = 0.0, acc1 = 0.0;
     auto store = [&](int round, ss_v2d v) {
@@ -281,6 +304,10 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
         parked = 0;
     };
     auto emit = [&]() { // this wave's slice of round r is complete
+        if (DOT) {
+            dacc = fma(bq.x, acc0, dacc);
+            dacc = fma(bq.y, acc1, dacc);
+        }
         if (parked == 0) park_first = r;
         park[parked * 64] = ss_v2d{acc0, acc1};
         if (++parked == kSsPark) flush();
@@ -295,6 +322,7 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
                     emit();
                     acc0 = acc1 = 0.0;
                     r++;
+                    if (DOT) bq = b_pair(r); // (needed at the END of the round that starts here)
                     __syncthreads(); // every wave is through with round r - 1: the ring entries about to be overwritten are dead
 #pragma unroll
                     for (int u = 0; u < kSsNewMax / 256; u++) {
@@ -317,6 +345,15 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
     }
     emit();
     flush();
+    if (DOT) {
+        __syncthreads(); // the window is free
+        double v = dacc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) ring[wv] = v;
+        __syncthreads();
+        if (tid == 0) Dt.partial[g] = ((ring[0] + ring[1]) + ring[2]) + ring[3];
+    }
 }
 
 } // namespace mi355

@@ -27,6 +27,7 @@ for s in "$@"; do
     ag)       step r4_ag 900 python -m pytest tests/test_gpu_parity.py tests/test_dist_single_process.py tests/test_bench_launch.py -x -q -m gpu -k "allgather or rccl_exchange or multirank_threads or bench_gpus_2" ;;
     spmm)     step r4_spmm 900 python -m pytest tests/test_spmm_gpu.py -x -q -m gpu && step r4_bench_spmm4 200 python bench.py --workload fe_spmm4 && step r4_bench_spmm8 200 python bench.py --workload fe_spmm8 ;;
     sstream)  step r4_sstream 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sliced_stream" && step r4_bench_c4 200 python bench.py && step r4_bench_c2 200 python bench.py --workload c2 && step r4_bench_c3 200 python bench.py --workload c3 ;;
+    dot)      step r4_dot 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "dot_in_its_epilogue or pipeline or random_patterns" && step r4_bench_c4 300 python bench.py ;;
     perm)     step r4_perm 600 python -m pytest tests/test_reorder_gpu.py tests/test_gpu_parity.py -x -q -m gpu -k "relabelled or reorder or sliced_stream or permuted or scrambled" && step r4_bench_c2_perm 200 python bench.py --workload c2_perm && step r4_bench_fe_perm 200 python bench.py --workload fe_perm && step r4_bench_mesh_perm 300 python bench.py --workload mesh_perm && step r4_bench_c2_perm_int 200 python bench.py --workload c2_perm --internal ;;
     *) echo "unknown step $s"; exit 2 ;;
   esac
