@@ -16,27 +16,7 @@ step() { # name timeout cmd...
 }
 for s in "$@"; do
   case $s in
-    kbench)   step kbench 300 ./tools/kbench 0 5000000 2000 5 50 ;;
     rocsparse) step rocsparse_c4 300 ./tools/rocsparse_cmp 0 5000000 && step rocsparse_c2 200 ./tools/rocsparse_cmp 0 1000000 && step rocsparse_sfe 300 ./tools/rocsparse_cmp 2 1400000 ;;
-    kbench_c2) step kbench_c2 200 ./tools/kbench 0 1000000 2000 5 100 ;;
-    kbench_sfe) step kbench_sfe 300 ./tools/kbench 2 1400000 2000 5 50 ;;
-    kbench_svar) step kbench_svar 300 ./tools/kbench 1 5000000 2000 5 50 ;;
-    kprof)    # PMC passes over a few kbench variants (KFILTER env), one rocprofv3 run per counter group
-              F="${KFILTER:-stream<2048>,E4 ring<512,2048,5120> 512,E7 ring2<512,2048,5120,D3> 512,NO GATHER}"
-              rm -rf gpurun_out/kprof; mkdir -p gpurun_out/kprof
-              step kprof_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kprof/trace -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              step kprof_sq1 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d gpurun_out/kprof/sq1 -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              step kprof_sq2 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/kprof/sq2 -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              step kprof_tc 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/kprof/tc -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              step kprof_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/kprof/fetch -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              ;;
-    kprof2)   F="${KFILTER:-ABL skeleton no y stores,ABL ring5a no reduce+gather+stage}"
-              rm -rf gpurun_out/kprof2; mkdir -p gpurun_out/kprof2
-              step kprof2_a 300 rocprofv3 --pmc SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d gpurun_out/kprof2/a -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              step kprof2_b 300 rocprofv3 --pmc TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/kprof2/b -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              step kprof2_c 300 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum --output-format csv -d gpurun_out/kprof2/c -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              step kprof2_d 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCC_TAG_STALL_sum --output-format csv -d gpurun_out/kprof2/d -- ./tools/kbench 0 5000000 2000 1 3 "$F"
-              ;;
     tests)    step tests 600 python -m pytest tests -x -q -m gpu ;;
     smoke)    step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)    step bench 400 python bench.py ;;
