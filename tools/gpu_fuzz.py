@@ -74,8 +74,26 @@ for seed in range(first, last):
     y = torch.full((nb,), float("nan"), dtype=torch.float64, device="cuda")
     try:
         mpk.SpMV_CSR(y, torch.from_numpy(xb).cuda(), A)
-        ok = np.array_equal(y.cpu().numpy().view(np.uint64), O.spmv(pb, cb, vb, xb).view(np.uint64))
+        yb_ref = O.spmv(pb, cb, vb, xb)
+        ok = np.array_equal(y.cpu().numpy().view(np.uint64), yb_ref.view(np.uint64))
         names.append(f"band(hb={hb},per={per},n={nb}):{A.kernel_name().split('<')[0][5:]}" + ("" if ok else "!!"))
+        bad += not ok
+        # the dot epilogue of the sliced stream, and the same band through a scattered row map (two 8-byte stores per lane)
+        bb = rng.uniform(-1, 1, nb)
+        y.fill_(float("nan"))
+        beta = float(mpk.SpMV_CSR_dot(y, torch.from_numpy(xb).cuda(), A, torch.from_numpy(bb).cuda()))
+        ok = np.array_equal(y.cpu().numpy().view(np.uint64), yb_ref.view(np.uint64)) and abs(beta - O.dot(bb, yb_ref)) <= 1e-13 * float(np.abs(bb * yb_ref).sum()) + 1e-300
+        names.append(("sdotE" if A.dot_in_epilogue() else "sdot2") + ("" if ok else "!!"))
+        bad += not ok
+        del A
+        rowmap = rng.permutation(nb + 11)[:nb].astype(np.int32)
+        A = mpk.csrmatrix(nb, pb, cb, vb, rowmap=rowmap).set_kernel("sstream")
+        ym = torch.full((nb + 11,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(ym, torch.from_numpy(xb).cuda(), A)
+        got = ym.cpu().numpy()
+        rest = np.ones(nb + 11, bool); rest[rowmap] = False
+        ok = np.array_equal(got[rowmap].view(np.uint64), yb_ref.view(np.uint64)) and np.isnan(got[rest]).all()
+        names.append("smap" + ("" if ok else "!!"))
         bad += not ok
     except mpk.MiError:
         names.append(f"band(hb={hb},per={per},n={nb}):n/a")
