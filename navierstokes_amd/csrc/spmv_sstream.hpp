@@ -38,6 +38,7 @@ constexpr int kSsSliceRows = 128;        // rows per slice = two per lane
 constexpr int kSsRound = 512;            // rows per round of a workgroup: four waves' slices
 constexpr int kSsNewMax = 1024;          // new window columns per round (four per thread, a round ahead in registers)
 constexpr int kSsPark = 20;              // slices of y parked per wave: 4 x 20 KiB beside the 64 KiB ring
+constexpr int kSsTail = 2;               // rounds of a workgroup whose sums stay parked until its end (the others are stored earlier)
 constexpr unsigned kSsPad = 0x8000u;     // slot flag (either half): padding place, not multiplied
 constexpr unsigned kSsFirst = 0x4000u;   // slot flag (low half): first step of a slice
 constexpr int kSsPadSteps = 64;          // steps of padding behind the last one: the stream's loads run ahead unclamped (D <= 16)
@@ -259,15 +260,8 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
     const int t0 = __builtin_amdgcn_readfirstlane(S.wptr[g * 4 + wv]);
     const int t_end = __builtin_amdgcn_readfirstlane(S.wptr[g * 4 + wv + 1]);
     const int clast = S.ncols - 1;
-    { // first fill of the window
-        const int2 w = S.win[r_begin];
-        for (int c = w.x + tid; c < w.x + w.y; c += 256) ring[c & (kSsRing - 1)] = x[c];
-    }
-    int r = r_begin; // the round this wave's current slice belongs to
-    double nx[kSsNewMax / 256]; // the NEXT round's new columns, a round ahead in registers
-    int2 wn = S.win[min(r + 1, r_end - 1)];
-#pragma unroll
-    for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = x[min(wn.x + tid + 256 * u, clast)];
+    // the stream's first D steps go out FIRST: they travel while the window fills (the fill's wait covers them: one memory latency
+    // in front of the loop instead of two)
     const ss_v2d* vb = S.val + lane;
     const unsigned* sb = S.slot + lane;
     ss_v2d a[D];
@@ -276,6 +270,15 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
     for (int d = 0; d < D; d++) {
         a[d] = NT ? __builtin_nontemporal_load(vb + (size_t)(t0 + d) * 64) : vb[(size_t)(t0 + d) * 64];
         sl[d] = sb[(size_t)(t0 + d) * 64];
+    }
+    int r = r_begin; // the round this wave's current slice belongs to
+    double nx[kSsNewMax / 256]; // the NEXT round's new columns, a round ahead in registers
+    int2 wn = S.win[min(r + 1, r_end - 1)];
+#pragma unroll
+    for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = x[min(wn.x + tid + 256 * u, clast)];
+    { // first fill of the window
+        const int2 w = S.win[r_begin];
+        for (int c = w.x + tid; c < w.x + w.y; c += 256) ring[c & (kSsRing - 1)] = x[c];
     }
     // DOT: b's pair for this lane's rows of round `round` (0 beyond the last row: those sums are 0 too)
     auto b_pair = [&](int round) -> ss_v2d {
@@ -310,7 +313,9 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
         }
         if (parked == 0) park_first = r;
         park[parked * 64] = ss_v2d{acc0, acc1};
-        if (++parked == kSsPark) flush();
+        // (stored when the park is full — and kSsTail rounds before the wave's last, so that the stores behind the last load are few:
+        // at 1 M rows a workgroup has 7-8 rounds and would otherwise store its whole share of y after everything else)
+        if (++parked == kSsPark || r == r_end - 1 - kSsTail) flush();
     };
     for (int t = t0; t < t_end; t += D) {
 #pragma unroll
