@@ -93,7 +93,11 @@ def load_traffic(workload, kernel_name):
                 norm = lambda a: a.replace(", false>", ">") if a.startswith("spmv_csr_ring<") and a.count(",") == 10 else a
                 same = lambda a, b: norm(a) == norm(b) or (a.startswith("spmv_csr_ring<") and norm(a).split(",")[:5] == norm(b).split(",")[:5]
                                                            and norm(a).split(",")[7:] == norm(b).split(",")[7:])
-                if d.get("workload") == workload and same(d.get("kernel", ""), kernel_name):
+                # (the variants of the sliced kernels — prefetch depth, temporal / non-temporal values, park form — read the same sliced copy:
+                # a profile of one instantiation describes the others)
+                family = lambda a: next((pre for pre in ("spmv_sstream<", "spmv_bcsr4_sell<") if a.startswith(pre)), None)
+                fam_same = family(kernel_name) is not None and family(kernel_name) == family(d.get("kernel", ""))
+                if d.get("workload") == workload and (same(d.get("kernel", ""), kernel_name) or fam_same):
                     best = (d.get("hbm_bytes_per_launch"), "profiles/" + f)
     return best if best else (None, None)
 
