@@ -126,11 +126,6 @@ static int spmv_with_dot_partials(mi_csr_t A, const double* d_x, double* d_y, co
         *np = A->ring.wgs;
         return MI_OK;
     }
-    if (sstream_dot_eligible(A, d_y, d_b)) { // the sliced-stream kernel's epilogue: one partial per workgroup
-        if ((rc = launch_sstream(A, d_x, d_y, nullptr, s, d_b, ws))) return rc;
-        *np = A->ss.nwg;
-        return MI_OK;
-    }
     if ((rc = launch_spmv(A, d_x, d_y, s))) return rc;
     int seg;
     red_geometry(A->n, np, &seg);
@@ -143,8 +138,7 @@ static int spmv_with_dot_partials(mi_csr_t A, const double* d_x, double* d_y, co
 extern "C" int mi_csr_dot_epilogue_info(mi_csr_t A, int* in_epilogue)
 {
     CHECK_ARG(A && in_epilogue, "null argument");
-    // (the sliced-stream kernel carries it too, for 16-byte aligned y and b: what every allocator hands out)
-    *in_epilogue = (ring_dot_eligible(A) || sstream_dot_eligible(A, nullptr, nullptr)) ? 1 : 0;
+    *in_epilogue = ring_dot_eligible(A) ? 1 : 0;
     return MI_OK;
 }
 

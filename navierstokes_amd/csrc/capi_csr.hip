@@ -104,9 +104,7 @@ static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol)
 
 // y = A x through the sliced-stream kernel (the caller has checked that the handle holds the copy and — unmapped rows — that y is
 // 16-byte aligned); rowmap: nullptr or the handle's row map
-// dot_b / dot_partial: nullptr, or the dot epilogue (unmapped rows, b 16-byte aligned: sstream_dot_eligible) — one partial per workgroup
-// (A->ss.nwg of them) lands in dot_partial
-int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s, const double* dot_b, double* dot_partial)
+int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s)
 {
     SstreamTable& T = A->ss;
     if (T.stale) { // the CSR values changed (or were never copied): refill the sliced values on this stream, in front of the product
@@ -117,25 +115,12 @@ int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap
         T.stale = false;
     }
     SsView S{reinterpret_cast<const ss_v2d*>(T.d_val), T.d_slot, T.d_wptr, T.d_rptr, reinterpret_cast<const int2*>(T.d_win), T.nwg, A->n, A->ncols, rowmap};
-    if (dot_b) {
-        if (rowmap || !dot_partial) return fail(MI_ERR_STATE, "sliced stream: the dot epilogue needs unmapped rows and a partials buffer");
-        const SsDot Dt{dot_b, dot_partial};
-        if (T.deep) {
-            if (T.nt) hipLaunchKernelGGL((spmv_sstream<12, true, 0, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y, Dt);
-            else hipLaunchKernelGGL((spmv_sstream<12, false, 0, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y, Dt);
-        } else {
-            if (T.nt) hipLaunchKernelGGL((spmv_sstream<8, true, 0, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y, Dt);
-            else hipLaunchKernelGGL((spmv_sstream<8, false, 0, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y, Dt);
-        }
-        HIP_TRY(hipGetLastError());
-        return MI_OK;
-    }
     if (T.deep) {
-        if (T.nt) hipLaunchKernelGGL((spmv_sstream<12, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y, SsDot{nullptr, nullptr});
-        else hipLaunchKernelGGL((spmv_sstream<12, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y, SsDot{nullptr, nullptr});
+        if (T.nt) hipLaunchKernelGGL((spmv_sstream<12, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
+        else hipLaunchKernelGGL((spmv_sstream<12, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
     } else {
-        if (T.nt) hipLaunchKernelGGL((spmv_sstream<8, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y, SsDot{nullptr, nullptr});
-        else hipLaunchKernelGGL((spmv_sstream<8, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y, SsDot{nullptr, nullptr});
+        if (T.nt) hipLaunchKernelGGL((spmv_sstream<8, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
+        else hipLaunchKernelGGL((spmv_sstream<8, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;

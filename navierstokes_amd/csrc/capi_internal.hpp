@@ -360,9 +360,7 @@ int part_push_window(mi_part_s* P);
 void part_push_layout(const mi_part_s* P, long long* layout /* [2*nranks + 1] */);
 int part_push_connect_bases(mi_part_s* P, void* const* bases /* [nranks] */, const long long* layouts);
 // capi_csr.hip: the sliced-stream kernel of a handle (spmv_sstream.hpp)
-int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s, const double* dot_b = nullptr, double* dot_partial = nullptr);
-// the sliced-stream launch of this handle can carry the dot epilogue for these vectors (unmapped, unreordered, y and b 16-byte aligned)
-bool sstream_dot_eligible(const mi_csr_s* A, const double* d_y, const double* d_b);
+int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s);
 // capi_bcsr.hip
 // the blocked copy's values were rewritten (by whoever holds d_coef): the sliced copy follows on the next product
 static inline void bcsr4_values_changed(mi_bcsr4_s* A) { if (A && A->d_sell_val) A->sell_stale = true; }

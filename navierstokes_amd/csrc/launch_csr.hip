@@ -35,14 +35,6 @@ bool ring_dot_eligible(const mi_csr_s* A)
            !(getenv("MI355_SPMV_DOT_EPILOGUE") && !strcmp(getenv("MI355_SPMV_DOT_EPILOGUE"), "0"));
 }
 
-bool sstream_dot_eligible(const mi_csr_s* A, const double* d_y, const double* d_b)
-{
-    if (A->inner || A->n == 0 || A->d_rowmap || A->y_offset || !A->ss.d_val) return false;
-    if (resolve_kernel(A) != MI_KERNEL_SSTREAM) return false;
-    if ((((uintptr_t)d_y) | ((uintptr_t)d_b)) & 15) return false;
-    return A->ss.nwg <= 1024 /* kMaxPartials */ && !(getenv("MI355_SPMV_DOT_EPILOGUE") && !strcmp(getenv("MI355_SPMV_DOT_EPILOGUE"), "0"));
-}
-
 int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool use_map, const RingComm* comm, const RingDot* dot)
 {
     if (dot && !ring_dot_eligible(A)) return fail(MI_ERR_STATE, "dot epilogue requested on a handle whose launch cannot carry it");
@@ -67,7 +59,8 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
         if (map || (((uintptr_t)yy) & 15) == 0) return launch_sstream(A, d_x, yy, map, s);
         kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // y only 8-byte aligned: the sliced kernel stores row pairs
     } else if (kid == MI_KERNEL_SSTREAM) {
-        kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // (the fused multi-GPU step and the dot epilogue live in the ring kernel)
+        kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // (the fused multi-GPU step and the dot epilogue live in the ring kernel; the sliced stream's own epilogue measured
+        // slower than product + separate dot: profiles/NOTES.md R4.4)
     }
     if (use_map) d_y += A->y_offset;
     CsrView V{};

@@ -232,18 +232,9 @@ __global__ __launch_bounds__(64) void csr_to_sstream_kernel(int nslices, int n, 
 
 // D steps of the stream in flight per lane; ONE workgroup of four waves per CU.  Workgroup b is taken as logical workgroup
 // (b % 8) * (G / 8) + b / 8 so that the workgroups that share an XCD stream neighbouring rows (their x lines meet in that XCD's L2).
-// ABL (tools/sstream_bench.hip only; invalid results): 1 no LDS gather, 2 no y stores.
-// DOT (mi_spmv_dot_dev / mi_spmv_orthogonalize_dev; unmapped rows only): each lane also multiplies its two finished row sums into a running
-// sum of b[row] * y[row] — b's pair of the round is loaded a round ahead, like the window's new columns — and the workgroup writes ONE
-// partial (wave shuffle tree, then the four waves in order: deterministic for a given plan), which the consumer adds in a fixed order
-// like the ring kernel's (spmv_ring.hpp: RingDot).
-struct SsDot {
-    const double* b;  // the dot's other vector, rows' numbering
-    double* partial;  // one double per workgroup of the launch
-};
-
-template <int D, bool NT, int ABL = 0, bool DOT = false>
-__global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __restrict__ x, double* __restrict__ y, SsDot Dt = SsDot{nullptr, nullptr})
+// ABL (tools/sstream_ablate.hip only; invalid results): 1 no LDS gather, 2 no y stores, 4 no new-column loads / window refills at the round boundaries.
+template <int D, bool NT, int ABL = 0>
+__global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __restrict__ x, double* __restrict__ y)
 {
     __shared__ double ring[kSsRing];
     __shared__ ss_v2d s_park[4 * kSsPark * 64];
@@ -253,10 +244,7 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
     ss_v2d* park = s_park + wv * kSsPark * 64 + lane;
     int parked = 0, park_first = 0; // (wave-uniform) the slices of rounds park_first .. park_first + parked - 1 are parked
     const int r_begin = S.rptr[g], r_end = S.rptr[g + 1];
-    if (r_begin >= r_end) {
-        if (DOT && tid == 0) Dt.partial[g] = 0.0; // every workgroup of the launch owns one partial
-        return;
-    }
+    if (r_begin >= r_end) return;
     const int t0 = __builtin_amdgcn_readfirstlane(S.wptr[g * 4 + wv]);
     const int t_end = __builtin_amdgcn_readfirstlane(S.wptr[g * 4 + wv + 1]);
     const int clast = S.ncols - 1;
@@ -275,22 +263,11 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
     double nx[kSsNewMax / 256]; // the NEXT round's new columns, a round ahead in registers
     int2 wn = S.win[min(r + 1, r_end - 1)];
 #pragma unroll
-    for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = x[min(wn.x + tid + 256 * u, clast)];
+    for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = (ABL & 4) ? 0.0 : x[min(wn.x + tid + 256 * u, clast)];
     { // first fill of the window
         const int2 w = S.win[r_begin];
         for (int c = w.x + tid; c < w.x + w.y; c += 256) ring[c & (kSsRing - 1)] = x[c];
     }
-    // DOT: b's pair for this lane's rows of round `round` (0 beyond the last row: those sums are 0 too)
-    auto b_pair = [&](int round) -> ss_v2d {
-        const int row0 = round * kSsRound + wv * kSsSliceRows + 2 * lane;
-        ss_v2d v = {0.0, 0.0};
-        if (row0 + 1 < S.n) v = *reinterpret_cast<const ss_v2d*>(Dt.b + row0); // (b as aligned as y: the host checks both)
-        else if (row0 < S.n) v.x = Dt.b[row0];
-        return v;
-    };
-    ss_v2d bq = {0.0, 0.0};
-    double dacc = 0.0;
-    if (DOT) bq = b_pair(r);
     __syncthreads();
     double acc0 = 0.0, acc1 = 0.0;
     auto store = [&](int round, ss_v2d v) {
@@ -307,10 +284,6 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
         parked = 0;
     };
     auto emit = [&]() { // this wave's slice of round r is complete
-        if (DOT) {
-            dacc = fma(bq.x, acc0, dacc);
-            dacc = fma(bq.y, acc1, dacc);
-        }
         if (parked == 0) park_first = r;
         park[parked * 64] = ss_v2d{acc0, acc1};
         // (stored when the park is full — and kSsTail rounds before the wave's last, so that the stores behind the last load are few:
@@ -327,17 +300,20 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
                     emit();
                     acc0 = acc1 = 0.0;
                     r++;
-                    if (DOT) bq = b_pair(r); // (needed at the END of the round that starts here)
                     __syncthreads(); // every wave is through with round r - 1: the ring entries about to be overwritten are dead
+                    if (!(ABL & 4)) {
 #pragma unroll
-                    for (int u = 0; u < kSsNewMax / 256; u++) {
-                        const int c = wn.x + tid + 256 * u;
-                        if (c < wn.x + wn.y) ring[c & (kSsRing - 1)] = nx[u];
+                        for (int u = 0; u < kSsNewMax / 256; u++) {
+                            const int c = wn.x + tid + 256 * u;
+                            if (c < wn.x + wn.y) ring[c & (kSsRing - 1)] = nx[u];
+                        }
                     }
                     __syncthreads();
-                    wn = S.win[min(r + 1, r_end - 1)];
+                    if (!(ABL & 4)) {
+                        wn = S.win[min(r + 1, r_end - 1)];
 #pragma unroll
-                    for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = x[min(wn.x + tid + 256 * u, clast)];
+                        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = x[min(wn.x + tid + 256 * u, clast)];
+                    }
                 }
                 const double x0 = (ABL & 1) ? 1.0 + lane : ring[s & (kSsRing - 1)], x1 = (ABL & 1) ? 0.5 : ring[(s >> 16) & (kSsRing - 1)];
                 const double n0 = fma(a[d].x, x0, acc0), n1 = fma(a[d].y, x1, acc1);
@@ -350,15 +326,6 @@ __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __re
     }
     emit();
     flush();
-    if (DOT) {
-        __syncthreads(); // the window is free
-        double v = dacc;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) ring[wv] = v;
-        __syncthreads();
-        if (tid == 0) Dt.partial[g] = ((ring[0] + ring[1]) + ring[2]) + ring[3];
-    }
 }
 
 } // namespace mi355
