@@ -23,9 +23,9 @@ static double run(const SsView& S, const double* x, double* y, int reps)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 5; i++) hipLaunchKernelGGL((spmv_sstream<D, NT, ABL, false>), dim3(S.nwg), dim3(256), 0, nullptr, S, x, y);
+    for (int i = 0; i < 5; i++) hipLaunchKernelGGL((spmv_sstream<D, NT, ABL>), dim3(S.nwg), dim3(256), 0, nullptr, S, x, y);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((spmv_sstream<D, NT, ABL, false>), dim3(S.nwg), dim3(256), 0, nullptr, S, x, y);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((spmv_sstream<D, NT, ABL>), dim3(S.nwg), dim3(256), 0, nullptr, S, x, y);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -62,7 +62,7 @@ int main(int argc, char** argv)
     printf("n %d nnz %lld  eligible %d (%s)  workgroups %d rounds %d steps %lld\n", n, nnz, (int)P.eligible, P.why, P.nwg, P.rounds, P.steps);
     if (!P.eligible) return 1;
     int *d_ptrow, *d_wptr, *d_rptr, *d_ss, *d_sl;
-    SsWin* d_win;
+    int2* d_win;
     unsigned* d_slot;
     double *d_coef, *d_x, *d_y;
     ss_v2d* d_val;
@@ -78,8 +78,8 @@ int main(int argc, char** argv)
     CK(hipMemcpy(d_wptr, P.wptr.data(), sizeof(int) * P.wptr.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_rptr, sizeof(int) * P.rptr.size()));
     CK(hipMemcpy(d_rptr, P.rptr.data(), sizeof(int) * P.rptr.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_win, sizeof(SsWin) * P.win.size()));
-    CK(hipMemcpy(d_win, P.win.data(), sizeof(SsWin) * P.win.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_win, sizeof(int2) * P.win.size()));
+    CK(hipMemcpy(d_win, P.win.data(), sizeof(int2) * P.win.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_ss, sizeof(int) * P.slice_step.size()));
     CK(hipMemcpy(d_ss, P.slice_step.data(), sizeof(int) * P.slice_step.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_sl, sizeof(int) * P.slice_len.size()));
@@ -97,7 +97,7 @@ int main(int argc, char** argv)
     CK(hipMalloc(&d_x, sizeof(double) * n));
     CK(hipMemcpy(d_x, hx.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_y, sizeof(double) * (n + 2)));
-    SsView S{d_val, d_slot, d_wptr, d_rptr, d_win, P.nwg, n, n, nullptr, P.ring};
+    SsView S{d_val, d_slot, d_wptr, d_rptr, d_win, P.nwg, n, n, nullptr};
     const double B = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     auto line = [&](const char* name, double us) { printf("%-56s %8.2f us   %6.0f GB/s algorithmic  (%.3f of 8 TB/s)\n", name, us, B / us / 1e3, B / us / 1e3 / 8000); fflush(stdout); };
     const int R = 50;
