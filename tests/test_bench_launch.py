@@ -59,3 +59,26 @@ def test_bench_single_process_prints_one_json_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["parity"]["bitwise"] is True and d["config"]["k"] == 4
     assert d["halo"]["exchange"] in ("event", "push", "rccl") and len(d["halo"]["ranks"]) == 3
+
+
+def test_roofline_traffic_comes_from_a_committed_profile_of_the_same_kernel_family():
+    """bench.py's roofline.traffic is the last PROFILED value (profiles/*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the
+    same command), looked up by workload and kernel.  The variants of a sliced kernel — prefetch depth, temporal / non-temporal values —
+    read the same sliced copy, so a profile of one describes the others; a kernel of another family, or another workload, gets none."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t8, src8 = bench.load_traffic("c4", "spmv_sstream<8, true, 0>")
+    t12, src12 = bench.load_traffic("c4", "spmv_sstream<12, false, 0>")
+    assert src8 == src12 == "profiles/r04_bench_c4_pmc.json" and t8 == t12
+    prof = json.load(open(os.path.join(ROOT, src8)))
+    assert prof["workload"] == "c4" and prof["kernel"].startswith("spmv_sstream<") and t8 == prof["hbm_bytes_per_launch"]
+    assert 0.8 * prof["algorithmic_bytes_per_launch"] < t8 < 1.1 * prof["algorithmic_bytes_per_launch"]  # (10 B per nonzero read where the CSR model counts 12)
+    # the gfx950 read correction is stated in the file the number comes from
+    assert prof["fetch_correction"] == 2.0 and prof["hbm_bytes_per_launch"] == prof["hbm_read_bytes_per_launch"] + prof["hbm_write_bytes_per_launch"]
+    tb, srcb = bench.load_traffic("fe_bcsr", "spmv_bcsr4_sell<8, true, 0, 2, 4>")
+    assert srcb == "profiles/r04_bench_fe_bcsr_pmc.json" and tb > 0
+    assert bench.load_traffic("c4", "some_other_kernel<1>") == (None, None)
+    assert bench.load_traffic("no_such_workload", "spmv_sstream<8, true, 0>") == (None, None)
