@@ -14,6 +14,12 @@ def once():
     yh = np.empty(400_000); mpk.SpMV_CSR(yh, synth.x_sin(0, 400_000), A); A.close() if hasattr(A, "close") else None
     B = mpk.csrmatrix(len(pf) - 1, pf, cf, vf); mpk.SpMV_CSR(yf, xf, B); del A, B
     dc = D.DistCSR(np.array([0, 400_000], np.int64), p, c, v); xe = dc.new_x_ext(); yy = dc.new_y(); dc.spmv(xe, yy); dc.close(); del dc
+    # round 4: a one-process multi-rank handle (two ranks on this card, event exchange), sliced copies of both kinds, a relabelled twin
+    M = mpk.DistMatrix(2, 400_000, p, c, v); hy = np.empty(400_000); M.spmv(hy, synth.x_sin(0, 400_000)); M.close()
+    os.environ["MI355_BCSR_SELL"] = "1"; os.environ["MI355_REORDER"] = "1"
+    pp, cc, vv, _ = synth.permute_nodes(pf, cf, vf, block=4, seed=3)
+    C = mpk.csrmatrix(len(pf) - 1, pp, cc, vv); mpk.SpMV_CSR(yf, xf, C); C.close()
+    del os.environ["MI355_BCSR_SELL"], os.environ["MI355_REORDER"]
     gc.collect()
 once(); base = used()
 for i in range(30): once()
