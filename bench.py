@@ -168,6 +168,7 @@ def self_launch(ngpus):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL, the push windows)
+    env.setdefault("MI355_BENCH_T0", repr(time.time()))  # the ranks' progress lines and the single-process budget count from HERE
     limit = int(os.environ.get("MI355_BENCH_LAUNCH_TIMEOUT", "1500"))
     # the child's stdout is filtered: the ONE JSON line goes to our stdout, anything else a rank or a backend prints there
     # (gloo's connection banner, for one) goes to stderr — the contract is one JSON line on stdout
@@ -284,7 +285,9 @@ def run_single_process_child(args, timeout_s=240):
     if "MI355_FORCE_DEVICE" in os.environ:  # development: every rank on one card
         env["MI355_DIST_DEVICES"] = os.environ["MI355_FORCE_DEVICE"]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, start_new_session=True)
+        # (in the caller's process group: self_launch's killpg on a timeout reaches this child too — a session of its own outlived a killed run
+        # while holding all N GPUs; subprocess.run kills the child itself when its own timeout expires)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
     except subprocess.TimeoutExpired:
         return dict(ok=False, note=f"child did not finish in {timeout_s} s")
     for line in reversed(r.stdout.splitlines()):
@@ -331,6 +334,7 @@ def main():
     from navierstokes_amd import dist as D
     from navierstokes_amd import mpk, synth
 
+    t_wall0 = time.time()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -433,9 +437,13 @@ def main():
         A = mpk.csrmatrix(n, p, c, v)
         if args.kernel != "auto":
             A.set_kernel(args.kernel)
+        torch.cuda.synchronize()
+        mem_before = torch.cuda.mem_get_info()[0]
         t_create = time.perf_counter()
         _ = A.handle
         t_create = time.perf_counter() - t_create
+        torch.cuda.synchronize()
+        handle_device_bytes = mem_before - torch.cuda.mem_get_info()[0]  # what mi_csr_create left allocated (its scratch is released before it returns)
         kernel_name = A.kernel_name()
         ring_cfg, ring_runs, ring_bad, ring_frac = A.ring_info()
         x = torch.from_numpy(x_host).cuda()
@@ -507,18 +515,34 @@ def main():
         probe_steps = max(5, min(args.steps, 50))
         probes, alive = {}, {}
         rccl_ranks = None
+        t_bench0 = float(os.environ.get("MI355_BENCH_T0", "0")) or time.time()  # (self_launch stamps its own start: python start-up and rendezvous count too)
+
+        def say(msg):  # progress on stderr, rank 0: the first real 8-GPU record explains itself even if it is cut short
+            if rank == 0:
+                print(f"[bench +{time.time() - t_bench0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+        say(f"{world} ranks up ({backend}); matrix generated; probing exchanges {want}")
+        phase_s = {}
         for ex in want:
+            t_ex = time.perf_counter()
+
+            def done(ex=ex, t_ex=t_ex):
+                phase_s[ex] = round(time.perf_counter() - t_ex, 2)
+                probes[ex]["probe_s"] = phase_s[ex]
+                say(f"exchange {ex}: {'ok, ' + str(probes[ex].get('step_us')) + ' us per step' if probes[ex]['ok'] else 'dropped: ' + probes[ex]['note'][:160]} ({phase_s[ex]} s)")
             try:
                 dcx = D.DistCSR(rs, p, c, v, kernel=None if args.kernel == "auto" else args.kernel, exchange=ex)
             except D.DistSetupError as e:  # raised on every rank alike
                 probes[ex] = dict(ok=False, note=str(e)[:200])
+                done()
                 continue
+            t_created = time.perf_counter() - t_ex
             got = "push" if dcx.push else (("allgather" if dcx.allgather else "native") if dcx.native else "torch")
             if ex in ("native", "allgather") or dcx.rccl_ranks:
                 rccl_ranks = dcx.rccl_ranks
             if got != ex:  # (a collective outcome: the same on every rank)
                 probes[ex] = dict(ok=False, note=f"did not come up on every rank, or failed its bitwise self-check against the torch.distributed exchange (DistCSR fell to '{got}')")
                 dcx.close()
+                done()
                 continue
             xx = dcx.new_x_ext()
             xx[: dcx.n_local] = torch.from_numpy(x_host).cuda()
@@ -548,6 +572,7 @@ def main():
                     dcx.close()
                 except Exception:  # noqa: BLE001
                     pass
+                done()
                 continue
             us = timed_max_us(stepx, probe_steps)
             fine = 1
@@ -561,16 +586,22 @@ def main():
                     dcx.close()
                 except Exception:  # noqa: BLE001
                     pass
+                done()
                 continue
             probes[ex] = dict(ok=True, step_us=round(us, 2),
                               form=("ONE launch per step" if dcx.push_fused else "four launches per step") if ex == "push" else
                                    ("RCCL send/recv on the partition's comm stream, events" if ex == "native" else
                                     "ONE ncclAllGather of every rank's boundary slice on the comm stream, events" if ex == "allgather" else
-                                    ("all_to_all_single over RCCL" if dcx._nccl else "host-staged (non-NCCL backend, development)")))
+                                    ("all_to_all_single over RCCL" if dcx._nccl else "host-staged (non-NCCL backend, development)")),
+                              create_s=round(t_created, 2),
+                              kernels=dict(interior=mpk.lib().mi_part_kernel_name(dcx._h, 0).decode(), boundary=mpk.lib().mi_part_kernel_name(dcx._h, 1).decode(),
+                                           one_launch_step=mpk.lib().mi_part_kernel_name(dcx._h, 2).decode() or None))
             alive[ex] = (dcx, stepx, xx, yy, pb)
+            done()
         if not alive:
             sys.exit("no halo exchange survived its checks on every rank: " + json.dumps(probes))
         chosen = args.exchange if args.exchange in alive else min(alive, key=lambda e: probes[e]["step_us"])
+        say(f"chosen: {chosen}; timed region next ({args.warmup} + {args.steps} steps)")
         for ex in list(alive):
             if ex != chosen:
                 alive.pop(ex)[0].close()
@@ -606,7 +637,9 @@ def main():
                                       compute_over_step=round(us_compute / us_step, 4),
                                       note="compute_only = pack + interior rows + boundary rows of the same rank with NO exchange, slowest rank; "
                                            "exposed = what the exchange adds to the step (negative: the one-launch step is cheaper than the three kernels it replaces)"),
-                         rccl_ranks=rccl_ranks, torch_backend=backend, torch_world=world)
+                         rccl_ranks=rccl_ranks, torch_backend=backend, torch_world=world,
+                         probe_seconds=dict(phase_s, note="wall seconds per candidate exchange on rank 0: DistCSR create (partition, pieces, their create-time "
+                                                          "measurements, the exchange's set-up and bitwise self-check) + dry run + timing"))
         del ybuf, sbuf
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
@@ -709,6 +742,22 @@ def main():
             step()  # leave ys[0] = A x for the parity check below
             torch.cuda.synchronize()
             del bvec, x3, z
+    # (3) what a Newton iteration pays beside its products (src/solve_newton.c:1245-1247: the Jacobian's VALUES change every iteration, the
+    #     pattern never): mi_csr_update_values_dev on the benched handle — CSR values, the sliced copy the headline kernel streams and the
+    #     blocked copy where there is one, refilled on the update's stream — and what the handle keeps allocated on the device.
+    if world == 1 and not bcsr and not args.no_extras and k == 1:
+        vdev = torch.from_numpy(np.ascontiguousarray(v)).cuda()  # the same values: the parity check below still sees the timed region's result
+        for _ in range(2):
+            A.update_values(vdev)
+        ev0.record()
+        for _ in range(5):
+            A.update_values(vdev)
+        ev1.record()
+        torch.cuda.synchronize()
+        extra["update_values_us"] = ev0.elapsed_time(ev1) * 1e3 / 5
+        del vdev
+        step()  # leave ys[0] = A x for the parity check below (computed from the refilled copies)
+        torch.cuda.synchronize()
     red_dev = "cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     if world > 1:
         tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=red_dev)
@@ -843,6 +892,15 @@ def main():
                                            protocol="SpMV -> orthogonalize (dot + AXPY) -> SpMV, mpk/SpMVmulti.cpp:559-574, device-resident, 50 passes; "
                                                     "spmv_us = (pass - orthogonalize alone) / 2; pass_dot_in_epilogue_us = the same pass through "
                                                     "mi_spmv_orthogonalize_dev (b . x1 accumulated in the first product's epilogue)")
+        if "update_values_us" in extra:
+            roofline["newton_refresh"] = dict(update_values_us=round(extra["update_values_us"], 1), products=round(extra["update_values_us"] / (launch_s * 1e6), 2),
+                                              device_bytes_per_nnz=round(handle_device_bytes / max(nnz_global, 1), 2), device_bytes=int(handle_device_bytes),
+                                              note="mi_csr_update_values_dev on the benched handle (a Newton loop's Jacobian: new values, same pattern; "
+                                                   "src/solve_newton.c:1245-1247) — ONE pass reads the caller's values and writes the CSR values and the sliced copy "
+                                                   "(+ the blocked copy's refill where the handle has one); `products` = that time in products of this line; "
+                                                   "device_bytes = device memory mi_csr_create left allocated (hipMemGetInfo around it): CSR arrays 12 B per nonzero, "
+                                                   "ring plan + 16-bit column stream ~2, the sliced copy ~10 where it won the create-time measurement (released otherwise), "
+                                                   "placed x / y scratch")
     out = dict(metric="fp64 CSR SpMV GFLOP/s & % HBM roofline @ nnz; 1/2/4/8 GPU", value=round(value, 2), unit="GFLOP/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(wall * 1e3 / args.steps, 5),
                higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
@@ -903,7 +961,16 @@ def main():
     if world == 1 and not bcsr:
         out["setup_breakdown_s"] = dict(generate_matrix_on_host=round(t_gen, 2), mi_csr_create=round(t_create, 2),
                                         note="mi_csr_create = upload + plans + the create-time measurements (kernel candidates, placement draws)")
-    if world > 1 and not args.no_single_process_extra and kind in ("s15", "fe") and not args.cold:
+    # (the one-process extra costs another mi_dist_create over all N devices: skipped — collectively, by rank 0's clock — when this run has
+    # already used more than 120 s, so that the whole command stays well inside the driver's window)
+    sp_budget_ok = True
+    if world > 1:
+        used = torch.tensor([time.time() - (float(os.environ.get("MI355_BENCH_T0", "0")) or t_wall0)], dtype=torch.float64, device=red_dev)
+        dist.broadcast(used, src=0)
+        sp_budget_ok = float(used) <= float(os.environ.get("MI355_BENCH_SP_BUDGET_S", "120"))
+        if not sp_budget_ok and rank == 0 and not args.no_single_process_extra:
+            out["single_process"] = dict(ok=False, skipped=True, note=f"skipped: the process-per-GPU path had used {float(used):.0f} s of wall time (> 120 s) when it was its turn")
+    if world > 1 and sp_budget_ok and not args.no_single_process_extra and kind in ("s15", "fe") and not args.cold:
         # the same workload through ONE process (mi_dist_*), as a child of rank 0.  The other ranks wait on the HOST — a key in the
         # process group's own TCP store — so that no collective kernel spins on their GPUs while the child measures; everything here
         # is bounded (child: 200 s; the wait: 260 s) and a failure costs the line nothing but the field.

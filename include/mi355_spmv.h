@@ -216,12 +216,20 @@ int mi_vec_free_placed(double* d_vec);
  * and times it — 8 / 12 steps of prefetch, non-temporal / temporal value loads — against the other candidates.  *built = 1 if the handle
  * holds the copy; *padding = padded places per nonzero; us[0..3] = microseconds per launch for D = 8 nt, D = 8 temporal, D = 12 nt,
  * D = 12 temporal (0 = not timed); *form = the variant in use (index into us).  y must be 16-byte aligned (else the handle's next-best
- * kernel runs that product). */
+ * kernel runs that product).  A copy that loses the create-time measurement is released again (mi_csr_set_kernel(MI_KERNEL_SSTREAM) rebuilds
+ * it on request); the sliced values follow every mi_csr_update_values* at once, on that call's stream (HIP-graph replays included). */
 int mi_csr_sstream_info(mi_csr_t A, int* built, int* rounds, long long* steps, double* padding, double us[4], int* form);
 /* host-only: build that plan exactly as mi_csr_create would and REPLAY it against the matrix (MI_ERR_STATE names the first violation:
  * every nonzero's slot is its column's ring slot and the column lies inside the window when its round runs; padding places are flagged).
  * *eligible = 0 with the reason in mi_last_error() when the matrix does not qualify. */
 int mi_sstream_plan_probe(int n, int ncols, const int* ptrow, const int* indcol, int* eligible, int* rounds, long long* steps, double* padding);
+/* the same for the two forms round 5 added: shift = 1 plans the rows one down (what mi_csr_create_mapped does for a piece whose rows go to
+ * y[r + odd offset]: row pairs stay 16-byte aligned); ghost_lo < ghost_hi: columns outside [ghost_lo, ghost_hi) are ghosts (a partition's
+ * combined piece, numbered [lower ghosts | owned | upper ghosts]): a workgroup whose windows hold one is marked (*ghost_workgroups counts
+ * them; the fused multi-GPU step makes them push and wait first) and gets one round less than its share.  rounds_min_max[2] = the
+ * shortest and the longest share of rounds.  The replay also checks the marks and the dealing. */
+int mi_sstream_plan_probe_ex(int n, int ncols, const int* ptrow, const int* indcol, int shift, int ghost_lo, int ghost_hi, int* eligible, int* rounds,
+                             long long* steps, double* padding, int* ghost_workgroups, int* rounds_min_max);
 /* Multi-window ring kernel (MI_KERNEL_MRING, mring_plan.hpp): mi_csr_create plans it for matrices the single ring does not serve
  * and keeps the plan when it serves >= 90 % of the nonzeros (MI355_MRING=0 never, =1 always keep); mi_csr_set_kernel builds it
  * on request.  us[0..1] = measured microseconds per launch, temporal / non-temporal value loads (MI355_MRING_NT=0|1 forces). */
@@ -427,6 +435,9 @@ int mi_part_send_counts(mi_part_t P, int* counts /* [nranks] */);
 int mi_part_local_csr(mi_part_t P, int which, int* nrows, const int** ptrow, const int** indcol_local,
                       const double** coef, const int** rowmap);
 int mi_part_combined_info(mi_part_t P, int* n_left);
+/* *contiguous = 1 when every send list of this rank is a run of consecutive local ids (banded partitions with whole-range halos): the
+ * RCCL step (mi_part_spmv_dev) then sends slices of x in place and launches no pack kernel. */
+int mi_part_sends_contiguous(mi_part_t P, int* contiguous);
 int mi_part_send_index(mi_part_t P, int* total, const int** local_idx /* packed by peer, ascending */);
 /* upload the two pieces and the send index to the current device */
 int mi_part_finalize(mi_part_t P);
@@ -493,6 +504,10 @@ int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_st
  * touch ghosts, which are ordered last) live inside that kernel (spmv_ring.hpp, FUSED; MI355_PUSH_FUSED=0 disables).
  * In the fused form the halo part of d_x_ext is neither read nor written. */
 int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
+/* the kernel a piece's products launch (as rocprofv3 names it): which = 0 the interior rows' piece, 1 the boundary rows', 2 the combined piece
+ * of the one-launch push step — spmv_sstream_fused<...> (round 5) wherever that piece holds a sliced copy, else the ring kernel's FUSED
+ * form or the blocked one; "" when the step is not fused.  The string lives until the thread's next call. */
+const char* mi_part_kernel_name(mi_part_t P, int which);
 /* Step down from the one-launch form to the four-launch form (push, interior rows, wait + copy, boundary rows).  All ranks must
  * drive the step the same way; the caller compares mi_part_push_info's `fused` across ranks and calls this where they differ. */
 int mi_part_push_unfuse(mi_part_t P);

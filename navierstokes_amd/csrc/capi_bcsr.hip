@@ -3,6 +3,8 @@
 #include "capi_internal.hpp"
 #include "spmv_bcsr_sell.hpp"
 
+static int sell_fill(mi_bcsr4_t A, hipStream_t s);
+
 // ---------------------------------------------------------------- BCSR 4x4
 extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef,
                                mi_bcsr4_t* out)
@@ -117,14 +119,30 @@ extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const i
                 (e = hipMemcpy(A->d_sell_col, P.col.data(), sizeof(unsigned) * P.col.size(), hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(A->d_sell_sptr, P.sptr.data(), sizeof(int) * P.sptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(A->d_sell_wrng, P.wrng.data(), sizeof(int) * P.wrng.size(), hipMemcpyHostToDevice)) != hipSuccess) {
-                mi_bcsr4_destroy(A);
-                return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 sliced copy: ") + hipGetErrorString(e));
+                // no room for a second copy of the block values (or a failed upload): the row-per-quad kernels serve the handle, as
+                // build_sstream does for the scalar format — a create that worked without the sliced copy must not fail because of it
+                (void)hipGetLastError();
+                dfree(A->d_sell_val); dfree(A->d_sell_col); dfree(A->d_sell_sptr); dfree(A->d_sell_wrng); dfree(A->d_sell_wrng2);
+                A->d_sell_val = nullptr;
+                A->d_sell_col = nullptr;
+                A->d_sell_sptr = A->d_sell_wrng = A->d_sell_wrng2 = nullptr;
+                A->sell_form = -1;
+                if (e != hipErrorOutOfMemory) {
+                    mi_bcsr4_destroy(A);
+                    return fail(MI_ERR_HIP, std::string("bcsr4 sliced copy: ") + hipGetErrorString(e));
+                }
             }
+            if (A->d_sell_val) {
             A->sell_nslices = P.nslices;
             A->sell_nwaves = P.nwaves;
             A->sell_nwaves2 = P2.nwaves;
             A->sell_nsteps = P.nsteps;
-            A->sell_stale = true; // filled on the first product's stream
+            // filled HERE and refilled where the block values change (mi_bcsr4_update_values*), on that call's stream — never lazily in
+            // front of a product: a product captured into a HIP graph holds only the product's node
+            if ((rc = sell_fill(A, nullptr)) != MI_OK) {
+                mi_bcsr4_destroy(A);
+                return rc;
+            }
             if (const char* fe = getenv("MI355_BCSR_SELL_FORM")) A->sell_form = std::max(0, std::min(3, atoi(fe))); // tests: one variant, unmeasured
             else if (forced) A->sell_form = 0;
             else if (!(at && !strcmp(at, "0"))) {
@@ -160,6 +178,7 @@ extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const i
                 if (e0) (void)hipEventDestroy(e0);
                 if (e1) (void)hipEventDestroy(e1);
             } else A->sell_form = 0; // no measurement: the sliced, non-temporal form for matrices of this size
+            }
         }
     }
     *out = A;
@@ -172,7 +191,12 @@ static int sell_fill(mi_bcsr4_t A, hipStream_t s)
     const int grid = std::max(1, std::min(A->sell_nslices, 8192));
     hipLaunchKernelGGL(bcsr4_to_sell_kernel, dim3((unsigned)grid), dim3(64), 0, s, A->sell_nslices, A->nbrows, A->d_ptrow, A->d_coef, A->d_sell_sptr, A->d_sell_val);
     HIP_TRY(hipGetLastError());
-    A->sell_stale = false;
+    return MI_OK;
+}
+
+int bcsr4_values_changed(mi_bcsr4_s* A, hipStream_t s)
+{
+    if (A && A->d_sell_val && A->nblocks > 0) return sell_fill(A, s);
     return MI_OK;
 }
 
@@ -244,8 +268,7 @@ extern "C" int mi_bcsr4_update_values_layout_dev(mi_bcsr4_t A, const double* d_c
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(transpose_blocks_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, A->nblocks, d_coef, A->d_coef);
     HIP_TRY(hipGetLastError());
-    bcsr4_values_changed(A);
-    return MI_OK;
+    return bcsr4_values_changed(A, (hipStream_t)s);
 }
 
 extern "C" int mi_bcsr4_tile_info(mi_bcsr4_t A, int* built, int* in_use, double* us_plain, double* us_tile)
@@ -265,7 +288,9 @@ extern "C" int mi_bcsr4_update_values(mi_bcsr4_t A, const double* coef)
     if (A->nblocks == 0) return MI_OK;
     CHECK_ARG(coef, "null coef");
     HIP_TRY(hipMemcpy(A->d_coef, coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyHostToDevice));
-    bcsr4_values_changed(A);
+    int rc = bcsr4_values_changed(A, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return MI_OK;
 }
 
@@ -274,9 +299,8 @@ extern "C" int mi_bcsr4_update_values_dev(mi_bcsr4_t A, const double* d_coef, mi
     CHECK_ARG(A, "null handle");
     if (A->nblocks == 0) return MI_OK;
     CHECK_ARG(d_coef, "null coef");
-    HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyDeviceToDevice, (hipStream_t)s));
-    bcsr4_values_changed(A);
-    return MI_OK;
+    if (d_coef != A->d_coef) HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return bcsr4_values_changed(A, (hipStream_t)s);
 }
 
 extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)
@@ -321,11 +345,7 @@ int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bo
     static const int chunk = getenv("MI355_BCSR_XCD_CHUNK") ? atoi(getenv("MI355_BCSR_XCD_CHUNK")) : 0;
     const int grid = nwg;
     // the sliced form (a relabelled matrix's blocked copy stores through its block-row map)
-    if (A->sell_form >= 0 && A->d_sell_val && !(A->sell_stale && stream_is_capturing((hipStream_t)s))) {
-        if (A->sell_stale) {
-            int rc = sell_fill(A, (hipStream_t)s);
-            if (rc) return rc;
-        }
+    if (A->sell_form >= 0 && A->d_sell_val) {
         // forms (mi_bcsr4_sell_info): 0 / 1 / 3 one wave per SIMD — one workgroup of four waves per CU, 8 (12) steps of prefetch,
         // non-temporal / temporal / non-temporal; 2 one workgroup of eight waves per CU, 4 steps, non-temporal.  All park y in LDS.
         const bool two = A->sell_form == 2;
@@ -630,7 +650,6 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
         const bool mapped = V.browmap != nullptr;
         auto run = [&](int form) -> hipError_t {
             if (form == kSpmmSell) {
-                if (A->sell_stale && sell_fill(A, st) != MI_OK) return hipErrorUnknown;
                 SellView Sv{A->d_sell_val, A->d_sell_col, A->d_sell_sptr, A->d_sell_wrng, A->sell_nslices, A->nbrows, V.browmap};
                 const int swg = A->sell_nwaves / 4;
                 if (m == 4) {
@@ -650,7 +669,7 @@ static int launch_spmm(mi_bcsr4_t A, int s, int arith, const double* X, long lon
         int form = kSpmmGather;
         const bool capturing = stream_is_capturing(st); // no first-use measurement (it synchronises) and no plan upload under capture
         if (capturing && A->spmm_choice[m] > 0 && (A->st_state == 1 || A->spmm_choice[m] - 1 == kSpmmSell) &&
-            !(A->spmm_choice[m] - 1 == kSpmmSell && (A->sell_stale || mapped)))
+            !(A->spmm_choice[m] - 1 == kSpmmSell && mapped))
             form = A->spmm_choice[m] - 1;
         const bool tiles = !capturing && build_spmm_tile(A) == 1;
         if (!capturing && (tiles || spmm_form_possible(A, m, kSpmmSell, mapped))) {

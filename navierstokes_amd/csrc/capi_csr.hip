@@ -1,7 +1,6 @@
 // capi_csr.hip: CSR handles — create (plans, autotuner, relabelling), update, info, products — part of libmi355spmv.so (see capi_internal.hpp for the layout of the library).
 // Built for gfx950 only; no CPU fallback anywhere: every compute entry point needs a HIP device.
 #include "capi_internal.hpp"
-#include "spmv_sstream.hpp"
 #include "reorder.hpp"
 #include "mring_plan.hpp"
 #include "tile_plan.hpp"
@@ -49,49 +48,53 @@ static void free_mring(mi_csr_t A)
 
 static void free_sstream(mi_csr_t A)
 {
-    dfree(A->ss.d_val);
-    dfree(A->ss.d_slot);
-    dfree(A->ss.d_wptr);
-    dfree(A->ss.d_rptr);
-    dfree(A->ss.d_win);
-    dfree(A->ss.d_slice_step);
-    dfree(A->ss.d_slice_len);
+    ss_free(A->ss.dev);
     A->ss = SstreamTable();
 }
 
 constexpr double kSsMaxPadding = 0.12; // padded places per nonzero from which the sliced copy is not worth its bytes
+// MI355_SSTREAM_MAX_PADDING=<places per nonzero> (tests: the reference-made goldens — a few hundred ragged rows — through the sliced kernels)
+static double ss_max_padding()
+{
+    if (const char* e = getenv("MI355_SSTREAM_MAX_PADDING")) return std::max(0.0, atof(e));
+    return kSsMaxPadding;
+}
 
 // The sliced copy of the sliced-stream kernel (spmv_sstream.hpp): plan + slot stream on the host, values filled on the device from the
-// handle's CSR values at the first product.  MI_OK with A->ss left empty when the matrix is not eligible.
-static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol)
+// handle's CSR values (already uploaded).  MI_OK with A->ss left empty when the matrix is not eligible.
+// A handle whose rows go to y[r + odd offset] (the interior rows of a rank) is planned one row down: its row pairs then start on
+// even rows of y and leave as 16-byte stores like any other's.  ghost_lo < ghost_hi: a combined piece of the fused multi-GPU step.
+static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol, int ghost_lo = 0, int ghost_hi = 0)
 {
-    if (A->ss.d_val) return MI_OK;
+    if (A->ss.dev.val) return MI_OK;
     SsPlanHost P;
-    build_sstream_plan(A->n, A->ncols, ptrow, indcol, kSsMaxPadding, P);
+    const int shift = (A->y_offset & 1) && !A->d_rowmap ? 1 : 0;
+    build_sstream_plan(A->n, A->ncols, ptrow, indcol, ss_max_padding(), P, true, shift, ghost_lo, ghost_hi);
     if (!P.eligible) return MI_OK;
     SstreamTable& T = A->ss;
-    hipError_t e;
-    const size_t vbytes = sizeof(ss_v2d) * (size_t)(P.steps + kSsPadSteps) * 64;
-    if ((e = hipMalloc(&T.d_val, vbytes)) != hipSuccess || (e = hipMalloc(&T.d_slot, sizeof(unsigned) * P.slot.size())) != hipSuccess ||
-        (e = hipMalloc(&T.d_wptr, sizeof(int) * P.wptr.size())) != hipSuccess || (e = hipMalloc(&T.d_rptr, sizeof(int) * P.rptr.size())) != hipSuccess ||
-        (e = hipMalloc(&T.d_win, sizeof(int2) * P.win.size())) != hipSuccess || (e = hipMalloc(&T.d_slice_step, sizeof(int) * P.slice_step.size())) != hipSuccess ||
-        (e = hipMalloc(&T.d_slice_len, sizeof(int) * P.slice_len.size())) != hipSuccess ||
-        (e = hipMemset((char*)T.d_val + sizeof(ss_v2d) * (size_t)P.steps * 64, 0, sizeof(ss_v2d) * (size_t)kSsPadSteps * 64)) != hipSuccess ||
-        (e = hipMemcpy(T.d_slot, P.slot.data(), sizeof(unsigned) * P.slot.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(T.d_wptr, P.wptr.data(), sizeof(int) * P.wptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(T.d_rptr, P.rptr.data(), sizeof(int) * P.rptr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(T.d_win, P.win.data(), sizeof(int2) * P.win.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(T.d_slice_step, P.slice_step.data(), sizeof(int) * P.slice_step.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(T.d_slice_len, P.slice_len.data(), sizeof(int) * P.slice_len.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+    hipError_t e = ss_upload(P, T.dev, ghost_lo < ghost_hi);
+    if (e != hipSuccess) {
         free_sstream(A);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return MI_OK; } // no room for a second copy of the matrix: the other kernels serve it
         return fail(MI_ERR_HIP, std::string("sliced copy: ") + hipGetErrorString(e));
     }
     T.nwg = P.nwg;
     T.rounds = P.rounds;
+    T.shift = P.shift;
     T.steps = P.steps;
     T.padding = (double)P.pad_places / (double)A->nnz;
-    T.stale = true;
+    T.max_slice_nnz = P.max_slice_nnz;
+    if (ghost_lo < ghost_hi) {
+        T.h_wg_halo = P.wg_halo;
+        T.h_wg = P.wg;
+    }
+    // the sliced values are filled HERE and refilled where the CSR values change (mi_csr_update_values*), on that call's stream — never
+    // lazily in front of a product: a product captured into a HIP graph holds only the product's node and must find the values in place
+    sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, A->d_coef, nullptr, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, nullptr);
+    if ((e = hipGetLastError()) != hipSuccess) {
+        free_sstream(A);
+        return fail(MI_ERR_HIP, std::string("sliced copy fill: ") + hipGetErrorString(e));
+    }
     T.nt = 10.0 * (double)A->nnz + 16.0 * (double)A->n > 0.75 * 256e6; // beyond the Infinity Cache: stream past it
     T.deep = T.nt;
     if (const char* fe = getenv("MI355_SSTREAM_FORM")) { // tests: one variant (0 D=8 nt, 1 D=8 temporal, 2 D=12 nt, 3 D=12 temporal)
@@ -102,25 +105,27 @@ static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol)
     return MI_OK;
 }
 
-// y = A x through the sliced-stream kernel (the caller has checked that the handle holds the copy and — unmapped rows — that y is
-// 16-byte aligned); rowmap: nullptr or the handle's row map
-int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s)
+// y = A x through the sliced-stream kernel (the caller has checked sstream_y_ok); rowmap: nullptr or the handle's row map
+int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s, const RingComm* comm)
 {
     SstreamTable& T = A->ss;
-    if (T.stale) { // the CSR values changed (or were never copied): refill the sliced values on this stream, in front of the product
-        const int nslices = 4 * T.rounds;
-        hipLaunchKernelGGL(csr_to_sstream_kernel, dim3((unsigned)std::min(nslices, 16384)), dim3(64), 0, s, nslices, A->n, A->d_ptrow, A->d_coef, T.d_slice_step,
-                           T.d_slice_len, reinterpret_cast<ss_v2d*>(T.d_val));
-        HIP_TRY(hipGetLastError());
-        T.stale = false;
-    }
-    SsView S{reinterpret_cast<const ss_v2d*>(T.d_val), T.d_slot, T.d_wptr, T.d_rptr, reinterpret_cast<const int2*>(T.d_win), T.nwg, A->n, A->ncols, rowmap};
-    if (T.deep) {
-        if (T.nt) hipLaunchKernelGGL((spmv_sstream<12, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
-        else hipLaunchKernelGGL((spmv_sstream<12, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
+    SsView S{T.dev.val, T.dev.slot, T.dev.wg, T.dev.win, T.nwg, A->n + T.shift, A->ncols, rowmap, T.shift};
+    double* yy = rowmap ? d_y : d_y - T.shift;
+    if (comm) {
+        const unsigned grid = (unsigned)(T.nwg + comm->push_wgs);
+        if (T.deep) {
+            if (T.nt) hipLaunchKernelGGL((spmv_sstream_fused<12, true>), dim3(grid), dim3(256), 0, s, S, d_x, yy, *comm);
+            else hipLaunchKernelGGL((spmv_sstream_fused<12, false>), dim3(grid), dim3(256), 0, s, S, d_x, yy, *comm);
+        } else {
+            if (T.nt) hipLaunchKernelGGL((spmv_sstream_fused<8, true>), dim3(grid), dim3(256), 0, s, S, d_x, yy, *comm);
+            else hipLaunchKernelGGL((spmv_sstream_fused<8, false>), dim3(grid), dim3(256), 0, s, S, d_x, yy, *comm);
+        }
+    } else if (T.deep) {
+        if (T.nt) hipLaunchKernelGGL((spmv_sstream<12, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, yy);
+        else hipLaunchKernelGGL((spmv_sstream<12, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, yy);
     } else {
-        if (T.nt) hipLaunchKernelGGL((spmv_sstream<8, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
-        else hipLaunchKernelGGL((spmv_sstream<8, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, d_y);
+        if (T.nt) hipLaunchKernelGGL((spmv_sstream<8, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, yy);
+        else hipLaunchKernelGGL((spmv_sstream<8, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, S, d_x, yy);
     }
     HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -540,14 +545,17 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         const char* se = getenv("MI355_SSTREAM");
         const char* ke = getenv("MI355_SPMV_KERNEL");
         const bool asked = (se && !strcmp(se, "1")) || (ke && !strcmp(ke, "sstream"));
-        // (row-mapped handles — partition pieces, the relabelled twin — included since the store goes through the map; not the fused
-        // multi-GPU step's combined piece, whose ghost columns only the ring kernel's FUSED form reads from the window)
-        if (n > 0 && nnz > 0 && !(ghost_lo < ghost_hi) && !(se && !strcmp(se, "0")) && (asked || nnz >= 200000)) {
-            const int rcs = build_sstream(A, ptrow, indcol);
+        // (row-mapped handles — partition pieces, the relabelled twin — included since the store goes through the map; since round 5 also
+        // the fused multi-GPU step's combined piece: spmv_sstream_fused reads its ghost columns from the receive window)
+        A->ghost_lo = ghost_lo;
+        A->ghost_hi = ghost_hi;
+        if (n > 0 && nnz > 0 && !(se && !strcmp(se, "0")) && (asked || nnz >= 200000)) {
+            const int rcs = build_sstream(A, ptrow, indcol, ghost_lo, ghost_hi);
             if (rcs != MI_OK) {
                 mi_csr_destroy(A);
                 return rcs;
             }
+            A->ss.asked = asked;
         }
     }
     // FE matrices: a blocked copy for the BCSR 4x4 kernel (same bits, 8.25 instead of 12 B per nonzero)
@@ -594,7 +602,7 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         else if (!strcmp(e, "bcsr4") && A->blocked) A->auto_kernel = MI_KERNEL_BCSR4;
         else if (!strcmp(e, "tile") && A->tile.d_desc) A->auto_kernel = MI_KERNEL_TILE;
         else if (!strcmp(e, "mring") && A->mring.d_plan) A->auto_kernel = MI_KERNEL_MRING;
-        else if (!strcmp(e, "sstream") && A->ss.d_val) A->auto_kernel = MI_KERNEL_SSTREAM;
+        else if (!strcmp(e, "sstream") && A->ss.dev.val) A->auto_kernel = MI_KERNEL_SSTREAM;
         else forced_kernel = false;
     }
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
@@ -705,7 +713,7 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
             const double best_csr = A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : (A->auto_kernel == MI_KERNEL_MRING ? best_mring : best_stream));
             if (better(A->tune_us_bcsr, best_csr)) A->auto_kernel = MI_KERNEL_BCSR4;
         }
-        if (A->ss.d_val && !getenv("MI355_SSTREAM_FORM")) { // the sliced stream against whatever won so far: 8 / 12 steps of prefetch x non-temporal / temporal value loads
+        if (A->ss.dev.val && !getenv("MI355_SSTREAM_FORM")) { // the sliced stream against whatever won so far: 8 / 12 steps of prefetch x non-temporal / temporal value loads
             const double best_so_far = A->auto_kernel == MI_KERNEL_BCSR4 ? A->tune_us_bcsr
                                        : A->auto_kernel == MI_KERNEL_RING ? best_ring : (A->auto_kernel == MI_KERNEL_TILE ? best_tile : (A->auto_kernel == MI_KERNEL_MRING ? best_mring : best_stream));
             A->kernel = MI_KERNEL_SSTREAM;
@@ -735,6 +743,15 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
                 A->ss.nt = (bf & 1) == 0;
                 A->ss.deep = bf >= 2;
                 if (better(bs, best_so_far)) A->auto_kernel = MI_KERNEL_SSTREAM;
+            }
+            // A sliced copy that lost the measurement is released (+10 B per nonzero and its padding): mi_csr_set_kernel(MI_KERNEL_SSTREAM)
+            // rebuilds it on demand.  Kept: one the environment asked for, and a combined piece's (the fused multi-GPU step takes the
+            // sliced stream wherever EVERY rank can: its choice is collective, not this rank's measurement).
+            if (A->auto_kernel != MI_KERNEL_SSTREAM && !A->ss.asked && !(ghost_lo < ghost_hi)) {
+                double keep_us[4];
+                for (int f = 0; f < 4; f++) keep_us[f] = A->ss.tune_us[f];
+                free_sstream(A);
+                for (int f = 0; f < 4; f++) A->ss.tune_us[f] = keep_us[f]; // (what it measured stays readable: mi_csr_sstream_info)
             }
         }
         // every further comparison on the SAME x / y scratch: where a vector lies in device memory moves a launch by a few per cent
@@ -1094,16 +1111,22 @@ __global__ __launch_bounds__(kWG) void bcsr4_values_from_csr_kernel(int nbrows, 
     }
 }
 
-static int refresh_blocked_values(mi_csr_t A, hipStream_t s)
+// every value refresh comes by here, on the stream the new CSR values were written on: the copies derived from them follow AT ONCE on
+// that stream (the sliced values of spmv_sstream unless the caller filled them in the same pass as the CSR values; the blocked copy and
+// its sliced values), so that stream order — and a HIP graph captured earlier — see them like the CSR values themselves
+static int refresh_blocked_values(mi_csr_t A, hipStream_t s, bool sliced_done = false)
 {
-    if (A->ss.d_val) A->ss.stale = true; // (every value refresh comes by here) the sliced copy follows on the next product's stream
+    if (A->ss.dev.val && !sliced_done) {
+        SstreamTable& T = A->ss;
+        sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, A->d_coef, nullptr, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, s);
+        HIP_TRY(hipGetLastError());
+    }
     if (!A->blocked || A->blocked->nbrows == 0) return MI_OK;
     const long long threads = 4LL * A->blocked->nbrows;
     hipLaunchKernelGGL(bcsr4_values_from_csr_kernel, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, s,
                        A->blocked->nbrows, A->d_ptrow, A->d_coef, A->blocked->d_ptrow, A->blocked->d_coef);
     HIP_TRY(hipGetLastError());
-    bcsr4_values_changed(A->blocked);
-    return MI_OK;
+    return bcsr4_values_changed(A->blocked, s);
 }
 
 // New coefficients for an unchanged sparsity pattern (what a Newton loop does to its Jacobian every
@@ -1132,7 +1155,13 @@ extern "C" int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_str
         HIP_TRY(hipGetLastError());
         return refresh_blocked_values(I, s);
     }
-    HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
+    if (A->ss.dev.val && d_coef != A->d_coef) { // ONE pass over the caller's values: the CSR values and the sliced values leave together
+        SstreamTable& T = A->ss;
+        sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, d_coef, A->d_coef, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, s);
+        HIP_TRY(hipGetLastError());
+        return refresh_blocked_values(A, s, true);
+    }
+    if (d_coef != A->d_coef) HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
     return refresh_blocked_values(A, s);
 }
 
@@ -1172,7 +1201,7 @@ int resolve_kernel(const mi_csr_s* A)
     if (k == MI_KERNEL_BCSR4 && !A->blocked) k = MI_KERNEL_STREAM;
     if (k == MI_KERNEL_TILE && !A->tile.d_desc) k = MI_KERNEL_STREAM;
     if (k == MI_KERNEL_MRING && !A->mring.d_plan) k = MI_KERNEL_STREAM;
-    if (k == MI_KERNEL_SSTREAM && !A->ss.d_val) k = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM;
+    if (k == MI_KERNEL_SSTREAM && !A->ss.dev.val) k = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM;
     return k;
 }
 
@@ -1370,33 +1399,57 @@ extern "C" int mi_csr_sstream_info(mi_csr_t A, int* built, int* rounds, long lon
 {
     CHECK_ARG(A, "null handle");
     if (A->inner) A = A->inner;
-    if (built) *built = A->ss.d_val != nullptr;
+    if (built) *built = A->ss.dev.val != nullptr;
     if (rounds) *rounds = A->ss.rounds;
     if (steps) *steps = A->ss.steps;
     if (padding) *padding = A->ss.padding;
     if (us)
         for (int f = 0; f < 4; f++) us[f] = A->ss.tune_us[f];
-    if (form) *form = A->ss.d_val ? (A->ss.deep ? 2 : 0) + (A->ss.nt ? 0 : 1) : -1;
+    if (form) *form = A->ss.dev.val ? (A->ss.deep ? 2 : 0) + (A->ss.nt ? 0 : 1) : -1;
     return MI_OK;
 }
 
 extern "C" int mi_sstream_plan_probe(int n, int ncols, const int* ptrow, const int* indcol, int* eligible, int* rounds, long long* steps, double* padding)
 {
+    return mi_sstream_plan_probe_ex(n, ncols, ptrow, indcol, 0, 0, 0, eligible, rounds, steps, padding, nullptr, nullptr);
+}
+
+extern "C" int mi_sstream_plan_probe_ex(int n, int ncols, const int* ptrow, const int* indcol, int shift, int ghost_lo, int ghost_hi, int* eligible, int* rounds,
+                                        long long* steps, double* padding, int* ghost_workgroups, int* rounds_min_max)
+{
     CHECK_ARG(n >= 0 && ncols >= 0 && ptrow && ptrow[0] == 0 && eligible, "bad argument");
+    CHECK_ARG(shift == 0 || shift == 1, "shift must be 0 or 1");
+    CHECK_ARG(ghost_lo >= 0 && ghost_hi <= ncols, "ghost range outside the columns");
     CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
     for (int i = 0; i < n; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
     for (int k = 0; k < ptrow[n]; k++) CHECK_ARG(indcol[k] >= 0 && indcol[k] < ncols, "column index outside [0, ncols)");
     SsPlanHost P;
-    build_sstream_plan(n, ncols, ptrow, indcol, kSsMaxPadding, P);
+    build_sstream_plan(n, ncols, ptrow, indcol, ss_max_padding(), P, true, shift, ghost_lo, ghost_hi);
     *eligible = P.eligible ? 1 : 0;
     if (rounds) *rounds = P.rounds;
     if (steps) *steps = P.steps;
     if (padding) *padding = ptrow[n] > 0 ? (double)P.pad_places / (double)ptrow[n] : 0.0;
+    if (ghost_workgroups) *ghost_workgroups = 0;
+    if (rounds_min_max) rounds_min_max[0] = rounds_min_max[1] = 0;
     if (!P.eligible) {
         g_err = std::string("not eligible: ") + P.why;
         return MI_OK;
     }
-    if (const char* bad = check_sstream_plan(P, n, ptrow, indcol)) return fail(MI_ERR_STATE, std::string("sliced-stream plan: ") + bad);
+    if (const char* bad = check_sstream_plan(P, n, ptrow, indcol, ghost_lo, ghost_hi)) return fail(MI_ERR_STATE, std::string("sliced-stream plan: ") + bad);
+    int gw = 0, rmin = 0x7fffffff, rmax = 0, rmax_ghost = 0;
+    for (int g = 0; g < P.nwg; g++) {
+        const int c = P.rptr[g + 1] - P.rptr[g];
+        gw += P.wg_halo[g];
+        rmin = std::min(rmin, c);
+        rmax = std::max(rmax, c);
+        if (P.wg_halo[g]) rmax_ghost = std::max(rmax_ghost, c);
+    }
+    // the dealing's promises: shares differ by at most one round (two with ghost slack in play), and a ghost-reading workgroup never
+    // carries the longest share when there is more than one round per workgroup to deal
+    if (rmax - rmin > (gw ? 1 + kSsGhostSlack : 1)) return fail(MI_ERR_STATE, "sliced-stream plan: the workgroups' shares differ by more than the dealing allows");
+    if (gw && gw < P.nwg && rmax > 1 && rmax_ghost >= rmax && P.rounds >= 2 * P.nwg) return fail(MI_ERR_STATE, "sliced-stream plan: a ghost-reading workgroup carries the longest share");
+    if (ghost_workgroups) *ghost_workgroups = gw;
+    if (rounds_min_max) { rounds_min_max[0] = rmin; rounds_min_max[1] = rmax; }
     return MI_OK;
 }
 
@@ -1630,8 +1683,18 @@ extern "C" int mi_csr_set_kernel(mi_csr_t A, int kernel_id)
     CHECK_ARG(A, "null handle");
     if (A->inner) A = A->inner;
     CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_SSTREAM, "unknown kernel id");
-    if (kernel_id == MI_KERNEL_SSTREAM && !A->ss.d_val)
-        return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_SSTREAM: the handle holds no sliced copy (the matrix is too small, pads too much, names ghost columns, or its rows do "
+    if (kernel_id == MI_KERNEL_SSTREAM && !A->ss.dev.val && A->nnz > 0 && A->d_indcol && !(getenv("MI355_SSTREAM") && !strcmp(getenv("MI355_SSTREAM"), "0"))) {
+        // not built at create (a small matrix) or released after losing the create-time measurement: built on request
+        int rc = need_device();
+        if (rc) return rc;
+        std::vector<int> back((size_t)A->nnz);
+        HIP_TRY(hipMemcpy(back.data(), A->d_indcol, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+        if ((rc = build_sstream(A, A->h_ptrow.data(), back.data(), A->ghost_lo, A->ghost_hi))) return rc;
+        A->ss.asked = true;
+        HIP_TRY(hipStreamSynchronize(nullptr)); // (the sliced values were filled on the null stream)
+    }
+    if (kernel_id == MI_KERNEL_SSTREAM && !A->ss.dev.val)
+        return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_SSTREAM: the handle holds no sliced copy (the matrix pads too much or its rows do "
                                         "not fit the sliding LDS window: mi_sstream_plan_probe says which)");
     if (kernel_id == MI_KERNEL_BCSR4 && !A->blocked)
         return fail(MI_ERR_UNSUPPORTED, "MI_KERNEL_BCSR4: this matrix has no exact 4x4 block structure (or is row-mapped)");

@@ -25,6 +25,7 @@
 #include "ring_plan.hpp"
 #include "spmv_kernels.hpp"
 #include "spmv_ring.hpp"
+#include "spmv_sstream.hpp"
 
 using namespace mi355;
 
@@ -123,21 +124,19 @@ struct TileTable {
     bool skew = false;                 // padded staging layout (see RingTable::skew)
 };
 
-// the sliced copy of the sliced-stream kernel (spmv_sstream.hpp); valid iff d_val != nullptr
+// the sliced copy of the sliced-stream kernel (spmv_sstream.hpp); valid iff dev.val != nullptr
 struct SstreamTable {
-    void* d_val = nullptr;        // ss_v2d [steps + pad][64]
-    unsigned* d_slot = nullptr;
-    int* d_wptr = nullptr;
-    int* d_rptr = nullptr;
-    int* d_win = nullptr;         // int2 per round
-    int* d_slice_step = nullptr;  // per slice (4 * round + wave): first step, steps — for value refills
-    int* d_slice_len = nullptr;
+    SsDevice dev;                 // values, slot stream, workgroup records, windows, slice tables (value refills), ghost marks
     int nwg = 0, rounds = 0;
+    int shift = 0;                // the rows are planned one down (an odd y offset: row pairs stay 16-byte aligned)
     long long steps = 0;
     double padding = 0.0;         // padded places per nonzero
+    int max_slice_nnz = 0;        // longest CSR segment of a slice (picks the refill kernel's LDS buffer)
     bool nt = true;               // non-temporal value loads (measured at create)
     bool deep = true;             // twelve steps of prefetch instead of eight (measured at create)
-    bool stale = false;           // the CSR values changed since the sliced values were filled: refilled on the next product's stream
+    bool asked = false;           // built because the environment or the caller asked for it: never released for losing a measurement
+    std::vector<int> h_wg_halo;   // a combined piece of the fused multi-GPU step: per workgroup, it reads ghost columns (empty otherwise)
+    std::vector<SsWg> h_wg;       // ... and its workgroup records (capi_part.hip writes the push links into them at connect time)
     double tune_us[4] = {0, 0, 0, 0}; // D = 8 nt, D = 8 temporal, D = 12 nt, D = 12 temporal
 };
 
@@ -151,12 +150,13 @@ struct mi_csr_s {
     int* d_rowmap = nullptr;
     bool mapped = false;  // created with a rowmap (device-only entry points, no powers)
     int y_offset = 0;     // a rowmap that is just "row r -> y[r + offset]" is applied as a pointer offset, not as a gather
+    int ghost_lo = 0, ghost_hi = 0; // ghost_lo < ghost_hi: a partition's combined piece, columns outside [ghost_lo, ghost_hi) are ghosts
     std::vector<int> h_ptrow; // kept to (re)build row-block tables
     std::map<int, BlockTable> tables;
     RingTable ring;           // valid iff ring.d_plan != nullptr
     TileTable tile;           // valid iff tile.d_desc != nullptr
     double tune_us_tile = 0.0, tune_us_tile_nt = 0.0;
-    SstreamTable ss;          // valid iff ss.d_val != nullptr
+    SstreamTable ss;          // valid iff ss.dev.val != nullptr
     MringTable mring;         // valid iff mring.d_plan != nullptr
     double tune_us_mring = 0.0, tune_us_mring_nt = 0.0;
     int kernel = MI_KERNEL_AUTO;
@@ -233,7 +233,6 @@ struct mi_bcsr4_s {
     int* d_sell_wrng2 = nullptr; // ... and [sell_nwaves2 + 1] for two (2048)
     int sell_nslices = 0, sell_nwaves = 0, sell_nwaves2 = 0;
     long long sell_nsteps = 0;
-    bool sell_stale = false;  // d_coef changed since the sliced copy was filled: refilled on the next product's stream
     int sell_form = -1;       // -1: not in use; else the variant the create-time measurement kept (kSellForms, capi_bcsr.hip)
     double tune_us_sell[4] = {0, 0, 0, 0};
     // x tiles of the multi-vector product (spmm_tile.hpp): lists per group of 128 block rows (st) and of 64 (st64: the eight-column
@@ -297,6 +296,7 @@ struct mi_part_s {
     // the one-launch form of the push step (spmv_ring.hpp, FUSED): all local rows in one ring-served, row-mapped piece
     mi_csr_t piece_all = nullptr;
     int* d_run_link = nullptr; // per run of piece_all: first push link it serves, or -1
+    const int* d_run_halo = nullptr; // per run (ring) / workgroup (sliced stream) of piece_all: it reads ghosts (owned by piece_all)
     int npush_runs = 0;
     bool fused = false;
     bool fused_bcsr = false;   // piece_all is served by the BCSR kernel: spmv_bcsr4_fused
@@ -359,9 +359,12 @@ hipError_t spmm_otile_launch(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const 
 int part_push_window(mi_part_s* P);
 void part_push_layout(const mi_part_s* P, long long* layout /* [2*nranks + 1] */);
 int part_push_connect_bases(mi_part_s* P, void* const* bases /* [nranks] */, const long long* layouts);
-// capi_csr.hip: the sliced-stream kernel of a handle (spmv_sstream.hpp)
-int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s);
+// capi_csr.hip: the sliced-stream kernel of a handle (spmv_sstream.hpp); d_y: where the handle's row 0 goes (unmapped) or the mapped vector's base;
+// comm: the fused multi-GPU step (the handle is a partition's combined piece with ghost marks)
+int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s, const RingComm* comm = nullptr);
+// the sliced-stream kernel can write this y (row pairs as 16 bytes; a mapped handle stores row by row)
+static inline bool sstream_y_ok(const mi_csr_s* A, const double* yy, const int* map) { return map || (((uintptr_t)(yy - A->ss.shift)) & 15) == 0; }
 // capi_bcsr.hip
-// the blocked copy's values were rewritten (by whoever holds d_coef): the sliced copy follows on the next product
-static inline void bcsr4_values_changed(mi_bcsr4_s* A) { if (A && A->d_sell_val) A->sell_stale = true; }
+// the blocked copy's values were rewritten on stream s (by whoever holds d_coef): the sliced copy follows at once, on the same stream
+int bcsr4_values_changed(mi_bcsr4_s* A, hipStream_t s);
 int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);

@@ -268,6 +268,14 @@ extern "C" int mi_part_combined_info(mi_part_t P, int* n_left)
     return MI_OK;
 }
 
+// 1 when every send list is a run of consecutive local ids (banded partitions): the RCCL step sends slices of x in place, no pack kernel
+extern "C" int mi_part_sends_contiguous(mi_part_t P, int* contiguous)
+{
+    CHECK_ARG(P && contiguous, "null argument");
+    *contiguous = P->plan.sends_set && P->plan.sends_contiguous ? 1 : 0;
+    return MI_OK;
+}
+
 extern "C" int mi_part_send_index(mi_part_t P, int* total, const int** local_idx)
 {
     CHECK_ARG(P, "null handle");
@@ -290,6 +298,7 @@ extern "C" int mi_part_finalize(mi_part_t P)
         rc = mi_csr_create_mapped((int)L.rowmap.size(), ncols, L.ptrow.data(), L.indcol.data(), L.coef.data(),
                                   L.rowmap.data(), &P->piece[w]);
         if (rc) return rc;
+        if (P->kernel == MI_KERNEL_SSTREAM) (void)mi_csr_set_kernel(P->piece[w], P->kernel); // builds the sliced copy where the piece is eligible
         P->piece[w]->kernel = P->kernel;
     }
     const size_t ns = P->plan.send_idx.size();
@@ -642,22 +651,34 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
         if (rc) return rc;
         mi_csr_t A = P->piece_all;
         if (P->kernel != MI_KERNEL_AUTO && P->kernel != MI_KERNEL_RING) A->kernel = P->kernel;
-        // Where the ring serves the combined piece it is taken even if another kernel measured a hair faster on this rank: the
-        // one-launch step saves three launches, and it only happens if EVERY rank has it (mi_part_push_unfuse) — a rank whose
-        // create-time measurement tipped the other way by noise would cost all of them the fused step.
-        if (P->kernel == MI_KERNEL_AUTO && A->ring.d_plan && A->ring.d_run_halo && A->ring.ok_fraction >= 0.90 && !A->blocked)
-            A->kernel = MI_KERNEL_RING;
-        P->fused = resolve_kernel(A) == MI_KERNEL_RING && A->ring.d_run_halo;
-        if (P->fused) { // push duty goes to the ghost-touching runs (short by construction): link l to the (l mod k)-th of them
-            std::vector<int> link((size_t)A->ring.wgs, -1);
+        // Which kernel carries the one-launch step.  Since round 5 the sliced stream (spmv_sstream_fused) wherever the combined piece
+        // holds its plan — the kernel of the single-GPU headline; a rank's share of C4 at N = 8: NOTES R5 — else the ring kernel's FUSED
+        // form.  Taken even if another kernel measured a hair faster on this rank: the one-launch step saves three launches, and it only
+        // happens if EVERY rank has it (mi_part_push_unfuse) — a rank whose create-time measurement tipped the other way by noise would
+        // cost all of them the fused step.  MI355_PUSH_FUSED_KERNEL=ring|sstream forces (A/B).
+        const char* fk = getenv("MI355_PUSH_FUSED_KERNEL");
+        const bool ss_ok = A->ss.dev.val && !A->ss.h_wg_halo.empty() && !A->blocked && !(fk && !strcmp(fk, "ring"));
+        const bool ring_ok = A->ring.d_plan && A->ring.d_run_halo && A->ring.ok_fraction >= 0.90 && !A->blocked && !(fk && !strcmp(fk, "sstream"));
+        if (P->kernel == MI_KERNEL_AUTO && ss_ok) A->kernel = MI_KERNEL_SSTREAM;
+        else if ((P->kernel == MI_KERNEL_AUTO || P->kernel == MI_KERNEL_RING) && ring_ok) A->kernel = MI_KERNEL_RING;
+        const bool by_ss = resolve_kernel(A) == MI_KERNEL_SSTREAM && ss_ok;
+        P->fused = by_ss || (resolve_kernel(A) == MI_KERNEL_RING && A->ring.d_run_halo);
+        if (P->fused) { // push duty goes to the ghost-touching runs / workgroups (short by construction): link l to the (l mod k)-th of them
+            const std::vector<int>& marks = by_ss ? A->ss.h_wg_halo : A->ring.h_run_halo;
+            P->d_run_halo = by_ss ? A->ss.dev.wg_halo : A->ring.d_run_halo;
+            std::vector<int> link(marks.size(), -1);
             int k = 0;
-            for (int g = 0; g < A->ring.wgs && k < P->n_links; g++)
-                if (A->ring.h_run_halo[g]) link[g] = k++;
+            for (size_t g = 0; g < marks.size() && k < P->n_links; g++)
+                if (marks[g]) link[g] = k++;
             P->npush_runs = k; // 0: no ghost runs in the plan -> dedicated push workgroups in front of the grid
             P->ghost_readers = false;
-            for (int v : A->ring.h_run_halo) P->ghost_readers = P->ghost_readers || v != 0;
-            HIP_TRY(hipMalloc(&P->d_run_link, sizeof(int) * link.size()));
+            for (int v : marks) P->ghost_readers = P->ghost_readers || v != 0;
+            HIP_TRY(hipMalloc(&P->d_run_link, sizeof(int) * std::max<size_t>(link.size(), 1)));
             HIP_TRY(hipMemcpy(P->d_run_link, link.data(), sizeof(int) * link.size(), hipMemcpyHostToDevice));
+            if (by_ss) { // the sliced stream reads its link out of the workgroup's record (one scalar load for the whole prologue)
+                for (size_t g = 0; g < link.size(); g++) A->ss.h_wg[g].link = link[g];
+                HIP_TRY(hipMemcpy(A->ss.dev.wg, A->ss.h_wg.data(), sizeof(SsWg) * A->ss.h_wg.size(), hipMemcpyHostToDevice));
+            }
         }
         // (only while the halo is small: the fused kernel reads ghosts straight from the UNCACHED window, every use of them, and
         // pushes through two workgroups — with an FE slab's boundary planes, 39 k ghosts for 163 k rows at N = 8, that made the
@@ -744,6 +765,20 @@ extern "C" int mi_part_push_unfuse(mi_part_t P)
     return MI_OK;
 }
 
+// the kernel a piece's products launch: which = 0 interior rows, 1 boundary rows, 2 the combined piece of the one-launch push step ("" if none)
+extern "C" const char* mi_part_kernel_name(mi_part_t P, int which)
+{
+    if (!P || which < 0 || which > 2) return "";
+    if (which < 2) return P->piece[which] ? mi_csr_kernel_name(P->piece[which]) : "";
+    if (!P->fused || !P->piece_all) return "";
+    if (P->fused_bcsr) return "spmv_bcsr4_fused";
+    static thread_local char nm[160];
+    const char* base = mi_csr_kernel_name(P->piece_all);
+    if (resolve_kernel(P->piece_all) == MI_KERNEL_SSTREAM) snprintf(nm, sizeof nm, "spmv_sstream_fused<%d, %s>", P->piece_all->ss.deep ? 12 : 8, P->piece_all->ss.nt ? "true" : "false");
+    else snprintf(nm, sizeof nm, "%s [FUSED]", base);
+    return nm;
+}
+
 extern "C" int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours)
 {
     CHECK_ARG(P, "null handle");
@@ -777,7 +812,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.flags = P->win_flags;
         C.nb = P->d_nb;
         C.halo = P->win_data + (size_t)(step & 1u) * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1);
-        C.run_halo = P->piece_all->ring.d_run_halo;
+        C.run_halo = P->d_run_halo;
         C.timeouts = P->d_timeouts;
         C.n_links = P->n_links;
         C.n_nb = P->n_nb;
@@ -849,10 +884,13 @@ extern "C" int mi_part_update_values(mi_part_t P, const double* coef)
 extern "C" int mi_part_set_kernel(mi_part_t P, int kernel_id)
 {
     CHECK_ARG(P, "null handle");
-    CHECK_ARG(kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_ROWPAR, "unknown kernel id");
+    CHECK_ARG((kernel_id >= MI_KERNEL_AUTO && kernel_id <= MI_KERNEL_ROWPAR) || kernel_id == MI_KERNEL_SSTREAM, "unknown kernel id (a partition takes AUTO, STREAM, RING, ROWPAR, SSTREAM)");
     P->kernel = kernel_id;
     for (int w = 0; w < 2; w++)
-        if (P->piece[w]) P->piece[w]->kernel = kernel_id;
+        if (P->piece[w]) { // (a piece that holds no sliced copy — too few rows, ragged — keeps its next-best kernel: resolve_kernel)
+            if (kernel_id == MI_KERNEL_SSTREAM) (void)mi_csr_set_kernel(P->piece[w], kernel_id);
+            P->piece[w]->kernel = kernel_id;
+        }
     return MI_OK;
 }
 

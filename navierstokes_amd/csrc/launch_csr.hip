@@ -41,8 +41,9 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
     if (A->n == 0) return MI_OK;
     // The fused multi-GPU step hands over a RingComm: its piece is numbered [ghosts | owned | ghosts], which only the ring
     // kernel's FUSED instantiation understands.  Any other launch would index x with that numbering — refuse, never drop it.
-    if (comm && (A->inner || A->d_rowmap || resolve_kernel(A) != MI_KERNEL_RING))
-        return fail(MI_ERR_STATE, "fused multi-GPU step: the combined piece must be an unmapped, unreordered, ring-served handle");
+    const bool ss_fused = comm && resolve_kernel(A) == MI_KERNEL_SSTREAM && !A->ss.h_wg_halo.empty();
+    if (comm && (A->inner || A->d_rowmap || (resolve_kernel(A) != MI_KERNEL_RING && !ss_fused)))
+        return fail(MI_ERR_STATE, "fused multi-GPU step: the combined piece must be an unmapped, unreordered handle served by the ring or the sliced-stream kernel");
     if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map
         double* xp = nullptr;
         int rc = reorder_scratch(A, s, &xp);
@@ -53,13 +54,14 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
         return launch_spmv(A->inner, xp, d_y, s, true);
     }
     int kid = resolve_kernel(A);
-    if (kid == MI_KERNEL_SSTREAM && !comm && !dot) {
+    if (kid == MI_KERNEL_SSTREAM && !dot && (!comm || ss_fused)) {
         const int* map = use_map ? A->d_rowmap : nullptr;
         double* yy = d_y + (use_map ? A->y_offset : 0);
-        if (map || (((uintptr_t)yy) & 15) == 0) return launch_sstream(A, d_x, yy, map, s);
-        kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // y only 8-byte aligned: the sliced kernel stores row pairs
+        if (sstream_y_ok(A, yy, map)) return launch_sstream(A, d_x, yy, map, s, comm);
+        if (comm) return fail(MI_ERR_ARG, "fused multi-GPU step: y must be 16-byte aligned");
+        kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // y's row pairs are not 16-byte aligned: the sliced kernel stores them whole
     } else if (kid == MI_KERNEL_SSTREAM) {
-        kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // (the fused multi-GPU step and the dot epilogue live in the ring kernel; the sliced stream's own epilogue measured
+        kid = A->ring.d_plan && A->ring.ok_fraction >= 0.90 ? MI_KERNEL_RING : MI_KERNEL_STREAM; // (the dot epilogue lives in the ring kernel; the sliced stream's own epilogue measured
         // slower than product + separate dot: profiles/NOTES.md R4.4)
     }
     if (use_map) d_y += A->y_offset;

@@ -81,6 +81,7 @@ def lib():
         "mi_part_push_connect": [_vp, _vp, _vp],
         "mi_part_spmv_push_dev": [_vp, _vp, _vp, _vp],
         "mi_part_push_info": [_vp, P(i), P(i), P(i)],
+        "mi_part_sends_contiguous": [_vp, P(i)],
         "mi_part_combined_info": [_vp, P(i)],
         "mi_part_push_disable": [_vp],
         "mi_part_push_unfuse": [_vp],
@@ -113,6 +114,7 @@ def lib():
         "mi_csr_mring_info": [_vp, P(i), P(i), P(i), P(d), P(d), P(i)],
         "mi_csr_sstream_info": [_vp, P(i), P(i), P(ll), P(d), P(d), P(i)],
         "mi_sstream_plan_probe": [i, i, _vp, _vp, P(i), P(i), P(ll), P(d)],
+        "mi_sstream_plan_probe_ex": [i, i, _vp, _vp, i, i, i, P(i), P(i), P(ll), P(d), P(i), P(i)],
         "mi_csr_placement_info": [_vp, P(i), P(i), P(d), i],
         "mi_vec_alloc_placed": [_vp, i, i, P(_vp), P(d), i, P(i)],
         "mi_vec_free_placed": [_vp],
@@ -201,6 +203,8 @@ def lib():
     for name in ("mi_dist_exchange_name", "mi_dist_exchange_note"):
         getattr(L, name).argtypes = [_vp]
         getattr(L, name).restype = _c.c_char_p
+    L.mi_part_kernel_name.argtypes = [_vp, i]
+    L.mi_part_kernel_name.restype = _c.c_char_p
     # diagnostics of include/mi355_devtools.h: present only in libmi355spmv_dev.so (`make devtools`; tools/ load it through
     # MI355_SPMV_LIBRARY), never in the product library
     for name, argt in {"mi_debug_xcc_map": [i, _vp], "mi_debug_touch_pages": [_vp, i, _vp, ll, _vp, ll],

@@ -48,7 +48,7 @@ def main():
     def mark(what):  # stage markers for a post-mortem of a stalled rank (MI355_TEST_TRACE=1)
         if trace:
             print(f"[rank {rank}] {what}", file=sys.stderr, flush=True)
-    for kernel in (None, "ring", "stream"):
+    for kernel in (None, "ring", "stream", "sstream"):
         mark(f"kernel={kernel}: create")
         dc = D.DistCSR(rs, p, c, v, kernel=kernel, exchange=exchange)
         mark(f"kernel={kernel}: created push={dc.push} fused={dc.push_fused} n_halo={dc.n_halo}")

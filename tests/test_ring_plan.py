@@ -224,3 +224,44 @@ def test_sliced_stream_plan_is_replayed_on_the_host():
     p, c, v = synth.rows("svar", 200_000, w=2000)  # 8..22 nonzeros per row: a slice pads to its longest row
     e, _, _, pad, why = probe(p, c, 200_000)
     assert e == 0 and "padding" in why and pad > 0.12, (pad, why)
+
+
+def test_sliced_stream_plan_with_a_row_shift_and_with_ghost_columns(monkeypatch):
+    """Round 5: the two forms a partition's pieces take (mi_sstream_plan_probe_ex builds them as mi_csr_create_mapped / the fused step's
+    combined piece would and replays them on the host).  shift = 1: the rows are planned one down (view row 0 does not exist) so that a
+    piece whose rows go to y[r + odd offset] keeps 16-byte row pairs.  Ghost columns ([lower ghosts | owned | upper ghosts] numbering of
+    partition.hpp: build_combined): every workgroup that names one is marked, the marked ones get a round less than their share, and the
+    shares differ by at most two rounds."""
+    import ctypes
+    L = mpk.lib()
+    monkeypatch.setenv("MI355_SSTREAM_MAX_PADDING", "1e9")  # (a few hundred rows: the one row a shift pushes into a slice of its own is all padding)
+
+    def probe(n, ncols, p, c, shift=0, glo=0, ghi=0):
+        e, r, gw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        st, pad = ctypes.c_longlong(), ctypes.c_double()
+        mm = (ctypes.c_int * 2)()
+        mpk.check(L.mi_sstream_plan_probe_ex(n, ncols, p.ctypes.data, c.ctypes.data, shift, glo, ghi, ctypes.byref(e), ctypes.byref(r), ctypes.byref(st),
+                                             ctypes.byref(pad), ctypes.byref(gw), mm))
+        return e.value, r.value, st.value, pad.value, gw.value, (mm[0], mm[1])
+
+    for n, w in ((70_001, 900), (3_000, 300), (1_001, 20), (511, 30), (512, 30), (513, 30), (300_000, 2000)):
+        p, c, _ = synth.rows("s15", n, w=w)
+        e0, r0, st0, pad0, _, _ = probe(n, n, p, c)
+        e1, r1, st1, pad1, _, _ = probe(n, n, p, c, shift=1)
+        assert e0 == 1 and e1 == 1, (n, w)
+        assert r1 == (n + 1 + 511) // 512 and r0 == (n + 511) // 512
+        assert st1 >= st0 - 15 and st1 <= st0 + 15 * 4, (st0, st1)  # the same rows, at most one slice more
+    # one rank's share of a band: rows [lo, hi) of a global band, columns renumbered [lower ghosts | owned | upper ghosts]
+    for nglob, lo, hi, w in ((400_000, 100_000, 200_000, 2000), (400_000, 0, 150_000, 2000), (400_000, 250_000, 400_000, 2000), (60_000, 20_000, 40_000, 300)):
+        p, c, _ = synth.rows("s15", nglob, lo, hi, w=w)
+        glo, ghi = max(0, lo - w), min(nglob, hi + w)  # whole ranges, as the partition's dense halo takes them
+        cl = (c - glo).astype(np.int32)
+        n, ncols = hi - lo, ghi - glo
+        e, r, st, pad, gw, (rmin, rmax) = probe(n, ncols, p, cl, 0, lo - glo, lo - glo + n)
+        assert e == 1, (nglob, lo, hi)
+        expect = (1 if lo > 0 else 0) + (1 if hi < nglob else 0)
+        per_side = -(-w // (max(rmin, 1) * 512)) + 1  # workgroups whose rows lie within w of a cut (a share is at least rmin rounds of 512 rows)
+        assert gw >= expect and gw <= expect * per_side, (gw, expect, per_side, rmin, rmax)
+        assert rmax - rmin <= 2
+        e2, _, _, _, gw2, _ = probe(n, ncols, p, cl)  # no ghost range given: nothing marked
+        assert e2 == 1 and gw2 == 0

@@ -1,12 +1,12 @@
 #!/bin/bash
-# round 4: every bench line README / DESIGN quote, one box, one after the other -> gpurun_out/r4_final_lines.jsonl
+# every bench line README / DESIGN quote, one box, one after the other -> gpurun_out/final_lines.jsonl (committed as profiles/rNN_bench_lines.jsonl)
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
-out=gpurun_out/r4_final_lines.jsonl; : > $out
+out=gpurun_out/final_lines.jsonl; : > $out
 run() { # args of bench.py
-  timeout -k 10 400 python3 bench.py "$@" > gpurun_out/r4_final_one.log 2>&1
+  timeout -k 10 400 python3 bench.py "$@" > gpurun_out/final_one.log 2>&1
   rc=$?
-  grep -h '^{"metric"' gpurun_out/r4_final_one.log >> $out
+  grep -h '^{"metric"' gpurun_out/final_one.log >> $out
   echo "bench.py $* -> rc=$rc ($(grep -c . $out) lines)"
   [ $rc -ge 124 ] && exit $rc
   return 0
@@ -24,4 +24,4 @@ run --workload c2_perm --internal
 run --workload fe_perm
 run --workload mesh_perm --internal
 run --cold --steps 30 --warmup 3 --no-cpu-baseline
-echo R4_FINAL_DONE
+echo FINAL_DONE

@@ -1,0 +1,32 @@
+#!/bin/bash
+# tools/r5_run.sh — steps of one gpurun call (round 5).  Each step logs under gpurun_out/; a step that times out or is killed
+# (rc >= 124) ends the script: no further GPU step is started behind it.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+step() { # name timeout cmd...
+  local name=$1 to=$2; shift 2
+  echo "=== $name ($(date +%T))"
+  timeout -k 10 "$to" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "=== $name rc=$rc"
+  tail -n "${TAILN:-12}" "gpurun_out/$name.log" | cut -c1-1800
+  if [ $rc -ge 124 ]; then echo "step $name timed out / was killed: stopping"; exit $rc; fi
+  return 0
+}
+for s in "$@"; do
+  case $s in
+    sim)      step r5_sim8 300 python tools/sim_rank.py 8 1 && step r5_sim4 300 python tools/sim_rank.py 4 1 && step r5_sim2 300 python tools/sim_rank.py 2 1 ;;
+    sim8prof) rm -rf gpurun_out/r5_sim8prof; step r5_sim8prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5_sim8prof -- python tools/sim_rank.py 8 1 && (find gpurun_out/r5_sim8prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r5_sim8_kernel_stats.csv; rm -rf gpurun_out/r5_sim8prof; head -12 gpurun_out/r5_sim8_kernel_stats.csv | cut -c1-200) ;;
+    sim8)     step r5_sim8 300 python tools/sim_rank.py 8 1 ;;
+    tests)    step r5_tests 1100 python -m pytest tests -x -q -m gpu ;;
+    smoke)    step r5_smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench)    step r5_bench_c4 300 python bench.py ;;
+    bench_c2) step r5_bench_c2 200 python bench.py --workload c2 --no-cpu-baseline ;;
+    bench_c3) step r5_bench_c3 200 python bench.py --workload c3 --no-cpu-baseline ;;
+    trace)    step r5_trace_c2 200 ./tools/sstream_trace 1000000 && step r5_trace_r8 200 ./tools/sstream_trace 625000 ;;
+    t_ss)     step r5_t_ss 1100 python -m pytest tests/test_gpu_parity.py tests/test_reorder_gpu.py -x -q -m gpu -k "sliced_stream or golden or graph_replay or sliced_copy or ranks_sharing_one_card or native_step or relabelled or pipeline or random_patterns" ;;
+    t_new)    step r5_t_new 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden or graph_replay or sliced_stream or sliced_copy" ;;
+    *) echo "unknown step $s"; exit 2 ;;
+  esac
+done

@@ -46,8 +46,11 @@ x_ext = torch.from_numpy(xe).cuda()
 y = torch.full((nl.value,), float("nan"), dtype=torch.float64, device="cuda")
 send = torch.empty(int(rc.sum()) + 1, dtype=torch.float64, device="cuda")
 sp = mpk._stream_ptr(); vp = ctypes.c_void_p
-def step():
-    mpk.check(L.mi_part_pack_dev(h, vp(x_ext.data_ptr()), vp(send.data_ptr()), sp))
+contig = ctypes.c_int()
+mpk.check(L.mi_part_sends_contiguous(h, ctypes.byref(contig)))
+def step():  # the RCCL-shaped route on ONE stream: [pack ->] interior -> boundary (in the real step the boundary rows run on the comm stream beside the interior rows)
+    if not contig.value:  # a banded partition's send lists are slices of x, sent in place (mi_part_spmv_dev: enqueue_exchange(d_x_direct)): no pack launch
+        mpk.check(L.mi_part_pack_dev(h, vp(x_ext.data_ptr()), vp(send.data_ptr()), sp))
     mpk.check(L.mi_part_spmv_interior_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp))
     mpk.check(L.mi_part_spmv_boundary_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp))
 for _ in range(20): step()
@@ -97,6 +100,7 @@ e1.record(); torch.cuda.synchronize()
 pwall = (time.perf_counter() - t0) / 500 * 1e6
 mpk.check(L.mi_part_status(h))
 fz = ctypes.c_int(); mpk.check(L.mi_part_push_info(h, None, ctypes.byref(fz), None))
+print(f"    kernels: interior {L.mi_part_kernel_name(h, 0).decode()} | boundary {L.mi_part_kernel_name(h, 1).decode()} | one-launch step {L.mi_part_kernel_name(h, 2).decode() or '-'}")
 print(f"    push step ({'ONE launch (fused)' if fz.value else 'push, interior, wait+copy, boundary'}; flags preset, pushes looped back): GPU {e0.elapsed_time(e1) / 500 * 1e3:.1f} us/step, "
       f"host {pwall:.1f} us/step to enqueue")
 x_ext[nl.value:] = halo_keep   # the looped-back window content is not this rank's true halo: restore it for the check below
@@ -104,4 +108,4 @@ y.fill_(float("nan")); step(); torch.cuda.synchronize()
 cl = np.where((c >= lo) & (c < hi), c - lo, nl.value + np.searchsorted(halo_ids, c)).astype(np.int32)
 ok = np.array_equal(O.spmv(p, cl, v, xe).view(np.uint64), y.cpu().numpy().view(np.uint64))
 print(f"N={N} rank={rank} rows={nl.value} halo={nh.value} interior={ni.value} boundary={nb.value}: "
-      f"pack+interior+boundary GPU {gpu_step_us:.1f} us/step, host wall {wall:.1f} us/step, bitwise={ok}")
+      f"{'interior+boundary (sends are slices of x: no pack)' if contig.value else 'pack+interior+boundary'} GPU {gpu_step_us:.1f} us/step, host wall {wall:.1f} us/step, bitwise={ok}")

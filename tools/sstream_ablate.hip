@@ -61,31 +61,15 @@ int main(int argc, char** argv)
     build_sstream_plan(n, n, ptrow.data(), indcol.data(), 0.12, P);
     printf("n %d nnz %lld  eligible %d (%s)  workgroups %d rounds %d steps %lld\n", n, nnz, (int)P.eligible, P.why, P.nwg, P.rounds, P.steps);
     if (!P.eligible) return 1;
-    int *d_ptrow, *d_wptr, *d_rptr, *d_ss, *d_sl;
-    int2* d_win;
-    unsigned* d_slot;
+    int* d_ptrow;
     double *d_coef, *d_x, *d_y;
-    ss_v2d* d_val;
     CK(hipMalloc(&d_ptrow, sizeof(int) * (n + 1)));
     CK(hipMemcpy(d_ptrow, ptrow.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_coef, sizeof(double) * nnz));
     CK(hipMemcpy(d_coef, coef.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_val, sizeof(ss_v2d) * (size_t)(P.steps + kSsPadSteps) * 64));
-    CK(hipMemset(d_val, 0, sizeof(ss_v2d) * (size_t)(P.steps + kSsPadSteps) * 64));
-    CK(hipMalloc(&d_slot, sizeof(unsigned) * P.slot.size()));
-    CK(hipMemcpy(d_slot, P.slot.data(), sizeof(unsigned) * P.slot.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_wptr, sizeof(int) * P.wptr.size()));
-    CK(hipMemcpy(d_wptr, P.wptr.data(), sizeof(int) * P.wptr.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_rptr, sizeof(int) * P.rptr.size()));
-    CK(hipMemcpy(d_rptr, P.rptr.data(), sizeof(int) * P.rptr.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_win, sizeof(int2) * P.win.size()));
-    CK(hipMemcpy(d_win, P.win.data(), sizeof(int2) * P.win.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_ss, sizeof(int) * P.slice_step.size()));
-    CK(hipMemcpy(d_ss, P.slice_step.data(), sizeof(int) * P.slice_step.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_sl, sizeof(int) * P.slice_len.size()));
-    CK(hipMemcpy(d_sl, P.slice_len.data(), sizeof(int) * P.slice_len.size(), hipMemcpyHostToDevice));
-    const int nslices = 4 * P.rounds;
-    hipLaunchKernelGGL(csr_to_sstream_kernel, dim3((unsigned)std::min(nslices, 16384)), dim3(64), 0, nullptr, nslices, n, d_ptrow, d_coef, d_ss, d_sl, d_val);
+    SsDevice Dv;
+    CK(ss_upload(P, Dv, false));
+    sstream_fill_values(P.rounds, n, 0, d_ptrow, d_coef, nullptr, Dv.slice_step, Dv.slice_len, Dv.val, P.max_slice_nnz, nullptr);
     CK(hipGetLastError());
     std::vector<double> hx(n), href(n);
     for (int i = 0; i < n; i++) hx[i] = sin(0.001 * i);
@@ -97,7 +81,7 @@ int main(int argc, char** argv)
     CK(hipMalloc(&d_x, sizeof(double) * n));
     CK(hipMemcpy(d_x, hx.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_y, sizeof(double) * (n + 2)));
-    SsView S{d_val, d_slot, d_wptr, d_rptr, d_win, P.nwg, n, n, nullptr};
+    SsView S{Dv.val, Dv.slot, Dv.wg, Dv.win, P.nwg, n, n, nullptr, 0};
     const double B = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     auto line = [&](const char* name, double us) { printf("%-56s %8.2f us   %6.0f GB/s algorithmic  (%.3f of 8 TB/s)\n", name, us, B / us / 1e3, B / us / 1e3 / 8000); fflush(stdout); };
     const int R = 50;
