@@ -26,6 +26,10 @@ int mi_debug_move_array(mi_csr_t A, int which, int how, unsigned long long* old_
 /* run-length experiments on one placement (tools/mring_skew_ab.py): re-plan the handle's multi-window ring kernel with runs alternately
  * skew_pct per cent longer / shorter (the longer dispatched to the older workgroup of every CU) INTO the device arrays it already has */
 int mi_debug_mring_replan(mi_csr_t A, int skew_pct, int* table_len, int* longest_run);
+/* timeline of ONE one-launch push step through the sliced stream (spmv_sstream_fused with its s_memrealtime stamps compiled in, D = 8,
+ * temporal; the MI355_PUSH_LOOPBACK arrangement of tools/sim_rank.py): host_out[4 * g + {0, 1, 2, 3}] = logical workgroup g's start, loop
+ * begin, loop end, end (100 MHz ticks); halo_out[g] = (reads ghosts) + 2 * (pushes) + 4 * rounds. */
+int mi_debug_part_push_trace(mi_part_t P, double* d_x_ext, double* d_y_local, int max_wgs, long long* host_out, int* wgs_out, int* halo_out);
 /* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
 int mi_part_push_debug_preset(mi_part_t P, unsigned value);
 

@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 400 /* 0.4.0 */
+#define MI355_SPMV_VERSION 500 /* 0.5.0: mi_bcsr4_spmm_info writes us[5] since 0.4 (it was us[4] in 0.3: a caller built against 0.3 must be rebuilt); 0.5 adds
+                                * mi_sstream_plan_probe_ex, mi_part_kernel_name, mi_part_sends_contiguous and refills sliced copies inside mi_*_update_values* */
 
 enum {
     MI_OK = 0,
@@ -360,8 +361,8 @@ int mi_bcsr4_tile_info(mi_bcsr4_t A, int* built, int* in_use, double* us_plain, 
  * (non-temporal where that measures faster) that never look at a row boundary; a slice's sums are parked in LDS and stored behind the
  * wave's last load (a store issued among the loads costs the read stream many times its bytes).  Same lanes per row, same fma order,
  * same bits.  Four variants are timed against the two forms above at create and the fastest of all runs (MI355_BCSR_SELL=0 never builds
- * it, =1 takes variant 0 unmeasured, MI355_BCSR_SELL_FORM=0..3 a given one).  Unmapped products only: the blocked copy of a relabelled
- * matrix keeps the forms above.  *form_in_use: -1 none; 0 one wave per SIMD, eight steps of prefetch, non-temporal value loads; 1 the
+ * it, =1 takes variant 0 unmeasured, MI355_BCSR_SELL_FORM=0..3 a given one).  The blocked copy of a relabelled matrix runs it too (a node's
+ * four sums leave through the block-row map).  The sliced values follow mi_bcsr4_update_values* at once, on that call's stream.  *form_in_use: -1 none; 0 one wave per SIMD, eight steps of prefetch, non-temporal value loads; 1 the
  * same with temporal loads; 2 two waves per SIMD (one workgroup of eight waves per CU), four steps, non-temporal; 3 as 0 with twelve steps;
  * *padding = padded places / blocks - 1; us[f] = microseconds per launch measured for variant f (0: not measured). */
 int mi_bcsr4_sell_info(mi_bcsr4_t A, int* built, int* form_in_use, long long* steps, double* padding, double us[4]);

@@ -186,6 +186,31 @@ __global__ __launch_bounds__(kRedWG) void ortho_update_kernel(int n, double alph
     }
 }
 
+// The same update for a vector spread over several ranks (mi_dist_orthogonalize*, capi_dist.hip): beta = the ranks' partial dots added
+// in RANK ORDER — what the host did with them until round 4, between two stream synchronisations — by every workgroup itself (the
+// same <= 64 numbers in the same order: the same bits everywhere, on every rank), then out = fma(-(alpha beta), b, x1) on this rank's
+// slice.  `parts` may live in pinned host memory (the event / push exchanges) or be the result of an ncclAllGather (the RCCL exchange).
+template <bool NT>
+__global__ __launch_bounds__(kRedWG) void ortho_update_ranks_kernel(int n, double alpha, int nparts, const double* parts, double* __restrict__ beta_out,
+                                                                    const double* __restrict__ b, const double* x1, double* out)
+{
+    __shared__ double s_beta;
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int r = 0; r < nparts; r++) t += __hip_atomic_load(parts + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (never from a stale cache line)
+        s_beta = t;
+        if (blockIdx.x == 0 && beta_out) beta_out[0] = t;
+    }
+    __syncthreads();
+    const double nab = -__dmul_rn(alpha, s_beta);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = fma(nab, ld1_stream<NT>(b + i), ld1_stream<NT>(x1 + i));
+        if (NT) __builtin_nontemporal_store(v, out + i);
+        else out[i] = v;
+    }
+}
+
 // One step of orthonormalize_against_basis (mpk/2SpMV.cpp:13-28), fused with the NEXT step's dot:
 //   d = sum of partial_in (fixed tree) = y . v;  y <- fma(-d, v, y);  partial_out[g] = (y_new . v_next) over segment g
 // so that a sweep against m vectors is m + 1 launches and reads y once per vector instead of twice

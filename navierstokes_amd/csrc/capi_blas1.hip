@@ -114,6 +114,20 @@ extern "C" int mi_orthogonalize_dev(int n, const double* d_b, const double* d_x1
     return MI_OK;
 }
 
+// the update of a distributed orthogonalize on one rank's slice: beta = sum of the ranks' partial dots in rank order (capi_dist.hip)
+int ortho_update_from_parts(int n, int nparts, const double* parts, double alpha, const double* d_b, const double* d_x1, double* d_x3, double* d_beta_out,
+                            hipStream_t s)
+{
+    CHECK_ARG(n >= 0 && nparts >= 1 && nparts <= 64 && parts, "bad argument");
+    CHECK_ARG(n == 0 || (d_b && d_x1 && d_x3), "null vector");
+    int grid = (n + kRedWG - 1) / kRedWG;
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+    if (blas1_nt(n)) hipLaunchKernelGGL(ortho_update_ranks_kernel<true>, dim3(grid), dim3(kRedWG), 0, s, n, alpha, nparts, parts, d_beta_out, d_b, d_x1, d_x3);
+    else hipLaunchKernelGGL(ortho_update_ranks_kernel<false>, dim3(grid), dim3(kRedWG), 0, s, n, alpha, nparts, parts, d_beta_out, d_b, d_x1, d_x3);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 // ---- product + dot in one pass (the f-4 pipeline SpMV -> dot + AXPY -> SpMV, mpk/SpMVmulti.cpp:563-569) -------------------
 // y = A x with the partial sums of b . y accumulated in the product's epilogue where the launch can carry it (the LEAN ring
 // kernel: ring_dot_eligible), else product and dot as separate launches — the same API either way.  *np = partials written to ws.

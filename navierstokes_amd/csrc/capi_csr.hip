@@ -87,6 +87,7 @@ static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol, int gh
     if (ghost_lo < ghost_hi) {
         T.h_wg_halo = P.wg_halo;
         T.h_wg = P.wg;
+        T.fusable = P.fusable;
     }
     // the sliced values are filled HERE and refilled where the CSR values change (mi_csr_update_values*), on that call's stream — never
     // lazily in front of a product: a product captured into a HIP graph holds only the product's node and must find the values in place
@@ -334,7 +335,8 @@ static int placement_draws(mi_csr_t A, double* tx, double* ty, bool keep_pair)
             draws = (int)std::min<size_t>((size_t)draws, mem_free / 8 / (sizeof(double) * (size_t)nnz));
         else (void)hipGetLastError();
     }
-    const bool blocked_choice = A->auto_kernel == MI_KERNEL_BCSR4 && A->blocked && A->blocked->d_coef;
+    // (a blocked copy served by its SLICED form streams d_sell_val, never d_coef: drawing d_coef there timed noise and could swap the array on it — ADVICE r4)
+    const bool blocked_choice = A->auto_kernel == MI_KERNEL_BCSR4 && A->blocked && A->blocked->d_coef && !(A->blocked->sell_form >= 0 && A->blocked->d_sell_val);
     const bool streams_coef = A->auto_kernel == MI_KERNEL_RING || A->auto_kernel == MI_KERNEL_MRING || A->auto_kernel == MI_KERNEL_STREAM || A->auto_kernel == MI_KERNEL_TILE || blocked_choice;
     if (!(draws > 0 && streams_coef && nnz >= kLargeNnz)) return MI_OK;
     struct Own {
@@ -893,7 +895,7 @@ static int maybe_reorder(mi_csr_t A, const int* ptrow, const int* indcol, const 
     if (env && !strcmp(env, "0")) return MI_OK;
     const int n = A->n;
     if (A->mapped || n != A->ncols || n < 8 || A->nnz == 0) return MI_OK;
-    if (!force && (n < 100000 || resolve_kernel(A) == MI_KERNEL_RING)) return MI_OK;
+    if (!force && (n < 100000 || resolve_kernel(A) == MI_KERNEL_RING || resolve_kernel(A) == MI_KERNEL_SSTREAM)) return MI_OK; // (a band served by its window: nothing to relabel)
     const int block = csr_has_block4_pattern(n, ptrow, indcol) ? 4 : 1;
     const double nn = (double)n / block;
     const double spread = mean_column_distance(n, ptrow, indcol, block);
@@ -1436,18 +1438,21 @@ extern "C" int mi_sstream_plan_probe_ex(int n, int ncols, const int* ptrow, cons
         return MI_OK;
     }
     if (const char* bad = check_sstream_plan(P, n, ptrow, indcol, ghost_lo, ghost_hi)) return fail(MI_ERR_STATE, std::string("sliced-stream plan: ") + bad);
-    int gw = 0, rmin = 0x7fffffff, rmax = 0, rmax_ghost = 0;
+    int gw = 0, rmin = 0x7fffffff, rmax = 0, rmax_ghost = 0, pmin = 0x7fffffff, pmax = 0;
     for (int g = 0; g < P.nwg; g++) {
         const int c = P.rptr[g + 1] - P.rptr[g];
         gw += P.wg_halo[g];
         rmin = std::min(rmin, c);
         rmax = std::max(rmax, c);
         if (P.wg_halo[g]) rmax_ghost = std::max(rmax_ghost, c);
+        else { pmin = std::min(pmin, c); pmax = std::max(pmax, c); }
     }
-    // the dealing's promises: shares differ by at most one round (two with ghost slack in play), and a ghost-reading workgroup never
-    // carries the longest share when there is more than one round per workgroup to deal
-    if (rmax - rmin > (gw ? 1 + kSsGhostSlack : 1)) return fail(MI_ERR_STATE, "sliced-stream plan: the workgroups' shares differ by more than the dealing allows");
+    // the dealing's promises: the shares of the workgroups that read no ghost differ by at most one round, a ghost-reading workgroup
+    // never carries the longest share when there is more than one round per workgroup to deal, and (checked in the replay above) takes
+    // all its columns in with its first fill
+    if (pmax > 0 && pmax - pmin > 1) return fail(MI_ERR_STATE, "sliced-stream plan: the workgroups' shares differ by more than a round");
     if (gw && gw < P.nwg && rmax > 1 && rmax_ghost >= rmax && P.rounds >= 2 * P.nwg) return fail(MI_ERR_STATE, "sliced-stream plan: a ghost-reading workgroup carries the longest share");
+    if (ghost_lo < ghost_hi && !P.fusable) g_err = "eligible, but a ghost-reading workgroup's columns do not fit its first fill: the fused step keeps the ring kernel";
     if (ghost_workgroups) *ghost_workgroups = gw;
     if (rounds_min_max) { rounds_min_max[0] = rmin; rounds_min_max[1] = rmax; }
     return MI_OK;

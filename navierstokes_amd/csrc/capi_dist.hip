@@ -22,6 +22,7 @@
 // Every row of y is the same CSR-ordered fma chain as on one GPU (PartPlan keeps each row's nonzeros in the caller's order), so
 // mi_dist_spmv returns mi_spmv's bits — and SpMV_CSR_FMA's (mpk/SpMV.cpp:41-56) — for every N.
 #include "capi_internal.hpp"
+#include "rccl_loader.hpp"
 
 #include <atomic>
 #include <condition_variable>
@@ -42,8 +43,10 @@ struct DistRank {
     hipStream_t stream = nullptr;
     hipEvent_t ev_push = nullptr, ev_done = nullptr;
     double* d_sendbuf = nullptr; // event exchange: packed entries of non-contiguous send lists
-    double* d_scal = nullptr;    // BLAS-1: this rank's partial
-    double* h_scal = nullptr;    // ... and where it lands on the host (pinned)
+    double* d_scal = nullptr;    // BLAS-1: this rank's partial [0], the global value as its update kernel summed it [1]
+    double* h_scal = nullptr;    // ... and where they land on the host (pinned): [0] partial, [1] global
+    double* d_parts = nullptr;   // RCCL exchange: every rank's partial, all-gathered (nranks doubles)
+    hipEvent_t ev_dot[2] = {nullptr, nullptr}; // my partial of an orthogonalize has landed in the shared table (two parities)
     int n_local = 0, n_halo = 0;
     long long row0 = 0, nnz0 = 0, nnz_local = 0;
     std::vector<int> nb;         // neighbours: ranks I send to or receive from
@@ -171,6 +174,9 @@ struct mi_dist_s {
     std::string note;         // how the exchange was chosen (what was tried, why it was dropped)
     Pool pool;
     std::mutex api_mu;        // one API call at a time per handle
+    double* h_parts = nullptr;  // orthogonalize without RCCL: the ranks' partials, 2 parities x nranks doubles of pinned memory every device reads
+    unsigned ortho_calls = 0;
+    std::vector<mi_dist_vec_t> live; // every vector handed out and not yet destroyed (mi_dist_destroy releases their device memory)
     mi_dist_vec_t vx = nullptr, vy = nullptr, vz = nullptr; // scratch of the host-pointer entry points
     std::vector<mi_dist_vec_t> vpow;
 };
@@ -192,7 +198,7 @@ std::mutex g_dev_mu[64]; // create-time work (kernel timing at finalize) of rank
 // Every rank's worker runs this for the same step; `ex` selects the exchange.  Workers call the pool barrier the same number of
 // times whatever fails (a failed rank skips its work, not its barriers).
 // rc_in: what an earlier step of the same job returned on this rank (a chain of steps stops working at its first failure)
-int dist_step(mi_dist_s* D, int r, int ex, const mi_dist_vec_s* x, const mi_dist_vec_s* y, int rc_in = MI_OK)
+int dist_step(mi_dist_s* D, int r, int ex, const mi_dist_vec_s* x, const mi_dist_vec_s* y, int rc_in = MI_OK, bool more_steps_in_job = false)
 {
     DistRank& me = D->R[r];
     const PartPlan& pl = me.part->plan;
@@ -225,7 +231,9 @@ int dist_step(mi_dist_s* D, int r, int ex, const mi_dist_vec_s* x, const mi_dist
     for (int p : me.nb) W_HIP(hipStreamWaitEvent(me.stream, D->R[p].ev_push, 0));
     if (rc == MI_OK) rc = mi_part_spmv_boundary_dev(me.part, x_ext, y_loc, me.stream);
     W_HIP(hipEventRecord(me.ev_done, me.stream));
-    D->pool.barrier(); // ... and every ev_done of this step before the next step's phase A
+    // ... and every ev_done of this step before the next step's phase A: a barrier when that step follows in THIS job (a chain of
+    // powers); the last step of a job needs none — the job's end is one (Pool::run returns when every worker has)
+    if (more_steps_in_job) D->pool.barrier();
     return rc;
 }
 
@@ -240,6 +248,10 @@ int vec_alloc(mi_dist_s* D, mi_dist_vec_t* out)
         const size_t len = (size_t)me.n_local + (size_t)me.n_halo + 64; // (64 spare entries: 16-byte tails of the BLAS-1 kernels never straddle the end)
         HIP_TRY(hipMalloc(&v->ext[r], sizeof(double) * len));
         HIP_TRY(hipMemsetAsync(v->ext[r], 0, sizeof(double) * len, me.stream));
+        // (create-time cost only) the zero fill is complete before anybody can use the vector: in the event exchange the PEERS write this
+        // vector's halo part from their streams, ordered behind this rank's ev_done of the previous step only — a fill still queued here
+        // could land on top of a neighbour's entries
+        HIP_TRY(hipStreamSynchronize(me.stream));
         return MI_OK;
     });
     if (rc) {
@@ -248,6 +260,7 @@ int vec_alloc(mi_dist_s* D, mi_dist_vec_t* out)
         delete v;
         return fail(rc, keep);
     }
+    D->live.push_back(v);
     *out = v;
     return MI_OK;
 }
@@ -255,6 +268,7 @@ int vec_alloc(mi_dist_s* D, mi_dist_vec_t* out)
 void vec_free(mi_dist_s* D, mi_dist_vec_t v)
 {
     if (!v) return;
+    D->live.erase(std::remove(D->live.begin(), D->live.end(), v), D->live.end());
     D->pool.run([&](int r) -> int {
         (void)hipStreamSynchronize(D->R[r].stream);
         dfree(v->ext[r]);
@@ -325,20 +339,49 @@ int dist_dot(mi_dist_s* D, const mi_dist_vec_s* a, const mi_dist_vec_s* b, doubl
     return MI_OK;
 }
 
+// x3 = x1 - alpha (b . x1) b over all ranks (orthogonalize, mpk/SpMVmulti.cpp:146-151) WITHOUT the host in the middle (round 5; until
+// round 4: partial dots to the host, a stream synchronise per rank, the sum on the host, then the updates).  Every rank's fixed-tree
+// partial goes into a table every rank reads — one ncclAllGather of a double where the ranks hold a communicator (the RCCL exchange;
+// SURVEY.md §8(e) "local two-stage reduce + a collective of one double"), else a slot of pinned host memory behind an event — and each
+// rank's update kernel adds the table up in RANK ORDER itself (the host's order: the same beta bit for bit as before) and applies it to
+// its slice.  Only a caller that wants beta on the host waits, at the end, for rank 0's copy of it.
 int dist_ortho(mi_dist_s* D, const mi_dist_vec_s* b, const mi_dist_vec_s* x1, mi_dist_vec_s* x3, double alpha, double* beta_out)
 {
-    double beta = 0.0;
-    int rc = dist_dot(D, b, x1, &beta);
-    if (rc) return rc;
-    if (beta_out) *beta_out = beta;
-    const double a = -(alpha * beta); // the reference's object code: one vfnmadd behind a rounded alpha * beta (profiles/NOTES.md §2)
-    return D->pool.run([&](int r) -> int {
-        const DistRank& me = D->R[r];
-        if (!me.n_local) return MI_OK;
-        if (x3->ext[r] != x1->ext[r])
-            HIP_TRY(hipMemcpyAsync(x3->ext[r], x1->ext[r], sizeof(double) * (size_t)me.n_local, hipMemcpyDeviceToDevice, me.stream));
-        return mi_axpy_dev(me.n_local, a, b->ext[r], x3->ext[r], me.stream); // x3_i = fma(a, b_i, x3_i): the reference's update bit for bit
+    const int N = D->nranks;
+    const unsigned par = D->ortho_calls++ & 1u;
+    const bool by_rccl = N > 1 && D->exchange == kExRccl && rccl_state().ok && rccl_state().AllGather;
+    int rc = D->pool.run([&](int r) -> int {
+        DistRank& me = D->R[r];
+        int rc = MI_OK; // (a failed rank skips its work, not its barrier)
+        const double* parts = nullptr;
+        if (me.n_local) rc = mi_dot_dev(me.n_local, b->ext[r], x1->ext[r], me.d_scal, me.stream);
+        else W_HIP(hipMemsetAsync(me.d_scal, 0, sizeof(double), me.stream));
+        if (N == 1) parts = me.d_scal;
+        else if (by_rccl) {
+            if (rc == MI_OK && rccl_state().AllGather(me.d_scal, me.d_parts, 1, kNcclDouble, me.part->comm, me.stream) != 0) rc = fail(MI_ERR_HIP, "ncclAllGather of the partial dots failed");
+            parts = me.d_parts;
+        } else {
+            double* slot = D->h_parts + (size_t)par * N;
+            W_HIP(hipMemcpyAsync(slot + r, me.d_scal, sizeof(double), hipMemcpyDeviceToHost, me.stream));
+            W_HIP(hipEventRecord(me.ev_dot[par], me.stream));
+            D->pool.barrier(); // every rank's event of THIS call is recorded before anybody waits for it
+            for (int p = 0; p < N; p++)
+                if (p != r) W_HIP(hipStreamWaitEvent(me.stream, D->R[p].ev_dot[par], 0));
+            parts = slot;
+            // (two parities: a rank overwrites its slot of parity `par` two calls later, after it has waited for every peer's event of the
+            // call in between — which each peer recorded behind its own update kernel of this call)
+        }
+        if (rc == MI_OK) rc = ortho_update_from_parts(me.n_local, N, parts, alpha, b->ext[r], x1->ext[r], x3->ext[r], me.d_scal + 1, me.stream);
+        if (beta_out && r == 0) {
+            W_HIP(hipMemcpyAsync(me.h_scal + 1, me.d_scal + 1, sizeof(double), hipMemcpyDeviceToHost, me.stream));
+            W_HIP(hipStreamSynchronize(me.stream));
+            if (rc == MI_OK) rc = mi_part_status(me.part);
+        }
+        return rc;
     });
+    if (rc) return rc;
+    if (beta_out) *beta_out = D->R[0].h_scal[1];
+    return MI_OK;
 }
 
 void dist_release(mi_dist_s* D)
@@ -346,6 +389,19 @@ void dist_release(mi_dist_s* D)
     if (!D->pool.th.empty()) {
         for (mi_dist_vec_t v : {D->vx, D->vy, D->vz}) vec_free(D, v);
         for (mi_dist_vec_t v : D->vpow) vec_free(D, v);
+        // vectors the caller still holds: their device memory goes with the handle; the small host object stays for the caller's
+        // mi_dist_vec_destroy, which finds D == nullptr and only deletes it (it used to dereference the freed handle: ADVICE r4)
+        const std::vector<mi_dist_vec_t> orphans = D->live;
+        for (mi_dist_vec_t v : orphans) {
+            D->pool.run([&](int r) -> int {
+                (void)hipStreamSynchronize(D->R[r].stream);
+                dfree(v->ext[r]);
+                v->ext[r] = nullptr;
+                return MI_OK;
+            });
+            v->D = nullptr;
+        }
+        D->live.clear();
         D->pool.run([&](int r) -> int {
             DistRank& me = D->R[r];
             if (me.stream) (void)hipStreamSynchronize(me.stream);
@@ -353,7 +409,10 @@ void dist_release(mi_dist_s* D)
             me.part = nullptr;
             dfree(me.d_sendbuf);
             dfree(me.d_scal);
+            dfree(me.d_parts);
             if (me.h_scal) (void)hipHostFree(me.h_scal);
+            for (hipEvent_t& e : me.ev_dot)
+                if (e) (void)hipEventDestroy(e);
             if (me.ev_push) (void)hipEventDestroy(me.ev_push);
             if (me.ev_done) (void)hipEventDestroy(me.ev_done);
             if (me.stream) (void)hipStreamDestroy(me.stream);
@@ -361,6 +420,7 @@ void dist_release(mi_dist_s* D)
         });
         D->pool.shutdown();
     }
+    if (D->h_parts) (void)hipHostFree(D->h_parts);
     delete D;
 }
 
@@ -586,16 +646,24 @@ extern "C" int mi_dist_create(int ndev, int n, const int* ptrow, const int* indc
             HIP_TRY(hipEventCreateWithFlags(&me.ev_push, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&me.ev_done, hipEventDisableTiming));
             HIP_TRY(hipMalloc(&me.d_sendbuf, sizeof(double) * std::max<size_t>(pl.send_idx.size(), 1)));
-            HIP_TRY(hipMalloc(&me.d_scal, sizeof(double)));
-            HIP_TRY(hipHostMalloc((void**)&me.h_scal, sizeof(double), hipHostMallocDefault));
+            HIP_TRY(hipMalloc(&me.d_scal, 2 * sizeof(double)));
+            HIP_TRY(hipMalloc(&me.d_parts, sizeof(double) * (size_t)std::max(N, 1)));
+            HIP_TRY(hipHostMalloc((void**)&me.h_scal, 2 * sizeof(double), hipHostMallocDefault));
+            for (hipEvent_t& e : me.ev_dot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             std::vector<int>().swap(me.ptrow);
             return MI_OK;
         });
+    if (rc == MI_OK && hipHostMalloc((void**)&D->h_parts, sizeof(double) * 2 * (size_t)std::max(N, 1), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        D->h_parts = nullptr;
+        rc = fail(MI_ERR_ALLOC, "pinned table of the ranks' partial dots");
+    }
     if (rc) {
         const std::string keep = g_err;
         dist_release(D);
         return fail(rc, "mi_dist_create: " + keep);
     }
+    memset(D->h_parts, 0, sizeof(double) * 2 * (size_t)std::max(N, 1));
     // the exchange: MI355_DIST_EXCHANGE=event|push|rccl forces one (an unavailable one fails the create); unset / auto: push where
     // every rank has its own device, then RCCL, then events — each candidate only after the bit-for-bit self-check
     const char* xe = getenv("MI355_DIST_EXCHANGE");
@@ -715,6 +783,10 @@ extern "C" int mi_dist_vec_create(mi_dist_t D, mi_dist_vec_t* out)
 extern "C" int mi_dist_vec_destroy(mi_dist_vec_t v)
 {
     if (!v) return MI_OK;
+    if (!v->D) { // its handle was destroyed first (mi_dist_destroy released the device memory)
+        delete v;
+        return MI_OK;
+    }
     std::lock_guard<std::mutex> lk(v->D->api_mu);
     vec_free(v->D, v);
     return MI_OK;
@@ -767,7 +839,7 @@ extern "C" int mi_dist_spmk_dev(mi_dist_t D, int k, mi_dist_vec_t x, const mi_di
         int rc = MI_OK;
         const mi_dist_vec_s* src = x;
         for (int p = 0; p < k; p++) {
-            rc = dist_step(D, r, ex, src, y_out[p], rc);
+            rc = dist_step(D, r, ex, src, y_out[p], rc, p + 1 < k);
             src = y_out[p];
         }
         return rc;

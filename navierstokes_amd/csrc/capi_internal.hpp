@@ -134,6 +134,7 @@ struct SstreamTable {
     int max_slice_nnz = 0;        // longest CSR segment of a slice (picks the refill kernel's LDS buffer)
     bool nt = true;               // non-temporal value loads (measured at create)
     bool deep = true;             // twelve steps of prefetch instead of eight (measured at create)
+    bool fusable = false;         // a combined piece's plan that spmv_sstream_fused can run (every ghost-reading workgroup's columns fit its first fill)
     bool asked = false;           // built because the environment or the caller asked for it: never released for losing a measurement
     std::vector<int> h_wg_halo;   // a combined piece of the fused multi-GPU step: per workgroup, it reads ghost columns (empty otherwise)
     std::vector<SsWg> h_wg;       // ... and its workgroup records (capi_part.hip writes the push links into them at connect time)
@@ -347,6 +348,8 @@ int spmk_unmapped(mi_csr_t H, int k, const double* d_x, double* const* d_y, hipS
 void spmk_release(mi_csr_t H);
 // capi_blas1.hip
 int gather_perm(mi_csr_t A, const double* d_x, double* d_xp, hipStream_t s);
+int ortho_update_from_parts(int n, int nparts, const double* parts, double alpha, const double* d_b, const double* d_x1, double* d_x3, double* d_beta_out,
+                            hipStream_t s);
 int scatter_perm(mi_csr_t A, const double* d_src, double* d_dst, hipStream_t s);
 // launch_spmm_tile.hip: the multi-vector product's tile form (spmm_tile.hpp), up to four columns
 constexpr size_t kLdsBytesPerCU = 160 * 1024;

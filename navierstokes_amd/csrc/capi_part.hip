@@ -651,15 +651,17 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
         if (rc) return rc;
         mi_csr_t A = P->piece_all;
         if (P->kernel != MI_KERNEL_AUTO && P->kernel != MI_KERNEL_RING) A->kernel = P->kernel;
-        // Which kernel carries the one-launch step.  Since round 5 the sliced stream (spmv_sstream_fused) wherever the combined piece
-        // holds its plan — the kernel of the single-GPU headline; a rank's share of C4 at N = 8: NOTES R5 — else the ring kernel's FUSED
-        // form.  Taken even if another kernel measured a hair faster on this rank: the one-launch step saves three launches, and it only
-        // happens if EVERY rank has it (mi_part_push_unfuse) — a rank whose create-time measurement tipped the other way by noise would
-        // cost all of them the fused step.  MI355_PUSH_FUSED_KERNEL=ring|sstream forces (A/B).
+        // Which kernel carries the one-launch step: the sliced stream (spmv_sstream_fused, round 5) or the ring kernel's FUSED form.  One of
+        // the two is taken even if a kernel WITHOUT a fused form measured a hair faster on this rank: the one-launch step saves three
+        // launches, and it only happens if EVERY rank has it (mi_part_push_unfuse) — a rank whose create-time measurement tipped the other
+        // way by noise would cost all of them the fused step.  MI355_PUSH_FUSED_KERNEL=ring|sstream forces (A/B).
         const char* fk = getenv("MI355_PUSH_FUSED_KERNEL");
-        const bool ss_ok = A->ss.dev.val && !A->ss.h_wg_halo.empty() && !A->blocked && !(fk && !strcmp(fk, "ring"));
+        const bool ss_ok = A->ss.dev.val && A->ss.fusable && !A->ss.h_wg_halo.empty() && !A->blocked && !(fk && !strcmp(fk, "ring"));
         const bool ring_ok = A->ring.d_plan && A->ring.d_run_halo && A->ring.ok_fraction >= 0.90 && !A->blocked && !(fk && !strcmp(fk, "sstream"));
-        if (P->kernel == MI_KERNEL_AUTO && ss_ok) A->kernel = MI_KERNEL_SSTREAM;
+        // (both are one-launch forms and may be mixed across ranks, so between the two this rank's own create-time measurement decides:
+        // at N = 2 — 37 M nonzeros per rank, beyond the Infinity Cache — the ring form measured 66 us against 70 on one box, at N = 8 the
+        // sliced stream 20.3 against 21.9)
+        if (P->kernel == MI_KERNEL_AUTO && ss_ok && !(ring_ok && A->auto_kernel == MI_KERNEL_RING)) A->kernel = MI_KERNEL_SSTREAM;
         else if ((P->kernel == MI_KERNEL_AUTO || P->kernel == MI_KERNEL_RING) && ring_ok) A->kernel = MI_KERNEL_RING;
         const bool by_ss = resolve_kernel(A) == MI_KERNEL_SSTREAM && ss_ok;
         P->fused = by_ss || (resolve_kernel(A) == MI_KERNEL_RING && A->ring.d_run_halo);
@@ -667,9 +669,14 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
             const std::vector<int>& marks = by_ss ? A->ss.h_wg_halo : A->ring.h_run_halo;
             P->d_run_halo = by_ss ? A->ss.dev.wg_halo : A->ring.d_run_halo;
             std::vector<int> link(marks.size(), -1);
+            // (alternately from the two ends of the row range: the ghost readers of a band are the first and the last few runs, and the
+            // two neighbours' pushes should not both fall to the runs in front)
+            std::vector<int> ghost_runs;
+            for (size_t g = 0; g < marks.size(); g++)
+                if (marks[g]) ghost_runs.push_back((int)g);
             int k = 0;
-            for (size_t g = 0; g < marks.size() && k < P->n_links; g++)
-                if (marks[g]) link[g] = k++;
+            for (size_t i = 0, lo_i = 0, hi_i = ghost_runs.size(); lo_i < hi_i && k < P->n_links; i++)
+                link[ghost_runs[(i & 1) ? --hi_i : lo_i++]] = k++;
             P->npush_runs = k; // 0: no ghost runs in the plan -> dedicated push workgroups in front of the grid
             P->ghost_readers = false;
             for (int v : marks) P->ghost_readers = P->ghost_readers || v != 0;

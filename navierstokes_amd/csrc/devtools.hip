@@ -186,3 +186,49 @@ extern "C" int mi_debug_mring_replan(mi_csr_t A, int skew_pct, int* table_len, i
     }
     return MI_OK;
 }
+
+// ---- timeline of ONE one-launch push step through the sliced stream (tools/sim_rank.py; MI355_PUSH_LOOPBACK arrangement) ----
+extern "C" int mi_debug_part_push_trace(mi_part_t P, double* d_x_ext, double* d_y_local, int max_wgs, long long* host_out, int* wgs_out, int* halo_out)
+{
+    CHECK_ARG(P && d_x_ext && d_y_local && host_out && wgs_out, "null argument");
+    if (!P->push_ready || !P->fused || !P->piece_all || resolve_kernel(P->piece_all) != MI_KERNEL_SSTREAM || !P->piece_all->ss.fusable)
+        return fail(MI_ERR_STATE, "the one-launch push step of this handle does not run the sliced stream");
+    mi_csr_t A = P->piece_all;
+    SstreamTable& T = A->ss;
+    CHECK_ARG(T.nwg <= max_wgs, "host buffer too small");
+    const PartPlan& pl = P->plan;
+    const unsigned step = ++P->push_step;
+    RingComm C{};
+    C.links = P->d_links;
+    C.send_idx = P->d_send_idx;
+    C.flags = P->win_flags;
+    C.nb = P->d_nb;
+    C.halo = P->win_data + (size_t)(step & 1u) * (size_t)(pl.n_halo > 0 ? pl.n_halo : 1);
+    C.run_halo = P->d_run_halo;
+    C.timeouts = P->d_timeouts;
+    C.n_links = P->n_links;
+    C.n_nb = P->n_nb;
+    C.n_local = pl.n_local;
+    C.n_left = pl.n_left;
+    C.run_link = P->d_run_link;
+    C.npush_runs = P->npush_runs;
+    C.push_wgs = (P->npush_runs == 0 && P->n_links > 0) ? kNXCD : 0;
+    C.step = step;
+    C.spin_max = 1u << kPushSpinLog2Default;
+    C.gate_push = P->ghost_readers ? 0 : 1;
+    unsigned long long* d_tr = nullptr;
+    HIP_TRY(hipMalloc(&d_tr, sizeof(unsigned long long) * 4 * (size_t)T.nwg));
+    HIP_TRY(hipMemset(d_tr, 0, sizeof(unsigned long long) * 4 * (size_t)T.nwg));
+    SsView S{T.dev.val, T.dev.slot, T.dev.wg, T.dev.win, T.nwg, A->n + T.shift, A->ncols, nullptr, T.shift};
+    S.trace = d_tr;
+    HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL((spmv_sstream_fused<8, false, 8>), dim3((unsigned)(T.nwg + C.push_wgs)), dim3(256), 0, nullptr, S, d_x_ext, d_y_local - T.shift, C);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, d_tr, sizeof(unsigned long long) * 4 * (size_t)T.nwg, hipMemcpyDeviceToHost));
+    dfree(d_tr);
+    *wgs_out = T.nwg;
+    if (halo_out)
+        for (int g = 0; g < T.nwg; g++) halo_out[g] = T.h_wg_halo[g] + 2 * (T.h_wg[g].link >= 0 ? 1 : 0) + 4 * (T.h_wg[g].r_end - T.h_wg[g].r_begin);
+    return MI_OK;
+}

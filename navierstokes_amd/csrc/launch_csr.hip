@@ -41,7 +41,7 @@ int launch_spmv(mi_csr_t A, const double* d_x, double* d_y, hipStream_t s, bool 
     if (A->n == 0) return MI_OK;
     // The fused multi-GPU step hands over a RingComm: its piece is numbered [ghosts | owned | ghosts], which only the ring
     // kernel's FUSED instantiation understands.  Any other launch would index x with that numbering — refuse, never drop it.
-    const bool ss_fused = comm && resolve_kernel(A) == MI_KERNEL_SSTREAM && !A->ss.h_wg_halo.empty();
+    const bool ss_fused = comm && resolve_kernel(A) == MI_KERNEL_SSTREAM && A->ss.fusable;
     if (comm && (A->inner || A->d_rowmap || (resolve_kernel(A) != MI_KERNEL_RING && !ss_fused)))
         return fail(MI_ERR_STATE, "fused multi-GPU step: the combined piece must be an unmapped, unreordered handle served by the ring or the sliced-stream kernel");
     if (A->inner) { // reordered: x into the new numbering, then the twin writes y through its row map

@@ -57,8 +57,11 @@ constexpr unsigned kSsFirst = 0x4000u;   // slot flag (low half): first step of 
 constexpr int kSsPadSteps = 64;          // steps of padding behind the last one: the stream's loads run ahead unclamped (D <= 16)
 constexpr int kSsMaxWgs = 256;           // one workgroup per CU
 constexpr int kSsFill = 24;              // first-window columns per thread loaded in ONE batch (6144 columns; wider windows take further batches of 8)
-constexpr int kSsGhostSlack = 2;         // rounds a ghost-reading workgroup of the fused step gets less than its share: its push (write-through stores, drain,
-                                         // flag: ~3 us) and its wait (poll + system-scope acquire: ~3 us) come first — two rounds of ~2.75 us (sim_rank 8 1: 21.7 us per step with one)
+constexpr int kSsGhostSlack = 3;         // rounds a ghost-reading workgroup of the fused step gets less than its share.  Its push (write-through stores, drain,
+                                         // flag), its wait (poll + system-scope acquire) and the uncached window loads come first: 3.8 us in front of the loop
+                                         // without push duty, 6.5-7.2 with (a plain workgroup: 2.3), and its rounds take 3.4 us instead of 2.7 (the window's
+                                         // loads return in order with the stream's) — sim_rank 8 1's trace, profiles/r05_sim_rank.txt: with a slack of two rounds
+                                         // the pushers were the launch's last workgroups in one launch of ten (20.1 us against 17.8)
 
 // everything a workgroup's prologue needs, as ONE 64-byte record (one scalar load)
 struct SsWg {
@@ -94,6 +97,7 @@ struct SsPlanHost {
     std::vector<int2> win;
     std::vector<SsWg> wg;
     std::vector<int> wg_halo;        // ghost columns given: per workgroup, its windows hold a ghost column (the fused step: it waits for the neighbours)
+    bool fusable = false;            // ghost columns given, and every such workgroup takes its whole column range in with its first fill (spmv_sstream_fused can run the plan)
     std::vector<unsigned> slot;      // [steps + kSsPadSteps][64]
 };
 
@@ -157,10 +161,15 @@ inline void build_sstream_plan(int n, int ncols, const int* ptrow, const int* in
         P.rptr.assign((size_t)nwg + 1, 0);
         for (int g = 0; g < nwg; g++) P.rptr[g + 1] = P.rptr[g] + cnt[g];
     };
-    // windows: per workgroup a monotone upper end; everything a round names must lie within kSsRing below it
+    // windows: per workgroup a monotone upper end; everything a round names must lie within kSsRing below it.  A workgroup whose
+    // windows hold a ghost column (the fused multi-GPU step) takes its WHOLE column range in with its first fill — ghosts are then
+    // read (from the receive window: uncached memory, a select per load) in its prologue only, and its loop is the plain
+    // kernel's, load for load — which needs that range to fit the ring: too_wide[g] says it does not (yet).
+    std::vector<char> too_wide((size_t)nwg, 0);
     auto windows = [&]() -> bool {
         P.win.assign((size_t)rounds, make_int2(0, 0));
         P.wg_halo.assign((size_t)nwg, 0);
+        std::fill(too_wide.begin(), too_wide.end(), 0);
         for (int g = 0; g < nwg; g++) {
             int allmin = 0x7fffffff;
             for (int r = P.rptr[g]; r < P.rptr[g + 1]; r++) allmin = std::min(allmin, cmin[r]);
@@ -178,7 +187,14 @@ inline void build_sstream_plan(int n, int ncols, const int* ptrow, const int* in
                 whi = nhi;
                 if (cmin[r] != 0x7fffffff && cmin[r] < whi - kSsRing) { P.why = "a round's rows reach further apart than the LDS ring holds"; return false; }
             }
-            if (ghosts && whi > wlo && (wlo < ghost_lo || whi > ghost_hi)) P.wg_halo[g] = 1;
+            if (ghosts && whi > wlo && (wlo < ghost_lo || whi > ghost_hi)) {
+                P.wg_halo[g] = 1;
+                if (whi - wlo > kSsRing) too_wide[g] = 1;
+                else { // everything up front: later rounds bring nothing
+                    P.win[P.rptr[g]] = make_int2(wlo, whi - wlo);
+                    for (int r = P.rptr[g] + 1; r < P.rptr[g + 1]; r++) P.win[r] = make_int2(whi, 0);
+                }
+            }
         }
         return true;
     };
@@ -186,14 +202,23 @@ inline void build_sstream_plan(int n, int ncols, const int* ptrow, const int* in
     deal(less);
     if (!windows()) return;
     if (ghosts)
-        for (int it = 0; it < 4; it++) { // who reads ghosts depends on the dealing and the dealing on who reads ghosts: a few rounds settle it
-            std::vector<int> want((size_t)nwg, 0);
-            for (int g = 0; g < nwg; g++) want[g] = P.wg_halo[g] ? kSsGhostSlack : 0;
-            if (want == less) break;
+        for (int it = 0; it < 64; it++) { // who reads ghosts depends on the dealing and the dealing on who reads ghosts (a workgroup that
+            // gives rounds away moves its neighbour's rows towards the cut, never away from it): a few passes settle it
+            std::vector<int> want = less;
+            bool changed = false;
+            for (int g = 0; g < nwg; g++) {
+                if (!P.wg_halo[g]) continue;
+                const int need = too_wide[g] ? std::max(less[g] + 1, kSsGhostSlack) : std::max(less[g], kSsGhostSlack);
+                if (need != less[g]) { want[g] = need; changed = true; }
+            }
+            if (!changed) break;
             less = want;
             deal(less);
             if (!windows()) return; // (the marks always describe the dealing in force, whatever the loop's last `less` was)
         }
+    P.fusable = ghosts;
+    for (int g = 0; g < nwg; g++)
+        if (P.wg_halo[g] && too_wide[g]) P.fusable = false; // (a ghost-reading workgroup's columns do not fit the ring even with one round: the ring kernel's FUSED form serves such a piece)
     // streams: workgroup by workgroup, wave by wave, round by round
     P.wptr.assign((size_t)nwg * 4 + 1, 0);
     P.slice_step.assign((size_t)rounds * 4, 0);
@@ -324,6 +349,9 @@ inline const char* check_sstream_plan(const SsPlanHost& P, int n, const int* ptr
             }
         }
         if (names_ghost && !P.wg_halo[g]) return "a workgroup names a ghost column and is not marked";
+        if (P.fusable && P.wg_halo[g])
+            for (int r = P.rptr[g] + 1; r < P.rptr[g + 1]; r++)
+                if (P.win[r].y != 0) return "a ghost-reading workgroup takes columns in after its first fill";
         if (W.halo != P.wg_halo[g]) return "a workgroup record's ghost mark disagrees with the plan's";
     }
     return nullptr;
@@ -431,35 +459,30 @@ inline hipError_t ss_upload(const SsPlanHost& P, SsDevice& Dv, bool ghosts)
 // lower ranks | owned | ghosts of higher ranks] (partition.hpp: build_combined), ghosts are read from this rank's receive window
 // (C.halo), a workgroup whose windows hold a ghost column (SsWg::halo) first does its share of the push (SsWg::link) and then
 // waits — bounded, loud — for every neighbour's flag of this step, its stream's first loads already in flight.
-template <int D, bool NT, int ABL, bool FUSED>
-__device__ __forceinline__ void ss_body(const SsView& S, const double* __restrict__ x, double* __restrict__ y, const RingComm& C)
+// MODE 0: the plain product.  MODE 1 / 2: a workgroup of the fused multi-GPU step that reads no ghost column (x is the owned part of
+// x_ext, columns offset by C.n_left: the plain kernel's code, nothing more — the first fused form ran EVERY workgroup through the
+// ghost-column selects, push and wait code: 21 KB of ISA against 13.7, 20.3 us per step against 18.7 for the same rows unfused) /
+// one that does (push duty, wait, ghost columns from the receive window).
+template <int D, bool NT, int ABL, int MODE>
+__device__ __forceinline__ void ss_body(const SsView& S, const SsWg& W, int g, const double* __restrict__ x_in, double* __restrict__ y, const RingComm& C,
+                                        double* ring /* [kSsRing], LDS */, ss_v2d* s_park /* [4 * kSsPark * 64], LDS */)
 {
-    __shared__ double ring[kSsRing];
-    __shared__ ss_v2d s_park[4 * kSsPark * 64];
+    constexpr bool GHOSTS = MODE == 2;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (FUSED && (int)blockIdx.x < C.push_wgs) { // fallback (a rank that sends and reads no ghost): dedicated push workgroups in front of the grid
-        if ((int)blockIdx.x < C.n_links) ring_push_gate<256>(C);
-        for (int l = blockIdx.x; l < C.n_links; l += C.push_wgs) ring_push_link<256>(C, x, l);
-        return;
-    }
-    const int bid = FUSED ? (int)blockIdx.x - C.push_wgs : (int)blockIdx.x;
-    const int per = S.nwg >> 3;
-    const int g = per > 0 && (S.nwg & 7) == 0 ? (bid & 7) * per + (bid >> 3) : bid;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const SsWg W = S.wg[g]; // (uniform address: one scalar load)
+    const double* __restrict__ x = MODE != 0 ? x_in - C.n_left : x_in; // (fused step: column c is owned entry c - n_left; ghost columns are read in MODE 2's first fill only)
     const int r_begin = W.r_begin, r_end = W.r_end;
-    if (r_begin >= r_end) return;
     if ((ABL & 8) && tid == 0) S.trace[4 * g] = __builtin_amdgcn_s_memrealtime();
     // (ghost mark and push link ride in the workgroup's record: two further dependent scalar loads in front of every workgroup's
     // first vector load cost the whole launch ~1.5 us — first form of this kernel, sim_rank 8 1)
-    const bool waits = FUSED && W.halo != 0;
-    if (FUSED && W.link >= 0 && C.npush_runs > 0) // push duty of this workgroup, before anything that could wait
-        for (int l = W.link; l < C.n_links; l += C.npush_runs) ring_push_link<256>(C, x, l);
+    if (GHOSTS && W.link >= 0 && C.npush_runs > 0) // push duty of this workgroup, before anything that could wait
+        for (int l = W.link; l < C.n_links; l += C.npush_runs) ring_push_link<256>(C, x_in, l);
     ss_v2d* park = s_park + wv * kSsPark * 64 + lane;
     int parked = 0, park_first = 0; // (wave-uniform) the slices of rounds park_first .. park_first + parked - 1 are parked
     const int t0 = wv == 0 ? W.t[0] : (wv == 1 ? W.t[1] : (wv == 2 ? W.t[2] : W.t[3]));
     const int t_end = wv == 0 ? W.t[1] : (wv == 1 ? W.t[2] : (wv == 2 ? W.t[3] : W.t[4]));
     const int clast = S.ncols - 1;
+    const int cfirst = MODE != 0 ? C.n_left : 0; // (fused step: the prefetch of a window's new columns never reaches in front of the owned entries)
     const ss_v2d* vb = S.val + lane;
     const unsigned* sb = S.slot + lane;
     ss_v2d a[D];
@@ -471,7 +494,7 @@ __device__ __forceinline__ void ss_body(const SsView& S, const double* __restric
             sl[d] = sb[(size_t)(t0 + d) * 64];
         }
     };
-    if (FUSED && waits) { // the stream's first steps travel while this workgroup waits for its neighbours' entries
+    if (GHOSTS) { // the stream's first steps travel while this workgroup waits for its neighbours' entries
         first_steps();
         push_wait_flags(C.flags, C.nb, C.n_nb, C.step, 0u, C.timeouts, C.spin_max, tid, 256);
         __syncthreads();
@@ -483,12 +506,15 @@ __device__ __forceinline__ void ss_body(const SsView& S, const double* __restric
     double nx[kSsNewMax / 256]; // the NEXT round's new columns, a round ahead in registers
     int2 wn = make_int2(W.w1_lo, W.w1_n);
     {
+        // (MODE 2: the first fill is the workgroup's WHOLE column range — the planner saw to it — so that this is the only place where
+        // a column can be a ghost; the next-round prefetch below and in the loop loads owned entries like the plain kernel's, into
+        // windows of zero new columns)
         double fx[kSsFill];
 #pragma unroll
-        for (int u = 0; u < kSsFill; u++) fx[u] = ring_ldx<FUSED>(x, C, min(W.w0_lo + tid + 256 * u, clast));
+        for (int u = 0; u < kSsFill; u++) fx[u] = GHOSTS ? ring_ldx<true>(x_in, C, min(W.w0_lo + tid + 256 * u, clast)) : x[min(W.w0_lo + tid + 256 * u, clast)];
 #pragma unroll
-        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = (ABL & 4) ? 0.0 : ring_ldx<FUSED>(x, C, min(wn.x + tid + 256 * u, clast));
-        if (!(FUSED && waits)) first_steps();
+        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = (ABL & 4) ? 0.0 : x[min(max(wn.x + tid + 256 * u, cfirst), clast)];
+        if (!GHOSTS) first_steps();
 #pragma unroll
         for (int u = 0; u < kSsFill; u++) {
             const int c = W.w0_lo + tid + 256 * u;
@@ -497,7 +523,7 @@ __device__ __forceinline__ void ss_body(const SsView& S, const double* __restric
         for (int c0 = W.w0_lo + 256 * kSsFill + tid; c0 < W.w0_lo + W.w0_n; c0 += 256 * 8) { // (a first window wider than 6144 columns)
             double f8[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) f8[u] = ring_ldx<FUSED>(x, C, min(c0 + 256 * u, clast));
+            for (int u = 0; u < 8; u++) f8[u] = GHOSTS ? ring_ldx<true>(x_in, C, min(c0 + 256 * u, clast)) : x[min(c0 + 256 * u, clast)];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (c0 + 256 * u < W.w0_lo + W.w0_n) ring[(c0 + 256 * u) & (kSsRing - 1)] = f8[u];
@@ -552,7 +578,7 @@ __device__ __forceinline__ void ss_body(const SsView& S, const double* __restric
                     if (!(ABL & 4)) {
                         wn = S.win[min(r + 1, r_end - 1)];
 #pragma unroll
-                        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = ring_ldx<FUSED>(x, C, min(wn.x + tid + 256 * u, clast));
+                        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = x[min(max(wn.x + tid + 256 * u, cfirst), clast)];
                     }
                 }
                 const double x0 = (ABL & 1) ? 1.0 + lane : ring[s & (kSsRing - 1)], x1 = (ABL & 1) ? 0.5 : ring[(s >> 16) & (kSsRing - 1)];
@@ -574,16 +600,39 @@ __device__ __forceinline__ void ss_body(const SsView& S, const double* __restric
     }
 }
 
+// block b -> logical workgroup (b % 8) * (G / 8) + b / 8 (the workgroups of one XCD stream neighbouring rows), and its record
+__device__ __forceinline__ int ss_logical_wg(const SsView& S, int bid)
+{
+    const int per = S.nwg >> 3;
+    return per > 0 && (S.nwg & 7) == 0 ? (bid & 7) * per + (bid >> 3) : bid;
+}
+
 template <int D, bool NT, int ABL = 0>
 __global__ __launch_bounds__(256) void spmv_sstream(SsView S, const double* __restrict__ x, double* __restrict__ y)
 {
-    ss_body<D, NT, ABL, false>(S, x, y, RingComm{});
+    const int g = ss_logical_wg(S, (int)blockIdx.x);
+    const SsWg W = S.wg[g]; // (uniform address: one scalar load)
+    if (W.r_begin >= W.r_end) return;
+    __shared__ double ring[kSsRing];
+    __shared__ ss_v2d s_park[4 * kSsPark * 64];
+    ss_body<D, NT, ABL, 0>(S, W, g, x, y, RingComm{}, ring, s_park);
 }
 
-template <int D, bool NT>
+template <int D, bool NT, int ABL = 0>
 __global__ __launch_bounds__(256) void spmv_sstream_fused(SsView S, const double* __restrict__ x, double* __restrict__ y, RingComm C)
 {
-    ss_body<D, NT, 0, true>(S, x, y, C);
+    if ((int)blockIdx.x < C.push_wgs) { // fallback (a rank that sends and reads no ghost): dedicated push workgroups in front of the grid
+        if ((int)blockIdx.x < C.n_links) ring_push_gate<256>(C);
+        for (int l = blockIdx.x; l < C.n_links; l += C.push_wgs) ring_push_link<256>(C, x, l);
+        return;
+    }
+    const int g = ss_logical_wg(S, (int)blockIdx.x - C.push_wgs);
+    const SsWg W = S.wg[g];
+    if (W.r_begin >= W.r_end) return;
+    __shared__ double ring[kSsRing];
+    __shared__ ss_v2d s_park[4 * kSsPark * 64];
+    if (W.halo) ss_body<D, NT, ABL, 2>(S, W, g, x, y, C, ring, s_park); // (workgroup-uniform: each workgroup runs ONE of the two bodies)
+    else ss_body<D, NT, ABL, 1>(S, W, g, x, y, C, ring, s_park);
 }
 
 } // namespace mi355

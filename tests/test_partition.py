@@ -1,6 +1,8 @@
 """Row-range partition planner (C++ behind mi_part_*), checked on the CPU: the
 partitioned SpMV — with halos moved by hand here, by gloo in
 test_dist_gloo.py — reproduces the global oracle SpMV BIT FOR BIT."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -89,9 +91,12 @@ def _band_plus_far_couplings(n, w, seed):
 
 @pytest.mark.parametrize("kind,n,w,nranks", [("s15", 6000, 300, 1), ("s15", 6000, 300, 2), ("svar", 5000, 200, 3),
                                               ("sfe", 4000, 240, 4), ("s15", 3000, 2000, 8), ("far", 6000, 150, 5),
-                                              ("far-exact", 6000, 150, 5)])
+                                              ("far-exact", 6000, 150, 5), ("s15-exact-split", 6000, 300, 3)])
 def test_partitioned_spmv_equals_global_bitwise(kind, n, w, nranks, monkeypatch):
     matrix = None
+    if kind == "s15-exact-split":  # the row-by-row split of rounds 1-4: every boundary row names a ghost column
+        monkeypatch.setenv("MI355_PART_CONTIGUOUS_INTERIOR", "0")
+        kind = "s15"
     if kind.startswith("far"):
         matrix = _band_plus_far_couplings(n, w, 5)
         monkeypatch.setenv("MI355_PART_DENSE_HALO", "0" if kind == "far-exact" else "1")
@@ -132,9 +137,18 @@ def test_partitioned_spmv_equals_global_bitwise(kind, n, w, nranks, monkeypatch)
             p, c, v, rmap = pl.local_piece(which)
             assert (c < pl.n_local).all() if which == 0 else True
             if which == 1 and len(rmap):
-                assert all((c[p[i]:p[i + 1]] >= pl.n_local).any() for i in range(len(rmap)))
+                # (round 5) a row of the boundary piece names a ghost column — or lies outside the ONE run of consecutive ghost-free rows
+                # that became the interior piece (then the interior piece's row map is a plain offset: rows r0, r0 + 1, ...)
+                names = np.array([(c[p[i]:p[i + 1]] >= pl.n_local).any() for i in range(len(rmap))])
+                if not names.all():
+                    imap = pl.local_piece(0)[3]
+                    assert len(imap) and (np.diff(imap) == 1).all(), "ghost-free rows in the boundary piece although the interior piece is scattered"
+                    free = rmap[~names]
+                    assert ((free < imap[0]) | (free > imap[-1])).all(), "a ghost-free row INSIDE the interior run was sent to the boundary piece"
             y_loc[rmap] = O.spmv(p, c, v, x_ext)
         assert_bit_equal(y_loc, y_ref[lo:hi], f"rank {r}/{nranks}")
+        if kind == "s15" and nranks > 1 and os.environ.get("MI355_PART_CONTIGUOUS_INTERIOR") != "0" and pl.n_interior > 0:
+            assert (np.diff(pl.local_piece(0)[3]) == 1).all(), "a band's interior piece must be one run of rows (a plain offset into y)"
         if nranks == 1:
             assert pl.n_halo == 0 and pl.n_boundary == 0
 

@@ -18,6 +18,8 @@ for s in "$@"; do
   case $s in
     sim)      step r5_sim8 300 python tools/sim_rank.py 8 1 && step r5_sim4 300 python tools/sim_rank.py 4 1 && step r5_sim2 300 python tools/sim_rank.py 2 1 ;;
     sim8prof) rm -rf gpurun_out/r5_sim8prof; step r5_sim8prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5_sim8prof -- python tools/sim_rank.py 8 1 && (find gpurun_out/r5_sim8prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r5_sim8_kernel_stats.csv; rm -rf gpurun_out/r5_sim8prof; head -12 gpurun_out/r5_sim8_kernel_stats.csv | cut -c1-200) ;;
+    quick)    step r5_quick_a 200 python tools/quick_ss.py 625000 && QUICK_ROW0=625000 step r5_quick_b 200 python tools/quick_ss.py 625000 && step r5_trace_r8 200 ./tools/sstream_trace 625000 ;;
+    quick_off) for o in 0 16 1722 1723; do QUICK_OFFSET=$o step r5_quick_off$o 200 python tools/quick_ss.py 625000 || exit 1; done ;;
     sim8)     step r5_sim8 300 python tools/sim_rank.py 8 1 ;;
     tests)    step r5_tests 1100 python -m pytest tests -x -q -m gpu ;;
     smoke)    step r5_smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;

@@ -53,22 +53,23 @@ def step():  # the RCCL-shaped route on ONE stream: [pack ->] interior -> bounda
         mpk.check(L.mi_part_pack_dev(h, vp(x_ext.data_ptr()), vp(send.data_ptr()), sp))
     mpk.check(L.mi_part_spmv_interior_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp))
     mpk.check(L.mi_part_spmv_boundary_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp))
-for _ in range(20): step()
+REPS = int(os.environ.get("SIM_RANK_REPS", "3000"))
+for _ in range(300): step()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0 = time.perf_counter(); e0.record()
-for _ in range(500): step()
+for _ in range(REPS): step()
 e1.record(); torch.cuda.synchronize()
-wall = (time.perf_counter() - t0) / 500 * 1e6
-gpu_step_us = e0.elapsed_time(e1) / 500 * 1e3
+wall = (time.perf_counter() - t0) / REPS * 1e6
+gpu_step_us = e0.elapsed_time(e1) / REPS * 1e3
 def only(fn, name):
-    for _ in range(20): fn()
+    for _ in range(300): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(500): fn()
+    for _ in range(REPS): fn()
     b.record(); torch.cuda.synchronize()
-    print(f"    {name}: {a.elapsed_time(b) / 500 * 1e3:.1f} us back-to-back")
+    print(f"    {name}: {a.elapsed_time(b) / REPS * 1e3:.1f} us back-to-back")
 only(lambda: mpk.check(L.mi_part_pack_dev(h, vp(x_ext.data_ptr()), vp(send.data_ptr()), sp)), "pack")
 only(lambda: mpk.check(L.mi_part_spmv_interior_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp)), "interior")
 only(lambda: mpk.check(L.mi_part_spmv_boundary_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp)), "boundary")
@@ -92,17 +93,40 @@ mpk.check(L.mi_part_push_debug_preset(h, 0x3fffffff))
 def pstep():
     mpk.check(L.mi_part_spmv_push_dev(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), sp))
 halo_keep = x_ext[nl.value:].clone()
-for _ in range(20): pstep()
+for _ in range(300): pstep()
 torch.cuda.synchronize()
 t0 = time.perf_counter(); e0.record()
-for _ in range(500): pstep()
+for _ in range(REPS): pstep()
+t_enq = (time.perf_counter() - t0) / REPS * 1e6
 e1.record(); torch.cuda.synchronize()
-pwall = (time.perf_counter() - t0) / 500 * 1e6
+pwall = (time.perf_counter() - t0) / REPS * 1e6
 mpk.check(L.mi_part_status(h))
 fz = ctypes.c_int(); mpk.check(L.mi_part_push_info(h, None, ctypes.byref(fz), None))
 print(f"    kernels: interior {L.mi_part_kernel_name(h, 0).decode()} | boundary {L.mi_part_kernel_name(h, 1).decode()} | one-launch step {L.mi_part_kernel_name(h, 2).decode() or '-'}")
-print(f"    push step ({'ONE launch (fused)' if fz.value else 'push, interior, wait+copy, boundary'}; flags preset, pushes looped back): GPU {e0.elapsed_time(e1) / 500 * 1e3:.1f} us/step, "
-      f"host {pwall:.1f} us/step to enqueue")
+print(f"    push step ({'ONE launch (fused)' if fz.value else 'push, interior, wait+copy, boundary'}; flags preset, pushes looped back): GPU {e0.elapsed_time(e1) / REPS * 1e3:.1f} us/step, "
+      f"host {t_enq:.1f} us/step to enqueue ({pwall:.1f} with the final synchronise)")
+if fz.value and "sstream" in L.mi_part_kernel_name(h, 2).decode() and hasattr(L, "mi_debug_part_push_trace"):
+    # where one launch of the fused sliced-stream step goes: s_memrealtime per workgroup, ghost-reading / pushing workgroups apart
+    G = 1024
+    acc = {}
+    for it in range(12):
+        buf, wg, fl = np.zeros(4 * G, np.int64), ctypes.c_int(), np.zeros(G, np.int32)
+        mpk.check(L.mi_debug_part_push_trace(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), G, buf.ctypes.data, ctypes.byref(wg), fl.ctypes.data))
+        if it < 2:
+            continue
+        t = buf[:4 * wg.value].reshape(-1, 4).astype(np.float64) * 0.01
+        ran = t[:, 3] > 0
+        t0 = t[ran, 0].min()
+        for cls, sel in (("plain", (fl[:wg.value] & 3) == 0), ("ghost reader", (fl[:wg.value] & 1) == 1), ("pusher", (fl[:wg.value] & 2) == 2)):
+            sel = sel & ran
+            if sel.any():
+                acc.setdefault(cls, []).append((t[sel, 0] - t0, t[sel, 1] - t[sel, 0], t[sel, 2] - t[sel, 1], t[sel, 3] - t0, (fl[:wg.value][sel] >> 2)))
+        acc.setdefault("all", []).append(t[ran, 3].max() - t0)
+    print(f"    one traced launch of the fused step (stamps compiled in; 10 launches): first start -> last end median {np.median(acc.pop('all')):.2f} us")
+    for cls, rows in acc.items():
+        st, fi, lo_, en, rd = (np.concatenate([r[i] for r in rows]) for i in range(5))
+        print(f"      {cls:12s} ({len(rows[0][0]):3d} workgroups, {rd.min()}-{rd.max()} rounds): start +{np.median(st):.2f}, start -> loop {np.median(fi):.2f} (max {fi.max():.2f}), "
+              f"loop {np.median(lo_):.2f}, end +{np.median(en):.2f} (max {en.max():.2f}) us")
 x_ext[nl.value:] = halo_keep   # the looped-back window content is not this rank's true halo: restore it for the check below
 y.fill_(float("nan")); step(); torch.cuda.synchronize()
 cl = np.where((c >= lo) & (c < hi), c - lo, nl.value + np.searchsorted(halo_ids, c)).astype(np.int32)

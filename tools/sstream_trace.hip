@@ -147,6 +147,21 @@ int main(int argc, char** argv)
     line("library kernel  D=12 temporal, back to back", run<12, false, 0>(S, d_x, d_y, R));
     line("  with the stamps compiled in  D=8 temporal", run<8, false, 8>(([&] { SsView T = S; unsigned long long* t; CK(hipMalloc(&t, 32 * (size_t)S.nwg)); T.trace = t; return T; })(), d_x, d_y, R));
     trace<8, false>("D=8 temporal", S, P, d_x, d_y);
+    { // the same loop with every byte served by the XCDs' L2s: every workgroup runs workgroup 0's rounds (the same ~0.6 MB of the stream;
+      // all of them store the same rows of y with the same values).  What a k-step that re-read its matrix slices from L2 would stream at.
+        SsPlanHost Q = P;
+        for (int g = 0; g < Q.nwg; g++) Q.wg[g] = P.wg[0];
+        for (int g = 0; g <= Q.nwg; g++) Q.rptr[g] = g == 0 ? P.rptr[0] : P.rptr[1]; // (for the trace's grouping by round count only)
+        SsWg* d_wg2;
+        CK(hipMalloc(&d_wg2, sizeof(SsWg) * Q.wg.size()));
+        CK(hipMemcpy(d_wg2, Q.wg.data(), sizeof(SsWg) * Q.wg.size(), hipMemcpyHostToDevice));
+        SsView S2 = S;
+        S2.wg = d_wg2;
+        const int rounds0 = P.rptr[1] - P.rptr[0];
+        const double us = run<8, false, 0>(S2, d_x, d_y, R);
+        printf("ALIASED to workgroup 0's %d rounds (matrix stream from L2): %.2f us per launch back to back\n", rounds0, us);
+        trace<8, false>("D=8 temporal, every workgroup on workgroup 0's rounds (L2-served)", S2, Q, d_x, d_y);
+    }
     trace<12, false>("D=12 temporal", S, P, d_x, d_y);
     trace<8, true>("D=8 nt", S, P, d_x, d_y);
     return 0;
