@@ -865,6 +865,13 @@ def main():
                                              frac_of_peak_if_fused_bytes=round(B_fused / step_s / 1e9 / HBM_PEAK_GBS, 4),
                                              note="time of the whole k-step over the bytes a perfectly fused kernel would move; "
                                                   "the gap to `frac` is what fusing the k sweeps could still buy")
+    if roofline["traffic"]:
+        # `frac` prices the ALGORITHMIC bytes (12 B per nonzero for CSR) over the launch time; the sliced kernels stream 10 B per
+        # nonzero, so it can pass 1.0 on a fast box without anything moving faster than the memory: the counter traffic over the same time says what did
+        roofline["frac_on_traffic"] = round(roofline["traffic"] / launch_s / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["frac_note"] = ("frac = algorithmic bytes / launch time / peak (the contract's definition); frac_on_traffic = the profiled fabric traffic of this kernel "
+                                 "(FETCH_SIZE x 2 + WRITE_SIZE) over the same time: what actually moved, as a fraction of the 8 TB/s peak — a frac above 1.0 means the "
+                                 "kernel's format holds fewer bytes than the CSR model charges for, not that memory ran above its peak")
     if world == 1 and not args.no_extras:
         # this box's own streaming rate: a plain read sweep over as many bytes as the kernel's format holds (MI355X boxes of one
         # pool differ by 10-20 % in it); NOT the roofline's peak — `frac` stays priced against the 8 TB/s spec

@@ -551,6 +551,11 @@ static int build_spmm_tile_plan(mi_bcsr4_t A, int per, int ucap, const std::vect
                 slots[k] = (unsigned short)(std::lower_bound(u.begin(), u.end(), (unsigned)indcol[k]) - u.begin());
         nodes.insert(nodes.end(), u.begin(), u.end());
         wg_ptr.push_back((int)nodes.size());
+        // (round 5) the tile's rows in ASCENDING order, not in the order the cluster grew: neighbouring lane groups then stream
+        // neighbouring rows' blocks (one run of the coefficient array per run of consecutive rows) and store neighbouring pieces of Y.
+        // MI355_SPMM_TILE_SORT=0: growth order (A/B).
+        static const bool sort_rows = !(getenv("MI355_SPMM_TILE_SORT") && !strcmp(getenv("MI355_SPMM_TILE_SORT"), "0"));
+        if (sort_rows) std::sort(order.begin() + w.first, order.begin() + w.second);
         for (int i = 0; i < per; i++) rows.push_back(w.first + i < w.second ? order[w.first + i] : -1 - order[w.first]);
     }
     const int ntiles = (int)wg_ptr.size() - 1;

@@ -608,6 +608,10 @@ int csr_create_impl(int n, int ncols, const int* ptrow, const int* indcol, const
         else forced_kernel = false;
     }
     const char* at = getenv("MI355_SPMV_AUTOTUNE");
+    // Too small to be measured (< 200 000 nonzeros: a partition's boundary rows, a test matrix): the stream kernel — a launch of as
+    // many workgroups as there are row blocks — not the ring kernel's persistent grid with its plan loads and window fill: a rank's
+    // 2 000 boundary rows cost 11-17 us through the ring and 4.8 through the stream kernel (profiles/r05_sp2_trace_tail.txt).
+    if (!forced_kernel && nnz < 200000 && A->auto_kernel == MI_KERNEL_RING && !(ghost_lo < ghost_hi)) A->auto_kernel = MI_KERNEL_STREAM;
     if (!forced_kernel && !(at && !strcmp(at, "0")) && nnz >= 200000) {
         // measure the candidates on this very matrix (x = 0: timing does not depend on the values):
         // ring (if it serves the matrix) and stream, each with temporal and non-temporal matrix loads

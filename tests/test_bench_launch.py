@@ -40,6 +40,16 @@ def test_bench_gpus_2_on_one_card_prints_one_json_line():
     assert h["exchanges"]["push"]["ok"], h["exchanges"]["push"]           # separate processes: the IPC windows must come up
     assert h["exchange_bytes_per_step"]["sent_all_ranks"] > 0 and h["overlap"]["compute_only_us"] > 0
     assert h["torch_world"] == 2 and "rccl_ranks" in h
+    # (round 5) the first real multi-GPU record must explain itself: seconds per candidate exchange, which kernels each one launches, why a
+    # dropped one was dropped, progress lines on stderr from the moment the ranks are up
+    assert set(h["probe_seconds"]) >= set(h["exchanges"]) and all(h["probe_seconds"][e] >= 0 for e in h["exchanges"])
+    for e, pr in h["exchanges"].items():
+        assert "probe_s" in pr and (pr["ok"] or len(pr["note"]) > 10), (e, pr)
+        if pr["ok"]:
+            assert pr["create_s"] >= 0 and pr["kernels"]["interior"] and pr["kernels"]["boundary"], (e, pr)
+    if h["exchanges"]["push"]["form"].startswith("ONE launch"):  # the fused step names its kernel (spmv_sstream_fused<...> or the ring's FUSED form)
+        assert h["exchanges"]["push"]["kernels"]["one_launch_step"], h["exchanges"]["push"]
+    assert "[bench +" in r.stderr and "probing exchanges" in r.stderr and "chosen:" in r.stderr, r.stderr[-1500:]
     # the one-process form of the same workload (mi_dist_*), timed by a child of rank 0 behind the timed region
     sp = d["single_process"]
     assert sp["ok"], sp

@@ -20,6 +20,10 @@ for s in "$@"; do
     sim8prof) rm -rf gpurun_out/r5_sim8prof; step r5_sim8prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5_sim8prof -- python tools/sim_rank.py 8 1 && (find gpurun_out/r5_sim8prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r5_sim8_kernel_stats.csv; rm -rf gpurun_out/r5_sim8prof; head -12 gpurun_out/r5_sim8_kernel_stats.csv | cut -c1-200) ;;
     quick)    step r5_quick_a 200 python tools/quick_ss.py 625000 && QUICK_ROW0=625000 step r5_quick_b 200 python tools/quick_ss.py 625000 && step r5_trace_r8 200 ./tools/sstream_trace 625000 ;;
     quick_off) for o in 0 16 1722 1723; do QUICK_OFFSET=$o step r5_quick_off$o 200 python tools/quick_ss.py 625000 || exit 1; done ;;
+    sp2)      MI355_DIST_DEVICES=0 step r5_bench_sp2 300 python bench.py --gpus 2 --single-process --workload c2 --steps 200 --warmup 20 ;;
+    sp2prof)  rm -rf gpurun_out/r5_sp2prof; MI355_DIST_DEVICES=0 step r5_sp2prof 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r5_sp2prof -- python bench.py --gpus 2 --single-process --workload c2 --steps 30 --warmup 5 --no-parity && (f=$(find gpurun_out/r5_sp2prof -name "*kernel_trace.csv" | head -1); python tools/trace_tail.py "$f" 60 > gpurun_out/r5_sp2_trace_tail.txt; rm -rf gpurun_out/r5_sp2prof; cat gpurun_out/r5_sp2_trace_tail.txt | cut -c1-200) ;;
+    spmm)     step r5_bench_spmm8 300 python bench.py --workload fe_spmm8 --no-cpu-baseline && MI355_SPMM_TILE_SORT=0 step r5_bench_spmm8_unsorted 300 python bench.py --workload fe_spmm8 --no-cpu-baseline && step r5_bench_spmm4 300 python bench.py --workload fe_spmm4 --no-cpu-baseline && step r5_t_spmm 600 python -m pytest tests/test_spmm_gpu.py -x -q -m gpu ;;
+    c3tcc)    for c in TCC_HIT_sum TCC_MISS_sum; do rm -rf gpurun_out/r5_c3_$c; step r5_c3_$c 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/r5_c3_$c -- python3 bench.py --workload c3 --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-extras || exit 1; python tools/pmc_summary.py gpurun_out/r5_c3_$c > gpurun_out/r5_c3_$c.txt 2>&1; rm -rf gpurun_out/r5_c3_$c; grep -B1 -A3 -E "spmk_|spmv_sstream|spmv_csr_ring" gpurun_out/r5_c3_$c.txt | head -30; done ;;
     sim8)     step r5_sim8 300 python tools/sim_rank.py 8 1 ;;
     tests)    step r5_tests 1100 python -m pytest tests -x -q -m gpu ;;
     smoke)    step r5_smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
