@@ -269,7 +269,10 @@ int mi_spmv_dev(mi_csr_t A, const double* d_x, double* d_y, mi_stream_t s);    /
  * SpM2V_CSR (mpk/SpM2V.cpp:79-112: y_out[0]=y, y_out[1]=z), SpM3V / SpM4V
  * (mpk/SpMVmulti0.cpp:132-155, :189-221: all intermediate powers returned).
  * Unlike the CPU first-touch traversal, rows of A^p x that no row references
- * as a column are computed too (SURVEY.md §8a-10 caveat). */
+ * as a column are computed too (SURVEY.md §8a-10 caveat).
+ * mi_spmk_dev is asynchronous on s — EXCEPT the first k-step of a handle at a given k (2 <= k <= 8) on an eligible ring-served
+ * matrix: that call times the one-launch form against k launches (a few dozen launches on s, then a stream synchronise) and keeps
+ * the faster (mi_csr_spmk_info says which).  Under stream capture nothing is measured and k plain launches are recorded. */
 int mi_spmk(mi_csr_t A, int k, const double* x, double* const* y_out);                      /* host */
 int mi_spmk_dev(mi_csr_t A, int k, const double* d_x, double* const* d_y_out, mi_stream_t s); /* device; d_y_out is a HOST array of k device pointers */
 

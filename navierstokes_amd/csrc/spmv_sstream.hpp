@@ -482,7 +482,11 @@ __device__ __forceinline__ void ss_body(const SsView& S, const SsWg& W, int g, c
     const int t0 = wv == 0 ? W.t[0] : (wv == 1 ? W.t[1] : (wv == 2 ? W.t[2] : W.t[3]));
     const int t_end = wv == 0 ? W.t[1] : (wv == 1 ? W.t[2] : (wv == 2 ? W.t[3] : W.t[4]));
     const int clast = S.ncols - 1;
-    const int cfirst = MODE != 0 ? C.n_left : 0; // (fused step: the prefetch of a window's new columns never reaches in front of the owned entries)
+    // (fused step: the prefetch of a window's new columns reaches neither in front of nor behind the OWNED entries — whatever lies
+    // beyond is never used (a plain workgroup names no ghost; a ghost reader's later windows are empty), and the caller's x need not
+    // extend there)
+    const int cfirst = MODE != 0 ? C.n_left : 0;
+    const int cowned = MODE != 0 ? C.n_left + C.n_local - 1 : clast;
     const ss_v2d* vb = S.val + lane;
     const unsigned* sb = S.slot + lane;
     ss_v2d a[D];
@@ -511,9 +515,9 @@ __device__ __forceinline__ void ss_body(const SsView& S, const SsWg& W, int g, c
         // windows of zero new columns)
         double fx[kSsFill];
 #pragma unroll
-        for (int u = 0; u < kSsFill; u++) fx[u] = GHOSTS ? ring_ldx<true>(x_in, C, min(W.w0_lo + tid + 256 * u, clast)) : x[min(W.w0_lo + tid + 256 * u, clast)];
+        for (int u = 0; u < kSsFill; u++) fx[u] = GHOSTS ? ring_ldx<true>(x_in, C, min(W.w0_lo + tid + 256 * u, clast)) : x[min(W.w0_lo + tid + 256 * u, cowned)];
 #pragma unroll
-        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = (ABL & 4) ? 0.0 : x[min(max(wn.x + tid + 256 * u, cfirst), clast)];
+        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = (ABL & 4) ? 0.0 : x[min(max(wn.x + tid + 256 * u, cfirst), cowned)];
         if (!GHOSTS) first_steps();
 #pragma unroll
         for (int u = 0; u < kSsFill; u++) {
@@ -523,7 +527,7 @@ __device__ __forceinline__ void ss_body(const SsView& S, const SsWg& W, int g, c
         for (int c0 = W.w0_lo + 256 * kSsFill + tid; c0 < W.w0_lo + W.w0_n; c0 += 256 * 8) { // (a first window wider than 6144 columns)
             double f8[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) f8[u] = GHOSTS ? ring_ldx<true>(x_in, C, min(c0 + 256 * u, clast)) : x[min(c0 + 256 * u, clast)];
+            for (int u = 0; u < 8; u++) f8[u] = GHOSTS ? ring_ldx<true>(x_in, C, min(c0 + 256 * u, clast)) : x[min(c0 + 256 * u, cowned)];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (c0 + 256 * u < W.w0_lo + W.w0_n) ring[(c0 + 256 * u) & (kSsRing - 1)] = f8[u];
@@ -578,7 +582,7 @@ __device__ __forceinline__ void ss_body(const SsView& S, const SsWg& W, int g, c
                     if (!(ABL & 4)) {
                         wn = S.win[min(r + 1, r_end - 1)];
 #pragma unroll
-                        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = x[min(max(wn.x + tid + 256 * u, cfirst), clast)];
+                        for (int u = 0; u < kSsNewMax / 256; u++) nx[u] = x[min(max(wn.x + tid + 256 * u, cfirst), cowned)];
                     }
                 }
                 const double x0 = (ABL & 1) ? 1.0 + lane : ring[s & (kSsRing - 1)], x1 = (ABL & 1) ? 0.5 : ring[(s >> 16) & (kSsRing - 1)];

@@ -95,6 +95,25 @@ for seed in range(first, last):
         ok = np.array_equal(got[rowmap].view(np.uint64), yb_ref.view(np.uint64)) and np.isnan(got[rest]).all()
         names.append("smap" + ("" if ok else "!!"))
         bad += not ok
+        # round 5: the same band behind a plain row offset (an odd one plans the rows one down: the sliced kernel keeps its 16-byte stores),
+        # in a random variant of the kernel, then with new values (the LDS-staged refill that writes the CSR and the sliced values in one pass)
+        del A
+        off = int(rng.integers(0, 9))
+        os.environ["MI355_SSTREAM_FORM"] = str(int(rng.integers(0, 4)))
+        A = mpk.csrmatrix(nb, pb, cb, vb, rowmap=(np.arange(nb) + off).astype(np.int32)).set_kernel("sstream")
+        yo_ = torch.full((nb + off + 2,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(yo_, torch.from_numpy(xb).cuda(), A)
+        got = yo_.cpu().numpy()
+        ok = np.array_equal(got[off:off + nb].view(np.uint64), yb_ref.view(np.uint64)) and np.isnan(got[:off]).all() and np.isnan(got[off + nb:]).all()
+        vb2 = vb * np.cos(np.arange(len(vb)))
+        A.update_values(torch.from_numpy(vb2).cuda())
+        yo_.fill_(float("nan"))
+        mpk.SpMV_CSR(yo_, torch.from_numpy(xb).cuda(), A)
+        got = yo_.cpu().numpy()
+        ok = ok and np.array_equal(got[off:off + nb].view(np.uint64), O.spmv(pb, cb, vb2, xb).view(np.uint64)) and np.isnan(got[:off]).all() and np.isnan(got[off + nb:]).all()
+        names.append(f"soff{off}f{os.environ['MI355_SSTREAM_FORM']}:{A.kernel_name().split('<')[0][5:]}" + ("" if ok else "!!"))
+        bad += not ok
+        del os.environ["MI355_SSTREAM_FORM"]
     except mpk.MiError:
         names.append(f"band(hb={hb},per={per},n={nb}):n/a")
     del A

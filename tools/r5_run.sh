@@ -24,6 +24,9 @@ for s in "$@"; do
     sp2prof)  rm -rf gpurun_out/r5_sp2prof; MI355_DIST_DEVICES=0 step r5_sp2prof 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r5_sp2prof -- python bench.py --gpus 2 --single-process --workload c2 --steps 30 --warmup 5 --no-parity && (f=$(find gpurun_out/r5_sp2prof -name "*kernel_trace.csv" | head -1); python tools/trace_tail.py "$f" 60 > gpurun_out/r5_sp2_trace_tail.txt; rm -rf gpurun_out/r5_sp2prof; cat gpurun_out/r5_sp2_trace_tail.txt | cut -c1-200) ;;
     spmm)     step r5_bench_spmm8 300 python bench.py --workload fe_spmm8 --no-cpu-baseline && MI355_SPMM_TILE_SORT=0 step r5_bench_spmm8_unsorted 300 python bench.py --workload fe_spmm8 --no-cpu-baseline && step r5_bench_spmm4 300 python bench.py --workload fe_spmm4 --no-cpu-baseline && step r5_t_spmm 600 python -m pytest tests/test_spmm_gpu.py -x -q -m gpu ;;
     c3tcc)    for c in TCC_HIT_sum TCC_MISS_sum; do rm -rf gpurun_out/r5_c3_$c; step r5_c3_$c 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/r5_c3_$c -- python3 bench.py --workload c3 --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-extras || exit 1; python tools/pmc_summary.py gpurun_out/r5_c3_$c > gpurun_out/r5_c3_$c.txt 2>&1; rm -rf gpurun_out/r5_c3_$c; grep -B1 -A3 -E "spmk_|spmv_sstream|spmv_csr_ring" gpurun_out/r5_c3_$c.txt | head -30; done ;;
+    c2forms)  for f in 0 1 2 3; do MI355_SSTREAM_FORM=$f step r5_bench_c2_form$f 300 python bench.py --workload c2 --kernel sstream --no-cpu-baseline || exit 1; done ;;
+    t_push)   step r5_t_push 900 python -m pytest tests/test_gpu_parity.py tests/test_dist_single_process.py tests/test_bench_launch.py -x -q -m gpu -k "ranks_sharing_one_card or native_step or bench_gpus_2 or single_process" ;;
+    fuzz)     step r5_fuzz 1100 python tools/gpu_fuzz.py ${FUZZ_FIRST:-600} ${FUZZ_LAST:-640} ;;
     sim8)     step r5_sim8 300 python tools/sim_rank.py 8 1 ;;
     tests)    step r5_tests 1100 python -m pytest tests -x -q -m gpu ;;
     smoke)    step r5_smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
