@@ -82,13 +82,13 @@ def test_roofline_traffic_comes_from_a_committed_profile_of_the_same_kernel_fami
     spec.loader.exec_module(bench)
     t8, src8 = bench.load_traffic("c4", "spmv_sstream<8, true, 0>")
     t12, src12 = bench.load_traffic("c4", "spmv_sstream<12, false, 0>")
-    assert src8 == src12 == "profiles/r04_bench_c4_pmc.json" and t8 == t12
+    assert src8 == src12 and src8.startswith("profiles/r") and src8.endswith("_bench_c4_pmc.json") and t8 == t12  # (the newest round's profile)
     prof = json.load(open(os.path.join(ROOT, src8)))
     assert prof["workload"] == "c4" and prof["kernel"].startswith("spmv_sstream<") and t8 == prof["hbm_bytes_per_launch"]
     assert 0.8 * prof["algorithmic_bytes_per_launch"] < t8 < 1.1 * prof["algorithmic_bytes_per_launch"]  # (10 B per nonzero read where the CSR model counts 12)
     # the gfx950 read correction is stated in the file the number comes from
     assert prof["fetch_correction"] == 2.0 and prof["hbm_bytes_per_launch"] == prof["hbm_read_bytes_per_launch"] + prof["hbm_write_bytes_per_launch"]
     tb, srcb = bench.load_traffic("fe_bcsr", "spmv_bcsr4_sell<8, true, 0, 2, 4>")
-    assert srcb == "profiles/r04_bench_fe_bcsr_pmc.json" and tb > 0
+    assert srcb.endswith("_bench_fe_bcsr_pmc.json") and tb > 0
     assert bench.load_traffic("c4", "some_other_kernel<1>") == (None, None)
     assert bench.load_traffic("no_such_workload", "spmv_sstream<8, true, 0>") == (None, None)
