@@ -617,7 +617,12 @@ class DistMatrix:
         check(lib().mi_dist_dot_dev(self._h, a._h, b._h, _c.byref(out)))
         return out.value
 
-    def orthogonalize_dev(self, b, x1, x3, alpha=1e-8):
+    def orthogonalize_dev(self, b, x1, x3, alpha=1e-8, want_beta=True):
+        """x3 = x1 - alpha (b . x1) b on distributed vectors.  want_beta=False: nothing is awaited (the ranks' partial dots meet on the
+        devices; returns None); else the call waits for rank 0's copy of beta and returns it."""
+        if not want_beta:
+            check(lib().mi_dist_orthogonalize_dev(self._h, b._h, x1._h, x3._h, float(alpha), None))
+            return None
         beta = _c.c_double()
         check(lib().mi_dist_orthogonalize_dev(self._h, b._h, x1._h, x3._h, float(alpha), _c.byref(beta)))
         return beta.value

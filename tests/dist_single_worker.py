@@ -74,6 +74,20 @@ def capi(N):
         beta3 = D.orthogonalize_dev(vb, vy, v3, 1e-8)
         assert beta3 == beta
         assert_bit_equal(v3.get(), x3, "orthogonalize_dev")
+        # (round 5) the update has no host in its middle: seven calls back to back on alternating vector pairs (the shared table of partial
+        # dots has two parities; every rank's update kernel adds the partials in rank order itself), one synchronisation at the end
+        b2 = np.sin(0.007 * np.arange(n)) + 0.25
+        vb2, v4 = D.vector(b2), D.vector()
+        betas = []
+        for t in range(7):
+            betas.append(D.orthogonalize_dev(vb if t % 2 == 0 else vb2, vy, v3 if t % 2 == 0 else v4, 1e-8, want_beta=t >= 5))
+        D.synchronize()
+        beta_b2 = D.dot(b2, Y[0])
+        assert betas[:5] == [None] * 5 and betas[5] == beta_b2 and betas[6] == beta, (betas, beta, beta_b2)
+        assert_bit_equal(v3.get(), x3, "orthogonalize_dev, repeated")
+        assert_bit_equal(v4.get(), O.ortho_update(1e-8 * beta_b2, b2, Y[0]), "orthogonalize_dev, second pair")
+        vb2.close()
+        v4.close()
         # new coefficients, same pattern
         v2 = v * np.cos(np.arange(len(v)))
         D.update_values(v2)
