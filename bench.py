@@ -745,8 +745,8 @@ def main():
     # (3) what a Newton iteration pays beside its products (src/solve_newton.c:1245-1247: the Jacobian's VALUES change every iteration, the
     #     pattern never): mi_csr_update_values_dev on the benched handle — CSR values, the sliced copy the headline kernel streams and the
     #     blocked copy where there is one, refilled on the update's stream — and what the handle keeps allocated on the device.
-    if world == 1 and not bcsr and not args.no_extras and k == 1:
-        vdev = torch.from_numpy(np.ascontiguousarray(v)).cuda()  # the same values: the parity check below still sees the timed region's result
+    if world == 1 and not args.no_extras and k == 1 and not W.get("spmm"):
+        vdev = torch.from_numpy(np.ascontiguousarray(bv if bcsr else v)).cuda()  # the same values: the parity check below still sees the timed region's result
         for _ in range(2):
             A.update_values(vdev)
         ev0.record()
@@ -901,7 +901,7 @@ def main():
                                                     "mi_spmv_orthogonalize_dev (b . x1 accumulated in the first product's epilogue)")
         if "update_values_us" in extra:
             roofline["newton_refresh"] = dict(update_values_us=round(extra["update_values_us"], 1), products=round(extra["update_values_us"] / (launch_s * 1e6), 2),
-                                              device_bytes_per_nnz=round(handle_device_bytes / max(nnz_global, 1), 2), device_bytes=int(handle_device_bytes),
+                                              device_bytes_per_nnz=None if bcsr else round(handle_device_bytes / max(nnz_global, 1), 2), device_bytes=None if bcsr else int(handle_device_bytes),
                                               note="mi_csr_update_values_dev on the benched handle (a Newton loop's Jacobian: new values, same pattern; "
                                                    "src/solve_newton.c:1245-1247) — ONE pass reads the caller's values and writes the CSR values and the sliced copy "
                                                    "(+ the blocked copy's refill where the handle has one); `products` = that time in products of this line; "

@@ -34,6 +34,8 @@ extern "C" int mi_bcsr4_create(int nbrows, int nbcols, const int* ptrow, const i
         mi_bcsr4_destroy(A);
         return fail(e == hipErrorOutOfMemory ? MI_ERR_ALLOC : MI_ERR_HIP, std::string("bcsr4 upload: ") + hipGetErrorString(e));
     }
+    for (int s0 = 0; s0 < nbrows; s0 += kSellRows) // values of the longest slice of 16 block rows (bcsr4_refresh_kernel picks its LDS buffer by it)
+        A->max_slice_vals = std::max(A->max_slice_vals, 16 * (ptrow[std::min(nbrows, s0 + kSellRows)] - ptrow[s0]));
     // The x tile per workgroup (spmv_bcsr4_tile): the distinct block columns of each group of 64 block rows, and every block's
     // position in its group's list.  Built when no group needs more than the tile holds; then both kernels are timed and the
     // faster is kept (MI355_BCSR_TILE=0 never builds it, =1 takes it unmeasured).
@@ -194,6 +196,44 @@ static int sell_fill(mi_bcsr4_t A, hipStream_t s)
     return MI_OK;
 }
 
+// the blocked copy of a CSR handle from that handle's (new) CSR values, d_src — and, when d_csr_out is given, the handle's CSR value
+// array — in one pass (bcsr4_refresh_kernel); every copy the blocked kernels read is current when this returns (in stream order)
+int bcsr4_refresh_from_csr(mi_bcsr4_s* A, const int* d_csr_ptrow, const double* d_src, double* d_csr_out, hipStream_t s)
+{
+    if (!A || A->nbrows == 0) return MI_OK;
+    const int nslices = (A->nbrows + kSellRows - 1) / kSellRows;
+    const int grid = std::max(1, std::min(nslices, 2048));
+    const int* sptr = A->d_sell_val ? A->d_sell_sptr : nullptr;
+    double* sv = A->d_sell_val;
+    if (A->max_slice_vals <= 4096) // 32 KB of LDS: four workgroups per CU (the FE rows of 56-60: 3 584-3 840 values per slice)
+        hipLaunchKernelGGL((bcsr4_refresh_kernel<4096>), dim3((unsigned)grid), dim3(256), 0, s, nslices, A->nbrows, d_csr_ptrow, d_src, d_csr_out, A->d_ptrow, A->d_coef, sptr, sv);
+    else if (A->max_slice_vals <= 16384)
+        hipLaunchKernelGGL((bcsr4_refresh_kernel<16384>), dim3((unsigned)std::min(grid, 256)), dim3(256), 0, s, nslices, A->nbrows, d_csr_ptrow, d_src, d_csr_out, A->d_ptrow, A->d_coef, sptr, sv);
+    else
+        hipLaunchKernelGGL((bcsr4_refresh_kernel<0>), dim3((unsigned)grid), dim3(256), 0, s, nslices, A->nbrows, d_csr_ptrow, d_src, d_csr_out, A->d_ptrow, A->d_coef, sptr, sv);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// new block values from a device array in the caller's layout: the handle's row-major blocks and the sliced values in one pass
+static int bcsr4_refresh_from_blocks(mi_bcsr4_s* A, const double* d_src, bool colmajor, hipStream_t s)
+{
+    if (!A || A->nbrows == 0 || A->nblocks == 0) return MI_OK;
+    const int nslices = (A->nbrows + kSellRows - 1) / kSellRows;
+    const int grid = std::max(1, std::min(nslices, 2048));
+    const int* sptr = A->d_sell_val ? A->d_sell_sptr : nullptr;
+    double* out = d_src == A->d_coef ? nullptr : A->d_coef;
+    if (colmajor && !out) return fail(MI_ERR_ARG, "column-major blocks cannot be transposed in place");
+    if (!out && !A->d_sell_val) return MI_OK;
+#define BR_LAUNCH(CAP_, CM_, G_) hipLaunchKernelGGL((bcsr4_blocks_refresh_kernel<CAP_, CM_>), dim3((unsigned)(G_)), dim3(256), 0, s, nslices, A->nbrows, A->d_ptrow, d_src, out, sptr, A->d_sell_val)
+    if (A->max_slice_vals <= 4096) { if (colmajor) BR_LAUNCH(4096, true, grid); else BR_LAUNCH(4096, false, grid); }
+    else if (A->max_slice_vals <= 16384) { if (colmajor) BR_LAUNCH(16384, true, std::min(grid, 256)); else BR_LAUNCH(16384, false, std::min(grid, 256)); }
+    else { if (colmajor) BR_LAUNCH(0, true, grid); else BR_LAUNCH(0, false, grid); }
+#undef BR_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 int bcsr4_values_changed(mi_bcsr4_s* A, hipStream_t s)
 {
     if (A && A->d_sell_val && A->nblocks > 0) return sell_fill(A, s);
@@ -220,16 +260,6 @@ static void transpose_blocks_host(long long nb, const double* src, double* dst)
     for (long long k = 0; k < nb; k++)
         for (int r = 0; r < 4; r++)
             for (int c = 0; c < 4; c++) dst[16 * k + 4 * r + c] = src[16 * k + 4 * c + r];
-}
-
-__global__ __launch_bounds__(256) void transpose_blocks_kernel(long long nb, const double* __restrict__ src, double* __restrict__ dst)
-{
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < 16 * nb; e += stride) {
-        const long long k = e >> 4;
-        const int r = (int)(e & 15) >> 2, c = (int)e & 3;
-        dst[e] = src[16 * k + 4 * c + r]; // coalesced stores; the 16 loads of a block hit one or two lines
-    }
 }
 
 extern "C" int mi_bcsr4_create_layout(int nbrows, int nbcols, const int* ptrow, const int* indcol, const double* coef, int layout,
@@ -264,11 +294,7 @@ extern "C" int mi_bcsr4_update_values_layout_dev(mi_bcsr4_t A, const double* d_c
     CHECK_ARG(layout == MI_BLOCK_ROWMAJOR || layout == MI_BLOCK_COLMAJOR, "unknown block layout");
     if (layout == MI_BLOCK_ROWMAJOR || A->nblocks == 0) return mi_bcsr4_update_values_dev(A, d_coef, s);
     CHECK_ARG(d_coef && d_coef != A->d_coef, "null coef, or the handle's own array");
-    long long grid = (16 * A->nblocks + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(transpose_blocks_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, A->nblocks, d_coef, A->d_coef);
-    HIP_TRY(hipGetLastError());
-    return bcsr4_values_changed(A, (hipStream_t)s);
+    return bcsr4_refresh_from_blocks(A, d_coef, true, (hipStream_t)s); // transposed on the way, blocks and sliced values in one pass
 }
 
 extern "C" int mi_bcsr4_tile_info(mi_bcsr4_t A, int* built, int* in_use, double* us_plain, double* us_tile)
@@ -299,8 +325,7 @@ extern "C" int mi_bcsr4_update_values_dev(mi_bcsr4_t A, const double* d_coef, mi
     CHECK_ARG(A, "null handle");
     if (A->nblocks == 0) return MI_OK;
     CHECK_ARG(d_coef, "null coef");
-    if (d_coef != A->d_coef) HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * 16 * (size_t)A->nblocks, hipMemcpyDeviceToDevice, (hipStream_t)s));
-    return bcsr4_values_changed(A, (hipStream_t)s);
+    return bcsr4_refresh_from_blocks(A, d_coef, false, (hipStream_t)s);
 }
 
 extern "C" int mi_bcsr4_destroy(mi_bcsr4_t A)

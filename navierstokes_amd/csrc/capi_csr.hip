@@ -1099,24 +1099,6 @@ extern "C" int mi_csr_destroy(mi_csr_t A)
     return MI_OK;
 }
 
-// Blocked copy's values from the CSR values already on the device: lane q of block row bi copies its
-// row's four coefficients of every block (32 B per lane and block; setup-time traffic).
-__global__ __launch_bounds__(kWG) void bcsr4_values_from_csr_kernel(int nbrows, const int* __restrict__ csr_ptrow,
-                                                                     const double* __restrict__ csr_coef,
-                                                                     const int* __restrict__ bptr, double* __restrict__ bval)
-{
-    const int g = blockIdx.x * kWG + threadIdx.x;
-    const int bi = g >> 2, q = g & 3;
-    if (bi >= nbrows) return;
-    const double* src = csr_coef + csr_ptrow[4 * bi + q];
-    const int b0 = bptr[bi], b1 = bptr[bi + 1];
-    for (int blk = b0; blk < b1; blk++) {
-        double* dst = bval + 16 * (size_t)blk + 4 * q;
-        const double* sp = src + 4 * (size_t)(blk - b0);
-        dst[0] = sp[0]; dst[1] = sp[1]; dst[2] = sp[2]; dst[3] = sp[3];
-    }
-}
-
 // every value refresh comes by here, on the stream the new CSR values were written on: the copies derived from them follow AT ONCE on
 // that stream (the sliced values of spmv_sstream unless the caller filled them in the same pass as the CSR values; the blocked copy and
 // its sliced values), so that stream order — and a HIP graph captured earlier — see them like the CSR values themselves
@@ -1128,11 +1110,7 @@ static int refresh_blocked_values(mi_csr_t A, hipStream_t s, bool sliced_done = 
         HIP_TRY(hipGetLastError());
     }
     if (!A->blocked || A->blocked->nbrows == 0) return MI_OK;
-    const long long threads = 4LL * A->blocked->nbrows;
-    hipLaunchKernelGGL(bcsr4_values_from_csr_kernel, dim3((unsigned)((threads + kWG - 1) / kWG)), dim3(kWG), 0, s,
-                       A->blocked->nbrows, A->d_ptrow, A->d_coef, A->blocked->d_ptrow, A->blocked->d_coef);
-    HIP_TRY(hipGetLastError());
-    return bcsr4_values_changed(A->blocked, s);
+    return bcsr4_refresh_from_csr(A->blocked, A->d_ptrow, A->d_coef, nullptr, s); // blocks and sliced values from the CSR values, one pass
 }
 
 // New coefficients for an unchanged sparsity pattern (what a Newton loop does to its Jacobian every
@@ -1140,13 +1118,32 @@ static int refresh_blocked_values(mi_csr_t A, hipStream_t s, bool sliced_done = 
 // ring plan, the 16-bit column stream and the kernel choice depend on the pattern alone and are kept;
 // the blocked copy's values are regenerated on the device.
 // values of a reordered twin from the caller's (original order) values: new row r' copies its segment
-__global__ __launch_bounds__(kWG) void permute_values_kernel(int n, const int* __restrict__ new_ptrow, const int* __restrict__ src_start,
-                                                              const double* __restrict__ src, double* __restrict__ dst)
+__global__ __launch_bounds__(256) void permute_values_kernel(int n, const int* __restrict__ new_ptrow, const int* __restrict__ src_start,
+                                                             const double* __restrict__ src, double* __restrict__ dst)
 {
-    const int r = blockIdx.x * kWG + threadIdx.x;
-    if (r >= n) return;
-    const int b = new_ptrow[r], len = new_ptrow[r + 1] - b, a = src_start[r];
-    for (int k = 0; k < len; k++) dst[b + k] = src[a + k];
+    // (round 5) 64 new rows per workgroup and turn: their destination is ONE contiguous segment, written coalesced; every element finds
+    // its row by bisection over the 65 row pointers in LDS and reads from that row's (contiguous) source segment.  The first form — a
+    // thread per row walking it — took 2.0-2.8 ms per value update of the relabelled mesh / FE matrices.
+    __shared__ int s_p[65], s_a[64];
+    const int tid = threadIdx.x;
+    for (int r0 = blockIdx.x * 64; r0 < n; r0 += gridDim.x * 64) {
+        const int nr = min(64, n - r0);
+        if (tid <= nr) s_p[tid] = new_ptrow[r0 + tid];
+        if (tid < nr) s_a[tid] = src_start[r0 + tid];
+        __syncthreads();
+        const int b0 = s_p[0], seg = s_p[nr] - b0;
+        for (int k = tid; k < seg; k += 256) {
+            const int p = b0 + k;
+            int lo = 0, hi = nr; // s_p[lo] <= p < s_p[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_p[mid] <= p) lo = mid;
+                else hi = mid;
+            }
+            dst[p] = src[s_a[lo] + (p - s_p[lo])];
+        }
+        __syncthreads();
+    }
 }
 
 extern "C" int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_stream_t s_)
@@ -1157,7 +1154,7 @@ extern "C" int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_str
     hipStream_t s = (hipStream_t)s_;
     if (A->inner) {
         mi_csr_t I = A->inner;
-        hipLaunchKernelGGL(permute_values_kernel, dim3((A->n + kWG - 1) / kWG), dim3(kWG), 0, s, A->n, I->d_ptrow, A->d_src_start, d_coef, I->d_coef);
+        hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)std::max(1, std::min((A->n + 63) / 64, 4096))), dim3(256), 0, s, A->n, I->d_ptrow, A->d_src_start, d_coef, I->d_coef);
         HIP_TRY(hipGetLastError());
         return refresh_blocked_values(I, s);
     }
@@ -1167,6 +1164,8 @@ extern "C" int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_str
         HIP_TRY(hipGetLastError());
         return refresh_blocked_values(A, s, true);
     }
+    if (A->blocked && A->blocked->nbrows > 0 && d_coef != A->d_coef) // the same pass for a blocked copy: CSR values, blocks and sliced values leave together
+        return bcsr4_refresh_from_csr(A->blocked, A->d_ptrow, d_coef, A->d_coef, s);
     if (d_coef != A->d_coef) HIP_TRY(hipMemcpyAsync(A->d_coef, d_coef, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToDevice, s));
     return refresh_blocked_values(A, s);
 }

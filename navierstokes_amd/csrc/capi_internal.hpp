@@ -234,6 +234,7 @@ struct mi_bcsr4_s {
     int* d_sell_wrng2 = nullptr; // ... and [sell_nwaves2 + 1] for two (2048)
     int sell_nslices = 0, sell_nwaves = 0, sell_nwaves2 = 0;
     long long sell_nsteps = 0;
+    int max_slice_vals = 0;   // values of the longest slice of 16 block rows (the refresh kernel's LDS buffer)
     int sell_form = -1;       // -1: not in use; else the variant the create-time measurement kept (kSellForms, capi_bcsr.hip)
     double tune_us_sell[4] = {0, 0, 0, 0};
     // x tiles of the multi-vector product (spmm_tile.hpp): lists per group of 128 block rows (st) and of 64 (st64: the eight-column
@@ -370,4 +371,6 @@ static inline bool sstream_y_ok(const mi_csr_s* A, const double* yy, const int* 
 // capi_bcsr.hip
 // the blocked copy's values were rewritten on stream s (by whoever holds d_coef): the sliced copy follows at once, on the same stream
 int bcsr4_values_changed(mi_bcsr4_s* A, hipStream_t s);
+// a CSR handle's blocked copy (blocks + sliced values) from its CSR values d_src, which also go to d_csr_out when that is given: one pass
+int bcsr4_refresh_from_csr(mi_bcsr4_s* A, const int* d_csr_ptrow, const double* d_src, double* d_csr_out, hipStream_t s);
 int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);

@@ -146,6 +146,119 @@ __global__ __launch_bounds__(64) void bcsr4_to_sell_kernel(int nslices, int nbro
     }
 }
 
+// A CSR handle's blocked copy refreshed from (new) CSR values in ONE pass (round 5; mi_csr_update_values*: a Newton loop's Jacobian,
+// src/solve_newton.c:1245-1247): a workgroup per slice of 16 block rows reads the slice's CSR segment (64 consecutive rows: contiguous)
+// once, coalesced, into LDS and writes from there (a) the handle's CSR values when csr_out is given, (b) the row-major 4x4 blocks, (c) the
+// sliced values — where round 4 made three passes (device-to-device copy, blocks gathered lane by lane from the CSR rows, sliced values
+// gathered lane by lane from the blocks): 888 us per update of the FE matrix, nine products.  CAP = LDS doubles (0: read straight from src).
+template <int CAP>
+__global__ __launch_bounds__(256) void bcsr4_refresh_kernel(int nslices, int nbrows, const int* __restrict__ csr_ptrow, const double* __restrict__ src,
+                                                            double* __restrict__ csr_out, const int* __restrict__ bptr, double* __restrict__ bval,
+                                                            const int* __restrict__ sptr, double* __restrict__ sell_val)
+{
+    __shared__ double buf[CAP > 0 ? CAP : 1];
+    __shared__ int rp[4 * kSellRows + 1]; // CSR row pointers of the slice's 64 rows
+    __shared__ int bp[kSellRows + 1];     // block pointers of its 16 block rows
+    const int tid = threadIdx.x;
+    for (int s = blockIdx.x; s < nslices; s += gridDim.x) {
+        if (tid <= 4 * kSellRows) rp[tid] = csr_ptrow[min(4 * kSellRows * s + tid, 4 * nbrows)];
+        if (tid <= kSellRows) bp[tid] = bptr[min(kSellRows * s + tid, nbrows)];
+        __syncthreads();
+        const int base = rp[0], seg = rp[4 * kSellRows] - base;
+        const bool staged = CAP > 0 && seg <= CAP; // (workgroup-uniform)
+        if (staged) {
+            for (int k0 = tid; k0 < seg; k0 += 4 * 256) { // four loads in flight per thread
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = src[base + min(k0 + 256 * u, seg - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (k0 + 256 * u < seg) {
+                        buf[k0 + 256 * u] = v[u];
+                        if (csr_out) csr_out[base + k0 + 256 * u] = v[u];
+                    }
+            }
+            __syncthreads();
+        } else if (csr_out) {
+            for (int k = tid; k < seg; k += 256) csr_out[base + k] = src[base + k];
+        }
+        auto at = [&](int row, int pos) -> double { return staged ? buf[rp[row] - base + pos] : src[rp[row] + pos]; }; // value `pos` of the slice's CSR row `row`
+        // (b) the blocks, block row by block row (16 x 15 = 240 values per FE block row: one turn of the 256 threads, contiguous in bval)
+        for (int r = 0; r < kSellRows; r++) {
+            const int nb = bp[r + 1] - bp[r];
+            for (int k = tid; k < 16 * nb; k += 256) bval[16 * (size_t)bp[r] + k] = at(4 * r + ((k >> 2) & 3), 4 * (k >> 4) + (k & 3));
+        }
+        // (c) the sliced values: step j = block j of every row as [half][lane][2]
+        if (sell_val) {
+            const int t0 = sptr[s], L = sptr[s + 1] - t0;
+            for (int k = tid; k < L * 128; k += 256) {
+                const int j = k >> 7, h = (k >> 6) & 1, lane = k & 63, r = lane >> 2, q = lane & 3;
+                sell_v2d v = {0.0, 0.0};
+                if (j < bp[r + 1] - bp[r]) {
+                    v.x = at(4 * r + q, 4 * j + 2 * h);
+                    v.y = at(4 * r + q, 4 * j + 2 * h + 1);
+                }
+                reinterpret_cast<sell_v2d*>(sell_val + (size_t)(t0 + j) * kSellStepDoubles)[h * 64 + lane] = v;
+            }
+        }
+        __syncthreads(); // rp / bp / buf are rewritten for the next slice
+    }
+}
+
+// The same for the BCSR API (mi_bcsr4_update_values*_dev; the PETSc seam hands over MATSEQBAIJ's column-major blocks: COLMAJOR, transposed on
+// the way — src/kernels/baij4_mad.c:73-76): a slice's blocks are contiguous in the caller's array; read once into LDS, written as the handle's
+// row-major blocks (bval_out; null when src IS that array) and as sliced values.  Round 4: a copy / transpose pass, then the lane-by-lane fill.
+template <int CAP, bool COLMAJOR>
+__global__ __launch_bounds__(256) void bcsr4_blocks_refresh_kernel(int nslices, int nbrows, const int* __restrict__ bptr, const double* __restrict__ src,
+                                                                   double* __restrict__ bval_out, const int* __restrict__ sptr, double* __restrict__ sell_val)
+{
+    __shared__ double buf[CAP > 0 ? CAP : 1];
+    __shared__ int bp[kSellRows + 1];
+    const int tid = threadIdx.x;
+    for (int s = blockIdx.x; s < nslices; s += gridDim.x) {
+        if (tid <= kSellRows) bp[tid] = bptr[min(kSellRows * s + tid, nbrows)];
+        __syncthreads();
+        const size_t base = 16 * (size_t)bp[0];
+        const int seg = 16 * (bp[kSellRows] - bp[0]);
+        const bool staged = CAP > 0 && seg <= CAP; // (workgroup-uniform)
+        const bool copy_in_stage = staged && !COLMAJOR && bval_out != nullptr; // row-major in, row-major out: the copy rides in the staging loop
+        if (staged) {
+            for (int k0 = tid; k0 < seg; k0 += 4 * 256) { // four loads in flight per thread
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = src[base + min(k0 + 256 * u, seg - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (k0 + 256 * u < seg) {
+                        buf[k0 + 256 * u] = v[u];
+                        if (copy_in_stage) bval_out[base + k0 + 256 * u] = v[u];
+                    }
+            }
+            __syncthreads();
+        }
+        auto el = [&](int blk, int q, int c) -> double { // element (row q, column c) of the slice's block `blk`, whatever the caller's layout
+            const int o = 16 * blk + (COLMAJOR ? 4 * c + q : 4 * q + c);
+            return staged ? buf[o] : src[base + o];
+        };
+        if (bval_out && !copy_in_stage)
+            for (int k = tid; k < seg; k += 256) bval_out[base + k] = el(k >> 4, (k >> 2) & 3, k & 3);
+        if (sell_val) {
+            const int t0 = sptr[s], L = sptr[s + 1] - t0;
+            for (int k = tid; k < L * 128; k += 256) {
+                const int j = k >> 7, h = (k >> 6) & 1, lane = k & 63, r = lane >> 2, q = lane & 3;
+                sell_v2d v = {0.0, 0.0};
+                if (j < bp[r + 1] - bp[r]) {
+                    const int blk = bp[r] - bp[0] + j;
+                    v.x = el(blk, q, 2 * h);
+                    v.y = el(blk, q, 2 * h + 1);
+                }
+                reinterpret_cast<sell_v2d*>(sell_val + (size_t)(t0 + j) * kSellStepDoubles)[h * 64 + lane] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // D steps of values and x in flight per lane, the block columns of D more.  One wave = one contiguous range of slices.
 // Workgroups of 256 threads = 4 independent waves; workgroup b is taken as logical workgroup (b % 8) * (G / 8) + b / 8, so that
 // the workgroups that share an XCD (b, b + 8, ...) stream neighbouring slices and share their x lines in that XCD's L2.
