@@ -227,7 +227,8 @@ int mi_sstream_plan_probe(int n, int ncols, const int* ptrow, const int* indcol,
 /* the same for the two forms round 5 added: shift = 1 plans the rows one down (what mi_csr_create_mapped does for a piece whose rows go to
  * y[r + odd offset]: row pairs stay 16-byte aligned); ghost_lo < ghost_hi: columns outside [ghost_lo, ghost_hi) are ghosts (a partition's
  * combined piece, numbered [lower ghosts | owned | upper ghosts]): a workgroup whose windows hold one is marked (*ghost_workgroups counts
- * them; the fused multi-GPU step makes them push and wait first) and gets one round less than its share.  rounds_min_max[2] = the
+ * them; the fused multi-GPU step makes them push and wait first), takes its whole column range in with its first fill and gets three rounds
+ * less than its share (fewer still where that range would not fit the 8192-column ring).  rounds_min_max[2] = the
  * shortest and the longest share of rounds.  The replay also checks the marks and the dealing. */
 int mi_sstream_plan_probe_ex(int n, int ncols, const int* ptrow, const int* indcol, int shift, int ghost_lo, int ghost_hi, int* eligible, int* rounds,
                              long long* steps, double* padding, int* ghost_workgroups, int* rounds_min_max);
@@ -503,10 +504,12 @@ int mi_part_allgather_info(mi_part_t P, int* ready, int* in_use, int* slice /* M
 int mi_part_push_export(mi_part_t P, void* handle64, long long* layout /* [2*nranks + 1] */);
 int mi_part_push_connect(mi_part_t P, const void* handles /* nranks x 64 B */, const long long* layouts /* nranks x (2*nranks+1) */);
 int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s);
-/* *fused = 1: the step is ONE launch — when all local rows form a piece the ring kernel serves, the push duty (first
- * workgroups of the grid) and the ghost reads (straight from the window, behind an in-kernel wait in the runs that
- * touch ghosts, which are ordered last) live inside that kernel (spmv_ring.hpp, FUSED; MI355_PUSH_FUSED=0 disables).
- * In the fused form the halo part of d_x_ext is neither read nor written. */
+/* *fused = 1: the step is ONE launch — when all local rows form a piece the sliced-stream kernel (round 5: spmv_sstream_fused) or the
+ * ring kernel (spmv_ring.hpp, FUSED) serves, the push duty and the ghost reads (straight from the window, behind an in-kernel wait)
+ * live inside that kernel, in the few workgroups / runs whose rows touch ghosts; these get a shorter share of the rows, push first and wait
+ * second (mi_part_kernel_name(P, 2) names the kernel; MI355_PUSH_FUSED=0 disables the form, MI355_PUSH_FUSED_KERNEL=ring|sstream forces
+ * one).  In the fused form the halo part of d_x_ext is neither read nor written (d_x_ext must still hold n_local + n_halo entries for
+ * the four-launch form the ranks may have to agree on). */
 int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
 /* the kernel a piece's products launch (as rocprofv3 names it): which = 0 the interior rows' piece, 1 the boundary rows', 2 the combined piece
  * of the one-launch push step — spmv_sstream_fused<...> (round 5) wherever that piece holds a sliced copy, else the ring kernel's FUSED
