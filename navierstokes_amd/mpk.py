@@ -527,7 +527,7 @@ class DistVector:
         return out
 
     def close(self):
-        if self._h is not None and self.D._h is not None:
+        if self._h is not None:  # (safe after its DistMatrix is closed: mi_dist_destroy released the device memory, this frees the host object)
             lib().mi_dist_vec_destroy(self._h)
         self._h = None
 

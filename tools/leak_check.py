@@ -20,6 +20,13 @@ def once():
     pp, cc, vv, _ = synth.permute_nodes(pf, cf, vf, block=4, seed=3)
     C = mpk.csrmatrix(len(pf) - 1, pp, cc, vv); mpk.SpMV_CSR(yf, xf, C); C.close()
     del os.environ["MI355_BCSR_SELL"], os.environ["MI355_REORDER"]
+    # round 5: value updates (fused refills), a sliced copy rebuilt on request, a row-offset piece (shifted plan), the distributed orthogonalize
+    A = mpk.csrmatrix(400_000, p, c, v); A.update_values(torch.from_numpy(v).cuda()); A.set_kernel("ring"); A.set_kernel("sstream"); mpk.SpMV_CSR(y, x, A); A.close()
+    E = mpk.csrmatrix(400_000, p, c, v, rowmap=(np.arange(400_000) + 3).astype(np.int32)).set_kernel("sstream")
+    yo = torch.empty(400_003, dtype=torch.float64, device="cuda"); mpk.SpMV_CSR(yo, x, E); E.close()
+    M = mpk.DistMatrix(2, 400_000, p, c, v); va, vb_, vc = M.vector(synth.x_sin(0, 400_000)), M.vector(synth.x_ones(400_000)), M.vector()
+    M.orthogonalize_dev(va, vb_, vc, 1e-8, want_beta=False); M.orthogonalize_dev(va, vb_, vc, 1e-8); M.close()  # (the vectors outlive the handle here: mi_dist_destroy releases their memory)
+    for t_ in (va, vb_, vc): t_.close()
     gc.collect()
 once(); base = used()
 for i in range(30): once()

@@ -29,6 +29,7 @@ for s in "$@"; do
     fuzz)     step r5_fuzz 1100 python tools/gpu_fuzz.py ${FUZZ_FIRST:-600} ${FUZZ_LAST:-640} ;;
     spmm_ucap) for u in "368,190" "368,150" "368,300"; do MI355_SPMM_TILE_UCAP=$u MI355_SPMM_TILE=3 step "r5_bench_spmm8_ucap_${u#*,}" 300 python bench.py --workload fe_spmm8 --no-cpu-baseline --no-extras || exit 1; done; MI355_SPMM_TILE=3 step r5_bench_spmm8_ucap_256 300 python bench.py --workload fe_spmm8 --no-cpu-baseline --no-extras ;;
     t_upd)    step r5_t_upd 900 python -m pytest tests/test_gpu_parity.py tests/test_reorder_gpu.py tests/test_spmm_gpu.py tests/test_shim_gpu.py -x -q -m gpu -k "update or refresh or graph_replay or sliced_copy or relabelled or reorder or column_major or fe_matrix or blocked" && for w in fe fe_bcsr fe_perm; do step r5_bench_upd_$w 300 python bench.py --workload $w --no-cpu-baseline $( [ $w = mesh_perm ] && echo --internal ) || exit 1; done ;;
+    leak)     step r5_leak 600 python tools/leak_check.py ;;
     sim8)     step r5_sim8 300 python tools/sim_rank.py 8 1 ;;
     tests)    step r5_tests 1100 python -m pytest tests -x -q -m gpu ;;
     smoke)    step r5_smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
