@@ -51,7 +51,10 @@ constexpr int kSsSliceRows = 128;        // rows per slice = two per lane
 constexpr int kSsRound = 512;            // rows per round of a workgroup: four waves' slices
 constexpr int kSsNewMax = 1024;          // new window columns per round (four per thread, a round ahead in registers)
 constexpr int kSsPark = 20;              // slices of y parked per wave: 4 x 20 KiB beside the 64 KiB ring
-constexpr int kSsTail = 2;               // rounds of a workgroup whose sums stay parked until its end (the others are stored earlier)
+#ifndef MI355_SS_TAIL
+#define MI355_SS_TAIL 2
+#endif
+constexpr int kSsTail = MI355_SS_TAIL;   // rounds of a workgroup whose sums stay parked until its end (the others are stored earlier; tools/ A/B it with -DMI355_SS_TAIL=n)
 constexpr unsigned kSsPad = 0x8000u;     // slot flag (either half): padding place, not multiplied
 constexpr unsigned kSsFirst = 0x4000u;   // slot flag (low half): first step of a slice
 constexpr int kSsPadSteps = 64;          // steps of padding behind the last one: the stream's loads run ahead unclamped (D <= 16)
