@@ -547,7 +547,10 @@ def test_native_step_single_rank():
                                                            (3, "sfe", 60_000, 1500, 29615, "push"),
                                                            # upwind coupling: the last rank sends but receives nothing (no ghost reader in
                                                            # its one-launch step: the pushers gate themselves, push_exchange.hpp)
-                                                           (3, "s15_up", 150_000, 2000, 29616, "push")])
+                                                           (3, "s15_up", 150_000, 2000, 29616, "push"),
+                                                           # (round 5) several rounds per workgroup of the sliced stream's fused step: ghost readers with
+                                                           # fewer rounds than their share, their whole column range taken in up front
+                                                           (2, "s15", 1_400_000, 2000, 29617, "push")])
 def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
     """The N>1 pipeline on real HIP kernels: `world` ranks (processes) on cuda:0, A x, A^2 x, A^3 x and a global dot, every
     rank's slice bitwise.  exchange "torch": halos over gloo, host-staged (RCCL rejects duplicate devices).  exchange "push":
