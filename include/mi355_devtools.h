@@ -30,6 +30,12 @@ int mi_debug_mring_replan(mi_csr_t A, int skew_pct, int* table_len, int* longest
  * temporal; the MI355_PUSH_LOOPBACK arrangement of tools/sim_rank.py): host_out[4 * g + {0, 1, 2, 3}] = logical workgroup g's start, loop
  * begin, loop end, end (100 MHz ticks); halo_out[g] = (reads ghosts) + 2 * (pushes) + 4 * rounds. */
 int mi_debug_part_push_trace(mi_part_t P, double* d_x_ext, double* d_y_local, int max_wgs, long long* host_out, int* wgs_out, int* halo_out);
+/* timing experiments on the staged one-launch step of a blocked rank: mode bits 1 nobody waits for the exchange, 2 no push, 4 no window
+   copy, 8 no wait for the neighbours.  Results are wrong afterwards: tools only. */
+int mi_debug_part_ext_mode(mi_part_t P, int mode);
+/* one traced launch of that step: host_out[3 g + {0,1,2}] = {start, wait over, end} of workgroup g in s_memrealtime ticks; modes_out[g] = -1 for an
+   exchange workgroup, else the unit's mode bits (1 waits, 2 sixteen lanes per block row) */
+int mi_debug_part_ext_trace(mi_part_t P, double* d_x_ext, double* d_y_local, int max_wgs, long long* host_out, int* wgs_out, int* modes_out);
 /* development aid (tools/sim_rank.py): preset every flag slot of this rank's window */
 int mi_part_push_debug_preset(mi_part_t P, unsigned value);
 

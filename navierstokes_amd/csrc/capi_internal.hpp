@@ -304,6 +304,14 @@ struct mi_part_s {
     bool fused_bcsr = false;   // piece_all is served by the BCSR kernel: spmv_bcsr4_fused
     bool ghost_readers = true; // some run / workgroup of the fused launch waits for the neighbours (false: the pushers wait)
     int* d_wg_halo = nullptr;  // per workgroup of that launch: its block rows touch a ghost node
+    // the wide-halo form of it (spmv_bcsr4_ext.hpp): piece_all numbered [owned | halo], exchange workgroups in front of the grid
+    bool fused_ext = false;
+    double* d_stage = nullptr;   // [n_halo] cached copy of the window's current parity
+    unsigned* d_ready = nullptr; // exchange workgroups done (up by ext_wgs per step)
+    int ext_wgs = 0;
+    int2* d_ext_units = nullptr; // per workgroup behind the exchange: {first block row, mode}
+    int n_ext_units = 0;
+    int ext_debug = 0; // devtools only (mi_debug_part_ext_mode): parts of the exchange left out, for timing
 };
 
 static inline size_t win_data_offset(int nranks) { return ((size_t)nranks * kWinFlagStride * sizeof(unsigned) + 255) / 256 * 256; }
@@ -363,6 +371,8 @@ hipError_t spmm_otile_launch(const mi_bcsr4_s* A, const SpmmTilePlan* Pl, const 
 int part_push_window(mi_part_s* P);
 void part_push_layout(const mi_part_s* P, long long* layout /* [2*nranks + 1] */);
 int part_push_connect_bases(mi_part_s* P, void* const* bases /* [nranks] */, const long long* layouts);
+// the staged one-launch step of a blocked rank (spmv_bcsr4_ext.hpp); trace: devtools only (3 stamps per workgroup of the grid)
+int part_ext_launch(mi_part_s* P, const double* d_x_ext, double* d_y_local, unsigned step, unsigned spin_max, hipStream_t s, unsigned long long* trace, int* grid_out);
 // capi_csr.hip: the sliced-stream kernel of a handle (spmv_sstream.hpp); d_y: where the handle's row 0 goes (unmapped) or the mapped vector's base;
 // comm: the fused multi-GPU step (the handle is a partition's combined piece with ghost marks)
 int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s, const RingComm* comm = nullptr);

@@ -3,11 +3,20 @@
 #include "capi_internal.hpp"
 #include "handoff_kernels.hpp"
 #include "push_kernels.hpp"
+#include "spmv_bcsr4_ext.hpp"
 #include "rccl_loader.hpp"
 
 // windows of ranks living in THIS process
 static std::map<std::string, void*> g_win_registry;
 static void part_comm_release(mi_part_s* P);
+// The blocked one-launch step reads ghosts straight from the (uncached) window up to this many of them; beyond, it stages them once
+// per step in a cached buffer (spmv_bcsr4_ext.hpp).
+// (MI355_PUSH_FUSED_WINDOW_MAX overrides: tests run the staged form on small matrices with 0)
+static int fused_window_halo_max()
+{
+    const char* e = getenv("MI355_PUSH_FUSED_WINDOW_MAX");
+    return e ? atoi(e) : 16384;
+}
 static int part_need_timeouts(mi_part_s* P);
 
 // ---------------------------------------------------------------- RCCL, resolved at run time (rccl_loader.hpp)
@@ -57,11 +66,17 @@ static void part_comm_release(mi_part_s* P)
     dfree(P->d_nb);
     dfree(P->d_run_link);
     dfree(P->d_wg_halo);
+    dfree(P->d_stage);
+    dfree(P->d_ready);
+    dfree(P->d_ext_units);
+    P->d_stage = nullptr;
+    P->d_ready = nullptr;
+    P->d_ext_units = nullptr;
     mi_csr_destroy(P->piece_all);
     P->piece_all = nullptr;
     P->d_run_link = nullptr;
     P->d_wg_halo = nullptr;
-    P->fused = P->fused_bcsr = false;
+    P->fused = P->fused_bcsr = P->fused_ext = false;
     P->win = nullptr;
     P->d_links = nullptr;
     P->d_nb = nullptr;
@@ -643,7 +658,58 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
     // The one-launch step needs all local rows as ONE piece that the ring kernel serves (the push duty and the ghost
     // reads live in that kernel).  MI355_PUSH_FUSED=0 keeps the four-launch form.
     const char* fe = getenv("MI355_PUSH_FUSED");
-    if (!(fe && !strcmp(fe, "0")) && pl.n_local > 0) {
+    // FE slabs (blocked, wide halo): the piece numbered as x_ext is, the exchange in front of the grid (spmv_bcsr4_ext.hpp).
+    // MI355_PUSH_FUSED_EXT=0 keeps the four-launch form for them.
+    const char* fx = getenv("MI355_PUSH_FUSED_EXT");
+    if (!(fe && !strcmp(fe, "0")) && !(fx && !strcmp(fx, "0")) && P->kernel == MI_KERNEL_AUTO && pl.n_local > 0 && pl.n_local % 4 == 0 && pl.n_halo % 4 == 0 &&
+        pl.n_halo > fused_window_halo_max() && P->n_links > 0) {
+        P->plan.build_all_ext();
+        const LocalPiece& L = P->plan.all_ext;
+        if (csr_has_block4_pattern(pl.n_local, L.ptrow.data(), L.indcol.data())) {
+            rc = csr_create_impl(pl.n_local, pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), nullptr, &P->piece_all);
+            if (rc) return rc;
+            mi_csr_t A = P->piece_all;
+            if (resolve_kernel(A) == MI_KERNEL_BCSR4 && A->blocked) {
+                const int nbr = pl.n_local / 4, per = kWG / 4, nwg = (nbr + per - 1) / per;
+                std::vector<int> wg_halo((size_t)nwg, 0);
+                for (int w = 0; w < nwg; w++) {
+                    const int r0 = 4 * w * per, r1 = std::min(pl.n_local, 4 * (w + 1) * per);
+                    for (int k = L.ptrow[r0]; k < L.ptrow[r1] && !wg_halo[w]; k++) wg_halo[w] = L.indcol[k] >= pl.n_local;
+                }
+                // a unit that waits starts late: four workgroups of 16 block rows, 16 lanes per row (spmv_bcsr4_ext.hpp); the others 64 rows, 4 lanes
+                // (MI355_PUSH_EXT_LANES16=0 none / 2 all of them: A/B)
+                const char* l16 = getenv("MI355_PUSH_EXT_LANES16");
+                const int l16mode = l16 ? atoi(l16) : 1;
+                std::vector<int2> units;
+                for (int w = 0; w < nwg; w++) {
+                    const bool wide = l16mode == 2 || (l16mode == 1 && wg_halo[w]);
+                    if (!wide) units.push_back(make_int2(w * per, wg_halo[w] ? 1 : 0));
+                    else
+                        for (int i = 0; i < 4; i++)
+                            if (w * per + 16 * i < nbr) units.push_back(make_int2(w * per + 16 * i, 2 | (wg_halo[w] ? 1 : 0)));
+                }
+                P->n_ext_units = (int)units.size();
+                HIP_TRY(hipMalloc(&P->d_ext_units, sizeof(int2) * units.size()));
+                HIP_TRY(hipMemcpy(P->d_ext_units, units.data(), sizeof(int2) * units.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(&P->d_stage, sizeof(double) * (size_t)pl.n_halo));
+                HIP_TRY(hipMemset(P->d_stage, 0, sizeof(double) * (size_t)pl.n_halo));
+                HIP_TRY(hipMalloc(&P->d_ready, sizeof(unsigned) * kExtReadyStride * (1 + kExtReadyLines)));
+                HIP_TRY(hipMemset(P->d_ready, 0, sizeof(unsigned) * kExtReadyStride * (1 + kExtReadyLines)));
+                // inbound workgroups: four 16-byte loads of the (uncached) window per thread.  Measured at 38 648 ghosts (sim_rank.py 8 1 fe):
+                // 4 workgroups 20.5 us per step, 8 17.6, 12 16.6, 19 15.3, 38 15.7, 76 16.9, 152 19.8 — every one of them polls the flags and
+                // invalidates its caches once.  (MI355_PUSH_EXT_WGS: A/B)
+                int xw = (pl.n_halo + 8 * kWG - 1) / (8 * kWG);
+                if (const char* e = getenv("MI355_PUSH_EXT_WGS")) xw = atoi(e);
+                P->ext_wgs = std::max(1, std::min(256, xw));
+                P->fused = P->fused_bcsr = P->fused_ext = true;
+                P->ghost_readers = true;
+            } else {
+                mi_csr_destroy(P->piece_all);
+                P->piece_all = nullptr;
+            }
+        }
+    }
+    if (!P->fused && !(fe && !strcmp(fe, "0")) && pl.n_local > 0) {
         P->plan.build_combined();
         const LocalPiece& L = P->plan.all;
         rc = csr_create_impl(pl.n_local, pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), nullptr, &P->piece_all,
@@ -691,7 +757,7 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
         // pushes through two workgroups — with an FE slab's boundary planes, 39 k ghosts for 163 k rows at N = 8, that made the
         // step 39 us where push + interior + wait-and-copy + boundary as separate launches cost less; sim_rank.py N 1 fe)
         if (!P->fused && resolve_kernel(A) == MI_KERNEL_BCSR4 && A->blocked && P->plan.n_left % 4 == 0 && pl.n_local % 4 == 0 &&
-            pl.n_halo % 4 == 0 && pl.n_halo <= 16384) {
+            pl.n_halo % 4 == 0 && pl.n_halo <= fused_window_halo_max()) {
             // FE matrices: the blocked copy of the combined piece, one launch of spmv_bcsr4_fused per step.  Which workgroups
             // (kWG / 4 block rows each) touch a ghost node:
             const int nbr = pl.n_local / 4, per = kWG / 4, nwg = (nbr + per - 1) / per;
@@ -739,9 +805,15 @@ extern "C" int mi_part_push_disable(mi_part_t P)
     dfree(P->d_nb);
     dfree(P->d_run_link);
     dfree(P->d_wg_halo);
+    dfree(P->d_stage);
+    dfree(P->d_ready);
+    dfree(P->d_ext_units);
+    P->d_stage = nullptr;
+    P->d_ready = nullptr;
+    P->d_ext_units = nullptr;
     P->d_run_link = nullptr;
     P->d_wg_halo = nullptr;
-    P->fused_bcsr = false;
+    P->fused_bcsr = P->fused_ext = false;
     mi_csr_destroy(P->piece_all);
     P->win = nullptr;
     P->d_links = nullptr;
@@ -762,9 +834,15 @@ extern "C" int mi_part_push_unfuse(mi_part_t P)
     CHECK_ARG(P, "null handle");
     if (!P->fused) return MI_OK;
     HIP_TRY(hipDeviceSynchronize());
-    P->fused = P->fused_bcsr = false;
+    P->fused = P->fused_bcsr = P->fused_ext = false;
     dfree(P->d_run_link);
     dfree(P->d_wg_halo);
+    dfree(P->d_stage);
+    dfree(P->d_ready);
+    dfree(P->d_ext_units);
+    P->d_stage = nullptr;
+    P->d_ready = nullptr;
+    P->d_ext_units = nullptr;
     P->d_run_link = nullptr;
     P->d_wg_halo = nullptr;
     mi_csr_destroy(P->piece_all);
@@ -778,6 +856,7 @@ extern "C" const char* mi_part_kernel_name(mi_part_t P, int which)
     if (!P || which < 0 || which > 2) return "";
     if (which < 2) return P->piece[which] ? mi_csr_kernel_name(P->piece[which]) : "";
     if (!P->fused || !P->piece_all) return "";
+    if (P->fused_ext) return "spmv_bcsr4_fused_ext";
     if (P->fused_bcsr) return "spmv_bcsr4_fused";
     static thread_local char nm[160];
     const char* base = mi_csr_kernel_name(P->piece_all);
@@ -794,6 +873,56 @@ extern "C" int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neigh
     if (neighbours) *neighbours = P->n_nb;
     return MI_OK;
 }
+// ONE launch: the exchange workgroups in front, the blocked product over all rows behind them (spmv_bcsr4_ext.hpp)
+int part_ext_launch(mi_part_s* P, const double* d_x_ext, double* d_y_local, unsigned step, unsigned spin_max, hipStream_t s, unsigned long long* trace, int* grid_out)
+{
+    const PartPlan& pl = P->plan;
+    if ((((uintptr_t)d_x_ext) & 15) != 0) return fail(MI_ERR_ARG, "the fused blocked step needs a 16-byte aligned x");
+    mi_bcsr4_t B = P->piece_all->blocked;
+    Bcsr4View V{B->nbrows, B->nbcols, B->d_ptrow, B->d_indcol, B->d_coef, nullptr};
+    ExtComm C;
+    C.links = P->d_links;
+    C.work = P->d_push_work;
+    C.link_chunks = P->d_link_chunks;
+    C.tickets = P->d_tickets;
+    C.send_idx = P->d_send_idx;
+    C.flags = P->win_flags;
+    C.nb = P->d_nb;
+    C.halo = P->win_data + (size_t)(step & 1u) * (size_t)pl.n_halo;
+    C.stage = P->d_stage;
+    C.ready = P->d_ready;
+    C.timeouts = P->d_timeouts;
+    C.n_work = P->n_push_work;
+    C.n_nb = P->n_nb;
+    C.n_local = pl.n_local;
+    C.n_halo = pl.n_halo;
+    C.xwgs = P->n_push_work + P->ext_wgs;
+    C.step = step;
+    C.spin_max = spin_max;
+    C.trace = trace;
+    if (P->ext_debug & 2) C.links = nullptr; // (devtools: the push workgroups leave at once)
+    if (P->ext_debug & 4) C.n_halo = 0;
+    if (P->ext_debug & 8) C.n_nb = 0;
+    const dim3 grid(P->n_ext_units + C.xwgs);
+    if (grid_out) *grid_out = (int)grid.x;
+    if (trace) {
+        hipLaunchKernelGGL((spmv_bcsr4_fused_ext<kBcsrDepth, 4, kWG, true>), grid, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_ext_units);
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
+    static const int depth = getenv("MI355_PUSH_EXT_DEPTH") ? atoi(getenv("MI355_PUSH_EXT_DEPTH")) : 24; // (A/B: blocks in flight, 4-lane rows / 16-lane rows)
+#define EXT_LAUNCH(P_, U_) hipLaunchKernelGGL((spmv_bcsr4_fused_ext<P_, U_, kWG>), grid, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_ext_units)
+    switch (depth) {
+    case 22: EXT_LAUNCH(2, 2); break;
+    case 23: EXT_LAUNCH(2, 3); break;
+    case 27: EXT_LAUNCH(2, 7); break;
+    default: EXT_LAUNCH(2, 4); break;
+    }
+#undef EXT_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_stream_t s_)
 {
     CHECK_ARG(P, "null handle");
@@ -812,6 +941,7 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
                                         "present an old step and every wait would pass at once); capture mi_part_spmv_dev (RCCL, events) instead");
     const unsigned step = ++P->push_step;
     static const unsigned spin_max = 1u << (getenv("MI355_PUSH_SPIN_LOG2") ? std::max(8, std::min(30, atoi(getenv("MI355_PUSH_SPIN_LOG2")))) : kPushSpinLog2Default);
+    if (P->fused_ext) return part_ext_launch(P, d_x_ext, d_y_local, step, spin_max, s, nullptr, nullptr);
     if (P->fused) { // ONE launch: push workgroups first, then the ring kernel over all rows, ghost readers waiting in-kernel
         RingComm C;
         C.links = P->d_links;
@@ -879,7 +1009,7 @@ extern "C" int mi_part_update_values(mi_part_t P, const double* coef)
         if (rc) return rc;
     }
     if (P->piece_all) {
-        LocalPiece& L = P->plan.all;
+        LocalPiece& L = P->fused_ext ? P->plan.all_ext : P->plan.all;
         CHECK_ARG(coef || L.coef.empty(), "null coef");
         for (size_t k = 0; k < L.coef.size(); k++) L.coef[k] = coef[k];
         int rc = mi_csr_update_values(P->piece_all, coef);

@@ -232,3 +232,47 @@ extern "C" int mi_debug_part_push_trace(mi_part_t P, double* d_x_ext, double* d_
         for (int g = 0; g < T.nwg; g++) halo_out[g] = T.h_wg_halo[g] + 2 * (T.h_wg[g].link >= 0 ? 1 : 0) + 4 * (T.h_wg[g].r_end - T.h_wg[g].r_begin);
     return MI_OK;
 }
+
+// ---- timing experiments on the staged one-launch step (spmv_bcsr4_ext.hpp): leave parts of it out.  Results are WRONG afterwards. ----
+// mode bits: 1 no workgroup waits for the exchange, 2 no push, 4 no window copy, 8 no wait for the neighbours' flags
+extern "C" int mi_debug_part_ext_mode(mi_part_t P, int mode)
+{
+    CHECK_ARG(P, "null handle");
+    if (!P->fused_ext) return fail(MI_ERR_STATE, "the handle does not run the staged one-launch step");
+    HIP_TRY(hipDeviceSynchronize());
+    P->ext_debug = mode;
+    if (mode & 1) {
+        std::vector<int2> u((size_t)P->n_ext_units);
+        HIP_TRY(hipMemcpy(u.data(), P->d_ext_units, sizeof(int2) * u.size(), hipMemcpyDeviceToHost));
+        for (int2& e : u) e.y &= ~1;
+        HIP_TRY(hipMemcpy(P->d_ext_units, u.data(), sizeof(int2) * u.size(), hipMemcpyHostToDevice));
+    }
+    return MI_OK;
+}
+
+// one traced launch of the staged step: host_out[3 g + {0, 1, 2}] = {start, wait over, end} of workgroup g (s_memrealtime ticks, 10 ns);
+// modes_out[g]: -2 a pushing workgroup, -1 a copying one, else the unit's mode bits
+extern "C" int mi_debug_part_ext_trace(mi_part_t P, double* d_x_ext, double* d_y_local, int max_wgs, long long* host_out, int* wgs_out, int* modes_out)
+{
+    CHECK_ARG(P && d_x_ext && d_y_local && host_out && wgs_out, "null argument");
+    if (!P->fused_ext) return fail(MI_ERR_STATE, "the handle does not run the staged one-launch step");
+    const int grid = P->n_ext_units + P->n_push_work + P->ext_wgs;
+    CHECK_ARG(grid <= max_wgs, "host buffer too small");
+    unsigned long long* d_tr = nullptr;
+    HIP_TRY(hipMalloc(&d_tr, sizeof(unsigned long long) * 3 * (size_t)grid));
+    HIP_TRY(hipMemset(d_tr, 0, sizeof(unsigned long long) * 3 * (size_t)grid));
+    HIP_TRY(hipDeviceSynchronize());
+    const unsigned step = ++P->push_step;
+    int rc = part_ext_launch(P, d_x_ext, d_y_local, step, 1u << kPushSpinLog2Default, nullptr, d_tr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, d_tr, sizeof(unsigned long long) * 3 * (size_t)grid, hipMemcpyDeviceToHost));
+    dfree(d_tr);
+    *wgs_out = grid;
+    if (modes_out) {
+        std::vector<int2> u((size_t)P->n_ext_units);
+        HIP_TRY(hipMemcpy(u.data(), P->d_ext_units, sizeof(int2) * u.size(), hipMemcpyDeviceToHost));
+        for (int g = 0; g < grid; g++) modes_out[g] = g < P->n_push_work ? -2 : (g < P->n_push_work + P->ext_wgs ? -1 : u[g - P->n_push_work - P->ext_wgs].y);
+    }
+    return MI_OK;
+}

@@ -192,6 +192,29 @@ struct PartPlan {
         }
     }
 
+    // All local rows in natural order with the columns as the pieces have them — [owned | halo], the layout of x_ext itself: the piece of
+    // the one-launch step that first copies its ghosts out of the receive window into x_ext's halo part (capi_part.hip, round 5).
+    LocalPiece all_ext;
+    void build_all_ext()
+    {
+        if (!all_ext.ptrow.empty()) return;
+        std::vector<int> where((size_t)n_local), which((size_t)n_local);
+        for (int w = 0; w < 2; w++)
+            for (size_t r = 0; r < piece[w].rowmap.size(); r++) {
+                where[piece[w].rowmap[r]] = (int)r;
+                which[piece[w].rowmap[r]] = w;
+            }
+        all_ext.ptrow.push_back(0);
+        for (int r = 0; r < n_local; r++) {
+            const LocalPiece& L = piece[which[r]];
+            for (int k = L.ptrow[where[r]]; k < L.ptrow[where[r] + 1]; k++) {
+                all_ext.indcol.push_back(L.indcol[k]);
+                all_ext.coef.push_back(L.coef[k]);
+            }
+            all_ext.ptrow.push_back((int)all_ext.indcol.size());
+        }
+    }
+
     std::string set_send(int peer, int count, const long long* ids)
     {
         if (peer < 0 || peer >= nranks || count < 0 || (count > 0 && !ids)) return "bad peer/count";

@@ -37,6 +37,7 @@
 namespace mi355 {
 
 constexpr int kWinFlagStride = 16; // unsigneds: one 64-byte line per sender
+constexpr int kPushChunk = 1024;    // doubles per {link, chunk} item of a chunked push (8 KB per workgroup: an FE slab's 150 KB plane goes out from ~19 CUs at once)
 
 // payload store that leaves for the peer at once (sc0 sc1), and the drain behind a batch of them
 __device__ __forceinline__ void push_store(double* p, double v)

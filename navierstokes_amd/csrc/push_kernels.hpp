@@ -12,17 +12,14 @@ namespace mi355 {
 // (an L2 write-back: microseconds, but amortised over 32 KB, where the write-through form — one fabric write per 8 bytes —
 // costs more).  The flag goes up when the link's last chunk is out: a ticket counter per link, bumped by every chunk's
 // workgroup after its drain / fence; the last arriver resets it and stores the flag.
-constexpr int kPushChunk = 1024; // 8 KB per workgroup: an FE slab's 150 KB plane goes out from ~19 CUs at once
 constexpr int kPushBigLink = 8192;
 
-__global__ __launch_bounds__(256) void halo_push_kernel(const PushLink* __restrict__ links, const int2* __restrict__ work,
-                                                        const int* __restrict__ link_chunks, unsigned* __restrict__ tickets,
-                                                        const int* __restrict__ send_idx, const double* __restrict__ x, unsigned step)
+// one {link, chunk} item of the push, by a workgroup of 256 threads
+__device__ __forceinline__ void push_chunk(const PushLink& L, int link, int chunk, const int* __restrict__ link_chunks, unsigned* __restrict__ tickets,
+                                           const int* __restrict__ send_idx, const double* __restrict__ x, unsigned step)
 {
-    const int2 w = work[blockIdx.x];
-    const PushLink L = links[w.x];
     double* dst = (step & 1u) ? L.dst[1] : L.dst[0];
-    const int i0 = w.y * kPushChunk, i1 = min(L.count, i0 + kPushChunk);
+    const int i0 = chunk * kPushChunk, i1 = min(L.count, i0 + kPushChunk);
     if (L.count >= kPushBigLink && L.first >= 0 && ((L.first | i0) & 1) == 0 && (((uintptr_t)dst | (uintptr_t)x) & 15) == 0) {
         const double2* s2 = reinterpret_cast<const double2*>(x + L.first + i0);
         double2* d2 = reinterpret_cast<double2*>(dst + i0);
@@ -40,12 +37,21 @@ __global__ __launch_bounds__(256) void halo_push_kernel(const PushLink* __restri
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned done = __hip_atomic_fetch_add(&tickets[w.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)done == link_chunks[w.x] - 1) { // the link's last chunk: everybody else's payload is out (their release, this acquire)
-            __hip_atomic_store(&tickets[w.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned done = __hip_atomic_fetch_add(&tickets[link], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)done == link_chunks[link] - 1) { // the link's last chunk: everybody else's payload is out (their release, this acquire)
+            __hip_atomic_store(&tickets[link], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(L.flag, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void halo_push_kernel(const PushLink* __restrict__ links, const int2* __restrict__ work,
+                                                        const int* __restrict__ link_chunks, unsigned* __restrict__ tickets,
+                                                        const int* __restrict__ send_idx, const double* __restrict__ x, unsigned step)
+{
+    const int2 w = work[blockIdx.x];
+    const PushLink L = links[w.x];
+    push_chunk(L, w.x, w.y, link_chunks, tickets, send_idx, x, step);
 }
 
 __global__ __launch_bounds__(256) void halo_wait_copy_kernel(const unsigned* flags, const int* __restrict__ nb, int n_nb, unsigned step,

@@ -208,7 +208,8 @@ def lib():
     # diagnostics of include/mi355_devtools.h: present only in libmi355spmv_dev.so (`make devtools`; tools/ load it through
     # MI355_SPMV_LIBRARY), never in the product library
     for name, argt in {"mi_debug_xcc_map": [i, _vp], "mi_debug_touch_pages": [_vp, i, _vp, ll, _vp, ll],
-                       "mi_part_push_debug_preset": [_vp, _c.c_uint], "mi_debug_part_push_trace": [_vp, _vp, _vp, i, _vp, P(i), _vp]}.items():
+                       "mi_part_push_debug_preset": [_vp, _c.c_uint], "mi_debug_part_push_trace": [_vp, _vp, _vp, i, _vp, P(i), _vp],
+                       "mi_debug_part_ext_mode": [_vp, i], "mi_debug_part_ext_trace": [_vp, _vp, _vp, i, _vp, P(i), _vp]}.items():
         if hasattr(L, name):
             fn = getattr(L, name)
             fn.argtypes = argt

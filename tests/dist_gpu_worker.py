@@ -55,6 +55,11 @@ def main():
         if upwind:
             assert (dc.n_halo == 0) == (rank == world - 1) and (dc.n_send == 0) == (rank == 0), (rank, dc.n_halo, dc.n_send)
         assert not dc.native  # gloo: no RCCL
+        expect = os.environ.get("MI355_TEST_EXPECT_FUSED")
+        if expect and kernel is None:  # the test asked for a particular form of the one-launch step
+            from navierstokes_amd import mpk
+            got = mpk.lib().mi_part_kernel_name(dc._h, 2).decode()
+            assert dc.push_fused and expect in got, (rank, got)
         assert dc.push == (exchange in ("push", "auto")), "peer-push exchange was requested but did not come up (or vice versa)"
         x_ext = dc.new_x_ext()
         x_ext[: dc.n_local] = torch.from_numpy(synth.x_sin(lo, hi)).cuda()

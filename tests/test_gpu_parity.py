@@ -550,7 +550,10 @@ def test_native_step_single_rank():
                                                            (3, "s15_up", 150_000, 2000, 29616, "push"),
                                                            # (round 5) several rounds per workgroup of the sliced stream's fused step: ghost readers with
                                                            # fewer rounds than their share, their whole column range taken in up front
-                                                           (2, "s15", 1_400_000, 2000, 29617, "push")])
+                                                           (2, "s15", 1_400_000, 2000, 29617, "push"),
+                                                           # (round 5) a blocked rank's one-launch step with the ghosts STAGED once per step
+                                                           # (spmv_bcsr4_ext.hpp; wide halos take it — here forced by a threshold of 0)
+                                                           (3, "sfe_ext", 60_000, 1500, 29618, "push")])
 def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
     """The N>1 pipeline on real HIP kernels: `world` ranks (processes) on cuda:0, A x, A^2 x, A^3 x and a global dot, every
     rank's slice bitwise.  exchange "torch": halos over gloo, host-staged (RCCL rejects duplicate devices).  exchange "push":
@@ -568,6 +571,9 @@ def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
     # four-process case.  A wait that gives up is still loud and fails the run.)
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MI355_DIST_FORCE_SELFCHECK="1", MI355_TEST_EXCHANGE=exchange,
                MI355_PUSH_SPIN_LOG2=os.environ.get("MI355_PUSH_SPIN_LOG2", "23"))
+    if kind == "sfe_ext":
+        kind = "sfe"
+        env.update(MI355_PUSH_FUSED_WINDOW_MAX="0", MI355_TEST_EXPECT_FUSED="spmv_bcsr4_fused_ext")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_gpu_worker.py"), kind, str(n), str(w)]

@@ -30,6 +30,11 @@ for s in "$@"; do
     spmm_ucap) for u in "368,190" "368,150" "368,300"; do MI355_SPMM_TILE_UCAP=$u MI355_SPMM_TILE=3 step "r5_bench_spmm8_ucap_${u#*,}" 300 python bench.py --workload fe_spmm8 --no-cpu-baseline --no-extras || exit 1; done; MI355_SPMM_TILE=3 step r5_bench_spmm8_ucap_256 300 python bench.py --workload fe_spmm8 --no-cpu-baseline --no-extras ;;
     t_upd)    step r5_t_upd 900 python -m pytest tests/test_gpu_parity.py tests/test_reorder_gpu.py tests/test_spmm_gpu.py tests/test_shim_gpu.py -x -q -m gpu -k "update or refresh or graph_replay or sliced_copy or relabelled or reorder or column_major or fe_matrix or blocked" && for w in fe fe_bcsr fe_perm; do step r5_bench_upd_$w 300 python bench.py --workload $w --no-cpu-baseline $( [ $w = mesh_perm ] && echo --internal ) || exit 1; done ;;
     leak)     step r5_leak 600 python tools/leak_check.py ;;
+    simfe_d)  for d in 22 23 24 27; do MI355_PUSH_EXT_DEPTH=$d SIM_RANK_EXT_PARTS=${PARTS:-0} step r5_simfe8_d$d 300 python tools/sim_rank.py 8 1 fe || exit 1; done; for l in 0 2; do MI355_PUSH_EXT_LANES16=$l SIM_RANK_EXT_PARTS=0 step r5_simfe8_l$l 300 python tools/sim_rank.py 8 1 fe || exit 1; done ;;
+    simfe_w)  for w in 4 8 12 19 38; do MI355_PUSH_EXT_WGS=$w SIM_RANK_EXT_PARTS=0 step r5_simfe8_w$w 300 python tools/sim_rank.py 8 1 fe || exit 1; done ;;
+    simfe)    step r5_simfe8 300 python tools/sim_rank.py 8 1 fe && MI355_PUSH_FUSED_EXT=0 step r5_simfe8_four 300 python tools/sim_rank.py 8 1 fe ;;
+    simfe_n)  for n in 8 4 2; do step r5_simfe$n 300 python tools/sim_rank.py $n 1 fe && MI355_PUSH_FUSED_EXT=0 step r5_simfe${n}_four 300 python tools/sim_rank.py $n 1 fe || exit 1; done ;;
+    t_ext)    step r5_t_ext 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ranks_sharing_one_card and sfe" ;;
     sim8)     step r5_sim8 300 python tools/sim_rank.py 8 1 ;;
     tests)    step r5_tests 1100 python -m pytest tests -x -q -m gpu ;;
     smoke)    step r5_smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;

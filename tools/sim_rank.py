@@ -127,6 +127,31 @@ if fz.value and "sstream" in L.mi_part_kernel_name(h, 2).decode() and hasattr(L,
         st, fi, lo_, en, rd = (np.concatenate([r[i] for r in rows]) for i in range(5))
         print(f"      {cls:12s} ({len(rows[0][0]):3d} workgroups, {rd.min()}-{rd.max()} rounds): start +{np.median(st):.2f}, start -> loop {np.median(fi):.2f} (max {fi.max():.2f}), "
               f"loop {np.median(lo_):.2f}, end +{np.median(en):.2f} (max {en.max():.2f}) us")
+if fz.value and "fused_ext" in L.mi_part_kernel_name(h, 2).decode() and hasattr(L, "mi_debug_part_ext_trace"):
+    G = 8192
+    rows = []
+    for it in range(8):
+        buf, wg, md = np.zeros(3 * G, np.int64), ctypes.c_int(), np.zeros(G, np.int32)
+        mpk.check(L.mi_debug_part_ext_trace(h, vp(x_ext.data_ptr()), vp(y.data_ptr()), G, buf.ctypes.data, ctypes.byref(wg), md.ctypes.data))
+        if it >= 2:
+            t = buf[:3 * wg.value].reshape(-1, 3).astype(np.float64) * 0.01
+            rows.append((t - t[:, 0].min(), md[:wg.value].copy()))
+    print(f"    one traced launch of the staged step (6 launches; us from the first workgroup's start): last end median {np.median([r[0][:, 2].max() for r in rows]):.2f}")
+    for cls, sel in (("push", lambda m: m == -2), ("wait + copy", lambda m: m == -1), ("plain units", lambda m: m == 0), ("waiting units", lambda m: (m >= 0) & ((m & 1) == 1))):
+        st = np.concatenate([r[0][sel(r[1]), 0] for r in rows]); wt = np.concatenate([r[0][sel(r[1]), 1] for r in rows]); en = np.concatenate([r[0][sel(r[1]), 2] for r in rows])
+        if len(st):
+            print(f"      {cls:14s} ({int(sel(rows[0][1]).sum()):4d} workgroups): start median {np.median(st):.2f} (max {st.max():.2f}), wait over {np.median(wt):.2f} (max {wt.max():.2f}), "
+                  f"end {np.median(en):.2f} (max {en.max():.2f}); wait over -> end median {np.median(en - wt):.2f} (max {(en - wt).max():.2f})")
+if fz.value and "fused_ext" in L.mi_part_kernel_name(h, 2).decode() and hasattr(L, "mi_debug_part_ext_mode") and os.environ.get("SIM_RANK_EXT_PARTS", "1") == "1":
+    # what each part of the staged one-launch step costs: the same launch with parts left out (results wrong; timing only)
+    for mode, name in ((2, "no push"), (4, "no window copy"), (6, "no push, no copy"), (1, "nobody waits"), (7, "no push, no copy, nobody waits")):
+        mpk.check(L.mi_debug_part_ext_mode(h, mode))
+        for _ in range(300): pstep()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(REPS): pstep()
+        e1.record(); torch.cuda.synchronize()
+        print(f"      staged step, {name}: {e0.elapsed_time(e1) / REPS * 1e3:.1f} us")
 x_ext[nl.value:] = halo_keep   # the looped-back window content is not this rank's true halo: restore it for the check below
 y.fill_(float("nan")); step(); torch.cuda.synchronize()
 cl = np.where((c >= lo) & (c < hi), c - lo, nl.value + np.searchsorted(halo_ids, c)).astype(np.int32)
