@@ -511,7 +511,8 @@ int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_st
  * one).  A rank whose rows have the 4x4 node structure runs the blocked kernel's one-launch forms: ghosts read from the window while
  * they are few (spmv_bcsr4_fused, n_halo <= 16 384), beyond that spmv_bcsr4_fused_ext (spmv_bcsr4_ext.hpp) — the launch's first workgroups
  * push, wait and copy the window once into a cached buffer of the handle, the workgroups whose rows name ghosts wait for THEM
- * (MI355_PUSH_FUSED_EXT=0 keeps the four launches for such ranks).  In the fused forms the halo part of d_x_ext is neither read nor
+ * (MI355_PUSH_FUSED_EXT=0 keeps the four launches for such ranks; ranks that share a device — a neighbour's window lives on this
+ * rank's device — run it as two launches, so that only the exchange's few workgroups wait in-kernel: MI355_PUSH_EXT_SPLIT=0|1 forces).  In the fused forms the halo part of d_x_ext is neither read nor
  * written (d_x_ext must still hold n_local + n_halo entries for the four-launch form the ranks may have to agree on). */
 int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
 /* the kernel a piece's products launch (as rocprofv3 names it): which = 0 the interior rows' piece, 1 the boundary rows', 2 the combined piece

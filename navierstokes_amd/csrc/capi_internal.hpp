@@ -310,7 +310,10 @@ struct mi_part_s {
     unsigned* d_ready = nullptr; // exchange workgroups done (up by ext_wgs per step)
     int ext_wgs = 0;
     int2* d_ext_units = nullptr; // per workgroup behind the exchange: {first block row, mode}
-    int n_ext_units = 0;
+    int n_ext_units = 0;         // plain units first, then the waiting ones
+    int n_ext_plain = 0;
+    bool peer_on_my_device = false; // a neighbour's window lives on this rank's device: ranks share a card
+    bool ext_split = false;      // two launches (exchange + plain units, then the waiting units): no workgroup but the exchange's waits in-kernel
     int ext_debug = 0; // devtools only (mi_debug_part_ext_mode): parts of the exchange left out, for timing
 };
 

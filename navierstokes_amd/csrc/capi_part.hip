@@ -590,6 +590,11 @@ extern "C" int mi_part_push_connect(mi_part_t P, const void* handles, const long
             memcpy(&h, key.data(), sizeof h);
             HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
             P->ipc_opened.push_back(base);
+            // another process's window on THIS device: the ranks share a card (forms that wait in many workgroups step down: part_ext_launch)
+            hipPointerAttribute_t at;
+            int dev = -1;
+            if (hipPointerGetAttributes(&at, base) == hipSuccess && hipGetDevice(&dev) == hipSuccess && at.device == dev) P->peer_on_my_device = true;
+            (void)hipGetLastError();
         }
         bases[p] = base;
     }
@@ -680,14 +685,22 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
                 // (MI355_PUSH_EXT_LANES16=0 none / 2 all of them: A/B)
                 const char* l16 = getenv("MI355_PUSH_EXT_LANES16");
                 const int l16mode = l16 ? atoi(l16) : 1;
-                std::vector<int2> units;
-                for (int w = 0; w < nwg; w++) {
-                    const bool wide = l16mode == 2 || (l16mode == 1 && wg_halo[w]);
-                    if (!wide) units.push_back(make_int2(w * per, wg_halo[w] ? 1 : 0));
-                    else
-                        for (int i = 0; i < 4; i++)
-                            if (w * per + 16 * i < nbr) units.push_back(make_int2(w * per + 16 * i, 2 | (wg_halo[w] ? 1 : 0)));
+                std::vector<int2> units; // the units that wait LAST: dispatched behind the others, and a launch of their own in the two-launch form
+                for (int pass = 0; pass < 2; pass++) {
+                    for (int w = 0; w < nwg; w++) {
+                        if ((wg_halo[w] != 0) != (pass == 1)) continue;
+                        const bool wide = l16mode == 2 || (l16mode == 1 && wg_halo[w]);
+                        if (!wide) units.push_back(make_int2(w * per, wg_halo[w] ? 1 : 0));
+                        else
+                            for (int i = 0; i < 4; i++)
+                                if (w * per + 16 * i < nbr) units.push_back(make_int2(w * per + 16 * i, 2 | (wg_halo[w] ? 1 : 0)));
+                    }
+                    if (pass == 0) P->n_ext_plain = (int)units.size();
                 }
+                // ranks sharing a card: two launches (spmv_bcsr4_ext.hpp says why); MI355_PUSH_EXT_SPLIT=0|1 forces (sim_rank.py loops its pushes back
+                // into its own window and asks for 0)
+                P->ext_split = P->peer_on_my_device;
+                if (const char* e = getenv("MI355_PUSH_EXT_SPLIT")) P->ext_split = atoi(e) != 0;
                 P->n_ext_units = (int)units.size();
                 HIP_TRY(hipMalloc(&P->d_ext_units, sizeof(int2) * units.size()));
                 HIP_TRY(hipMemcpy(P->d_ext_units, units.data(), sizeof(int2) * units.size(), hipMemcpyHostToDevice));
@@ -856,7 +869,7 @@ extern "C" const char* mi_part_kernel_name(mi_part_t P, int which)
     if (!P || which < 0 || which > 2) return "";
     if (which < 2) return P->piece[which] ? mi_csr_kernel_name(P->piece[which]) : "";
     if (!P->fused || !P->piece_all) return "";
-    if (P->fused_ext) return "spmv_bcsr4_fused_ext";
+    if (P->fused_ext) return P->ext_split ? "spmv_bcsr4_fused_ext x2 (ranks share a device: two launches)" : "spmv_bcsr4_fused_ext";
     if (P->fused_bcsr) return "spmv_bcsr4_fused";
     static thread_local char nm[160];
     const char* base = mi_csr_kernel_name(P->piece_all);
@@ -900,10 +913,12 @@ int part_ext_launch(mi_part_s* P, const double* d_x_ext, double* d_y_local, unsi
     C.step = step;
     C.spin_max = spin_max;
     C.trace = trace;
+    C.nowait = 0;
     if (P->ext_debug & 2) C.links = nullptr; // (devtools: the push workgroups leave at once)
     if (P->ext_debug & 4) C.n_halo = 0;
     if (P->ext_debug & 8) C.n_nb = 0;
-    const dim3 grid(P->n_ext_units + C.xwgs);
+    const bool split = P->ext_split && !trace && P->n_ext_units > P->n_ext_plain;
+    const dim3 grid((split ? P->n_ext_plain : P->n_ext_units) + C.xwgs);
     if (grid_out) *grid_out = (int)grid.x;
     if (trace) {
         hipLaunchKernelGGL((spmv_bcsr4_fused_ext<kBcsrDepth, 4, kWG, true>), grid, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_ext_units);
@@ -919,6 +934,13 @@ int part_ext_launch(mi_part_s* P, const double* d_x_ext, double* d_y_local, unsi
     default: EXT_LAUNCH(2, 4); break;
     }
 #undef EXT_LAUNCH
+    if (split) { // the units that name ghosts, behind the exchange by stream order
+        ExtComm C2 = C;
+        C2.xwgs = C2.n_work = 0;
+        C2.nowait = 1;
+        hipLaunchKernelGGL((spmv_bcsr4_fused_ext<kBcsrDepth, 4, kWG>), dim3(P->n_ext_units - P->n_ext_plain), dim3(kWG), 0, s, V, d_x_ext, d_y_local, C2,
+                           P->d_ext_units + P->n_ext_plain);
+    }
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }

@@ -13,6 +13,10 @@
 // Why no cache invalidate is needed behind the wait: `stage` is read by nobody in this launch before `ready` says so (only
 // ghost-marked workgroups name halo columns, and they wait first), the launch began with the usual invalidate, and the exchange's
 // stores are write-through and drained before the count goes up — so no XCD's L2 and no CU's L1 can hold a line of it from before.
+// Ranks that SHARE a card (a test arrangement, or more ranks than GPUs) must not wait in a quarter of their workgroups: four
+// processes' waiting workgroups fill every wave slot of the card before the last process's exchange workgroups have one — seen as
+// a give-up of all four (bench.py --gpus 4 --workload fe on one card).  There the step is TWO launches of this kernel: exchange +
+// the units that name no ghost, then the units that do (nowait); capi_part.hip decides (a neighbour's window lives on this device).
 // (The halo part of x_ext itself would not do as the staging place: the 128-byte line where it begins also holds the last owned
 // entries, which anybody may have read already.)  Same arithmetic and order as spmv_bcsr4: same bits.
 #pragma once
@@ -37,6 +41,7 @@ struct ExtComm {
     unsigned* timeouts;
     int n_work, n_nb, n_local, n_halo, xwgs; // workgroups [0, n_work) push, [n_work, xwgs) wait and copy, the rest multiply
     unsigned step, spin_max;
+    int nowait;              // the launch holds only units behind a finished exchange (the two-launch form): nobody polls
     unsigned long long* trace; // devtools (TR): per workgroup {start, wait over, end} in s_memrealtime ticks
 };
 
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(T) void spmv_bcsr4_fused_ext(Bcsr4View A, const dou
     const int2 unit = units[(int)blockIdx.x - C.xwgs];
     const unsigned nbl = (unsigned)C.n_local >> 2;
     const double* xs = C.stage - (size_t)C.n_local; // block column c >= nbl: stage + 4 (c - nbl)
-    if (unit.y & 1) { // its rows name ghost nodes: `stage` must hold this step's
+    if ((unit.y & 1) && !C.nowait) { // its rows name ghost nodes: `stage` must hold this step's
         if (tid == 0) {
             const unsigned* line = C.ready + kExtReadyStride * (1 + ((int)blockIdx.x & (kExtReadyLines - 1)));
             unsigned spins = 0;

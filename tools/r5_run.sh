@@ -32,7 +32,8 @@ for s in "$@"; do
     leak)     step r5_leak 600 python tools/leak_check.py ;;
     simfe_d)  for d in 22 23 24 27; do MI355_PUSH_EXT_DEPTH=$d SIM_RANK_EXT_PARTS=${PARTS:-0} step r5_simfe8_d$d 300 python tools/sim_rank.py 8 1 fe || exit 1; done; for l in 0 2; do MI355_PUSH_EXT_LANES16=$l SIM_RANK_EXT_PARTS=0 step r5_simfe8_l$l 300 python tools/sim_rank.py 8 1 fe || exit 1; done ;;
     simfe_w)  for w in 4 8 12 19 38; do MI355_PUSH_EXT_WGS=$w SIM_RANK_EXT_PARTS=0 step r5_simfe8_w$w 300 python tools/sim_rank.py 8 1 fe || exit 1; done ;;
-    simfe)    step r5_simfe8 300 python tools/sim_rank.py 8 1 fe && MI355_PUSH_FUSED_EXT=0 step r5_simfe8_four 300 python tools/sim_rank.py 8 1 fe ;;
+    simfe)    step r5_simfe8 300 python tools/sim_rank.py 8 1 fe && MI355_PUSH_EXT_SPLIT=1 SIM_RANK_EXT_PARTS=0 step r5_simfe8_split 300 python tools/sim_rank.py 8 1 fe && MI355_PUSH_FUSED_EXT=0 step r5_simfe8_four 300 python tools/sim_rank.py 8 1 fe ;;
+    fe4)      MI355_FORCE_DEVICE=0 MI355_BENCH_BACKEND=gloo step r5_bench_fe4 500 python bench.py --gpus 4 --workload fe --steps 50 --warmup 5 --no-cpu-baseline ;;
     simfe_n)  for n in 8 4 2; do step r5_simfe$n 300 python tools/sim_rank.py $n 1 fe && MI355_PUSH_FUSED_EXT=0 step r5_simfe${n}_four 300 python tools/sim_rank.py $n 1 fe || exit 1; done ;;
     t_ext)    step r5_t_ext 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ranks_sharing_one_card and sfe" ;;
     sim8)     step r5_sim8 300 python tools/sim_rank.py 8 1 ;;

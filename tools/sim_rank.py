@@ -5,6 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # diagnostics live in the devtools build of the library (make -C navierstokes_amd/csrc devtools; include/mi355_devtools.h)
 os.environ.setdefault("MI355_SPMV_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "navierstokes_amd", "csrc", "libmi355spmv_dev.so"))
+os.environ.setdefault("MI355_PUSH_EXT_SPLIT", "0")  # (the looped-back window lives on this device, which otherwise reads as "ranks share a card")
 os.environ["MI355_PUSH_LOOPBACK"] = "1"  # this tool maps its OWN window as every peer's (flags preset, nothing waits)
 from navierstokes_amd import mpk, synth, dist as D
 from oracle import oracle as O
