@@ -31,6 +31,33 @@ namespace mi355 {
 constexpr int kSpmmTileThreads = 512;              // 128 block rows per workgroup
 constexpr int kSpmmTileRows = kSpmmTileThreads / 4;
 
+// The tile's x blocks into LDS: thread u takes node u of the tile's list in all S columns — one index load, then 2 S 16-byte loads
+// in flight at once, then the LDS writes.  (Round 5: the earlier form — elements (column, node) dealt over all threads, four per
+// thread, the writes under `if (e < total)` — compiled into four dependent index -> x -> write sequences per thread, each waiting
+// for the one before (the loads had been sunk into the conditional writes), plus a software integer division per element.)
+template <int S, int T>
+__device__ __forceinline__ void spmm_gather_nodes(const unsigned* __restrict__ nodes, int U, const double* __restrict__ X, long long ldx, double* s_xt, int tid)
+{
+    constexpr int REC = 4 * S + 2;
+    for (int u = tid; u < U; u += T) {
+        const unsigned node = nodes[u];
+        double2 v0[S], v1[S];
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            const double2* xb = reinterpret_cast<const double2*>(X + (size_t)j * ldx + 4 * (size_t)node);
+            v0[j] = xb[0];
+            v1[j] = xb[1];
+        }
+        __builtin_amdgcn_sched_barrier(0); // every load is out before the first write waits for one
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            double2* d = reinterpret_cast<double2*>(s_xt + (size_t)u * REC + 4 * j);
+            d[0] = v0[j];
+            d[1] = v1[j];
+        }
+    }
+}
+
 template <int S, int ARITH, int P>
 __global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_tile(Bcsr4View A, Bcsr4Tile Tl, const double* __restrict__ X, long long ldx,
                                                                      double* __restrict__ Y, long long ldy, int nwg, int xcd_chunk)
@@ -63,28 +90,7 @@ __global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_tile(Bcsr4View A,
     }
     // the tile: element e = (column j, list position u), u fastest — neighbouring threads read neighbouring nodes of one
     // column (ascending, often adjacent in memory); four elements per thread in flight at a time
-    const int total = U * S;
-    for (int e0 = tid; e0 < total; e0 += 4 * T) {
-        double2 v0[4], v1[4];
-        int jj[4], uu[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int e = min(e0 + r * T, total - 1);
-            jj[r] = e / U;
-            uu[r] = e - jj[r] * U;
-            const unsigned node = Tl.nodes[u0 + uu[r]];
-            const double2* xb = reinterpret_cast<const double2*>(X + (size_t)jj[r] * ldx + 4 * (size_t)node);
-            v0[r] = xb[0];
-            v1[r] = xb[1];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (e0 + r * T < total) {
-                double2* d = reinterpret_cast<double2*>(s_xt + (size_t)uu[r] * REC + 4 * jj[r]);
-                d[0] = v0[r];
-                d[1] = v1[r];
-            }
-    }
+    spmm_gather_nodes<S, T>(Tl.nodes + u0, U, X, ldx, s_xt, tid);
     __syncthreads();
     double acc[S];
 #pragma unroll
@@ -170,28 +176,7 @@ __global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_otile(Bcsr4View A
         a[t] = ldc(blk);
         sl[t] = Tl.slots[blk];
     }
-    const int total = U * S;
-    for (int e0 = tid; e0 < total; e0 += 4 * T) {
-        double2 v0[4], v1[4];
-        int jj[4], uu[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int e = min(e0 + r * T, total - 1);
-            jj[r] = e / U;
-            uu[r] = e - jj[r] * U;
-            const unsigned node = Tl.nodes[u0 + uu[r]];
-            const double2* xb = reinterpret_cast<const double2*>(X + (size_t)jj[r] * ldx + 4 * (size_t)node);
-            v0[r] = xb[0];
-            v1[r] = xb[1];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (e0 + r * T < total) {
-                double2* d = reinterpret_cast<double2*>(s_xt + (size_t)uu[r] * REC + 4 * jj[r]);
-                d[0] = v0[r];
-                d[1] = v1[r];
-            }
-    }
+    spmm_gather_nodes<S, T>(Tl.nodes + u0, U, X, ldx, s_xt, tid);
     __syncthreads();
     double acc[SL];
 #pragma unroll
@@ -214,7 +199,11 @@ __global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_otile(Bcsr4View A
             if (ia + t < ia1) { // uniform within the octet
 #pragma unroll
                 for (int j = 0; j < SL; j++) {
+#ifdef SPMM_ABL_LDS
+                    const double2 v01 = xs[0], v23 = xs[1];
+#else
                     const double2 v01 = xs[2 * j], v23 = xs[2 * j + 1];
+#endif
                     if (ARITH == 0) {
                         double sacc = acc[j];
                         sacc = fma(c0, v01.x, sacc);
