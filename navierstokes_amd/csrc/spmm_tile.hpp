@@ -199,11 +199,7 @@ __global__ __launch_bounds__(kSpmmTileThreads) void spmm_bcsr4_otile(Bcsr4View A
             if (ia + t < ia1) { // uniform within the octet
 #pragma unroll
                 for (int j = 0; j < SL; j++) {
-#ifdef SPMM_ABL_LDS
-                    const double2 v01 = xs[0], v23 = xs[1];
-#else
                     const double2 v01 = xs[2 * j], v23 = xs[2 * j + 1];
-#endif
                     if (ARITH == 0) {
                         double sacc = acc[j];
                         sacc = fma(c0, v01.x, sacc);
