@@ -396,6 +396,21 @@ int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bo
     return MI_OK;
 }
 
+void bcsr4_drop_sliced(mi_bcsr4_s* A)
+{
+    if (!A || !A->d_sell_val) return;
+    (void)hipDeviceSynchronize();
+    dfree(A->d_sell_val);
+    dfree(A->d_sell_col);
+    dfree(A->d_sell_sptr);
+    dfree(A->d_sell_wrng);
+    dfree(A->d_sell_wrng2);
+    A->d_sell_val = nullptr;
+    A->d_sell_col = nullptr;
+    A->d_sell_sptr = A->d_sell_wrng = A->d_sell_wrng2 = nullptr;
+    A->sell_form = -1;
+}
+
 extern "C" int mi_bcsr4_spmv_dev(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s)
 {
     return launch_bcsr4(A, d_x, d_y, s, true);

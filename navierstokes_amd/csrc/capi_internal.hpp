@@ -384,6 +384,8 @@ static inline bool sstream_y_ok(const mi_csr_s* A, const double* yy, const int* 
 // capi_bcsr.hip
 // the blocked copy's values were rewritten on stream s (by whoever holds d_coef): the sliced copy follows at once, on the same stream
 int bcsr4_values_changed(mi_bcsr4_s* A, hipStream_t s);
+// give the sliced copy up (a handle whose products never run the sliced kernels: the partition's combined piece of a blocked one-launch step)
+void bcsr4_drop_sliced(mi_bcsr4_s* A);
 // a CSR handle's blocked copy (blocks + sliced values) from its CSR values d_src, which also go to d_csr_out when that is given: one pass
 int bcsr4_refresh_from_csr(mi_bcsr4_s* A, const int* d_csr_ptrow, const double* d_src, double* d_csr_out, hipStream_t s);
 int launch_bcsr4(mi_bcsr4_t A, const double* d_x, double* d_y, mi_stream_t s, bool use_map);

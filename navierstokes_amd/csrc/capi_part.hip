@@ -714,6 +714,7 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
                 int xw = (pl.n_halo + 8 * kWG - 1) / (8 * kWG);
                 if (const char* e = getenv("MI355_PUSH_EXT_WGS")) xw = atoi(e);
                 P->ext_wgs = std::max(1, std::min(256, xw));
+                bcsr4_drop_sliced(A->blocked); // (the step's kernel reads the row-major blocks)
                 P->fused = P->fused_bcsr = P->fused_ext = true;
                 P->ghost_readers = true;
             } else {
@@ -782,6 +783,7 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
             }
             HIP_TRY(hipMalloc(&P->d_wg_halo, sizeof(int) * wg_halo.size()));
             HIP_TRY(hipMemcpy(P->d_wg_halo, wg_halo.data(), sizeof(int) * wg_halo.size(), hipMemcpyHostToDevice));
+            bcsr4_drop_sliced(A->blocked); // (spmv_bcsr4_fused reads the row-major blocks)
             P->fused = P->fused_bcsr = true;
             P->ghost_readers = false;
             for (int v : wg_halo) P->ghost_readers = P->ghost_readers || v != 0;
