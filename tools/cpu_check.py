@@ -1,3 +1,4 @@
+"""Dev tool: the CPU baselines of bench.py side by side at C4 size — the oracle's fma chain and the reference's own object code (oracle/_ref), scalar / opt / fma, with and without the cache flush (profiles/NOTES.md: the cpu_baseline numbers)."""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
