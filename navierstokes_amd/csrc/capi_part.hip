@@ -674,7 +674,9 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
             rc = csr_create_impl(pl.n_local, pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), nullptr, &P->piece_all);
             if (rc) return rc;
             mi_csr_t A = P->piece_all;
-            if (resolve_kernel(A) == MI_KERNEL_BCSR4 && A->blocked) {
+            // (the blocked copy is enough: whether this rank's create-time measurement put a CSR kernel a hair ahead of the blocked one must
+            // not decide — the one-launch step only happens if EVERY rank has it, mi_part_push_unfuse)
+            if (A->blocked) {
                 const int nbr = pl.n_local / 4, per = kWG / 4, nwg = (nbr + per - 1) / per;
                 std::vector<int> wg_halo((size_t)nwg, 0);
                 for (int w = 0; w < nwg; w++) {
