@@ -508,16 +508,17 @@ int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_st
  * ring kernel (spmv_ring.hpp, FUSED) serves, the push duty and the ghost reads (straight from the window, behind an in-kernel wait)
  * live inside that kernel, in the few workgroups / runs whose rows touch ghosts; these get a shorter share of the rows, push first and wait
  * second (mi_part_kernel_name(P, 2) names the kernel; MI355_PUSH_FUSED=0 disables the form, MI355_PUSH_FUSED_KERNEL=ring|sstream forces
- * one).  A rank whose rows have the 4x4 node structure runs the blocked kernel's one-launch forms: ghosts read from the window while
- * they are few (spmv_bcsr4_fused, n_halo <= 16 384), beyond that spmv_bcsr4_fused_ext (spmv_bcsr4_ext.hpp) — the launch's first workgroups
- * push, wait and copy the window once into a cached buffer of the handle, the workgroups whose rows name ghosts wait for THEM
- * (MI355_PUSH_FUSED_EXT=0 keeps the four launches for such ranks; ranks that share a device — a neighbour's window lives on this
- * rank's device — run it as two launches, so that only the exchange's few workgroups wait in-kernel: MI355_PUSH_EXT_SPLIT=0|1 forces).  In the fused forms the halo part of d_x_ext is neither read nor
- * written (d_x_ext must still hold n_local + n_halo entries for the four-launch form the ranks may have to agree on). */
+ * one).  A rank whose rows have the 4x4 node structure runs the blocked kernel's one-launch form, spmv_bcsr4_fused_ext
+ * (spmv_bcsr4_ext.hpp): the launch's first workgroups push, wait and copy the window once into a cached buffer of the handle, the
+ * workgroups whose rows name ghosts wait for THEM and read that buffer (MI355_PUSH_FUSED_EXT=0 keeps the four launches for such
+ * ranks; ranks that share a device — a neighbour's window lives on this rank's device — run it as two launches, so that only the
+ * exchange's few workgroups wait in-kernel: MI355_PUSH_EXT_SPLIT=0|1 forces).  In the fused forms the halo part of d_x_ext is
+ * neither read nor written (d_x_ext must still hold n_local + n_halo entries for the four-launch form the ranks may have to
+ * agree on). */
 int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
 /* the kernel a piece's products launch (as rocprofv3 names it): which = 0 the interior rows' piece, 1 the boundary rows', 2 the combined piece
  * of the one-launch push step — spmv_sstream_fused<...> (round 5) wherever that piece holds a sliced copy, else the ring kernel's FUSED
- * form or a blocked one (spmv_bcsr4_fused, spmv_bcsr4_fused_ext); "" when the step is not fused.  The string lives until the thread's next call. */
+ * form or the blocked one (spmv_bcsr4_fused_ext); "" when the step is not fused.  The string lives until the thread's next call. */
 const char* mi_part_kernel_name(mi_part_t P, int which);
 /* Step down from the one-launch form to the four-launch form (push, interior rows, wait + copy, boundary rows).  All ranks must
  * drive the step the same way; the caller compares mi_part_push_info's `fused` across ranks and calls this where they differ. */

@@ -301,10 +301,8 @@ struct mi_part_s {
     const int* d_run_halo = nullptr; // per run (ring) / workgroup (sliced stream) of piece_all: it reads ghosts (owned by piece_all)
     int npush_runs = 0;
     bool fused = false;
-    bool fused_bcsr = false;   // piece_all is served by the BCSR kernel: spmv_bcsr4_fused
     bool ghost_readers = true; // some run / workgroup of the fused launch waits for the neighbours (false: the pushers wait)
-    int* d_wg_halo = nullptr;  // per workgroup of that launch: its block rows touch a ghost node
-    // the wide-halo form of it (spmv_bcsr4_ext.hpp): piece_all numbered [owned | halo], exchange workgroups in front of the grid
+    // the blocked (FE) form of it (spmv_bcsr4_ext.hpp): piece_all numbered [owned | halo], exchange workgroups in front of the grid, ghosts staged
     bool fused_ext = false;
     double* d_stage = nullptr;   // [n_halo] cached copy of the window's current parity
     unsigned* d_ready = nullptr; // exchange workgroups done (up by ext_wgs per step)

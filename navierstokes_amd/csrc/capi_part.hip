@@ -9,14 +9,6 @@
 // windows of ranks living in THIS process
 static std::map<std::string, void*> g_win_registry;
 static void part_comm_release(mi_part_s* P);
-// The blocked one-launch step reads ghosts straight from the (uncached) window up to this many of them; beyond, it stages them once
-// per step in a cached buffer (spmv_bcsr4_ext.hpp).
-// (MI355_PUSH_FUSED_WINDOW_MAX overrides: tests run the staged form on small matrices with 0)
-static int fused_window_halo_max()
-{
-    const char* e = getenv("MI355_PUSH_FUSED_WINDOW_MAX");
-    return e ? atoi(e) : 16384;
-}
 static int part_need_timeouts(mi_part_s* P);
 
 // ---------------------------------------------------------------- RCCL, resolved at run time (rccl_loader.hpp)
@@ -65,7 +57,6 @@ static void part_comm_release(mi_part_s* P)
     P->d_tickets = nullptr;
     dfree(P->d_nb);
     dfree(P->d_run_link);
-    dfree(P->d_wg_halo);
     dfree(P->d_stage);
     dfree(P->d_ready);
     dfree(P->d_ext_units);
@@ -75,8 +66,7 @@ static void part_comm_release(mi_part_s* P)
     mi_csr_destroy(P->piece_all);
     P->piece_all = nullptr;
     P->d_run_link = nullptr;
-    P->d_wg_halo = nullptr;
-    P->fused = P->fused_bcsr = P->fused_ext = false;
+    P->fused = P->fused_ext = false;
     P->win = nullptr;
     P->d_links = nullptr;
     P->d_nb = nullptr;
@@ -663,11 +653,13 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
     // The one-launch step needs all local rows as ONE piece that the ring kernel serves (the push duty and the ghost
     // reads live in that kernel).  MI355_PUSH_FUSED=0 keeps the four-launch form.
     const char* fe = getenv("MI355_PUSH_FUSED");
-    // FE slabs (blocked, wide halo): the piece numbered as x_ext is, the exchange in front of the grid (spmv_bcsr4_ext.hpp).
-    // MI355_PUSH_FUSED_EXT=0 keeps the four-launch form for them.
+    // Ranks whose rows have the 4x4 node structure (FE): the piece numbered as x_ext is, the exchange in front of the grid, the ghosts
+    // staged once per step (spmv_bcsr4_ext.hpp).  MI355_PUSH_FUSED_EXT=0 keeps the four-launch form for them.  (Up to round 5 halos of
+    // <= 16 384 ghosts took a form that read every ghost use from the uncached window, spmv_bcsr4_fused: 14.5 against 7.8 us per step for
+    // a 41^3-node box at N = 4, 8.5 against 6.8 for a 31^3-node one — removed.)
     const char* fx = getenv("MI355_PUSH_FUSED_EXT");
     if (!(fe && !strcmp(fe, "0")) && !(fx && !strcmp(fx, "0")) && P->kernel == MI_KERNEL_AUTO && pl.n_local > 0 && pl.n_local % 4 == 0 && pl.n_halo % 4 == 0 &&
-        pl.n_halo > fused_window_halo_max() && P->n_links > 0) {
+        P->n_links > 0) {
         P->plan.build_all_ext();
         const LocalPiece& L = P->plan.all_ext;
         if (csr_has_block4_pattern(pl.n_local, L.ptrow.data(), L.indcol.data())) {
@@ -706,8 +698,8 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
                 P->n_ext_units = (int)units.size();
                 HIP_TRY(hipMalloc(&P->d_ext_units, sizeof(int2) * units.size()));
                 HIP_TRY(hipMemcpy(P->d_ext_units, units.data(), sizeof(int2) * units.size(), hipMemcpyHostToDevice));
-                HIP_TRY(hipMalloc(&P->d_stage, sizeof(double) * (size_t)pl.n_halo));
-                HIP_TRY(hipMemset(P->d_stage, 0, sizeof(double) * (size_t)pl.n_halo));
+                HIP_TRY(hipMalloc(&P->d_stage, sizeof(double) * (size_t)std::max(pl.n_halo, 2)));
+                HIP_TRY(hipMemset(P->d_stage, 0, sizeof(double) * (size_t)std::max(pl.n_halo, 2)));
                 HIP_TRY(hipMalloc(&P->d_ready, sizeof(unsigned) * kExtReadyStride * (1 + kExtReadyLines)));
                 HIP_TRY(hipMemset(P->d_ready, 0, sizeof(unsigned) * kExtReadyStride * (1 + kExtReadyLines)));
                 // inbound workgroups: four 16-byte loads of the (uncached) window per thread.  Measured at 38 648 ghosts (sim_rank.py 8 1 fe):
@@ -717,7 +709,7 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
                 if (const char* e = getenv("MI355_PUSH_EXT_WGS")) xw = atoi(e);
                 P->ext_wgs = std::max(1, std::min(256, xw));
                 bcsr4_drop_sliced(A->blocked); // (the step's kernel reads the row-major blocks)
-                P->fused = P->fused_bcsr = P->fused_ext = true;
+                P->fused = P->fused_ext = true;
                 P->ghost_readers = true;
             } else {
                 mi_csr_destroy(P->piece_all);
@@ -769,27 +761,6 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
                 HIP_TRY(hipMemcpy(A->ss.dev.wg, A->ss.h_wg.data(), sizeof(SsWg) * A->ss.h_wg.size(), hipMemcpyHostToDevice));
             }
         }
-        // (only while the halo is small: the fused kernel reads ghosts straight from the UNCACHED window, every use of them, and
-        // pushes through two workgroups — with an FE slab's boundary planes, 39 k ghosts for 163 k rows at N = 8, that made the
-        // step 39 us where push + interior + wait-and-copy + boundary as separate launches cost less; sim_rank.py N 1 fe)
-        if (!P->fused && resolve_kernel(A) == MI_KERNEL_BCSR4 && A->blocked && P->plan.n_left % 4 == 0 && pl.n_local % 4 == 0 &&
-            pl.n_halo % 4 == 0 && pl.n_halo <= fused_window_halo_max()) {
-            // FE matrices: the blocked copy of the combined piece, one launch of spmv_bcsr4_fused per step.  Which workgroups
-            // (kWG / 4 block rows each) touch a ghost node:
-            const int nbr = pl.n_local / 4, per = kWG / 4, nwg = (nbr + per - 1) / per;
-            const int nl0 = P->plan.n_left, nl1 = P->plan.n_left + pl.n_local;
-            std::vector<int> wg_halo((size_t)nwg, 0);
-            for (int w = 0; w < nwg; w++) {
-                const int r0 = 4 * w * per, r1 = std::min(pl.n_local, 4 * (w + 1) * per);
-                for (int k = L.ptrow[r0]; k < L.ptrow[r1] && !wg_halo[w]; k++) wg_halo[w] = L.indcol[k] < nl0 || L.indcol[k] >= nl1;
-            }
-            HIP_TRY(hipMalloc(&P->d_wg_halo, sizeof(int) * wg_halo.size()));
-            HIP_TRY(hipMemcpy(P->d_wg_halo, wg_halo.data(), sizeof(int) * wg_halo.size(), hipMemcpyHostToDevice));
-            bcsr4_drop_sliced(A->blocked); // (spmv_bcsr4_fused reads the row-major blocks)
-            P->fused = P->fused_bcsr = true;
-            P->ghost_readers = false;
-            for (int v : wg_halo) P->ghost_readers = P->ghost_readers || v != 0;
-        }
         if (!P->fused) {
             mi_csr_destroy(P->piece_all);
             P->piece_all = nullptr;
@@ -821,7 +792,6 @@ extern "C" int mi_part_push_disable(mi_part_t P)
     P->d_tickets = nullptr;
     dfree(P->d_nb);
     dfree(P->d_run_link);
-    dfree(P->d_wg_halo);
     dfree(P->d_stage);
     dfree(P->d_ready);
     dfree(P->d_ext_units);
@@ -829,8 +799,7 @@ extern "C" int mi_part_push_disable(mi_part_t P)
     P->d_ready = nullptr;
     P->d_ext_units = nullptr;
     P->d_run_link = nullptr;
-    P->d_wg_halo = nullptr;
-    P->fused_bcsr = P->fused_ext = false;
+    P->fused_ext = false;
     mi_csr_destroy(P->piece_all);
     P->win = nullptr;
     P->d_links = nullptr;
@@ -851,9 +820,8 @@ extern "C" int mi_part_push_unfuse(mi_part_t P)
     CHECK_ARG(P, "null handle");
     if (!P->fused) return MI_OK;
     HIP_TRY(hipDeviceSynchronize());
-    P->fused = P->fused_bcsr = P->fused_ext = false;
+    P->fused = P->fused_ext = false;
     dfree(P->d_run_link);
-    dfree(P->d_wg_halo);
     dfree(P->d_stage);
     dfree(P->d_ready);
     dfree(P->d_ext_units);
@@ -861,7 +829,6 @@ extern "C" int mi_part_push_unfuse(mi_part_t P)
     P->d_ready = nullptr;
     P->d_ext_units = nullptr;
     P->d_run_link = nullptr;
-    P->d_wg_halo = nullptr;
     mi_csr_destroy(P->piece_all);
     P->piece_all = nullptr;
     return MI_OK;
@@ -874,7 +841,6 @@ extern "C" const char* mi_part_kernel_name(mi_part_t P, int which)
     if (which < 2) return P->piece[which] ? mi_csr_kernel_name(P->piece[which]) : "";
     if (!P->fused || !P->piece_all) return "";
     if (P->fused_ext) return P->ext_split ? "spmv_bcsr4_fused_ext x2 (ranks share a device: two launches)" : "spmv_bcsr4_fused_ext";
-    if (P->fused_bcsr) return "spmv_bcsr4_fused";
     static thread_local char nm[160];
     const char* base = mi_csr_kernel_name(P->piece_all);
     if (resolve_kernel(P->piece_all) == MI_KERNEL_SSTREAM) snprintf(nm, sizeof nm, "spmv_sstream_fused<%d, %s>", P->piece_all->ss.deep ? 12 : 8, P->piece_all->ss.nt ? "true" : "false");
@@ -987,17 +953,6 @@ extern "C" int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_l
         C.step = step;
         C.spin_max = spin_max;
         C.gate_push = P->ghost_readers ? 0 : 1; // nobody in this launch waits for the neighbours: the pushers do (push_exchange.hpp)
-        if (P->fused_bcsr) {
-            if ((((uintptr_t)d_x_ext) & 15) != 0) return fail(MI_ERR_ARG, "the fused blocked step needs a 16-byte aligned x");
-            mi_bcsr4_t B = P->piece_all->blocked;
-            Bcsr4View V{B->nbrows, B->nbcols, B->d_ptrow, B->d_indcol, B->d_coef, nullptr};
-            C.push_wgs = kNXCD; // dedicated push workgroups in front: the grid is many times the resident capacity
-            C.npush_runs = 0;
-            const int nwg = (4 * B->nbrows + kWG - 1) / kWG;
-            hipLaunchKernelGGL((spmv_bcsr4_fused<kBcsrDepth, kWG>), dim3(nwg + C.push_wgs), dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_wg_halo);
-            HIP_TRY(hipGetLastError());
-            return MI_OK;
-        }
         if ((rc = launch_spmv(P->piece_all, d_x_ext, d_y_local, s, true, &C))) return rc;
         return MI_OK;
     }

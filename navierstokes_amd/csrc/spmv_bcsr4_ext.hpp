@@ -1,24 +1,34 @@
-// spmv_bcsr4_ext.hpp — the one-launch push step of a BLOCKED (FE) rank with a WIDE halo (round 5).
+// spmv_bcsr4_ext.hpp — the one-launch push step of a BLOCKED (FE) rank: the ghosts staged once per step (round 5).
 //
-// spmv_bcsr4_fused (spmv_ring.hpp) reads every ghost use straight from the receive window.  The window is uncached, an FE node's
-// entries are used by ~27 block rows, and a slab's two boundary planes are a quarter of a rank's columns at N = 8 (38 648 ghosts
-// for 163 k rows): that form measured 39 us where the four separate launches took 28.7.  Here the first xwgs workgroups of the grid
-// are the EXCHANGE.  They push this rank's entries (push_kernels.hpp's chunks and tickets), wait for the neighbours' flags, copy
-// the window ONCE into `stage` — an ordinary, cached device buffer of the handle — with write-through stores, drain, and count
-// themselves into `ready`.  A workgroup whose block rows name a ghost node (wg_halo) waits until all xwgs have
-// (ready - xwgs * step >= 0; bounded by spin_max, loud through `timeouts`), then runs the product like every other one.  The matrix
-// is numbered as x_ext is, [owned | halo]: a block column below n_local / 4 reads the caller's x, one above reads `stage` — a select
-// of the base address, no branch.
+// The first form of this step (spmv_bcsr4_fused, removed) read every ghost use straight from the receive window.  The window is
+// uncached and an FE node's entries are used by ~15 block rows: with a slab's two boundary planes (38 648 ghosts for 163 k rows at
+// N = 8) that form took 39 us where four separate launches took 28.7, and it lost to this one at 13 784 and 7 944 ghosts too.
 //
-// Why no cache invalidate is needed behind the wait: `stage` is read by nobody in this launch before `ready` says so (only
-// ghost-marked workgroups name halo columns, and they wait first), the launch began with the usual invalidate, and the exchange's
-// stores are write-through and drained before the count goes up — so no XCD's L2 and no CU's L1 can hold a line of it from before.
+// The matrix is numbered as x_ext is, [owned | halo].  The grid, in dispatch order:
+//   * n_work PUSH workgroups, one per 8 KB chunk of a link (push_exchange.hpp: kPushChunk): my entries into the neighbour's window with
+//     write-through 16-byte stores, a drain, a relaxed ticket; the link's last chunk raises the flag.  No fence: an L2 write-back
+//     under the running product cost 8 us per step.
+//   * xwgs - n_work COPY workgroups: wait for every neighbour's flag of this step (relaxed polls, ONE acquire), copy the window into
+//     `stage` — an ordinary, cached device buffer of the handle — with write-through stores, drain; the last of them (a ticket) writes
+//     the step number to kExtReadyLines separate lines.
+//   * the product's units (capi_part.hip builds the table): 64 block rows, four lanes per block row, spmv_bcsr4's loop — except for
+//     units whose rows name a ghost node.  Those come LAST, poll ONE of the ready lines (all of them on one address delayed the word
+//     by 8 us; bounded by spin_max, loud through `timeouts`), and are dealt as four workgroups with SIXTEEN lanes per block row
+//     (bcsr4_ext_row16): they start ~10 us late and have a quarter of the load chain in front of them.
+// A block column below n_local / 4 reads the caller's x, one above reads `stage` — a select of the base address, no branch.
+//
+// Why no cache invalidate is needed behind the wait: `stage` is read by nobody in this launch before the ready lines say so (only
+// ghost-marked units name halo columns, and they wait first), the launch began with the usual invalidate, and the copy workgroups'
+// stores are write-through and drained before the ticket — so no XCD's L2 and no CU's L1 can hold a line of it from before.
+// (The halo part of x_ext itself would not do as the staging place: the 128-byte line where it begins also holds the last owned
+// entries, which anybody may have read already.)
+//
 // Ranks that SHARE a card (a test arrangement, or more ranks than GPUs) must not wait in a quarter of their workgroups: four
 // processes' waiting workgroups fill every wave slot of the card before the last process's exchange workgroups have one — seen as
 // a give-up of all four (bench.py --gpus 4 --workload fe on one card).  There the step is TWO launches of this kernel: exchange +
 // the units that name no ghost, then the units that do (nowait); capi_part.hip decides (a neighbour's window lives on this device).
-// (The halo part of x_ext itself would not do as the staging place: the 128-byte line where it begins also holds the last owned
-// entries, which anybody may have read already.)  Same arithmetic and order as spmv_bcsr4: same bits.
+//
+// Same arithmetic and order as spmv_bcsr4 in both row forms: same bits.  Measured: profiles/NOTES.md R5.6.
 #pragma once
 #include "push_exchange.hpp"
 #include "spmv_kernels.hpp"

@@ -431,85 +431,6 @@ __global__ __launch_bounds__(T) void spmv_csr_ring(CsrView A, const int4* __rest
     }
 }
 
-// ---------------------------------------------------------------------------
-// The fused multi-GPU step on the BLOCKED matrix (FE matrices across ranks): spmv_bcsr4 (spmv_kernels.hpp) over all local
-// block rows in natural order, block columns numbered [ghost nodes of lower ranks | owned | ghost nodes of higher ranks].
-// The first push_wgs workgroups of the grid do the peer push and exit (the grid is many times the resident capacity, so
-// they delay nothing); a workgroup whose block rows touch a ghost node (wg_halo: the first and last workgroups of a
-// banded partition) waits for the neighbours' flags before its first load — the first ones start at once and finish a
-// little later, the last ones start late anyway; ghost x blocks are read from the receive window.  Same arithmetic and
-// order as spmv_bcsr4: bit-identical to it and to the CSR fma chain.
-// ---------------------------------------------------------------------------
-template <int P, int T>
-__global__ __launch_bounds__(T) void spmv_bcsr4_fused(Bcsr4View A, const double* __restrict__ x, double* __restrict__ y, RingComm C,
-                                                      const int* __restrict__ wg_halo)
-{
-    if ((int)blockIdx.x < C.push_wgs) {
-        if ((int)blockIdx.x < C.n_links) ring_push_gate<T>(C);
-        for (int l = blockIdx.x; l < C.n_links; l += C.push_wgs) ring_push_link<T>(C, x, l);
-        return;
-    }
-    const int wg = (int)blockIdx.x - C.push_wgs;
-    if (wg_halo[wg]) {
-        push_wait_flags(C.flags, C.nb, C.n_nb, C.step, 0u, C.timeouts, C.spin_max, threadIdx.x, T);
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    }
-    const int g = wg * T + threadIdx.x;
-    const int bi = g >> 2, q = g & 3;
-    if (bi >= A.nbrows) return;
-    const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
-    const int ia0 = A.ptrow[bi], ia1 = A.ptrow[bi + 1];
-    const int nlb = C.n_left >> 2, nob = C.n_local >> 2; // ghost / owned NODES in front
-    auto xblock = [&](unsigned cn) -> const double2* {
-        const int o = (int)cn - nlb;
-        const double* p = o < 0 ? C.halo + 4 * (size_t)cn : (o < nob ? x + 4 * (size_t)o : C.halo + 4 * ((size_t)cn - nob));
-        return reinterpret_cast<const double2*>(p);
-    };
-    double s = 0.0;
-    if (ia0 < ia1) {
-        const int last = ia1 - 1;
-        const double* cq = A.coef + 4 * q;
-        double2 a01[P], a23[P], x01[P], x23[P];
-        unsigned cn[P];
-#pragma unroll
-        for (int t = 0; t < P; t++) {
-            const int blk = min(ia0 + t, last);
-            const double2* row = reinterpret_cast<const double2*>(cq + 16 * (size_t)blk);
-            a01[t] = row[0];
-            a23[t] = row[1];
-            cn[t] = ucol[blk];
-        }
-#pragma unroll
-        for (int t = 0; t < P; t++) {
-            const double2* xb = xblock(cn[t]);
-            x01[t] = xb[0];
-            x23[t] = xb[1];
-        }
-#pragma unroll
-        for (int t = 0; t < P; t++) cn[t] = ucol[min(ia0 + P + t, last)];
-        for (int ia = ia0; ia < ia1; ia += P) {
-#pragma unroll
-            for (int t = 0; t < P; t++) {
-                const double2 c01 = a01[t], c23 = a23[t], v01 = x01[t], v23 = x23[t];
-                const int nb = min(ia + t + P, last);
-                const double2* nrow = reinterpret_cast<const double2*>(cq + 16 * (size_t)nb);
-                a01[t] = nrow[0];
-                a23[t] = nrow[1];
-                const double2* nxb = xblock(cn[t]);
-                x01[t] = nxb[0];
-                x23[t] = nxb[1];
-                cn[t] = ucol[min(ia + t + 2 * P, last)];
-                if (ia + t < ia1) {
-                    s = fma(c01.x, v01.x, s);
-                    s = fma(c01.y, v01.y, s);
-                    s = fma(c23.x, v23.x, s);
-                    s = fma(c23.y, v23.y, s);
-                }
-            }
-        }
-    }
-    y[4 * (size_t)bi + q] = s;
-}
+// (The fused multi-GPU step on the BLOCKED matrix lives in spmv_bcsr4_ext.hpp.)
 
 } // namespace mi355

@@ -552,7 +552,7 @@ def test_native_step_single_rank():
                                                            # fewer rounds than their share, their whole column range taken in up front
                                                            (2, "s15", 1_400_000, 2000, 29617, "push"),
                                                            # (round 5) a blocked rank's one-launch step with the ghosts STAGED once per step
-                                                           # (spmv_bcsr4_ext.hpp; wide halos take it — here forced by a threshold of 0)
+                                                           # (spmv_bcsr4_ext.hpp), the ONE-launch form forced
                                                            (3, "sfe_ext", 60_000, 1500, 29618, "push"),
                                                            # ... and as the library runs it when it finds a neighbour's window on its own device (ranks
                                                            # sharing a card, as here): two launches, only the exchange's workgroups wait in-kernel
@@ -576,11 +576,11 @@ def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
                MI355_PUSH_SPIN_LOG2=os.environ.get("MI355_PUSH_SPIN_LOG2", "23"))
     if kind == "sfe_ext":  # the one-launch form, forced (few workgroups here: the card has room for every rank's waiting ones)
         kind = "sfe"
-        env.update(MI355_PUSH_FUSED_WINDOW_MAX="0", MI355_PUSH_EXT_SPLIT="0", MI355_TEST_EXPECT_FUSED="=spmv_bcsr4_fused_ext")
+        env.update(MI355_PUSH_EXT_SPLIT="0", MI355_TEST_EXPECT_FUSED="=spmv_bcsr4_fused_ext")
     elif kind == "sfe_ext2":
         kind = "sfe"
         env.pop("MI355_PUSH_EXT_SPLIT", None)
-        env.update(MI355_PUSH_FUSED_WINDOW_MAX="0", MI355_TEST_EXPECT_FUSED="spmv_bcsr4_fused_ext x2")
+        env.update(MI355_TEST_EXPECT_FUSED="spmv_bcsr4_fused_ext x2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_gpu_worker.py"), kind, str(n), str(w)]

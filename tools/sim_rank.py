@@ -13,7 +13,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 what = sys.argv[3] if len(sys.argv) > 3 else "c4"   # "c4": S15 5 M rows; "fe": the 68^3-cell FE matrix, cuts at node boundaries
 if what == "fe":
-    P_, C_, V_ = synth.fe_matrix(68)
+    P_, C_, V_ = synth.fe_matrix(int(os.environ.get("SIM_FE_CELLS", "68")))
     n = len(P_) - 1
     rs = D.balanced_row_starts(n, N, np.diff(P_), align=4)
     lo, hi = int(rs[rank]), int(rs[rank + 1])
