@@ -232,6 +232,10 @@ int mi_sstream_plan_probe(int n, int ncols, const int* ptrow, const int* indcol,
  * shortest and the longest share of rounds.  The replay also checks the marks and the dealing. */
 int mi_sstream_plan_probe_ex(int n, int ncols, const int* ptrow, const int* indcol, int shift, int ghost_lo, int ghost_hi, int* eligible, int* rounds,
                              long long* steps, double* padding, int* ghost_workgroups, int* rounds_min_max);
+/* ... and of its cut-ring form for rows that name several column neighbourhoods (3-D mesh operators in natural node order;
+ * navierstokes_amd/csrc/spmv_sstream_mw.hpp): built as mi_csr_create builds it when the one-window plan is not eligible, and replayed —
+ * every nonzero must find its column at its slot of the cut ring when its round runs.  Host only. */
+int mi_sstream_mw_plan_probe(int n, int ncols, const int* ptrow, const int* indcol, int shift, int* eligible, int* rounds, long long* steps, double* padding);
 /* Multi-window ring kernel (MI_KERNEL_MRING, mring_plan.hpp): mi_csr_create plans it for matrices the single ring does not serve
  * and keeps the plan when it serves >= 90 % of the nonzeros (MI355_MRING=0 never, =1 always keep); mi_csr_set_kernel builds it
  * on request.  us[0..1] = measured microseconds per launch, temporal / non-temporal value loads (MI355_MRING_NT=0|1 forces). */

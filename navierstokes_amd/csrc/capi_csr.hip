@@ -70,9 +70,19 @@ static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol, int gh
     SsPlanHost P;
     const int shift = (A->y_offset & 1) && !A->d_rowmap ? 1 : 0;
     build_sstream_plan(A->n, A->ncols, ptrow, indcol, ss_max_padding(), P, true, shift, ghost_lo, ghost_hi);
-    if (!P.eligible) return MI_OK;
     SstreamTable& T = A->ss;
-    hipError_t e = ss_upload(P, T.dev, ghost_lo < ghost_hi);
+    hipError_t e;
+    if (!P.eligible) {
+        // rows that name several column neighbourhoods (3-D mesh operators in natural order): the cut-ring form (spmv_sstream_mw.hpp).
+        // Not for a combined piece with ghost columns (the fused step has no such form).  MI355_SSTREAM_MW=0: never.
+        if (ghost_lo < ghost_hi || (getenv("MI355_SSTREAM_MW") && !strcmp(getenv("MI355_SSTREAM_MW"), "0"))) return MI_OK;
+        SsMwPlanHost M;
+        build_sstream_mw_plan(A->n, A->ncols, ptrow, indcol, ss_max_padding(), M, shift);
+        if (!M.eligible) return MI_OK;
+        e = ss_mw_upload(M, T.dev);
+        T.mw = e == hipSuccess;
+        P = M; // (the tables both forms share: rounds, steps, slices)
+    } else e = ss_upload(P, T.dev, ghost_lo < ghost_hi);
     if (e != hipSuccess) {
         free_sstream(A);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return MI_OK; } // no room for a second copy of the matrix: the other kernels serve it
@@ -91,7 +101,7 @@ static int build_sstream(mi_csr_t A, const int* ptrow, const int* indcol, int gh
     }
     // the sliced values are filled HERE and refilled where the CSR values change (mi_csr_update_values*), on that call's stream — never
     // lazily in front of a product: a product captured into a HIP graph holds only the product's node and must find the values in place
-    sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, A->d_coef, nullptr, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, nullptr);
+    sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, A->d_coef, nullptr, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, nullptr, T.mw ? 1 : 0);
     if ((e = hipGetLastError()) != hipSuccess) {
         free_sstream(A);
         return fail(MI_ERR_HIP, std::string("sliced copy fill: ") + hipGetErrorString(e));
@@ -112,6 +122,19 @@ int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap
     SstreamTable& T = A->ss;
     SsView S{T.dev.val, T.dev.slot, T.dev.wg, T.dev.win, T.nwg, A->n + T.shift, A->ncols, rowmap, T.shift};
     double* yy = rowmap ? d_y : d_y - T.shift;
+    if (T.mw) {
+        if (comm) return fail(MI_ERR_STATE, "the cut-ring sliced stream has no fused multi-GPU form");
+        SsMwView V{S, T.dev.winK};
+        if (T.deep) {
+            if (T.nt) hipLaunchKernelGGL((spmv_sstream_mw<12, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, V, d_x, yy);
+            else hipLaunchKernelGGL((spmv_sstream_mw<12, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, V, d_x, yy);
+        } else {
+            if (T.nt) hipLaunchKernelGGL((spmv_sstream_mw<8, true>), dim3((unsigned)T.nwg), dim3(256), 0, s, V, d_x, yy);
+            else hipLaunchKernelGGL((spmv_sstream_mw<8, false>), dim3((unsigned)T.nwg), dim3(256), 0, s, V, d_x, yy);
+        }
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
     if (comm) {
         const unsigned grid = (unsigned)(T.nwg + comm->push_wgs);
         if (T.deep) {
@@ -1106,7 +1129,7 @@ static int refresh_blocked_values(mi_csr_t A, hipStream_t s, bool sliced_done = 
 {
     if (A->ss.dev.val && !sliced_done) {
         SstreamTable& T = A->ss;
-        sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, A->d_coef, nullptr, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, s);
+        sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, A->d_coef, nullptr, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, s, T.mw ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     if (!A->blocked || A->blocked->nbrows == 0) return MI_OK;
@@ -1160,7 +1183,7 @@ extern "C" int mi_csr_update_values_dev(mi_csr_t A, const double* d_coef, mi_str
     }
     if (A->ss.dev.val && d_coef != A->d_coef) { // ONE pass over the caller's values: the CSR values and the sliced values leave together
         SstreamTable& T = A->ss;
-        sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, d_coef, A->d_coef, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, s);
+        sstream_fill_values(T.rounds, A->n, T.shift, A->d_ptrow, d_coef, A->d_coef, T.dev.slice_step, T.dev.slice_len, T.dev.val, T.max_slice_nnz, s, T.mw ? 1 : 0);
         HIP_TRY(hipGetLastError());
         return refresh_blocked_values(A, s, true);
     }
@@ -1461,6 +1484,28 @@ extern "C" int mi_sstream_plan_probe_ex(int n, int ncols, const int* ptrow, cons
     return MI_OK;
 }
 
+// the cut-ring form's plan (spmv_sstream_mw.hpp) built as mi_csr_create would and replayed against the matrix (host only: no device needed)
+extern "C" int mi_sstream_mw_plan_probe(int n, int ncols, const int* ptrow, const int* indcol, int shift, int* eligible, int* rounds, long long* steps, double* padding)
+{
+    CHECK_ARG(n >= 0 && ncols >= 0 && ptrow && ptrow[0] == 0 && eligible, "bad argument");
+    CHECK_ARG(shift == 0 || shift == 1, "shift must be 0 or 1");
+    CHECK_ARG(ptrow[n] == 0 || indcol, "indcol is null");
+    for (int i = 0; i < n; i++) CHECK_ARG(ptrow[i] <= ptrow[i + 1], "ptrow must be non-decreasing");
+    for (int k = 0; k < ptrow[n]; k++) CHECK_ARG(indcol[k] >= 0 && indcol[k] < ncols, "column index outside [0, ncols)");
+    SsMwPlanHost P;
+    build_sstream_mw_plan(n, ncols, ptrow, indcol, ss_max_padding(), P, shift);
+    *eligible = P.eligible ? 1 : 0;
+    if (rounds) *rounds = P.rounds;
+    if (steps) *steps = P.steps;
+    if (padding) *padding = ptrow[n] > 0 ? (double)P.pad_places / (double)ptrow[n] : 0.0;
+    if (!P.eligible) {
+        g_err = std::string("not eligible: ") + P.why;
+        return MI_OK;
+    }
+    if (const char* bad = check_sstream_mw_plan(P, n, ptrow, indcol)) return fail(MI_ERR_STATE, std::string("cut-ring sliced-stream plan: ") + bad);
+    return MI_OK;
+}
+
 extern "C" int mi_csr_block4_structure(int n, const int* ptrow, const int* indcol, int* is_blocked, long long* nblocks)
 {
     CHECK_ARG(n >= 0 && ptrow && is_blocked, "bad argument");
@@ -1757,7 +1802,8 @@ extern "C" const char* mi_csr_kernel_name(mi_csr_t A)
     }
     case MI_KERNEL_SSTREAM: {
         static thread_local char nm[64];
-        snprintf(nm, sizeof nm, "spmv_sstream<%d, %s, 0>", A->ss.deep ? 12 : 8, A->ss.nt ? "true" : "false");
+        if (A->ss.mw) snprintf(nm, sizeof nm, "spmv_sstream_mw<%d, %s>", A->ss.deep ? 12 : 8, A->ss.nt ? "true" : "false");
+        else snprintf(nm, sizeof nm, "spmv_sstream<%d, %s, 0>", A->ss.deep ? 12 : 8, A->ss.nt ? "true" : "false");
         return nm;
     }
     case MI_KERNEL_TILE: {

@@ -25,7 +25,7 @@
 #include "ring_plan.hpp"
 #include "spmv_kernels.hpp"
 #include "spmv_ring.hpp"
-#include "spmv_sstream.hpp"
+#include "spmv_sstream_mw.hpp"
 
 using namespace mi355;
 
@@ -126,6 +126,7 @@ struct TileTable {
 
 // the sliced copy of the sliced-stream kernel (spmv_sstream.hpp); valid iff dev.val != nullptr
 struct SstreamTable {
+    bool mw = false; // the cut-ring form (spmv_sstream_mw.hpp): several column neighbourhoods per row (3-D mesh operators)
     SsDevice dev;                 // values, slot stream, workgroup records, windows, slice tables (value refills), ghost marks
     int nwg = 0, rounds = 0;
     int shift = 0;                // the rows are planned one down (an odd y offset: row pairs stay 16-byte aligned)
@@ -378,7 +379,7 @@ int part_ext_launch(mi_part_s* P, const double* d_x_ext, double* d_y_local, unsi
 // comm: the fused multi-GPU step (the handle is a partition's combined piece with ghost marks)
 int launch_sstream(mi_csr_t A, const double* d_x, double* d_y, const int* rowmap, hipStream_t s, const RingComm* comm = nullptr);
 // the sliced-stream kernel can write this y (row pairs as 16 bytes; a mapped handle stores row by row)
-static inline bool sstream_y_ok(const mi_csr_s* A, const double* yy, const int* map) { return map || (((uintptr_t)(yy - A->ss.shift)) & 15) == 0; }
+static inline bool sstream_y_ok(const mi_csr_s* A, const double* yy, const int* map) { return map || A->ss.mw || (((uintptr_t)(yy - A->ss.shift)) & 15) == 0; } // (the cut-ring form stores row by row)
 // capi_bcsr.hip
 // the blocked copy's values were rewritten on stream s (by whoever holds d_coef): the sliced copy follows at once, on the same stream
 int bcsr4_values_changed(mi_bcsr4_s* A, hipStream_t s);

@@ -370,7 +370,7 @@ inline const char* check_sstream_plan(const SsPlanHost& P, int n, const int* ptr
 template <int CAP>
 __global__ __launch_bounds__(256) void sstream_fill_kernel(int nslices, int n, int shift, const int* __restrict__ ptrow, const double* __restrict__ src,
                                                            double* __restrict__ csr_out, const int* __restrict__ slice_step, const int* __restrict__ slice_len,
-                                                           ss_v2d* __restrict__ val)
+                                                           ss_v2d* __restrict__ val, int pair64)
 {
     __shared__ double buf[CAP > 0 ? CAP : 1];
     __shared__ int rp[kSsSliceRows + 1];
@@ -394,10 +394,12 @@ __global__ __launch_bounds__(256) void sstream_fill_kernel(int nslices, int n, i
         const int t0 = slice_step[sidx], L = slice_len[sidx];
         for (int q = tid; q < L * 64; q += 256) {
             const int j = q >> 6, lane = q & 63;
-            const int a0 = rp[2 * lane], a1 = rp[2 * lane + 1], a2 = rp[2 * lane + 2];
+            // the lane's two rows: 2 l and 2 l + 1, or (pair64: the cut-ring form, spmv_sstream_mw.hpp) l and l + 64
+            const int ra = pair64 ? lane : 2 * lane, rb = pair64 ? lane + 64 : 2 * lane + 1;
+            const int a0 = rp[ra], a1 = rp[ra + 1], b0 = rp[rb], b1 = rp[rb + 1];
             ss_v2d v = {0.0, 0.0};
             if (j < a1 - a0) v.x = staged ? buf[a0 - base + j] : src[a0 + j];
-            if (j < a2 - a1) v.y = staged ? buf[a1 - base + j] : src[a1 + j];
+            if (j < b1 - b0) v.y = staged ? buf[b0 - base + j] : src[b0 + j];
             val[(size_t)(t0 + j) * 64 + lane] = v;
         }
         __syncthreads(); // rp / buf are rewritten for the next slice
@@ -406,16 +408,16 @@ __global__ __launch_bounds__(256) void sstream_fill_kernel(int nslices, int n, i
 
 // host: enqueue the fill of all 4 * rounds slices on stream s; max_slice_nnz = the longest slice's CSR segment (SsPlanHost)
 inline void sstream_fill_values(int rounds, int n, int shift, const int* d_ptrow, const double* d_src, double* d_csr_out, const int* d_slice_step,
-                                const int* d_slice_len, ss_v2d* d_val, int max_slice_nnz, hipStream_t s)
+                                const int* d_slice_len, ss_v2d* d_val, int max_slice_nnz, hipStream_t s, int pair64 = 0)
 {
     const int nslices = 4 * rounds;
     if (nslices <= 0) return;
     if (max_slice_nnz <= 2048) // (S15: 1920 values per slice) 16 KB of LDS: eight workgroups per CU
-        hipLaunchKernelGGL((sstream_fill_kernel<2048>), dim3((unsigned)std::min(nslices, 2048)), dim3(256), 0, s, nslices, n, shift, d_ptrow, d_src, d_csr_out, d_slice_step, d_slice_len, d_val);
+        hipLaunchKernelGGL((sstream_fill_kernel<2048>), dim3((unsigned)std::min(nslices, 2048)), dim3(256), 0, s, nslices, n, shift, d_ptrow, d_src, d_csr_out, d_slice_step, d_slice_len, d_val, pair64);
     else if (max_slice_nnz <= 8192) // (the FE rows of 56: 7168) 64 KB: two per CU
-        hipLaunchKernelGGL((sstream_fill_kernel<8192>), dim3((unsigned)std::min(nslices, 1024)), dim3(256), 0, s, nslices, n, shift, d_ptrow, d_src, d_csr_out, d_slice_step, d_slice_len, d_val);
+        hipLaunchKernelGGL((sstream_fill_kernel<8192>), dim3((unsigned)std::min(nslices, 1024)), dim3(256), 0, s, nslices, n, shift, d_ptrow, d_src, d_csr_out, d_slice_step, d_slice_len, d_val, pair64);
     else
-        hipLaunchKernelGGL((sstream_fill_kernel<0>), dim3((unsigned)std::min(nslices, 2048)), dim3(256), 0, s, nslices, n, shift, d_ptrow, d_src, d_csr_out, d_slice_step, d_slice_len, d_val);
+        hipLaunchKernelGGL((sstream_fill_kernel<0>), dim3((unsigned)std::min(nslices, 2048)), dim3(256), 0, s, nslices, n, shift, d_ptrow, d_src, d_csr_out, d_slice_step, d_slice_len, d_val, pair64);
 }
 
 // device copy of a plan (library and tools/ alike): allocate + upload; on failure everything is released and the error returned
@@ -427,9 +429,11 @@ struct SsDevice {
     int* slice_step = nullptr;
     int* slice_len = nullptr;
     int* wg_halo = nullptr; // plans with ghost columns only
+    int2* winK = nullptr;   // the cut-ring form only (spmv_sstream_mw.hpp): [4 * rounds] intakes per sub-ring
 };
 inline void ss_free(SsDevice& Dv)
 {
+    (void)hipFree(Dv.winK);
     (void)hipFree(Dv.val); (void)hipFree(Dv.slot); (void)hipFree(Dv.wg); (void)hipFree(Dv.win); (void)hipFree(Dv.slice_step); (void)hipFree(Dv.slice_len); (void)hipFree(Dv.wg_halo);
     Dv = SsDevice();
 }

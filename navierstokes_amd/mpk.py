@@ -115,6 +115,7 @@ def lib():
         "mi_csr_sstream_info": [_vp, P(i), P(i), P(ll), P(d), P(d), P(i)],
         "mi_sstream_plan_probe": [i, i, _vp, _vp, P(i), P(i), P(ll), P(d)],
         "mi_sstream_plan_probe_ex": [i, i, _vp, _vp, i, i, i, P(i), P(i), P(ll), P(d), P(i), P(i)],
+        "mi_sstream_mw_plan_probe": [i, i, _vp, _vp, i, P(i), P(i), P(ll), P(d)],
         "mi_csr_placement_info": [_vp, P(i), P(i), P(d), i],
         "mi_vec_alloc_placed": [_vp, i, i, P(_vp), P(d), i, P(i)],
         "mi_vec_free_placed": [_vp],

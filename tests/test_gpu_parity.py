@@ -1254,6 +1254,58 @@ def _band(n, ncols, hb, per, seed, empty_every=0):
     return np.array(ptr, np.int32), np.array(col, np.int32), rng.uniform(-1, 1, len(col))
 
 
+@pytest.mark.parametrize("form", ["0", "1", "2", "3"])
+def test_mesh_operator_through_the_cut_ring_sliced_stream(form, monkeypatch):
+    """Round 5: spmv_sstream_mw (spmv_sstream_mw.hpp) — the sliced stream with its LDS ring cut into four sub-rings, for rows that name
+    several column neighbourhoods: the P1 pressure operator of src/integration.c on Kuhn meshes in natural node order (a node's plane and
+    the two next to it).  Forced in each of the four variants: bit-equal to the oracle's fma chain (SpMV_CSR_FMA, mpk/SpMV.cpp:41-56) at
+    two sizes (the planes must lie further apart than the one-window form's ring holds, or that form takes the matrix), after a value
+    refresh, as the kernel behind the k = 3 powers, through a y that is only 8-byte aligned (that product takes another kernel) and through
+    row maps (a partition piece's rows: odd and even offsets, scattered)."""
+    monkeypatch.setenv("MI355_SSTREAM", "1")
+    monkeypatch.setenv("MI355_SSTREAM_FORM", form)
+    for cells in (62, 75):
+        p, c, v = synth.pressure_matrix(cells)
+        n = len(p) - 1
+        A = mpk.csrmatrix(n, p, c, v).set_kernel("sstream")
+        assert A.kernel_name().startswith("spmv_sstream_mw<") and A.sstream_info()["form"] == int(form), (A.kernel_name(), A.sstream_info())
+        x = synth.x_sin(0, n)
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            mpk.SpMV_CSR(y, dev(x), A)
+        assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v, x), f"mesh {cells}^3 {A.kernel_name()}")
+    v2 = v * np.cos(np.arange(len(v)))
+    A.update_values(v2)
+    mpk.SpMV_CSR(y, dev(x), A)
+    assert_bit_equal(y.cpu().numpy(), O.spmv(p, c, v2, x), "after mi_csr_update_values")
+    outs = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3)]
+    for _ in range(2):
+        mpk.SpMkV(outs, dev(x), A)
+    Y = O.spmk_chain(3, p, c, v2, x)
+    for q in range(3):
+        assert_bit_equal(outs[q].cpu().numpy(), Y[q], f"powers over a cut-ring handle, power {q + 1}: {A.spmk_info(3)}")
+    ybig = torch.full((n + 1,), float("nan"), dtype=torch.float64, device="cuda")
+    mpk.SpMV_CSR(ybig[1:], dev(x), A)
+    assert_bit_equal(ybig[1:].cpu().numpy(), O.spmv(p, c, v2, x), "8-byte aligned y")
+    p, c, v = synth.pressure_matrix(62)
+    n = len(p) - 1
+    x = synth.x_sin(0, n)
+    yo = O.spmv(p, c, v, x)
+    rng = np.random.default_rng(5)
+    for tag, rowmap in (("offset 5", (np.arange(n) + 5).astype(np.int32)), ("offset 6", (np.arange(n) + 6).astype(np.int32)),
+                        ("scattered", rng.permutation(n + 9)[:n].astype(np.int32))):
+        A = mpk.csrmatrix(n, p, c, v, rowmap=rowmap).set_kernel("sstream")
+        assert A.kernel_name().startswith("spmv_sstream_mw<"), A.kernel_name()
+        yy = torch.full((n + 9,), float("nan"), dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            mpk.SpMV_CSR(yy, dev(x), A)
+        got = yy.cpu().numpy()
+        assert_bit_equal(got[rowmap], yo, f"row-mapped ({tag}) {A.kernel_name()}")
+        rest = np.ones(n + 9, bool)
+        rest[rowmap] = False
+        assert np.isnan(got[rest]).all(), f"row-mapped ({tag}): wrote rows outside the map"
+
+
 @pytest.mark.parametrize("form", ["8nt", "8t", "12nt", "12t"])
 def test_sliced_stream_kernel(form, monkeypatch):
     """spmv_sstream (spmv_sstream.hpp; SpMV_CSR*, mpk/SpMV.cpp:6-85): the sliced copy streamed by one wave per SIMD, a lane per row

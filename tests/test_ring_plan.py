@@ -199,6 +199,51 @@ def test_one_launch_powers_step_dependencies_cover_every_load():
         assert e == 1 and md <= 64, (n, hb, e, runs, md)
 
 
+def test_cut_ring_sliced_stream_plan_is_replayed_on_the_host():
+    """Round 5: the sliced stream's cut-ring form (spmv_sstream_mw.hpp) for rows that name several column neighbourhoods — a 3-D mesh
+    operator in natural node order names the node's plane and the two next to it.  mi_sstream_mw_plan_probe builds the plan as mi_csr_create
+    does when the one-window plan is not eligible and replays it with the cut ring simulated: every nonzero must find ITS column at its slot
+    when its round runs.  Eligible: the P1 pressure operator on Kuhn meshes (also planned one row down), two far-apart bands; not eligible
+    (and saying why): a band wider than a sub-ring, five neighbourhoods per row."""
+    import ctypes
+    L = mpk.lib()
+
+    def probe(p, c, n, shift=0):
+        p = np.ascontiguousarray(p, np.int32)
+        c = np.ascontiguousarray(c, np.int32)
+        e, r, st, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_double()
+        mpk.check(L.mi_sstream_mw_plan_probe(n, n, p.ctypes.data, c.ctypes.data, shift, ctypes.byref(e), ctypes.byref(r), ctypes.byref(st), ctypes.byref(pad)))
+        return e.value, r.value, st.value, pad.value, L.mi_last_error().decode()
+
+    for cells in (20, 33, 70):
+        p, c, v = synth.pressure_matrix(cells)
+        n = len(p) - 1
+        for shift in (0, 1):
+            e, rounds, steps, pad, why = probe(p, c, n, shift)
+            assert e == 1 and rounds == (n + shift + 511) // 512 and pad < 0.12, (cells, shift, e, rounds, pad, why)
+        if cells == 70:  # three planes 5041 columns apart + a round's 512 rows: more than the one-window ring holds
+            e1, r1, s1, p1 = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_double()
+            mpk.check(L.mi_sstream_plan_probe(n, n, p.ctypes.data, c.ctypes.data, ctypes.byref(e1), ctypes.byref(r1), ctypes.byref(s1), ctypes.byref(p1)))
+            assert e1.value == 0
+
+    def bands(n, k, gap, width=5):  # k bands of `width` columns, `gap` apart: rows name k neighbourhoods
+        offs = np.concatenate([np.arange(width) - width // 2 + (j - k // 2) * gap for j in range(k)])
+        cols = np.arange(n)[:, None] + offs[None, :]
+        keep = (cols >= 0) & (cols < n)
+        p = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
+        return p, cols[keep].astype(np.int32)
+    p, c = bands(60_000, 3, 9000)
+    assert probe(p, c, 60_000)[0] == 1
+    p, c = bands(60_000, 4, 5000)
+    assert probe(p, c, 60_000)[0] == 1
+    p, c = bands(60_000, 5, 5000)
+    e, _, _, _, why = probe(p, c, 60_000)
+    assert e == 0 and "four" in why, why
+    p, c, v = synth.rows("s15", 100_000, w=2000)  # one neighbourhood of 4000 + 512 columns: wider than a sub-ring
+    e, _, _, _, why = probe(p, c, 100_000)
+    assert e == 0 and "sub-ring" in why, why
+
+
 def test_sliced_stream_plan_is_replayed_on_the_host():
     """mi_sstream_plan_probe builds the sliced-stream kernel's plan (spmv_sstream.hpp) as mi_csr_create would and replays it: every
     nonzero's slot is its column's ring slot, every column lies inside the sliding window when its round runs, padding places and slice

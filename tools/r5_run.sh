@@ -37,6 +37,8 @@ for s in "$@"; do
     permprof) for w in c2_perm fe_perm; do rm -rf gpurun_out/r5_pp_$w; step r5_pp_$w 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5_pp_$w -- python3 bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --no-parity --no-extras || exit 1; find gpurun_out/r5_pp_$w -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r5_pp_${w}_kernel_stats.csv; rm -rf gpurun_out/r5_pp_$w; head -8 gpurun_out/r5_pp_${w}_kernel_stats.csv | cut -c1-220; done ;;
     simfe_small) for c in 40 30; do SIM_FE_CELLS=$c SIM_RANK_EXT_PARTS=0 step r5_simfe_c${c} 300 python tools/sim_rank.py 4 1 fe || exit 1; done ;;
     dfuzz)    step r5_dist_fuzz 1100 python tools/dist_fuzz.py ${FUZZ_FIRST:-1} ${FUZZ_LAST:-40} ;;
+    b_mw)     step r5_bench_mesh_ss 300 python bench.py --workload mesh --kernel sstream --no-cpu-baseline --no-extras ;;
+    t_mw)     step r5_t_mw 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cut_ring or sliced_stream_kernel" && step r5_bench_mesh 300 python bench.py --workload mesh --no-cpu-baseline && step r5_bench_mesh_ss 300 python bench.py --workload mesh --kernel sstream --no-cpu-baseline --no-extras && step r5_bench_mesh_small 300 python bench.py --workload mesh_small --no-cpu-baseline --no-extras ;;
     simfe_n)  for n in 8 4 2; do step r5_simfe$n 300 python tools/sim_rank.py $n 1 fe && MI355_PUSH_FUSED_EXT=0 step r5_simfe${n}_four 300 python tools/sim_rank.py $n 1 fe || exit 1; done ;;
     t_ext)    step r5_t_ext 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ranks_sharing_one_card and sfe" ;;
     sim8)     step r5_sim8 300 python tools/sim_rank.py 8 1 ;;
