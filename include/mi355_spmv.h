@@ -218,7 +218,12 @@ int mi_vec_free_placed(double* d_vec);
  * holds the copy; *padding = padded places per nonzero; us[0..3] = microseconds per launch for D = 8 nt, D = 8 temporal, D = 12 nt,
  * D = 12 temporal (0 = not timed); *form = the variant in use (index into us).  y must be 16-byte aligned (else the handle's next-best
  * kernel runs that product).  A copy that loses the create-time measurement is released again (mi_csr_set_kernel(MI_KERNEL_SSTREAM) rebuilds
- * it on request); the sliced values follow every mi_csr_update_values* at once, on that call's stream (HIP-graph replays included). */
+ * it on request); the sliced values follow every mi_csr_update_values* at once, on that call's stream (HIP-graph replays included).
+ * A matrix whose rows name SEVERAL column neighbourhoods further apart than that window holds — a 3-D mesh operator in natural node
+ * order: a node's plane and the two next to it — gets the CUT-RING form of the same kernel (spmv_sstream_mw.hpp; mi_csr_kernel_name says
+ * spmv_sstream_mw<...>): four sub-rings of 2048 columns, each following one neighbourhood; eligible with at most four neighbourhoods per
+ * 512-row round (gaps of more than 512 columns separate them), none wider than 2048 columns.  Same id, same info call; any y alignment.
+ * MI355_SSTREAM_MW=0 disables the form. */
 int mi_csr_sstream_info(mi_csr_t A, int* built, int* rounds, long long* steps, double* padding, double us[4], int* form);
 /* host-only: build that plan exactly as mi_csr_create would and REPLAY it against the matrix (MI_ERR_STATE names the first violation:
  * every nonzero's slot is its column's ring slot and the column lies inside the window when its round runs; padding places are flagged).
