@@ -117,6 +117,39 @@ for seed in range(first, last):
     except mpk.MiError:
         names.append(f"band(hb={hb},per={per},n={nb}):n/a")
     del A
+    # round 5: rows that name several column neighbourhoods (k bands far apart, ragged at the ends, a few columns dropped): the cut-ring form of
+    # the sliced stream where its planner takes the pattern (spmv_sstream_mw), in a random variant, also after a value refresh and behind a row offset
+    nm = int(rng.choice([30_000, 120_000, 400_000]))
+    kb = int(rng.integers(2, 5))
+    gap = int(rng.integers(2600, 30_000))
+    wid = int(rng.integers(1, 6))
+    offs = np.concatenate([np.arange(wid) * int(rng.integers(1, 40)) + (jb - kb // 2) * gap for jb in range(kb)])
+    cols = np.arange(nm)[:, None] + offs[None, :]
+    keep = (cols >= 0) & (cols < nm) & (rng.random(cols.shape) > 0.03)
+    pm = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
+    cm = cols[keep].astype(np.int32)
+    vm = rng.uniform(-1, 1, len(cm))
+    xm = rng.uniform(-1, 1, nm)
+    offm = int(rng.integers(0, 5))
+    os.environ["MI355_SSTREAM_FORM"] = str(int(rng.integers(0, 4)))
+    try:
+        A = mpk.csrmatrix(nm, pm, cm, vm, rowmap=(np.arange(nm) + offm).astype(np.int32) if offm else None).set_kernel("sstream")
+        ym = torch.full((nm + offm + 2,), float("nan"), dtype=torch.float64, device="cuda")
+        mpk.SpMV_CSR(ym, torch.from_numpy(xm).cuda(), A)
+        got = ym.cpu().numpy()
+        ok = np.array_equal(got[offm:offm + nm].view(np.uint64), O.spmv(pm, cm, vm, xm).view(np.uint64)) and np.isnan(got[:offm]).all() and np.isnan(got[offm + nm:]).all()
+        vm2 = vm * np.sin(1 + np.arange(len(vm)))
+        A.update_values(torch.from_numpy(vm2).cuda())
+        ym.fill_(float("nan"))
+        mpk.SpMV_CSR(ym, torch.from_numpy(xm).cuda(), A)
+        got = ym.cpu().numpy()
+        ok = ok and np.array_equal(got[offm:offm + nm].view(np.uint64), O.spmv(pm, cm, vm2, xm).view(np.uint64))
+        names.append(f"bands(k={kb},gap={gap},n={nm},off={offm}):{A.kernel_name().split('<')[0][5:]}" + ("" if ok else "!!"))
+        bad += not ok
+        del A
+    except mpk.MiError:
+        names.append(f"bands(k={kb},gap={gap},n={nm}):n/a")
+    del os.environ["MI355_SSTREAM_FORM"]
     os.environ["MI355_BCSR_SELL"] = "1"
     nbr = int(rng.choice([300, 5000, 40000]))
     bl = rng.integers(0, 20, nbr)
