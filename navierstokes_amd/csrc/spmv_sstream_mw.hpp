@@ -331,8 +331,9 @@ __device__ __forceinline__ bool ss_mw_locate(const SsMw4& w, int idx, int& c, in
     return idx < p4;
 }
 
-// Four waves, as spmv_sstream: between rounds — two barriers — the sub-rings take in their new columns, which were loaded a round ahead
-// into registers: ONE 16-byte load per thread and sub-ring (two neighbouring columns; at most 512 new columns per sub-ring and round — the
+// Four waves, as spmv_sstream; the sub-rings take in a round's new columns TWO rounds ahead — loaded into registers during round r - 2,
+// written into the cut ring during round r - 1 (the planner guarantees that nothing that round reads lies where they go), so that a round
+// boundary is one barrier: ONE 16-byte load per thread and sub-ring (two neighbouring columns; at most 512 new columns per sub-ring and round — the
 // planner spreads what exceeds that over earlier rounds), the workgroup's intake table staged in LDS at its start.
 // What was tried on the way (the 5 M-row mesh; the same launch with the intake compiled out: 124 us): the four intakes laid end to end
 // over the threads (comparison chains per element), eight 8-byte loads per thread, the table through vector loads consumed at once —
@@ -373,6 +374,15 @@ __global__ __launch_bounds__(256) void spmv_sstream_mw(SsMwView V, const double*
             if (wn[k].y > 0) nx[k] = *reinterpret_cast<const ss_v2d_u*>(x + min(max(wn[k].x + 2 * tid, 0), clast - 1)); // (wave-uniform branch; 16 bytes at an 8-byte aligned address)
         }
     };
+    auto take_in = [&]() {
+#pragma unroll
+        for (int k = 0; k < kSsMwRings; k++) {
+            const int c = wn[k].x + 2 * tid, j = 2 * tid;
+            // (a pair clamped at the vector's end was loaded one column down: its first word is then the neighbour's)
+            if (j < wn[k].y) ring[k * kSsMwCap + (c & (kSsMwCap - 1))] = c > clast - 1 ? nx[k].y : nx[k].x;
+            if (j + 1 < wn[k].y) ring[k * kSsMwCap + ((c + 1) & (kSsMwCap - 1))] = nx[k].y;
+        }
+    };
     {
         // the first fill — every sub-ring's whole interval — in flight at once, IN FRONT of the stream's first D steps (spmv_sstream.hpp says why)
         const SsMw4 w0 = ss_mw_load(V.winK, r_begin);
@@ -383,6 +393,16 @@ __global__ __launch_bounds__(256) void spmv_sstream_mw(SsMwView V, const double*
             int c, pos;
             (void)ss_mw_locate(w0, tid + 256 * u, c, pos);
             fx[u] = x[min(max(c, 0), clast)];
+        }
+        if (r_begin + 1 < r_end) { // ... and the second round's intake with it (the table is not in LDS yet)
+            const SsMw4 w1 = ss_mw_load(V.winK, r_begin + 1);
+            wn[0] = make_int2(w1.lo0, w1.n0);
+            wn[1] = make_int2(w1.lo1, w1.n1);
+            wn[2] = make_int2(w1.lo2, w1.n2);
+            wn[3] = make_int2(w1.lo3, w1.n3);
+#pragma unroll
+            for (int k = 0; k < kSsMwRings; k++)
+                if (wn[k].y > 0) nx[k] = *reinterpret_cast<const ss_v2d_u*>(x + min(max(wn[k].x + 2 * tid, 0), clast - 1));
         }
         int2 tb[2] = {make_int2(0, 0), make_int2(0, 0)};
         const int nt = kSsMwRings * (r_end - r_begin);
@@ -403,6 +423,7 @@ __global__ __launch_bounds__(256) void spmv_sstream_mw(SsMwView V, const double*
         for (int u = 0; u < 2; u++)
             if (tid + 256 * u < nt) s_tab[tid + 256 * u] = tb[u];
         for (int i0 = 512 + tid; i0 < nt; i0 += 256) s_tab[i0] = V.winK[(size_t)kSsMwRings * r_begin + i0]; // (more than 128 rounds per workgroup)
+        if (r_begin + 1 < r_end) take_in();
         for (int i0 = 256 * kSsMwFill + tid; i0 < total; i0 += 256 * 8) { // (first fills of more than 4096 columns)
             double f8[8];
 #pragma unroll
@@ -418,8 +439,10 @@ __global__ __launch_bounds__(256) void spmv_sstream_mw(SsMwView V, const double*
             }
         }
     }
-    __syncthreads();
-    issue(r_begin + 1);
+    __syncthreads(); // (the table is in LDS; the first fill is in place)
+    // Round r + 1's columns are WRITTEN while round r runs — nothing round r reads lies where they go (the planner's promise, replayed by
+    // check_sstream_mw_plan) — so a round boundary is ONE barrier, and the writes are off the path between barriers.
+    if (r_begin + 1 < r_end) issue(r_begin + 2);
     double acc0 = 0.0, acc1 = 0.0;
     auto store = [&](int round, ss_v2d v) {
         const int v0 = round * kSsRound + wv * kSsSliceRows + lane, v1 = v0 + 64; // the lane's view rows: two 8-byte stores, each a wave's 512 contiguous bytes
@@ -450,16 +473,11 @@ __global__ __launch_bounds__(256) void spmv_sstream_mw(SsMwView V, const double*
                     emit();
                     acc0 = acc1 = 0.0;
                     r++;
-                    __syncthreads(); // every wave is through with round r - 1: the ring entries about to be overwritten are dead
-#pragma unroll
-                    for (int k = 0; k < kSsMwRings; k++) {
-                        const int c = wn[k].x + 2 * tid, j = 2 * tid;
-                        // (a pair clamped at the vector's end was loaded one column down: its first word is then the neighbour's)
-                        if (j < wn[k].y) ring[k * kSsMwCap + (c & (kSsMwCap - 1))] = c > clast - 1 ? nx[k].y : nx[k].x;
-                        if (j + 1 < wn[k].y) ring[k * kSsMwCap + ((c + 1) & (kSsMwCap - 1))] = nx[k].y;
+                    __syncthreads(); // every wave is through with round r - 1, and round r's columns (written during it) are in place
+                    if (r + 1 < r_end) {
+                        take_in();    // round r + 1's, loaded during round r - 1
+                        issue(r + 2);
                     }
-                    __syncthreads();
-                    issue(r + 1);
                 }
                 const double x0 = ring[s & (kSsRing - 1)], x1 = ring[(s >> 16) & (kSsRing - 1)];
                 const double n0 = fma(a[d].x, x0, acc0), n1 = fma(a[d].y, x1, acc1);

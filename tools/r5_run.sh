@@ -38,6 +38,7 @@ for s in "$@"; do
     simfe_small) for c in 40 30; do SIM_FE_CELLS=$c SIM_RANK_EXT_PARTS=0 step r5_simfe_c${c} 300 python tools/sim_rank.py 4 1 fe || exit 1; done ;;
     dfuzz)    step r5_dist_fuzz 1100 python tools/dist_fuzz.py ${FUZZ_FIRST:-1} ${FUZZ_LAST:-40} ;;
     b_mw)     step r5_bench_mesh_ss 300 python bench.py --workload mesh --kernel sstream --no-cpu-baseline --no-extras ;;
+    b_mw_small) step r5_bench_mesh_small_ss 300 python bench.py --workload mesh_small --kernel sstream --no-cpu-baseline --no-extras ;;
     t_mw)     step r5_t_mw 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cut_ring or sliced_stream_kernel" && step r5_bench_mesh 300 python bench.py --workload mesh --no-cpu-baseline && step r5_bench_mesh_ss 300 python bench.py --workload mesh --kernel sstream --no-cpu-baseline --no-extras && step r5_bench_mesh_small 300 python bench.py --workload mesh_small --no-cpu-baseline --no-extras ;;
     simfe_n)  for n in 8 4 2; do step r5_simfe$n 300 python tools/sim_rank.py $n 1 fe && MI355_PUSH_FUSED_EXT=0 step r5_simfe${n}_four 300 python tools/sim_rank.py $n 1 fe || exit 1; done ;;
     t_ext)    step r5_t_ext 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ranks_sharing_one_card and sfe" ;;
