@@ -33,12 +33,19 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    Pg, Cg, Vg = synth.rows(kind, n, w=w)
+    if kind == "mesh":  # the P1 pressure operator on a Kuhn mesh of n cells per edge, natural node order: wide halos (a plane each side), and
+        Pg, Cg, Vg = synth.pressure_matrix(n)  # interior pieces that take the cut-ring sliced stream where they are large enough
+        n = len(Pg) - 1
+    else:
+        Pg, Cg, Vg = synth.rows(kind, n, w=w)
     if upwind:
         Pg, Cg, Vg = upper_part(Pg, Cg, Vg, 0)
     rs = D.balanced_row_starts(n, world, np.diff(Pg), align=4 if kind == "sfe" else 1)  # FE-like: cut at node boundaries
     lo, hi = int(rs[rank]), int(rs[rank + 1])
-    p, c, v = synth.rows(kind, n, lo, hi, w=w)
+    if kind == "mesh":
+        p, c, v = (Pg[lo:hi + 1] - Pg[lo]).astype(np.int32), Cg[Pg[lo]:Pg[hi]].copy(), Vg[Pg[lo]:Pg[hi]].copy()
+    else:
+        p, c, v = synth.rows(kind, n, lo, hi, w=w)
     if upwind:
         p, c, v = upper_part(p, c, v, lo)
     ok = True

@@ -556,7 +556,10 @@ def test_native_step_single_rank():
                                                            (3, "sfe_ext", 60_000, 1500, 29618, "push"),
                                                            # ... and as the library runs it when it finds a neighbour's window on its own device (ranks
                                                            # sharing a card, as here): two launches, only the exchange's workgroups wait in-kernel
-                                                           (3, "sfe_ext2", 60_000, 1500, 29619, "push")])
+                                                           (3, "sfe_ext2", 60_000, 1500, 29619, "push"),
+                                                           # (round 5) a 3-D mesh operator over ranks: wide halos (a plane each side: the four-launch step),
+                                                           # interior pieces served by the cut-ring sliced stream where forced ("sstream" in the worker's kernel loop)
+                                                           (2, "mesh", 70, 0, 29620, "push")])
 def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
     """The N>1 pipeline on real HIP kernels: `world` ranks (processes) on cuda:0, A x, A^2 x, A^3 x and a global dot, every
     rank's slice bitwise.  exchange "torch": halos over gloo, host-staged (RCCL rejects duplicate devices).  exchange "push":
