@@ -75,22 +75,37 @@ inline void build_sstream_mw_plan(int n, int ncols, const int* ptrow, const int*
     std::vector<std::array<Iv, kSsMwRings>> riv((size_t)rounds);
     std::vector<int> rnk((size_t)rounds, 0);
     {
-        std::vector<int> cols;
-        for (int r = 0; r < rounds; r++) {
-            cols.assign(indcol + PT(r * kSsRound), indcol + PT(std::min(nv, (r + 1) * kSsRound)));
-            std::sort(cols.begin(), cols.end());
-            cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-            int nk = 0;
-            for (size_t i = 0; i < cols.size(); i++) {
-                if (i == 0 || cols[i] - cols[i - 1] > kSsMwGap) {
-                    if (nk == kSsMwRings) { P.why = "a round's rows name more than four column neighbourhoods"; return; }
-                    riv[r][nk++] = Iv{cols[i], cols[i] + 1};
-                } else riv[r][nk - 1].hi = cols[i] + 1;
+        // (rounds are independent: over the host's threads, like the slot fill below — the 5 M-row mesh sorts 74 M column indices here)
+        unsigned nth = std::thread::hardware_concurrency();
+        nth = nth > 16 ? 16 : (nth < 1 ? 1 : nth);
+        if (rounds < 64) nth = 1;
+        std::vector<const char*> bad((size_t)nth, nullptr);
+        auto scan = [&](unsigned th, int ra, int rb) {
+            std::vector<int> cols;
+            for (int r = ra; r < rb && !bad[th]; r++) {
+                cols.assign(indcol + PT(r * kSsRound), indcol + PT(std::min(nv, (r + 1) * kSsRound)));
+                std::sort(cols.begin(), cols.end());
+                cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+                int nk = 0;
+                for (size_t i = 0; i < cols.size() && !bad[th]; i++) {
+                    if (i == 0 || cols[i] - cols[i - 1] > kSsMwGap) {
+                        if (nk == kSsMwRings) { bad[th] = "a round's rows name more than four column neighbourhoods"; break; }
+                        riv[r][nk++] = Iv{cols[i], cols[i] + 1};
+                    } else riv[r][nk - 1].hi = cols[i] + 1;
+                }
+                for (int j = 0; j < nk && !bad[th]; j++)
+                    if (riv[r][j].hi - riv[r][j].lo > kSsMwCap) bad[th] = "a column neighbourhood is wider than a sub-ring";
+                rnk[r] = nk;
             }
-            for (int j = 0; j < nk; j++)
-                if (riv[r][j].hi - riv[r][j].lo > kSsMwCap) { P.why = "a column neighbourhood is wider than a sub-ring"; return; }
-            rnk[r] = nk;
+        };
+        if (nth == 1) scan(0, 0, rounds);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned k = 0; k < nth; k++) th.emplace_back(scan, k, (int)((long long)rounds * k / nth), (int)((long long)rounds * (k + 1) / nth));
+            for (std::thread& x : th) x.join();
         }
+        for (unsigned k = 0; k < nth; k++)
+            if (bad[k]) { P.why = bad[k]; return; }
     }
     // sub-rings: an interval follows the sub-ring of the interval it continues
     P.winK.assign((size_t)rounds * kSsMwRings, make_int2(0, 0));
