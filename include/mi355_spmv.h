@@ -521,13 +521,15 @@ int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_st
  * (spmv_bcsr4_ext.hpp): the launch's first workgroups push, wait and copy the window once into a cached buffer of the handle, the
  * workgroups whose rows name ghosts wait for THEM and read that buffer (MI355_PUSH_FUSED_EXT=0 keeps the four launches for such
  * ranks; ranks that share a device — a neighbour's window lives on this rank's device — run it as two launches, so that only the
- * exchange's few workgroups wait in-kernel: MI355_PUSH_EXT_SPLIT=0|1 forces).  In the fused forms the halo part of d_x_ext is
+ * exchange's few workgroups wait in-kernel: MI355_PUSH_EXT_SPLIT=0|1 forces).  A rank that gets none of these forms (scalar rows, a halo
+ * too wide for the sliced stream's and the ring's fused forms: a 3-D mesh operator over ranks) runs the same staged step on the stream
+ * kernel's row blocks, spmv_csr_fused_ext (MI355_PUSH_FUSED_CSR_EXT=0 keeps the four launches).  In the fused forms the halo part of d_x_ext is
  * neither read nor written (d_x_ext must still hold n_local + n_halo entries for the four-launch form the ranks may have to
  * agree on). */
 int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neighbours);
 /* the kernel a piece's products launch (as rocprofv3 names it): which = 0 the interior rows' piece, 1 the boundary rows', 2 the combined piece
  * of the one-launch push step — spmv_sstream_fused<...> (round 5) wherever that piece holds a sliced copy, else the ring kernel's FUSED
- * form or the blocked one (spmv_bcsr4_fused_ext); "" when the step is not fused.  The string lives until the thread's next call. */
+ * form, the blocked one (spmv_bcsr4_fused_ext) or the staged scalar one (spmv_csr_fused_ext); "" when the step is not fused.  The string lives until the thread's next call. */
 const char* mi_part_kernel_name(mi_part_t P, int which);
 /* Step down from the one-launch form to the four-launch form (push, interior rows, wait + copy, boundary rows).  All ranks must
  * drive the step the same way; the caller compares mi_part_push_info's `fused` across ranks and calls this where they differ. */

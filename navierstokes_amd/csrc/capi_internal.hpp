@@ -313,6 +313,8 @@ struct mi_part_s {
     int n_ext_plain = 0;
     bool peer_on_my_device = false; // a neighbour's window lives on this rank's device: ranks share a card
     bool ext_split = false;      // two launches (exchange + plain units, then the waiting units): no workgroup but the exchange's waits in-kernel
+    bool ext_csr = false;        // the staged step on SCALAR rows (spmv_csr_fused_ext): d_ext_order instead of d_ext_units
+    unsigned* d_ext_order = nullptr; // per workgroup behind the exchange: its row block of piece_all's 1024-nonzero table, bit 31: it waits
     int ext_debug = 0; // devtools only (mi_debug_part_ext_mode): parts of the exchange left out, for timing
 };
 

@@ -60,9 +60,12 @@ static void part_comm_release(mi_part_s* P)
     dfree(P->d_stage);
     dfree(P->d_ready);
     dfree(P->d_ext_units);
+    dfree(P->d_ext_order);
     P->d_stage = nullptr;
     P->d_ready = nullptr;
     P->d_ext_units = nullptr;
+    P->d_ext_order = nullptr;
+    P->ext_csr = false;
     mi_csr_destroy(P->piece_all);
     P->piece_all = nullptr;
     P->d_run_link = nullptr;
@@ -766,6 +769,46 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
             P->piece_all = nullptr;
         }
     }
+    // ... and for SCALAR rows that got no one-launch form above (no 4x4 structure; a halo too wide for the sliced stream's and the ring's fused
+    // forms — a 3-D mesh operator over ranks: a plane of ghosts each side): the staged step on the stream kernel's row blocks
+    // (spmv_csr_fused_ext, spmv_bcsr4_ext.hpp).  MI355_PUSH_FUSED_CSR_EXT=0 keeps the four launches.
+    const char* fc = getenv("MI355_PUSH_FUSED_CSR_EXT");
+    if (!P->fused && !(fe && !strcmp(fe, "0")) && !(fx && !strcmp(fx, "0")) && !(fc && !strcmp(fc, "0")) && P->kernel == MI_KERNEL_AUTO && pl.n_local > 0 &&
+        P->n_links > 0) {
+        P->plan.build_all_ext();
+        const LocalPiece& L = P->plan.all_ext;
+        rc = csr_create_impl(pl.n_local, pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), nullptr, &P->piece_all);
+        if (rc) return rc;
+        mi_csr_t A = P->piece_all;
+        BlockTable* T = nullptr;
+        if ((rc = get_table(A, 1024, &T))) return rc;
+        std::vector<int2> blk((size_t)T->nblk + 1);
+        HIP_TRY(hipMemcpy(blk.data(), T->d_blk, sizeof(int2) * blk.size(), hipMemcpyDeviceToHost));
+        std::vector<unsigned> order;
+        order.reserve((size_t)T->nblk);
+        for (int pass = 0; pass < 2; pass++) { // the blocks that name a ghost LAST: dispatched behind the others, and a launch of their own in the two-launch form
+            for (int b = 0; b < T->nblk; b++) {
+                bool halo = false;
+                for (int k = blk[b].y; k < blk[b + 1].y && !halo; k++) halo = L.indcol[k] >= pl.n_local;
+                if (halo == (pass == 1)) order.push_back((unsigned)b | (halo ? 0x80000000u : 0u));
+            }
+            if (pass == 0) P->n_ext_plain = (int)order.size();
+        }
+        P->n_ext_units = (int)order.size();
+        HIP_TRY(hipMalloc(&P->d_ext_order, sizeof(unsigned) * std::max<size_t>(order.size(), 1)));
+        HIP_TRY(hipMemcpy(P->d_ext_order, order.data(), sizeof(unsigned) * order.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&P->d_stage, sizeof(double) * (size_t)std::max(pl.n_halo, 2)));
+        HIP_TRY(hipMemset(P->d_stage, 0, sizeof(double) * (size_t)std::max(pl.n_halo, 2)));
+        HIP_TRY(hipMalloc(&P->d_ready, sizeof(unsigned) * kExtReadyStride * (1 + kExtReadyLines)));
+        HIP_TRY(hipMemset(P->d_ready, 0, sizeof(unsigned) * kExtReadyStride * (1 + kExtReadyLines)));
+        int xw = (pl.n_halo + 8 * kWG - 1) / (8 * kWG);
+        if (const char* e = getenv("MI355_PUSH_EXT_WGS")) xw = atoi(e);
+        P->ext_wgs = std::max(1, std::min(256, xw));
+        P->ext_split = P->peer_on_my_device;
+        if (const char* e = getenv("MI355_PUSH_EXT_SPLIT")) P->ext_split = atoi(e) != 0;
+        P->fused = P->fused_ext = P->ext_csr = true;
+        P->ghost_readers = true;
+    }
     return MI_OK;
 }
 
@@ -795,9 +838,12 @@ extern "C" int mi_part_push_disable(mi_part_t P)
     dfree(P->d_stage);
     dfree(P->d_ready);
     dfree(P->d_ext_units);
+    dfree(P->d_ext_order);
     P->d_stage = nullptr;
     P->d_ready = nullptr;
     P->d_ext_units = nullptr;
+    P->d_ext_order = nullptr;
+    P->ext_csr = false;
     P->d_run_link = nullptr;
     P->fused_ext = false;
     mi_csr_destroy(P->piece_all);
@@ -825,9 +871,12 @@ extern "C" int mi_part_push_unfuse(mi_part_t P)
     dfree(P->d_stage);
     dfree(P->d_ready);
     dfree(P->d_ext_units);
+    dfree(P->d_ext_order);
     P->d_stage = nullptr;
     P->d_ready = nullptr;
     P->d_ext_units = nullptr;
+    P->d_ext_order = nullptr;
+    P->ext_csr = false;
     P->d_run_link = nullptr;
     mi_csr_destroy(P->piece_all);
     P->piece_all = nullptr;
@@ -840,6 +889,7 @@ extern "C" const char* mi_part_kernel_name(mi_part_t P, int which)
     if (!P || which < 0 || which > 2) return "";
     if (which < 2) return P->piece[which] ? mi_csr_kernel_name(P->piece[which]) : "";
     if (!P->fused || !P->piece_all) return "";
+    if (P->fused_ext && P->ext_csr) return P->ext_split ? "spmv_csr_fused_ext x2 (ranks share a device: two launches)" : "spmv_csr_fused_ext";
     if (P->fused_ext) return P->ext_split ? "spmv_bcsr4_fused_ext x2 (ranks share a device: two launches)" : "spmv_bcsr4_fused_ext";
     static thread_local char nm[160];
     const char* base = mi_csr_kernel_name(P->piece_all);
@@ -860,9 +910,7 @@ extern "C" int mi_part_push_info(mi_part_t P, int* ready, int* fused, int* neigh
 int part_ext_launch(mi_part_s* P, const double* d_x_ext, double* d_y_local, unsigned step, unsigned spin_max, hipStream_t s, unsigned long long* trace, int* grid_out)
 {
     const PartPlan& pl = P->plan;
-    if ((((uintptr_t)d_x_ext) & 15) != 0) return fail(MI_ERR_ARG, "the fused blocked step needs a 16-byte aligned x");
-    mi_bcsr4_t B = P->piece_all->blocked;
-    Bcsr4View V{B->nbrows, B->nbcols, B->d_ptrow, B->d_indcol, B->d_coef, nullptr};
+    if (!P->ext_csr && (((uintptr_t)d_x_ext) & 15) != 0) return fail(MI_ERR_ARG, "the fused blocked step needs a 16-byte aligned x");
     ExtComm C;
     C.links = P->d_links;
     C.work = P->d_push_work;
@@ -890,6 +938,28 @@ int part_ext_launch(mi_part_s* P, const double* d_x_ext, double* d_y_local, unsi
     const bool split = P->ext_split && !trace && P->n_ext_units > P->n_ext_plain;
     const dim3 grid((split ? P->n_ext_plain : P->n_ext_units) + C.xwgs);
     if (grid_out) *grid_out = (int)grid.x;
+    if (P->ext_csr) { // scalar rows: the stream kernel's row blocks of piece_all
+        mi_csr_t A = P->piece_all;
+        BlockTable* T = nullptr;
+        int rc = get_table(A, 1024, &T);
+        if (rc) return rc;
+        CsrView V{A->n, A->ncols, A->d_ptrow, A->d_indcol, A->d_coef, nullptr, T->d_blk, nullptr, T->nblk};
+        if (trace) hipLaunchKernelGGL((spmv_csr_fused_ext<1024, false, true>), grid, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_ext_order);
+        else if (A->stream_nt) hipLaunchKernelGGL((spmv_csr_fused_ext<1024, true>), grid, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_ext_order);
+        else hipLaunchKernelGGL((spmv_csr_fused_ext<1024, false>), grid, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_ext_order);
+        if (split) { // the blocks that name ghosts, behind the exchange by stream order
+            ExtComm C2 = C;
+            C2.xwgs = C2.n_work = 0;
+            C2.nowait = 1;
+            const dim3 g2(P->n_ext_units - P->n_ext_plain);
+            if (A->stream_nt) hipLaunchKernelGGL((spmv_csr_fused_ext<1024, true>), g2, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C2, P->d_ext_order + P->n_ext_plain);
+            else hipLaunchKernelGGL((spmv_csr_fused_ext<1024, false>), g2, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C2, P->d_ext_order + P->n_ext_plain);
+        }
+        HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
+    mi_bcsr4_t B = P->piece_all->blocked;
+    Bcsr4View V{B->nbrows, B->nbcols, B->d_ptrow, B->d_indcol, B->d_coef, nullptr};
     if (trace) {
         hipLaunchKernelGGL((spmv_bcsr4_fused_ext<kBcsrDepth, 4, kWG, true>), grid, dim3(kWG), 0, s, V, d_x_ext, d_y_local, C, P->d_ext_units);
         HIP_TRY(hipGetLastError());

@@ -241,7 +241,12 @@ extern "C" int mi_debug_part_ext_mode(mi_part_t P, int mode)
     if (!P->fused_ext) return fail(MI_ERR_STATE, "the handle does not run the staged one-launch step");
     HIP_TRY(hipDeviceSynchronize());
     P->ext_debug = mode;
-    if (mode & 1) {
+    if ((mode & 1) && P->ext_csr) {
+        std::vector<unsigned> o((size_t)P->n_ext_units);
+        HIP_TRY(hipMemcpy(o.data(), P->d_ext_order, sizeof(unsigned) * o.size(), hipMemcpyDeviceToHost));
+        for (unsigned& e : o) e &= 0x7fffffffu;
+        HIP_TRY(hipMemcpy(P->d_ext_order, o.data(), sizeof(unsigned) * o.size(), hipMemcpyHostToDevice));
+    } else if (mode & 1) {
         std::vector<int2> u((size_t)P->n_ext_units);
         HIP_TRY(hipMemcpy(u.data(), P->d_ext_units, sizeof(int2) * u.size(), hipMemcpyDeviceToHost));
         for (int2& e : u) e.y &= ~1;
@@ -269,7 +274,11 @@ extern "C" int mi_debug_part_ext_trace(mi_part_t P, double* d_x_ext, double* d_y
     HIP_TRY(hipMemcpy(host_out, d_tr, sizeof(unsigned long long) * 3 * (size_t)grid, hipMemcpyDeviceToHost));
     dfree(d_tr);
     *wgs_out = grid;
-    if (modes_out) {
+    if (modes_out && P->ext_csr) {
+        std::vector<unsigned> o((size_t)P->n_ext_units);
+        HIP_TRY(hipMemcpy(o.data(), P->d_ext_order, sizeof(unsigned) * o.size(), hipMemcpyDeviceToHost));
+        for (int g = 0; g < grid; g++) modes_out[g] = g < P->n_push_work ? -2 : (g < P->n_push_work + P->ext_wgs ? -1 : (int)(o[g - P->n_push_work - P->ext_wgs] >> 31));
+    } else if (modes_out) {
         std::vector<int2> u((size_t)P->n_ext_units);
         HIP_TRY(hipMemcpy(u.data(), P->d_ext_units, sizeof(int2) * u.size(), hipMemcpyDeviceToHost));
         for (int g = 0; g < grid; g++) modes_out[g] = g < P->n_push_work ? -2 : (g < P->n_push_work + P->ext_wgs ? -1 : u[g - P->n_push_work - P->ext_wgs].y);

@@ -175,16 +175,16 @@ __device__ __forceinline__ void bcsr4_ext_row16(const Bcsr4View& A, const double
 
 // units[wg] = {first block row, mode}: mode bit 0 the workgroup waits for the exchange (its rows name ghost nodes), bit 1 it runs the
 // 16-lanes-per-row form on 16 block rows (else 4 lanes per row, 64 block rows, P blocks in flight per thread)
-template <int P, int U, int T, bool TR = false>
-__global__ __launch_bounds__(T) void spmv_bcsr4_fused_ext(Bcsr4View A, const double* __restrict__ x, double* __restrict__ y, ExtComm C, const int2* __restrict__ units)
+// the exchange workgroups of a staged step (blockIdx.x < C.xwgs): push or wait + copy, as the header says; true: this workgroup was one
+template <int T, bool TR>
+__device__ __forceinline__ bool ext_exchange(const ExtComm& C, const double* __restrict__ x)
 {
     const int tid = threadIdx.x;
     auto stamp = [&](int k) {
         if (TR && tid == 0) C.trace[3 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memrealtime();
     };
-    stamp(0);
-    if ((int)blockIdx.x < C.n_work) { // ---- the exchange, outbound: one {link, chunk} item of my entries into a neighbour's window
-        if (!C.links) return; // (devtools timing runs only)
+    if ((int)blockIdx.x < C.n_work) { // ---- outbound: one {link, chunk} item of my entries into a neighbour's window
+        if (!C.links) return true; // (devtools timing runs only)
         const int2 it = C.work[blockIdx.x]; // (write-through stores and a drain, no fence: an L2 write-back under the running product cost 8 us per step)
         const PushLink L = C.links[it.x];
         double* dst = (C.step & 1u) ? L.dst[1] : L.dst[0];
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(T) void spmv_bcsr4_fused_ext(Bcsr4View A, const dou
             }
         }
         stamp(2);
-        return;
+        return true;
     }
-    if ((int)blockIdx.x < C.xwgs) { // ---- the exchange, inbound: the window into `stage` once every neighbour's entries of this step have landed
+    if ((int)blockIdx.x < C.xwgs) { // ---- inbound: the window into `stage` once every neighbour's entries of this step have landed
         const int cw = (int)blockIdx.x - C.n_work, ncw = C.xwgs - C.n_work;
         for (int j = tid; j < C.n_nb; j += T) { // (push_wait_flags with relaxed polls: an acquire per poll is a cache invalidate per poll, under the running product)
             const unsigned* f = C.flags + (size_t)C.nb[j] * kWinFlagStride;
@@ -251,29 +251,45 @@ __global__ __launch_bounds__(T) void spmv_bcsr4_fused_ext(Bcsr4View A, const dou
         __syncthreads();
         if (s_last && tid < kExtReadyLines) __hip_atomic_store(C.ready + kExtReadyStride * (1 + tid), C.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stamp(2);
-        return;
+        return true;
     }
+    return false;
+}
+
+// a workgroup whose rows name ghosts: wait (thread 0 polls ONE of the ready lines; bounded, loud) until `stage` holds this step's
+__device__ __forceinline__ void ext_wait_ready(const ExtComm& C)
+{
+    if (threadIdx.x == 0) {
+        const unsigned* line = C.ready + kExtReadyStride * (1 + ((int)blockIdx.x & (kExtReadyLines - 1)));
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - C.step) < 0) {
+            if (spins < 4096) __builtin_amdgcn_s_sleep(1);
+            else __builtin_amdgcn_s_sleep(127);
+            ++spins;
+            if (spins == 64 && __hip_atomic_load(C.timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break; // an earlier wait gave up already
+            if (spins > C.spin_max) {
+                __hip_atomic_fetch_add(C.timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");
+}
+
+template <int P, int U, int T, bool TR = false>
+__global__ __launch_bounds__(T) void spmv_bcsr4_fused_ext(Bcsr4View A, const double* __restrict__ x, double* __restrict__ y, ExtComm C, const int2* __restrict__ units)
+{
+    const int tid = threadIdx.x;
+    auto stamp = [&](int k) {
+        if (TR && tid == 0) C.trace[3 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    if (ext_exchange<T, TR>(C, x)) return;
     const int2 unit = units[(int)blockIdx.x - C.xwgs];
     const unsigned nbl = (unsigned)C.n_local >> 2;
     const double* xs = C.stage - (size_t)C.n_local; // block column c >= nbl: stage + 4 (c - nbl)
-    if ((unit.y & 1) && !C.nowait) { // its rows name ghost nodes: `stage` must hold this step's
-        if (tid == 0) {
-            const unsigned* line = C.ready + kExtReadyStride * (1 + ((int)blockIdx.x & (kExtReadyLines - 1)));
-            unsigned spins = 0;
-            while ((int)(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - C.step) < 0) {
-                if (spins < 4096) __builtin_amdgcn_s_sleep(1);
-                else __builtin_amdgcn_s_sleep(127);
-                ++spins;
-                if (spins == 64 && __hip_atomic_load(C.timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break; // an earlier wait gave up already
-                if (spins > C.spin_max) {
-                    __hip_atomic_fetch_add(C.timeouts, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-        asm volatile("" ::: "memory");
-    }
+    if ((unit.y & 1) && !C.nowait) ext_wait_ready(C); // its rows name ghost nodes: `stage` must hold this step's
     stamp(1);
     if (unit.y & 2) {
         const int bi = unit.x + (tid >> 4), l = tid & 15;
@@ -281,6 +297,98 @@ __global__ __launch_bounds__(T) void spmv_bcsr4_fused_ext(Bcsr4View A, const dou
     } else {
         const int bi = unit.x + (tid >> 2), q = tid & 3;
         if (bi < A.nbrows) y[4 * (size_t)bi + q] = bcsr4_ext_row<P>(A, x, xs, nbl, bi, q);
+    }
+    if (TR) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp(2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same step for SCALAR rows (a rank whose piece has no 4x4 structure and whose halo is too wide for the sliced stream's or the ring's
+// fused forms — a 3-D mesh operator over ranks: a plane of ghosts each side): spmv_csr_stream's row blocks (spmv_kernels.hpp: <= NNZB
+// nonzeros, coalesced loads, the x gather, one thread per row walking its LDS segment: the CSR fma chain) on the piece numbered
+// [owned | halo], the gather taking columns >= n_local from `stage`.  order[i] = the block workgroup i (behind the exchange) takes,
+// bit 31 set if its rows name a ghost: those come last and wait for the exchange.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NNZB, bool NT, bool TR = false>
+__global__ __launch_bounds__(kWG) void spmv_csr_fused_ext(CsrView A, const double* __restrict__ x, double* __restrict__ y, ExtComm C, const unsigned* __restrict__ order)
+{
+    constexpr int PER = NNZB / kWG;
+    constexpr int LDSN = NNZB + NNZB / 32 + 1;
+    __shared__ double s_c[LDSN];
+    __shared__ double s_x[LDSN];
+    const int tid = threadIdx.x;
+    auto stamp = [&](int k) {
+        if (TR && tid == 0) C.trace[3 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    if (ext_exchange<kWG, TR>(C, x)) return;
+    const unsigned ob = order[(int)blockIdx.x - C.xwgs];
+    const int b = (int)(ob & 0x7fffffffu);
+    if ((ob >> 31) && !C.nowait) ext_wait_ready(C);
+    stamp(1);
+    const unsigned nl = (unsigned)C.n_local;
+    const double* xs = C.stage - (size_t)C.n_local; // column c >= n_local: stage[c - n_local]
+    auto xat = [&](unsigned c) { return (c < nl ? x : xs)[c]; };
+    const int2 d0 = A.blk[b];
+    const int2 d1 = A.blk[b + 1];
+    const int r0 = d0.x, p0 = d0.y, r1 = d1.x, p1 = d1.y;
+    const int nn = p1 - p0;
+    const int myrow = r0 + tid;
+    if (nn == 0) { // a block of empty rows
+        for (int r = myrow; r < r1; r += kWG) y[r] = 0.0;
+    } else if (nn <= NNZB) { // (spmv_csr_stream's phases, comments there)
+        const int last = nn - 1;
+        const int rowc = min(myrow, r1 - 1);
+        const int pa = A.ptrow[rowc];
+        const int pe = A.ptrow[rowc + 1];
+        const unsigned* ucol = reinterpret_cast<const unsigned*>(A.indcol);
+        double c[PER];
+        unsigned j[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * kWG, last);
+            if (NT) {
+                c[i] = __builtin_nontemporal_load(&A.coef[p0 + k]);
+                j[i] = __builtin_nontemporal_load(&ucol[p0 + k]);
+            } else {
+                c[i] = A.coef[p0 + k];
+                j[i] = ucol[p0 + k];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double xv[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) xv[i] = xat(j[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = min(tid + i * kWG, last);
+            s_c[sk(k)] = c[i];
+            s_x[sk(k)] = xv[i];
+        }
+        __syncthreads();
+        if (myrow < r1) y[myrow] = row_chain<8>(s_c, s_x, pa - p0, pe - p0);
+        for (int r = myrow + kWG; r < r1; r += kWG) { // blocks of very short rows hold more than kWG rows
+            const int ra = A.ptrow[r] - p0, re = A.ptrow[r + 1] - p0;
+            y[r] = row_chain<8>(s_c, s_x, ra, re);
+        }
+    } else { // one row longer than a block: chunk by chunk, thread 0 carries the chain
+        double s = 0.0;
+        for (int base = p0; base < p1; base += NNZB) {
+            const int m = min(NNZB, p1 - base);
+            for (int k = tid; k < m; k += kWG) {
+                s_c[sk(k)] = A.coef[base + k];
+                s_x[sk(k)] = xat((unsigned)A.indcol[base + k]);
+            }
+            __syncthreads();
+            if (tid == 0)
+                for (int k = 0; k < m; k++) s = fma(s_c[sk(k)], s_x[sk(k)], s);
+            __syncthreads();
+        }
+        if (tid == 0) y[r0] = s;
     }
     if (TR) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -559,7 +559,10 @@ def test_native_step_single_rank():
                                                            (3, "sfe_ext2", 60_000, 1500, 29619, "push"),
                                                            # (round 5) a 3-D mesh operator over ranks: wide halos (a plane each side: the four-launch step),
                                                            # interior pieces served by the cut-ring sliced stream where forced ("sstream" in the worker's kernel loop)
-                                                           (2, "mesh", 70, 0, 29620, "push")])
+                                                           (2, "mesh", 70, 0, 29620, "push"),
+                                                           # ... and its staged one-launch step (spmv_csr_fused_ext): forced one launch, and as the library runs
+                                                           # it for ranks sharing a card (two launches)
+                                                           (2, "mesh_ext", 70, 0, 29621, "push"), (2, "mesh_ext2", 70, 0, 29622, "push")])
 def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
     """The N>1 pipeline on real HIP kernels: `world` ranks (processes) on cuda:0, A x, A^2 x, A^3 x and a global dot, every
     rank's slice bitwise.  exchange "torch": halos over gloo, host-staged (RCCL rejects duplicate devices).  exchange "push":
@@ -580,6 +583,14 @@ def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
     if kind == "sfe_ext":  # the one-launch form, forced (few workgroups here: the card has room for every rank's waiting ones)
         kind = "sfe"
         env.update(MI355_PUSH_EXT_SPLIT="0", MI355_TEST_EXPECT_FUSED="=spmv_bcsr4_fused_ext")
+    elif kind == "mesh_ext":
+        kind = "mesh"
+        # (MI355_PUSH_FUSED_KERNEL=sstream: not the ring kernel's fused form, which takes such a rank when its plan serves it)
+        env.update(MI355_PUSH_EXT_SPLIT="0", MI355_PUSH_FUSED_KERNEL="sstream", MI355_TEST_EXPECT_FUSED="=spmv_csr_fused_ext")
+    elif kind == "mesh_ext2":
+        kind = "mesh"
+        env.pop("MI355_PUSH_EXT_SPLIT", None)
+        env.update(MI355_PUSH_FUSED_KERNEL="sstream", MI355_TEST_EXPECT_FUSED="spmv_csr_fused_ext x2")
     elif kind == "sfe_ext2":
         kind = "sfe"
         env.pop("MI355_PUSH_EXT_SPLIT", None)

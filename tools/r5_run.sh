@@ -40,6 +40,7 @@ for s in "$@"; do
     b_mw)     step r5_bench_mesh_ss 300 python bench.py --workload mesh --kernel sstream --no-cpu-baseline --no-extras ;;
     b_mw_small) step r5_bench_mesh_small_ss 300 python bench.py --workload mesh_small --kernel sstream --no-cpu-baseline --no-extras ;;
     t_mw)     step r5_t_mw 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cut_ring or sliced_stream_kernel" && step r5_bench_mesh 300 python bench.py --workload mesh --no-cpu-baseline && step r5_bench_mesh_ss 300 python bench.py --workload mesh --kernel sstream --no-cpu-baseline --no-extras && step r5_bench_mesh_small 300 python bench.py --workload mesh_small --no-cpu-baseline --no-extras ;;
+    simmesh)  for n in 8 4; do step r5_simmesh$n 400 python tools/sim_rank.py $n 1 mesh || exit 1; done ;;
     simfe_n)  for n in 8 4 2; do step r5_simfe$n 300 python tools/sim_rank.py $n 1 fe && MI355_PUSH_FUSED_EXT=0 step r5_simfe${n}_four 300 python tools/sim_rank.py $n 1 fe || exit 1; done ;;
     t_ext)    step r5_t_ext 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ranks_sharing_one_card and sfe" ;;
     t_meshd)  step r5_t_meshd 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ranks_sharing_one_card and mesh" ;;

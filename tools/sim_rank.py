@@ -12,10 +12,10 @@ from oracle import oracle as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 what = sys.argv[3] if len(sys.argv) > 3 else "c4"   # "c4": S15 5 M rows; "fe": the 68^3-cell FE matrix, cuts at node boundaries
-if what == "fe":
-    P_, C_, V_ = synth.fe_matrix(int(os.environ.get("SIM_FE_CELLS", "68")))
+if what in ("fe", "mesh"):  # "mesh": the P1 pressure operator on a 170^3-cell Kuhn mesh, natural node order (5 M rows; SIM_MESH_CELLS)
+    P_, C_, V_ = synth.fe_matrix(int(os.environ.get("SIM_FE_CELLS", "68"))) if what == "fe" else synth.pressure_matrix(int(os.environ.get("SIM_MESH_CELLS", "170")))
     n = len(P_) - 1
-    rs = D.balanced_row_starts(n, N, np.diff(P_), align=4)
+    rs = D.balanced_row_starts(n, N, np.diff(P_), align=4 if what == "fe" else 1)
     lo, hi = int(rs[rank]), int(rs[rank + 1])
     p, c, v = (P_[lo:hi + 1] - P_[lo]).astype(np.int32), C_[P_[lo]:P_[hi]].copy(), V_[P_[lo]:P_[hi]].copy()
     del P_, C_, V_
@@ -129,7 +129,7 @@ if fz.value and "sstream" in L.mi_part_kernel_name(h, 2).decode() and hasattr(L,
         print(f"      {cls:12s} ({len(rows[0][0]):3d} workgroups, {rd.min()}-{rd.max()} rounds): start +{np.median(st):.2f}, start -> loop {np.median(fi):.2f} (max {fi.max():.2f}), "
               f"loop {np.median(lo_):.2f}, end +{np.median(en):.2f} (max {en.max():.2f}) us")
 if fz.value and "fused_ext" in L.mi_part_kernel_name(h, 2).decode() and hasattr(L, "mi_debug_part_ext_trace"):
-    G = 8192
+    G = 65536
     rows = []
     for it in range(8):
         buf, wg, md = np.zeros(3 * G, np.int64), ctypes.c_int(), np.zeros(G, np.int32)
