@@ -35,8 +35,9 @@
 extern "C" {
 #endif
 
-#define MI355_SPMV_VERSION 500 /* 0.5.0: mi_bcsr4_spmm_info writes us[5] since 0.4 (it was us[4] in 0.3: a caller built against 0.3 must be rebuilt); 0.5 adds
-                                * mi_sstream_plan_probe_ex, mi_part_kernel_name, mi_part_sends_contiguous and refills sliced copies inside mi_*_update_values* */
+#define MI355_SPMV_VERSION 501 /* 0.5.1: mi_bcsr4_spmm_info writes us[5] since 0.4 (it was us[4] in 0.3: a caller built against 0.3 must be rebuilt); 0.5 adds
+                                * mi_sstream_plan_probe_ex, mi_part_kernel_name, mi_part_sends_contiguous and refills sliced copies inside mi_*_update_values*;
+                                * 0.5.1 adds mi_sstream_mw_plan_probe (nothing changed for a caller built against 0.5.0) */
 
 enum {
     MI_OK = 0,

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     assert not missing, f"declared in include/mi355_spmv.h but not exported: {missing}"
     L.mi_version.restype = ctypes.c_int
-    assert L.mi_version() == 500
+    assert L.mi_version() == 501
 
 
 def test_product_library_carries_no_debug_entry_points():
