@@ -517,7 +517,7 @@ int mi_part_spmv_push_dev(mi_part_t P, double* d_x_ext, double* d_y_local, mi_st
 /* *fused = 1: the step is ONE launch — when all local rows form a piece the sliced-stream kernel (round 5: spmv_sstream_fused) or the
  * ring kernel (spmv_ring.hpp, FUSED) serves, the push duty and the ghost reads (straight from the window, behind an in-kernel wait)
  * live inside that kernel, in the few workgroups / runs whose rows touch ghosts; these get a shorter share of the rows, push first and wait
- * second (mi_part_kernel_name(P, 2) names the kernel; MI355_PUSH_FUSED=0 disables the form, MI355_PUSH_FUSED_KERNEL=ring|sstream forces
+ * second (mi_part_kernel_name(P, 2) names the kernel; MI355_PUSH_FUSED=0 disables the form, MI355_PUSH_FUSED_KERNEL=ring|sstream|csr_ext forces
  * one).  A rank whose rows have the 4x4 node structure runs the blocked kernel's one-launch form, spmv_bcsr4_fused_ext
  * (spmv_bcsr4_ext.hpp): the launch's first workgroups push, wait and copy the window once into a cached buffer of the handle, the
  * workgroups whose rows name ghosts wait for THEM and read that buffer (MI355_PUSH_FUSED_EXT=0 keeps the four launches for such

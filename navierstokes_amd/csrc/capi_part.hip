@@ -720,7 +720,9 @@ int part_push_connect_bases(mi_part_s* P, void* const* bases, const long long* l
             }
         }
     }
-    if (!P->fused && !(fe && !strcmp(fe, "0")) && pl.n_local > 0) {
+    // (MI355_PUSH_FUSED_KERNEL=csr_ext: none of the two forms below — the staged scalar step further down instead: tests, A/B)
+    const char* fk0 = getenv("MI355_PUSH_FUSED_KERNEL");
+    if (!P->fused && !(fe && !strcmp(fe, "0")) && !(fk0 && !strcmp(fk0, "csr_ext")) && pl.n_local > 0) {
         P->plan.build_combined();
         const LocalPiece& L = P->plan.all;
         rc = csr_create_impl(pl.n_local, pl.n_local + pl.n_halo, L.ptrow.data(), L.indcol.data(), L.coef.data(), nullptr, &P->piece_all,

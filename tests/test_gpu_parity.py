@@ -585,12 +585,12 @@ def test_ranks_sharing_one_card(world, kind, n, w, port, exchange):
         env.update(MI355_PUSH_EXT_SPLIT="0", MI355_TEST_EXPECT_FUSED="=spmv_bcsr4_fused_ext")
     elif kind == "mesh_ext":
         kind = "mesh"
-        # (MI355_PUSH_FUSED_KERNEL=sstream: not the ring kernel's fused form, which takes such a rank when its plan serves it)
-        env.update(MI355_PUSH_EXT_SPLIT="0", MI355_PUSH_FUSED_KERNEL="sstream", MI355_TEST_EXPECT_FUSED="=spmv_csr_fused_ext")
+        # (MI355_PUSH_FUSED_KERNEL=csr_ext: not the ring kernel's fused form, which takes such a rank when its plan serves it)
+        env.update(MI355_PUSH_EXT_SPLIT="0", MI355_PUSH_FUSED_KERNEL="csr_ext", MI355_TEST_EXPECT_FUSED="=spmv_csr_fused_ext")
     elif kind == "mesh_ext2":
         kind = "mesh"
         env.pop("MI355_PUSH_EXT_SPLIT", None)
-        env.update(MI355_PUSH_FUSED_KERNEL="sstream", MI355_TEST_EXPECT_FUSED="spmv_csr_fused_ext x2")
+        env.update(MI355_PUSH_FUSED_KERNEL="csr_ext", MI355_TEST_EXPECT_FUSED="spmv_csr_fused_ext x2")
     elif kind == "sfe_ext2":
         kind = "sfe"
         env.pop("MI355_PUSH_EXT_SPLIT", None)
